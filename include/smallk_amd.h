@@ -1,0 +1,199 @@
+/*
+ * include/smallk_amd.h -- C ABI of the MI355X-native dense NMF solver.
+ *
+ * This is the drop-in boundary for the smallk hot path: plain
+ * pointers and sizes, no C++ or torch types.  Every entry point names the
+ * reference interface it stands in for (paths relative to /root/reference).
+ * The C++ facade (include/smallk.hpp, include/nmf.hpp) and the Python mirror of
+ * pysmallk (smallk_amd/api.py) are both thin layers over these symbols.
+ *
+ * Conventions (same as the reference's inner seam, common/include/nmf.hpp:77-81):
+ *   - host matrices are fp64, column-major, leading dimension >= height;
+ *   - W (m x k) and H (k x n) are in/out: initial guess in, factors out;
+ *   - return values are `Result` codes (nmf.hpp:17-26) plus two negative
+ *     extensions for device errors; smk_last_error() gives the text;
+ *   - not thread safe (the reference is not either: smallk.cpp:46-67).
+ */
+#ifndef SMALLK_AMD_H
+#define SMALLK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum Result, common/include/nmf.hpp:17-26 */
+enum {
+    SMK_OK = 0,
+    SMK_NOTINITIALIZED = -1,
+    SMK_INITIALIZED = -2,
+    SMK_BAD_PARAM = -3,
+    SMK_FAILURE = -4,
+    SMK_SIZE_TOO_LARGE = -5,
+    SMK_FLATCLUST_FAILURE = -6,
+    /* extensions (never produced by the reference) */
+    SMK_DEVICE_ERROR = -100, /* HIP runtime error, see smk_last_error() */
+    SMK_UNSUPPORTED = -101   /* valid for the reference, not built here (RANK2, k > 64) */
+};
+
+/* enum NmfAlgorithm, common/include/nmf.hpp:28-34 (NOT smallk::Algorithm's order) */
+enum { SMK_ALG_MU = 0, SMK_ALG_HALS = 1, SMK_ALG_RANK2 = 2, SMK_ALG_BPP = 3 };
+
+/* enum NmfProgressAlgorithm, common/include/nmf.hpp:37-41 */
+enum { SMK_PROG_PG_RATIO = 0, SMK_PROG_DELTA_FNORM = 1 };
+
+/* how A is held in HBM (device-side option; the host API stays fp64) */
+enum { SMK_STORE_F32 = 0, SMK_STORE_BF16 = 1 };
+
+/* struct NmfOptions, common/include/nmf.hpp:55-69 (bool -> int) */
+typedef struct smk_options {
+    double tol;
+    int algorithm;
+    int prog_est_algorithm;
+    int height;
+    int width;
+    int k;
+    int min_iter;
+    int max_iter;
+    int tolcount;
+    int max_threads; /* accepted, unused on the device path */
+    int verbose;
+    int normalize;
+} smk_options;
+
+/* struct NmfStats, common/include/nmf.hpp:43-53 */
+typedef struct smk_stats {
+    unsigned long long elapsed_us;
+    int iteration_count;
+} smk_stats;
+
+typedef struct smk_matrix smk_matrix; /* A (and A') resident in HBM, possibly a column shard */
+typedef struct smk_solver smk_solver; /* one NmfSolve<> instance */
+
+/* ---- lifecycle: NmfInitialize / NmfIsInitialized / NmfFinalize, nmf.hpp:71-73 ------------ */
+int smk_initialize(int device_ordinal); /* -1: keep the current HIP device */
+int smk_is_initialized(void);           /* SMK_INITIALIZED or SMK_NOTINITIALIZED */
+void smk_finalize(void);
+const char* smk_last_error(void);
+int smk_device_cu_count(void);
+
+/* IsValid(const NmfOptions&, bool validate_matrix), common/src/nmf_options.cpp:23-112 */
+int smk_is_valid(const smk_options* opts, int validate_matrix);
+
+/* Use an existing HIP stream (e.g. torch's current stream) instead of the library's own. */
+int smk_set_stream(void* hip_stream);
+
+/* ---- one shot: Result Nmf(const NmfOptions&, double* A, int ldA, double* W, int ldW,
+ *      double* H, int ldH, NmfStats&), common/include/nmf.hpp:77-81 / src/nmf.cpp:173-229.
+ *      `storage` chooses how A sits in HBM (the reference has no such knob). */
+int smk_nmf_dense(const smk_options* opts, const double* A, int64_t ldA, double* W, int64_t ldW,
+                  double* H, int64_t ldH, smk_stats* stats, int storage);
+
+/* ---- device-resident A (replaces the DenseMatrix view of buf_a, nmf.cpp:224) ---------------
+ * A matrix object holds the column shard [col0, col0 + ncols_local) of a height x width_global
+ * matrix, plus its transpose (the reference's BPP solver keeps At too, nmf_solver_bpp.hpp:319). */
+int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0,
+                      int64_t ncols_local, int storage);
+/* copy a host fp64 column-major block (height x ncols_local, the shard) into HBM */
+int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld);
+/* fill with the counter-based uniform [0,1) generator (matrixgen UNIFORM, matrixgen/src/main.cpp:64-72);
+ * element (r, c) depends only on (seed, global index), so shards agree with the whole. */
+int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed);
+/* read the shard back as fp64 (tests) */
+int smk_matrix_download_f64(const smk_matrix* a, double* host, int64_t ld);
+void smk_matrix_destroy(smk_matrix* a);
+/* same generator on the host, for W0/H0 (RandomMatrix stand-in, smallk.cpp:533,554) */
+void smk_uniform_fill_host(double* buf, int64_t ld, int64_t rows, int64_t cols, int64_t r0, int64_t c0,
+                           int64_t global_height, uint64_t seed, int quant /* 0: 24 bit, 1: bf16 */);
+
+/* ---- solver object = NmfSolve<> (common/include/nmf_solve_generic.hpp:34-140) ---------------- */
+int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matrix* a);
+void smk_solver_destroy(smk_solver* s);
+/* W0 (m x k) and the local H0 shard (k x ncols_local); runs solver.Init + progress_est->Init (:62-63) */
+int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const double* H0, int64_t ldH);
+/* the whole driver loop with stopping rule, final NormalizeAndScale, stats (:67-139) */
+int smk_solver_run(smk_solver* s, smk_stats* stats);
+/* enqueue `iters` solver iterations without convergence checks (the min_iter branch, :81-95);
+ * asynchronous: returns before the GPU finishes. */
+int smk_solver_iterate(smk_solver* s, int iters);
+int smk_solver_sync(smk_solver* s); /* wait + report solver failures (Result code) */
+/* progress metric of the last iteration that computed one (PG ratio or delta-Fnorm) */
+int smk_solver_progress(smk_solver* s, double* metric);
+/* optional final NormalizeAndScale (normalize.hpp:118-140), then copy factors to the host */
+int smk_solver_get_factors(smk_solver* s, int normalize, double* W, int64_t ldW, double* H, int64_t ldH);
+int smk_solver_iteration_count(const smk_solver* s);
+
+/* measurement: HIP events around the streaming-product launches (stream of the solver) */
+int smk_solver_enable_timing(smk_solver* s, int on);
+/* which: 0 = W'A pass, 1 = H*At pass.  Returns total ms and launch count since enable. */
+int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* launches);
+/* algorithmic bytes / flops one launch of pass `which` moves (len*ncols*sizeof(elt), 2*k*len*ncols) */
+int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double* flops);
+
+/* ---- multi-GPU: A and H column sharded, W replicated.  The only exchange steps are
+ * sum-all-reduces of HH' (k x k), H*At (k x m) and one scalar; the host supplies the collective
+ * (torch.distributed / RCCL).  `ptr` is device memory inside the registered workspace. */
+typedef int (*smk_allreduce_fn)(void* user, void* ptr, int64_t count, int dtype /*0 f32, 1 f64*/);
+int smk_solver_comm_workspace_bytes(const smk_solver* s, size_t* bytes);
+int smk_solver_set_comm(smk_solver* s, int rank, int world, smk_allreduce_fn fn, void* user,
+                        void* workspace, size_t workspace_bytes);
+
+/* ---- CSV files: WriteDelimitedFile / LoadDelimitedFile, common/include/delimited_file.hpp:49-135 ----
+ * (row-major text, scientific notation; used for w.csv / h.csv and init files) */
+int smk_write_csv(const double* buf, unsigned ldim, unsigned height, unsigned width, const char* filename,
+                  unsigned precision);
+int smk_load_csv(const char* filename, double* out, unsigned long capacity, unsigned* height, unsigned* width);
+
+/* ---- flat handles onto the public C++ API `namespace smallk` (include/smallk.hpp), one per entry of
+ * pysmallk's extern block (pysmallk/interface/smallk_lib.pyx:42-88), for bindings that cannot call C++
+ * (ctypes, cgo, JNI).  Functions that can throw return 0 = ok, 1 = std::logic_error,
+ * 2 = std::runtime_error; the message is in smk_api_last_exception(). */
+const char* smk_api_last_exception(void);
+int smk_api_initialize(void);                /* smallk::Initialize   smallk.cpp:114-119 */
+int smk_api_is_initialized(void);            /* smallk::IsInitialized */
+void smk_api_finalize(void);                 /* smallk::Finalize */
+void smk_api_reset(void);                    /* smallk::Reset        smallk.cpp:81-111 */
+void smk_api_seed_rng(int seed);             /* smallk::SeedRNG */
+unsigned smk_api_get_major_version(void);
+unsigned smk_api_get_minor_version(void);
+unsigned smk_api_get_patch_level(void);
+int smk_api_load_matrix_file(const char* path);                                 /* LoadMatrix(string) :163 */
+int smk_api_load_matrix_dense(const double* buf, unsigned ldim, unsigned height, unsigned width); /* :204 */
+int smk_api_load_matrix_sparse(unsigned height, unsigned width, unsigned nz, const double* data,
+                               const unsigned* row_indices, const unsigned* col_offsets);       /* :268 */
+int smk_api_is_matrix_loaded(void);
+int smk_api_set_output_dir(const char* dir);  /* SetOutputDir :348-380 */
+const char* smk_api_get_output_dir(void);
+void smk_api_set_output_precision(unsigned digits);
+unsigned smk_api_get_output_precision(void);
+int smk_api_set_nmf_tolerance(double tol);
+double smk_api_get_nmf_tolerance(void);
+void smk_api_set_max_iter(unsigned v);
+unsigned smk_api_get_max_iter(void);
+void smk_api_set_min_iter(unsigned v);
+unsigned smk_api_get_min_iter(void);
+void smk_api_set_max_threads(unsigned v);
+unsigned smk_api_get_max_threads(void);
+void smk_api_set_max_terms(unsigned v);
+unsigned smk_api_get_max_terms(void);
+void smk_api_set_output_format(int xml0_json1);
+int smk_api_get_output_format(void);
+int smk_api_set_hiernmf2_tolerance(double tol);
+double smk_api_get_hiernmf2_tolerance(void);
+void smk_api_set_device_storage(int storage);   /* extension: SMK_STORE_F32 / SMK_STORE_BF16 */
+int smk_api_get_device_storage(void);
+unsigned smk_api_get_iteration_count(void);
+/* smallk::Nmf(k, algorithm, initfile_w, initfile_h), smallk.cpp:471-650; `algorithm` is numbered
+ * like smallk::Algorithm: MU 0, BPP 1, HALS 2, RANK2 3 (smallk.hpp:34-40) */
+int smk_api_nmf(unsigned k, int algorithm, const char* initfile_w, const char* initfile_h);
+const double* smk_api_locked_buffer_w(unsigned* ldim, unsigned* height, unsigned* width);   /* :653-661 */
+const double* smk_api_locked_buffer_h(unsigned* ldim, unsigned* height, unsigned* width);   /* :664-672 */
+int smk_api_hiernmf2(unsigned num_clusters);            /* next tier: reports "not built" */
+int smk_api_load_dictionary_file(const char* path);     /* next tier */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMALLK_AMD_H */

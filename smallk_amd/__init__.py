@@ -1,0 +1,13 @@
+"""smallk_amd -- MI355X-native dense NMF (MU / HALS / BPP) behind the libsmallk API.
+
+The numeric path is hand-written HIP for gfx950 in ``smallk_amd/csrc`` behind the C ABI
+``include/smallk_amd.h``; this package is the host-side mirror of the reference's Python
+surface (pysmallk ``SmallkAPI``) plus thin object wrappers.  No CPU fallback exists.
+"""
+from . import _lib
+from .solver import (DenseMatrix, NmfSolver, NmfResult, nmf, initialize, finalize, is_initialized,
+                     make_options, uniform_host, set_stream)
+from .api import SmallkAPI
+
+__all__ = ["DenseMatrix", "NmfSolver", "NmfResult", "nmf", "initialize", "finalize", "is_initialized",
+           "make_options", "uniform_host", "set_stream", "SmallkAPI", "_lib"]

@@ -1,0 +1,149 @@
+"""ctypes binding of libsmallk_amd.so (the C ABI in include/smallk_amd.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C smallk_amd/csrc``.
+There is NO CPU fallback: if the shared object is missing, importing the product
+fails loudly; if no GPU is present, ``initialize()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsmallk_amd.so")
+
+# Result codes (include/smallk_amd.h)
+OK, NOTINITIALIZED, INITIALIZED, BAD_PARAM, FAILURE, SIZE_TOO_LARGE = 0, -1, -2, -3, -4, -5
+DEVICE_ERROR, UNSUPPORTED = -100, -101
+ALG_MU, ALG_HALS, ALG_RANK2, ALG_BPP = 0, 1, 2, 3
+PROG_PG_RATIO, PROG_DELTA_FNORM = 0, 1
+STORE_F32, STORE_BF16 = 0, 1
+
+RESULT_NAMES = {0: "OK", -1: "NOTINITIALIZED", -2: "INITIALIZED", -3: "BAD_PARAM", -4: "FAILURE",
+                -5: "SIZE_TOO_LARGE", -6: "FLATCLUST_FAILURE", -100: "DEVICE_ERROR", -101: "UNSUPPORTED"}
+
+
+class Options(C.Structure):
+    """struct smk_options == NmfOptions (common/include/nmf.hpp:55-69)."""
+    _fields_ = [("tol", C.c_double), ("algorithm", C.c_int), ("prog_est_algorithm", C.c_int),
+                ("height", C.c_int), ("width", C.c_int), ("k", C.c_int),
+                ("min_iter", C.c_int), ("max_iter", C.c_int), ("tolcount", C.c_int),
+                ("max_threads", C.c_int), ("verbose", C.c_int), ("normalize", C.c_int)]
+
+
+class Stats(C.Structure):
+    """struct smk_stats == NmfStats (common/include/nmf.hpp:43-53)."""
+    _fields_ = [("elapsed_us", C.c_ulonglong), ("iteration_count", C.c_int)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+# every symbol include/smallk_amd.h declares: name -> (restype, argtypes)
+_dp = C.POINTER(C.c_double)
+_i64 = C.c_int64
+_vp = C.c_void_p
+SYMBOLS = {
+    "smk_initialize": (C.c_int, [C.c_int]),
+    "smk_is_initialized": (C.c_int, []),
+    "smk_finalize": (None, []),
+    "smk_last_error": (C.c_char_p, []),
+    "smk_device_cu_count": (C.c_int, []),
+    "smk_is_valid": (C.c_int, [C.POINTER(Options), C.c_int]),
+    "smk_set_stream": (C.c_int, [_vp]),
+    "smk_nmf_dense": (C.c_int, [C.POINTER(Options), _dp, _i64, _dp, _i64, _dp, _i64, C.POINTER(Stats), C.c_int]),
+    "smk_matrix_create": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _i64, C.c_int]),
+    "smk_matrix_upload_f64": (C.c_int, [_vp, _dp, _i64]),
+    "smk_matrix_fill_uniform": (C.c_int, [_vp, C.c_uint64]),
+    "smk_matrix_download_f64": (C.c_int, [_vp, _dp, _i64]),
+    "smk_matrix_destroy": (None, [_vp]),
+    "smk_uniform_fill_host": (None, [_dp, _i64, _i64, _i64, _i64, _i64, _i64, C.c_uint64, C.c_int]),
+    "smk_solver_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Options), _vp]),
+    "smk_solver_destroy": (None, [_vp]),
+    "smk_solver_set_factors": (C.c_int, [_vp, _dp, _i64, _dp, _i64]),
+    "smk_solver_run": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "smk_solver_iterate": (C.c_int, [_vp, C.c_int]),
+    "smk_solver_sync": (C.c_int, [_vp]),
+    "smk_solver_progress": (C.c_int, [_vp, _dp]),
+    "smk_solver_get_factors": (C.c_int, [_vp, C.c_int, _dp, _i64, _dp, _i64]),
+    "smk_solver_iteration_count": (C.c_int, [_vp]),
+    "smk_solver_enable_timing": (C.c_int, [_vp, C.c_int]),
+    "smk_solver_kernel_time": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int)]),
+    "smk_solver_kernel_work": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "smk_solver_comm_workspace_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
+    "smk_solver_set_comm": (C.c_int, [_vp, C.c_int, C.c_int, ALLREDUCE_FN, _vp, _vp, C.c_size_t]),
+    # CSV helpers (facade.cpp; reference delimited_file.hpp:49-135)
+    "smk_write_csv": (C.c_int, [_dp, C.c_uint, C.c_uint, C.c_uint, C.c_char_p, C.c_uint]),
+    "smk_load_csv": (C.c_int, [C.c_char_p, _dp, C.c_ulong, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    # flat handles onto namespace smallk (facade.cpp; pysmallk/interface/smallk_lib.pyx:42-88)
+    "smk_api_last_exception": (C.c_char_p, []),
+    "smk_api_initialize": (C.c_int, []),
+    "smk_api_is_initialized": (C.c_int, []),
+    "smk_api_finalize": (None, []),
+    "smk_api_reset": (None, []),
+    "smk_api_seed_rng": (None, [C.c_int]),
+    "smk_api_get_major_version": (C.c_uint, []),
+    "smk_api_get_minor_version": (C.c_uint, []),
+    "smk_api_get_patch_level": (C.c_uint, []),
+    "smk_api_load_matrix_file": (C.c_int, [C.c_char_p]),
+    "smk_api_load_matrix_dense": (C.c_int, [_dp, C.c_uint, C.c_uint, C.c_uint]),
+    "smk_api_load_matrix_sparse": (C.c_int, [C.c_uint, C.c_uint, C.c_uint, _dp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "smk_api_is_matrix_loaded": (C.c_int, []),
+    "smk_api_set_output_dir": (C.c_int, [C.c_char_p]),
+    "smk_api_get_output_dir": (C.c_char_p, []),
+    "smk_api_set_output_precision": (None, [C.c_uint]),
+    "smk_api_get_output_precision": (C.c_uint, []),
+    "smk_api_set_nmf_tolerance": (C.c_int, [C.c_double]),
+    "smk_api_get_nmf_tolerance": (C.c_double, []),
+    "smk_api_set_max_iter": (None, [C.c_uint]),
+    "smk_api_get_max_iter": (C.c_uint, []),
+    "smk_api_set_min_iter": (None, [C.c_uint]),
+    "smk_api_get_min_iter": (C.c_uint, []),
+    "smk_api_set_max_threads": (None, [C.c_uint]),
+    "smk_api_get_max_threads": (C.c_uint, []),
+    "smk_api_set_max_terms": (None, [C.c_uint]),
+    "smk_api_get_max_terms": (C.c_uint, []),
+    "smk_api_set_output_format": (None, [C.c_int]),
+    "smk_api_get_output_format": (C.c_int, []),
+    "smk_api_set_hiernmf2_tolerance": (C.c_int, [C.c_double]),
+    "smk_api_get_hiernmf2_tolerance": (C.c_double, []),
+    "smk_api_set_device_storage": (None, [C.c_int]),
+    "smk_api_get_device_storage": (C.c_int, []),
+    "smk_api_get_iteration_count": (C.c_uint, []),
+    "smk_api_nmf": (C.c_int, [C.c_uint, C.c_int, C.c_char_p, C.c_char_p]),
+    "smk_api_locked_buffer_w": (_dp, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "smk_api_locked_buffer_h": (_dp, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "smk_api_hiernmf2": (C.c_int, [C.c_uint]),
+    "smk_api_load_dictionary_file": (C.c_int, [C.c_char_p]),
+}
+
+_lib = None
+
+
+class SmallkError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: {RESULT_NAMES.get(code, code)}" + (f" ({detail})" if detail else ""))
+
+
+def lib():
+    """Load the shared library (no compute, no GPU needed for loading)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C smallk_amd/csrc`.  There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, where):
+    if rc != OK:
+        detail = lib().smk_last_error()
+        raise SmallkError(rc, where, detail.decode() if detail else "")
+    return rc

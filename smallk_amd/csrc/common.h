@@ -1,0 +1,105 @@
+// smallk_amd/csrc/common.h -- shared host-side declarations for the MI355X NMF library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include <string>
+
+namespace smk {
+
+typedef int64_t i64;
+
+// Device storage of the big matrix A (and its transpose).
+enum Storage { STORE_F32 = 0, STORE_BF16 = 1 };
+
+inline int elem_size(int storage) { return storage == STORE_BF16 ? 2 : 4; }
+
+// Row padding of every stored big matrix (zero filled): lets the streaming
+// kernel read whole 64/128-row stages without bounds checks.
+constexpr i64 ROW_PAD = 128;
+// Column padding = columns per workgroup tile of the streaming kernel.
+constexpr i64 COL_PAD = 128;
+
+inline i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
+
+// padded k handled by the column-per-thread kernels
+inline int kp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64; }
+// number of 32-wide k tiles of the streaming product
+inline int kt_of(int k) { return (k + 31) / 32; }
+
+void set_error(const std::string& msg);
+
+#define SMK_HIP(expr)                                                                   \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            ::smk::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));        \
+            return -100; /* SMK_DEVICE_ERROR */                                         \
+        }                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// kernel launchers (kernels.hip).  All asynchronous on `st`.
+// X-side matrices are fp64, column-major k x N with leading dimension k
+// ("H layout"; W is kept transposed as Wt, k x m).
+// P = fp32 partial products from the streaming kernel: [S][ncols_pad][KPP].
+// ---------------------------------------------------------------------------
+struct PartialView {
+    const float* p;   // base
+    int S;            // number of partial slabs to sum
+    i64 slab;         // elements between slabs (= ncols_pad * kpp)
+    int kpp;          // padded k of a column in P (multiple of 32)
+};
+
+int launch_fill_uniform(void* buf, int storage, i64 ld, i64 rows, i64 cols, i64 rows_pad, i64 cols_pad,
+                        i64 r0, i64 c0, i64 gheight, uint64_t seed, int quant, hipStream_t st);
+int launch_convert_f64(const double* src, i64 ld_src, void* dst, int storage, i64 ld_dst, i64 rows, i64 cols,
+                       hipStream_t st);
+int launch_transpose_store(const void* src, i64 ld_src, void* dst, i64 ld_dst, int storage, i64 rows, i64 cols,
+                           hipStream_t st);
+int launch_transpose_f64(const double* src, i64 ld_src, double* dst, i64 ld_dst, i64 rows, i64 cols, hipStream_t st);
+
+// packed MFMA operand of X (k x N): bytes needed
+size_t packed_bytes(int storage, int k, i64 N, int nsplit);
+int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st);
+
+// streaming product: P[s][j][:] = sum over the rows of split s of X[:,row] * B[row, j]
+struct BigProdPlan {
+    int S;          // row splits
+    i64 stages;     // total stages = ceil(len / MB)
+    i64 nst;        // stages per split
+    i64 tiles;      // column tiles of 128
+    int kt, nsplit, storage;
+    i64 ncols_pad;
+    size_t p_elems; // floats needed for P
+};
+BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus);
+int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, float* P, hipStream_t st);
+const void* bigprod_kernel_ptr(const BigProdPlan& pl);
+
+int launch_reduce_partials(PartialView pv, int k, i64 N, float* out /* [N][kpp] */, hipStream_t st);
+
+int launch_gram(const double* X, int k, i64 N, double* G /* KP x KP */, double* scratch, int max_blocks, hipStream_t st);
+size_t gram_scratch_elems(int k, int max_blocks);
+
+int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
+int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
+// gradient G*X - R, optional store, projected-gradient partial sums -> pg_accum[slot] += sum
+int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
+                   double* pg_partials, double* pg_accum, int slot, hipStream_t st);
+// projected-gradient sum from an existing gradient array
+int launch_pg_from_grad(const double* X, const double* Y, int k, i64 N, double* pg_partials, double* pg_accum,
+                        int slot, hipStream_t st);
+// HALS W update (all k columns, k+1 launches); norms scratch: [k][nblocks] + ...
+int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, hipStream_t st);
+size_t hals_w_scratch_elems(int k, i64 M);
+// BPP / NNLS block principal pivoting over all columns
+int launch_nnls_bpp(double* X, double* Y, int k, i64 N, PartialView R, const double* G, int* fail_flag,
+                    int iter_tag, hipStream_t st);
+// normalisation: scale Wt rows by 1/nu_c, H rows by nu_c where nu_c^2 = G[c][c]
+int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int* fail_flag, hipStream_t st);
+// delta-fnorm: out[0] = sum (W - Wprev)^2, out[1] = sum W^2 ; then Wprev = W
+int launch_delta_fnorm(const double* W, double* Wprev, i64 count, double* partials, double* out2, hipStream_t st);
+int launch_zero_f64(double* p, i64 n, hipStream_t st);
+
+}  // namespace smk

@@ -1,0 +1,644 @@
+// smallk_amd/csrc/facade.cpp -- C++ host layer above the C ABI:
+//   * the inner seam  ::Nmf(NmfOptions, ...)           (reference common/src/nmf.cpp:173-229)
+//   * the public API  namespace smallk                 (reference smallk/src/smallk.cpp:81-672)
+//   * CSV reader/writer used by LoadMatrix / init files / w.csv, h.csv
+//                                                       (reference common/include/delimited_file.hpp:49-135)
+// Same names, argument meaning, clamping and exception types as the reference; the numeric
+// work is delegated to the GPU solver through include/smallk_amd.h.
+#include "../../include/nmf.hpp"
+#include "../../include/smallk.hpp"
+#include "../../include/smallk_amd.h"
+
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+#include <thread>
+
+// =============================================================================================
+// CSV (delimited) files
+// =============================================================================================
+namespace smallk_amd_io {
+
+// Row-major text, `precision` digits, scientific notation, ',' between values, '\n' per row:
+// byte-identical to WriteDelimitedFile (delimited_file.hpp:49-76).
+bool WriteCsv(const double* buffer, unsigned int ldim, unsigned int height, unsigned int width,
+              const std::string& filename, unsigned int precision)
+{
+    std::ofstream out(filename);
+    if (!out) return false;
+    out << std::scientific;
+    out.precision(precision);
+    for (unsigned int r = 0; r != height; ++r) {
+        for (unsigned int c = 0; c + 1 < width; ++c) out << buffer[(size_t)c * ldim + r] << ',';
+        out << buffer[(size_t)(width - 1) * ldim + r] << std::endl;
+    }
+    out.close();
+    return true;
+}
+
+static bool is_comment(const std::string& line) { return !line.empty() && (line[0] == '#' || line[0] == '%'); }
+
+// Reads a dense CSV into a column-major buffer (ldim = height).  Leading blank/comment lines are
+// skipped; width = delimiters in the first data line + 1; height = number of remaining lines
+// (LoadDelimitedFile, delimited_file.hpp:79-135; GetDimensions, delimited_file.cpp:72-98).
+bool LoadCsv(std::vector<double>& buffer, unsigned int& height, unsigned int& width, const std::string& filename)
+{
+    std::ifstream in(filename);
+    if (!in) return false;
+    std::string line;
+    std::vector<std::string> rows;
+    bool started = false;
+    while (std::getline(in, line)) {
+        if (!started) {
+            if (line.empty() || is_comment(line)) continue;
+            started = true;
+        }
+        // the reference stops counting at a final line without '\n' only if it is empty
+        rows.push_back(line);
+    }
+    while (!rows.empty() && rows.back().empty()) rows.pop_back();
+    if (rows.empty()) return false;
+    width = 1 + (unsigned int)std::count(rows[0].begin(), rows[0].end(), ',');
+    height = (unsigned int)rows.size();
+    buffer.assign((size_t)height * width, 0.0);
+    for (unsigned int r = 0; r < height; ++r) {
+        std::istringstream data(rows[r]);
+        char dummy;
+        for (unsigned int c = 0; c != width; ++c) {
+            double v = 0.0;
+            data >> v;
+            data >> dummy;
+            buffer[(size_t)c * height + r] = v;
+        }
+    }
+    return true;
+}
+
+}  // namespace smallk_amd_io
+
+extern "C" int smk_write_csv(const double* buf, unsigned ldim, unsigned height, unsigned width,
+                             const char* filename, unsigned precision)
+{
+    return smallk_amd_io::WriteCsv(buf, ldim, height, width, filename, precision) ? 1 : 0;
+}
+
+extern "C" int smk_load_csv(const char* filename, double* out, unsigned long cap, unsigned* height, unsigned* width)
+{
+    std::vector<double> v;
+    unsigned h = 0, w = 0;
+    if (!smallk_amd_io::LoadCsv(v, h, w, filename)) return 0;
+    *height = h;
+    *width = w;
+    if ((unsigned long)h * w > cap) return -1;
+    std::memcpy(out, v.data(), sizeof(double) * (size_t)h * w);
+    return 1;
+}
+
+// =============================================================================================
+// inner seam: nmf.hpp
+// =============================================================================================
+static int g_nmf_storage = SMK_STORE_F32;
+
+void NmfSetDeviceStorage(int storage) { g_nmf_storage = (storage == SMK_STORE_BF16) ? SMK_STORE_BF16 : SMK_STORE_F32; }
+int NmfGetDeviceStorage() { return g_nmf_storage; }
+
+void NmfInitialize(int /*argc*/, char* /*argv*/[])
+{
+    if (smk_initialize(-1) != SMK_OK) throw std::runtime_error(std::string("NmfInitialize: ") + smk_last_error());
+}
+
+Result NmfIsInitialized() { return smk_is_initialized() == SMK_INITIALIZED ? Result::INITIALIZED : Result::NOTINITIALIZED; }
+
+void NmfFinalize() { smk_finalize(); }
+
+static smk_options to_c(const NmfOptions& o)
+{
+    smk_options c;
+    c.tol = o.tol;
+    c.algorithm = (int)o.algorithm;                 // same numbering as NmfAlgorithm
+    c.prog_est_algorithm = (int)o.prog_est_algorithm;
+    c.height = o.height; c.width = o.width; c.k = o.k;
+    c.min_iter = o.min_iter; c.max_iter = o.max_iter; c.tolcount = o.tolcount;
+    c.max_threads = o.max_threads;
+    c.verbose = o.verbose ? 1 : 0;
+    c.normalize = o.normalize ? 1 : 0;
+    return c;
+}
+
+bool IsValid(const NmfOptions& opts, bool validate_matrix)
+{
+    smk_options c = to_c(opts);
+    return smk_is_valid(&c, validate_matrix ? 1 : 0) != 0;
+}
+
+static Result to_result(int rc)
+{
+    switch (rc) {
+        case SMK_OK: return Result::OK;
+        case SMK_NOTINITIALIZED: return Result::NOTINITIALIZED;
+        case SMK_INITIALIZED: return Result::INITIALIZED;
+        case SMK_BAD_PARAM: return Result::BAD_PARAM;
+        case SMK_SIZE_TOO_LARGE: return Result::SIZE_TOO_LARGE;
+        case SMK_FAILURE: return Result::FAILURE;
+        default:
+            // device errors / unsupported algorithm have no Result code in the reference: surface loudly
+            throw std::runtime_error(std::string("smallk_amd device path: ") + smk_last_error());
+    }
+}
+
+Result Nmf(const NmfOptions& options, double* buf_a, int ldim_a, double* buf_w, int ldim_w, double* buf_h,
+           int ldim_h, NmfStats& stats)
+{
+    if (smk_is_initialized() != SMK_INITIALIZED) {
+        std::cerr << "nmflib error: nmf_initialize() must be called prior to any factorization routine\n" << std::endl;
+        return Result::NOTINITIALIZED;
+    }
+    if (!IsValid(options)) return Result::BAD_PARAM;
+    // leading-dimension violations throw in the reference (nmf.cpp:213-219)
+    if (ldim_w < options.height) throw std::logic_error("nmflib error: leading dimension of W return buffer too small");
+    if (ldim_h < options.k) throw std::logic_error("nmflib error: leading dimension of H return buffer too small");
+    if (options.algorithm == NmfAlgorithm::RANK2 && options.k != 2) throw std::runtime_error("rank2 algorithm requires k == 2");
+    smk_options c = to_c(options);
+    smk_stats st{0, 0};
+    int rc = smk_nmf_dense(&c, buf_a, ldim_a, buf_w, ldim_w, buf_h, ldim_h, &st, g_nmf_storage);
+    stats.elapsed_us = st.elapsed_us;
+    stats.iteration_count = st.iteration_count;
+    return to_result(rc);
+}
+
+Result NmfSparse(const NmfOptions&, const unsigned int, const unsigned int, const unsigned int, const unsigned int*,
+                 const unsigned int*, const double*, double*, int, double*, int, NmfStats&)
+{
+    throw std::runtime_error("smallk_amd: NmfSparse is not built on the MI355X path yet (dense input only)");
+}
+
+// =============================================================================================
+// outer seam: namespace smallk  (global state, not thread safe -- as the reference, smallk.cpp:46-67)
+// =============================================================================================
+namespace smallk {
+
+static bool matrix_loaded = false;
+static std::vector<double> buf_a, buf_w, buf_h;
+static unsigned int m = 0u, n = 0u, k = 0u;
+static unsigned int ldim_a = 0u, ldim_w = 0u, ldim_h = 0u;
+static double nmf_tolerance = 0.005;
+static double hier_nmf2_tolerance = 0.0001;
+static unsigned int max_iter = 5000, min_iter = 5, max_threads = 1, maxterms = 5, outprecision = 6;
+static OutputFormat clustfile_format = OutputFormat::JSON;
+static std::string outdir, matrix_filepath;
+static uint64_t rng_seed = 0;
+static uint64_t rng_draws = 0;            // so that successive RandomMatrix calls differ
+static DeviceStorage device_storage = DEVICE_F32;
+static NmfStats last_stats;
+
+static const std::string DEFAULT_FILENAME_W("w.csv");
+static const std::string DEFAULT_FILENAME_H("h.csv");
+
+static unsigned int hw_threads()
+{
+    unsigned int t = std::thread::hardware_concurrency();
+    return t == 0 ? 2 : t;
+}
+
+// smallk.cpp:81-111
+void Reset()
+{
+    min_iter = 5;
+    max_iter = 5000;
+    nmf_tolerance = 0.005;
+    hier_nmf2_tolerance = 0.0001;
+    max_threads = hw_threads();
+    maxterms = 5;
+    outprecision = 6;
+    clustfile_format = OutputFormat::JSON;
+    outdir = std::string("");
+    matrix_loaded = false;
+    matrix_filepath.clear();
+    buf_a.clear(); buf_w.clear(); buf_h.clear();
+    m = n = k = ldim_a = ldim_w = ldim_h = 0u;
+}
+
+// smallk.cpp:114-119 (time seeded RNG; GPU init replaces EL::Initialize)
+void Initialize(int& /*argc*/, char**& /*argv*/)
+{
+    Reset();
+    rng_seed = (uint64_t)std::chrono::high_resolution_clock::now().time_since_epoch().count();
+    rng_draws = 0;
+    if (smk_initialize(-1) != SMK_OK) throw std::runtime_error(std::string("smallk error (Initialize): ") + smk_last_error());
+}
+
+bool IsInitialized() { return smk_is_initialized() == SMK_INITIALIZED; }
+void Finalize() { smk_finalize(); }
+
+unsigned int GetMajorVersion() { return SMALLK_MAJOR_VERSION; }
+unsigned int GetMinorVersion() { return SMALLK_MINOR_VERSION; }
+unsigned int GetPatchLevel() { return SMALLK_PATCH_LEVEL; }
+std::string GetVersionString()
+{
+    std::ostringstream v;
+    v << GetMajorVersion() << "." << GetMinorVersion() << "." << GetPatchLevel();
+    return v.str();
+}
+
+void SeedRNG(const int seed) { rng_seed = (uint64_t)(int64_t)seed; rng_draws = 0; }
+
+// uniform [0,1) init (RandomMatrix, center .5 radius .5: matrix_generator.hpp:61-82).  The
+// reference's stream depends on its thread count; here it is the counter-based generator.
+static void RandomMatrix(double* buf, unsigned int ld, unsigned int h, unsigned int w)
+{
+    smk_uniform_fill_host(buf, ld, h, w, 0, 0, h, rng_seed + 0x9E37u * (++rng_draws), 0);
+}
+
+static bool has_ext(const std::string& path, const char* ext)
+{
+    size_t dot = path.find_last_of('.');
+    if (dot == std::string::npos) return false;
+    std::string e = path.substr(dot + 1);
+    std::transform(e.begin(), e.end(), e.begin(), [](unsigned char ch) { return (char)std::toupper(ch); });
+    return e == ext;
+}
+
+// smallk.cpp:163-201
+void LoadMatrix(const std::string& filepath)
+{
+    if (filepath.empty()) throw std::runtime_error("smallk error (LoadMatrix): matrix filename is invalid.");
+    std::cout << "Loading matrix..." << std::endl;
+    matrix_loaded = false;
+    if (has_ext(filepath, "MTX"))
+        throw std::runtime_error("smallk error (LoadMatrix): MatrixMarket/sparse input is not built on the MI355X path yet: " + filepath);
+    bool ok = smallk_amd_io::LoadCsv(buf_a, m, n, filepath);
+    if (!ok || buf_a.size() < (size_t)m * n) {
+        matrix_filepath.clear();
+        throw std::runtime_error("smallk error (LoadMatrix): load failed for file " + filepath);
+    }
+    ldim_a = m;
+    matrix_loaded = true;
+    matrix_filepath = filepath;
+}
+
+// Dense column-major buffer (documented semantics, smallk.hpp:176-188).  The reference's copy
+// loop (smallk.cpp:249-255) swaps height and width and is only right for square input; this
+// implements what the header documents.
+void LoadMatrix(const double* buffer, const unsigned int ldim, const unsigned int height, const unsigned int width)
+{
+    std::cout << "Loading dense matrix..." << std::endl;
+    matrix_loaded = false;
+    if (0 == height) throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): invalid height input.");
+    if (0 == width) throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): invalid width input.");
+    if (!buffer) throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): empty data pointer.");
+    if (ldim < height) throw std::runtime_error("smallk error (LoadMatrix): leading dimension smaller than height.");
+    buf_a.resize((size_t)height * width);
+    ldim_a = height;
+    for (unsigned int c = 0; c != width; ++c)
+        for (unsigned int r = 0; r != height; ++r) buf_a[(size_t)c * height + r] = buffer[(size_t)c * ldim + r];
+    m = height;
+    n = width;
+    matrix_loaded = true;
+    matrix_filepath = "NA";
+}
+
+void LoadMatrix(const unsigned int, const unsigned int, const unsigned int, const std::vector<double>&,
+                const std::vector<unsigned int>&, const std::vector<unsigned int>&)
+{
+    throw std::runtime_error("smallk error (LoadMatrix): sparse input is not built on the MI355X path yet.");
+}
+
+bool IsMatrixLoaded() { return matrix_loaded; }
+
+std::string GetOutputDir() { return outdir; }
+
+static std::string ensure_trailing_sep(const std::string& s)
+{
+    if (s.empty()) return std::string("");
+    return s[s.size() - 1] == '/' ? s : s + '/';
+}
+
+// smallk.cpp:348-380
+void SetOutputDir(const std::string& output_dir)
+{
+    std::ostringstream msg;
+    msg << "smallk error (SetOutputDir): ";
+    std::string full_path;
+    if (!output_dir.empty() && ('/' != output_dir[0])) {
+        char* cur = getcwd(nullptr, 0);
+        if (!cur) { msg << "could not determine current directory."; throw std::runtime_error(msg.str()); }
+        full_path = ensure_trailing_sep(std::string(cur));
+        free(cur);
+    }
+    full_path += output_dir;
+    struct stat st;
+    if (!(0 == stat(full_path.c_str(), &st) && (S_IFDIR == (st.st_mode & S_IFDIR)))) {
+        msg << "the directory \"" << full_path << "\" does not exist.";
+        throw std::logic_error(msg.str());
+    }
+    outdir = ensure_trailing_sep(full_path);
+}
+
+double GetNmfTolerance() { return nmf_tolerance; }
+double GetHierNmf2Tolerance() { return hier_nmf2_tolerance; }
+unsigned int GetMaxIter() { return max_iter; }
+unsigned int GetMinIter() { return min_iter; }
+unsigned int GetMaxThreads() { return max_threads; }
+unsigned int GetMaxTerms() { return maxterms; }
+unsigned int GetOutputPrecision() { return outprecision; }
+OutputFormat GetOutputFormat() { return clustfile_format; }
+
+void SetNmfTolerance(const double tol)
+{
+    if ((tol <= 0.0) || (tol >= 1.0)) throw std::logic_error("smallk error (SetNmfTolerance): require 0.0 < tol < 1.0");
+    nmf_tolerance = tol;
+}
+void SetHierNmf2Tolerance(const double tol)
+{
+    if ((tol <= 0.0) || (tol >= 1.0)) throw std::logic_error("smallk error (SetHierNmf2Tolerance): require 0.0 < tol < 1.0");
+    hier_nmf2_tolerance = tol;
+}
+void SetMaxIter(const unsigned int v) { max_iter = v == 0 ? 1 : v; }
+void SetMinIter(const unsigned int v) { min_iter = v == 0 ? 1 : v; }
+void SetMaxThreads(const unsigned int mt)
+{
+    max_threads = std::min(mt, hw_threads());
+    if (0 == max_threads) max_threads = 1;
+}
+void SetMaxTerms(const unsigned int v) { maxterms = v == 0 ? 1 : v; }
+void SetOutputPrecision(const unsigned int num_digits)
+{
+    outprecision = num_digits;
+    if (0 == outprecision) outprecision = 1;
+    if (outprecision > (unsigned)std::numeric_limits<double>::max_digits10) outprecision = std::numeric_limits<double>::max_digits10;
+}
+void SetOutputFormat(const OutputFormat format) { clustfile_format = format; }
+
+void SetDeviceStorage(const DeviceStorage s) { device_storage = (s == DEVICE_BF16) ? DEVICE_BF16 : DEVICE_F32; }
+DeviceStorage GetDeviceStorage() { return device_storage; }
+unsigned int GetIterationCount() { return (unsigned int)last_stats.iteration_count; }
+unsigned long long GetElapsedMicroseconds() { return last_stats.elapsed_us; }
+
+static std::string elapsed_string(unsigned long long us)
+{   // utils.cpp:172-218
+    const unsigned long long S = 1000000ull, M = 60 * S, HR = 60 * M;
+    unsigned long long hrs = 0, min = 0, sec = 0, e = us;
+    if (e >= HR) { hrs = e / HR; e -= hrs * HR; }
+    if (e >= M) { min = e / M; e -= min * M; }
+    if (e >= S) { sec = e / S; e -= sec * S; }
+    double seconds = (double)sec + e / 1.0e6;
+    char buf[256];
+    if (hrs > 0) snprintf(buf, sizeof(buf), "%d hours %d min %.3f sec.", (int)hrs, (int)min, seconds);
+    else if (min > 0) snprintf(buf, sizeof(buf), "%d min %.3f sec.", (int)min, seconds);
+    else snprintf(buf, sizeof(buf), "%.3f sec.", seconds);
+    return std::string(buf);
+}
+
+static void print_opts(const NmfOptions& o)
+{   // smallk.cpp:869-917
+    using std::cout; using std::endl;
+    cout << "\n                parameters: \n" << endl;
+    cout << "\t         algorithm: ";
+    switch (o.algorithm) {
+        case NmfAlgorithm::MU: cout << "Multiplicative Updating"; break;
+        case NmfAlgorithm::HALS: cout << "HALS"; break;
+        case NmfAlgorithm::RANK2: cout << "Rank 2"; break;
+        case NmfAlgorithm::BPP: cout << "Nonnegative Least Squares with Block Principal Pivoting"; break;
+    }
+    cout << endl;
+    cout << "\tstopping criterion: "
+         << (o.prog_est_algorithm == NmfProgressAlgorithm::PG_RATIO ? "Ratio of Projected Gradients" : "Relative Change in the F-norm of W")
+         << endl;
+    cout << "\t            height: " << o.height << endl;
+    cout << "\t             width: " << o.width << endl;
+    cout << "\t                 k: " << o.k << endl;
+    cout << "\t           miniter: " << o.min_iter << endl;
+    cout << "\t           maxiter: " << o.max_iter << endl;
+    cout << "\t               tol: " << o.tol << endl;
+    cout << "\t        matrixfile: " << matrix_filepath << endl;
+    cout << "\t        maxthreads: " << o.max_threads << endl;
+    cout << endl;
+}
+
+// smallk.cpp:471-650
+void Nmf(const unsigned int kval, const Algorithm algorithm, const std::string& csv_file_w, const std::string& csv_file_h)
+{
+    if (!matrix_loaded) throw std::logic_error("smallk error (NMF): no matrix has been loaded.");
+    if (max_iter < min_iter) throw std::logic_error("smallk error (NMF): min_iterations exceeds max_iterations.");
+    if (0 == kval) throw std::logic_error("smallk error (NMF): k must be greater than 0.");
+    if ((uint64_t)m * kval > (uint64_t)std::numeric_limits<int>::max())
+        throw std::logic_error("smallk error (Nmf): mxk matrix W is too large.");
+    if ((uint64_t)kval * n > (uint64_t)std::numeric_limits<int>::max())
+        throw std::logic_error("smallk error (Nmf): kxn matrix H is too large.");
+    k = kval;
+
+    NmfOptions opts;
+    switch (algorithm) {      // smallk::Algorithm and NmfAlgorithm are numbered differently (:497-513)
+        case Algorithm::MU: opts.algorithm = NmfAlgorithm::MU; break;
+        case Algorithm::HALS: opts.algorithm = NmfAlgorithm::HALS; break;
+        case Algorithm::RANK2: opts.algorithm = NmfAlgorithm::RANK2; break;
+        case Algorithm::BPP: opts.algorithm = NmfAlgorithm::BPP; break;
+        default: throw std::logic_error("smallk error (NMF): unknown NMF algorithm.");
+    }
+    if (NmfAlgorithm::RANK2 == opts.algorithm) k = 2;
+    ldim_w = m;
+    ldim_h = k;
+    if (buf_w.size() < (size_t)m * k) buf_w.resize((size_t)m * k);
+    if (buf_h.size() < (size_t)k * n) buf_h.resize((size_t)k * n);
+
+    bool ok = true;
+    unsigned int height_w = m, width_w = k, height_h = k, width_h = n;
+    std::cout << "Initializing matrix W..." << std::endl;
+    if (csv_file_w.empty()) RandomMatrix(&buf_w[0], ldim_w, m, k);
+    else ok = smallk_amd_io::LoadCsv(buf_w, height_w, width_w, csv_file_w);
+    if (!ok) throw std::runtime_error("smallk error (Nmf): load failed for file \"" + csv_file_w + "\"");
+    if ((height_w != m) || (width_w != k)) {
+        std::cerr << "\tdimensions of matrix W are " << height_w << " x " << width_w << std::endl;
+        std::cerr << "\texpected " << m << " x " << k << std::endl;
+        throw std::logic_error("smallk error (Nmf): non-conformant matrix W.");
+    }
+    std::cout << "Initializing matrix H..." << std::endl;
+    if (csv_file_h.empty()) RandomMatrix(&buf_h[0], ldim_h, k, n);
+    else ok = smallk_amd_io::LoadCsv(buf_h, height_h, width_h, csv_file_h);
+    if (!ok) throw std::runtime_error("smallk error (Nmf): load failed for file \"" + csv_file_h + "\"");
+    if ((height_h != k) || (width_h != n)) {
+        std::cerr << "\tdimensions of matrix H are " << height_h << " x " << width_h << std::endl;
+        std::cerr << "\texpected " << k << " x " << n << std::endl;
+        throw std::logic_error("smallk error (Nmf): non-conformant matrix H.");
+    }
+
+    // MU -> DELTA_FNORM, everything else PG_RATIO (:581-584)
+    opts.prog_est_algorithm = (NmfAlgorithm::MU == opts.algorithm) ? NmfProgressAlgorithm::DELTA_FNORM : NmfProgressAlgorithm::PG_RATIO;
+    opts.tol = nmf_tolerance;
+    opts.height = m;
+    opts.width = n;
+    opts.k = k;
+    opts.min_iter = min_iter;
+    opts.max_iter = max_iter;
+    opts.tolcount = 1;
+    opts.max_threads = max_threads;
+    opts.verbose = true;
+    opts.normalize = true;
+    print_opts(opts);
+
+    NmfStats stats;
+    const int saved = NmfGetDeviceStorage();
+    NmfSetDeviceStorage((int)device_storage);
+    Result result;
+    try {
+        result = ::Nmf(opts, &buf_a[0], ldim_a, &buf_w[0], ldim_w, &buf_h[0], ldim_h, stats);
+    } catch (...) {
+        NmfSetDeviceStorage(saved);
+        throw;
+    }
+    NmfSetDeviceStorage(saved);
+    last_stats = stats;
+
+    std::cout << "Elapsed wall clock time: " << elapsed_string(stats.elapsed_us) << std::endl << std::endl;
+    if (Result::OK != result) throw std::runtime_error("smallk error (Nmf): NMF solver failure.");
+
+    const std::string outfile_w = outdir.empty() ? DEFAULT_FILENAME_W : outdir + DEFAULT_FILENAME_W;
+    const std::string outfile_h = outdir.empty() ? DEFAULT_FILENAME_H : outdir + DEFAULT_FILENAME_H;
+    std::cout << "Writing output files..." << std::endl;
+    if (!smallk_amd_io::WriteCsv(&buf_w[0], ldim_w, m, k, outfile_w, outprecision))
+        throw std::runtime_error("smallk error (Nmf): could not write W result.");
+    if (!smallk_amd_io::WriteCsv(&buf_h[0], ldim_h, k, n, outfile_h, outprecision))
+        throw std::runtime_error("smallk error (Nmf): could not write H result.");
+}
+
+const double* LockedBufferW(unsigned int& ldim, unsigned int& height, unsigned int& width)
+{
+    ldim = m; height = m; width = k;
+    return buf_w.empty() ? nullptr : &buf_w[0];
+}
+
+const double* LockedBufferH(unsigned int& ldim, unsigned int& height, unsigned int& width)
+{
+    ldim = k; height = k; width = n;
+    return buf_h.empty() ? nullptr : &buf_h[0];
+}
+
+// ---- next tier ----------------------------------------------------------------------------
+static void not_built(const char* what)
+{
+    throw std::runtime_error(std::string("smallk error (") + what + "): not built on the MI355X path yet.");
+}
+void LoadDictionary(const std::string&) { not_built("LoadDictionary"); }
+void LoadDictionary(const std::vector<std::string>&) { not_built("LoadDictionary"); }
+void HierNmf2(const unsigned int) { not_built("HierNmf2"); }
+void HierNmf2WithFlat(const unsigned int) { not_built("HierNmf2WithFlat"); }
+
+}  // namespace smallk
+
+// =============================================================================================
+// extern "C" handles onto namespace smallk for bindings that cannot speak C++ (ctypes, cgo, JNI).
+// One function per entry of the reference's Cython extern block
+// (pysmallk/interface/smallk_lib.pyx:42-88).  C++ exceptions become a status code
+// (1 = std::logic_error, 2 = std::runtime_error / other) plus smk_api_last_exception().
+// =============================================================================================
+static std::string g_api_exc;
+
+template <typename F>
+static int api_guard(F&& f)
+{
+    try {
+        f();
+        g_api_exc.clear();
+        return 0;
+    } catch (const std::logic_error& e) {
+        g_api_exc = e.what();
+        return 1;
+    } catch (const std::exception& e) {
+        g_api_exc = e.what();
+        return 2;
+    } catch (...) {
+        g_api_exc = "unknown exception";
+        return 2;
+    }
+}
+
+extern "C" {
+
+const char* smk_api_last_exception(void) { return g_api_exc.c_str(); }
+
+int smk_api_initialize(void)
+{
+    static int argc = 0;
+    static char** argv = nullptr;
+    return api_guard([&] { smallk::Initialize(argc, argv); });
+}
+int smk_api_is_initialized(void) { return smallk::IsInitialized() ? 1 : 0; }
+void smk_api_finalize(void) { smallk::Finalize(); }
+void smk_api_reset(void) { smallk::Reset(); }
+void smk_api_seed_rng(int seed) { smallk::SeedRNG(seed); }
+unsigned smk_api_get_major_version(void) { return smallk::GetMajorVersion(); }
+unsigned smk_api_get_minor_version(void) { return smallk::GetMinorVersion(); }
+unsigned smk_api_get_patch_level(void) { return smallk::GetPatchLevel(); }
+
+int smk_api_load_matrix_file(const char* path) { return api_guard([&] { smallk::LoadMatrix(std::string(path ? path : "")); }); }
+int smk_api_load_matrix_dense(const double* buf, unsigned ldim, unsigned height, unsigned width)
+{
+    return api_guard([&] { smallk::LoadMatrix(buf, ldim, height, width); });
+}
+int smk_api_load_matrix_sparse(unsigned height, unsigned width, unsigned nz, const double* data,
+                               const unsigned* row_indices, const unsigned* col_offsets)
+{
+    return api_guard([&] {
+        std::vector<double> d(data, data + nz);
+        std::vector<unsigned> ri(row_indices, row_indices + nz), co(col_offsets, col_offsets + width + 1);
+        smallk::LoadMatrix(height, width, nz, d, ri, co);
+    });
+}
+int smk_api_is_matrix_loaded(void) { return smallk::IsMatrixLoaded() ? 1 : 0; }
+
+int smk_api_set_output_dir(const char* dir) { return api_guard([&] { smallk::SetOutputDir(std::string(dir ? dir : "")); }); }
+const char* smk_api_get_output_dir(void)
+{
+    static std::string s;
+    s = smallk::GetOutputDir();
+    return s.c_str();
+}
+void smk_api_set_output_precision(unsigned d) { smallk::SetOutputPrecision(d); }
+unsigned smk_api_get_output_precision(void) { return smallk::GetOutputPrecision(); }
+int smk_api_set_nmf_tolerance(double tol) { return api_guard([&] { smallk::SetNmfTolerance(tol); }); }
+double smk_api_get_nmf_tolerance(void) { return smallk::GetNmfTolerance(); }
+void smk_api_set_max_iter(unsigned v) { smallk::SetMaxIter(v); }
+unsigned smk_api_get_max_iter(void) { return smallk::GetMaxIter(); }
+void smk_api_set_min_iter(unsigned v) { smallk::SetMinIter(v); }
+unsigned smk_api_get_min_iter(void) { return smallk::GetMinIter(); }
+void smk_api_set_max_threads(unsigned v) { smallk::SetMaxThreads(v); }
+unsigned smk_api_get_max_threads(void) { return smallk::GetMaxThreads(); }
+void smk_api_set_max_terms(unsigned v) { smallk::SetMaxTerms(v); }
+unsigned smk_api_get_max_terms(void) { return smallk::GetMaxTerms(); }
+void smk_api_set_output_format(int f) { smallk::SetOutputFormat(f == 0 ? smallk::XML : smallk::JSON); }
+int smk_api_get_output_format(void) { return (int)smallk::GetOutputFormat(); }
+int smk_api_set_hiernmf2_tolerance(double tol) { return api_guard([&] { smallk::SetHierNmf2Tolerance(tol); }); }
+double smk_api_get_hiernmf2_tolerance(void) { return smallk::GetHierNmf2Tolerance(); }
+void smk_api_set_device_storage(int s) { smallk::SetDeviceStorage(s == 1 ? smallk::DEVICE_BF16 : smallk::DEVICE_F32); }
+int smk_api_get_device_storage(void) { return (int)smallk::GetDeviceStorage(); }
+unsigned smk_api_get_iteration_count(void) { return smallk::GetIterationCount(); }
+
+/* algorithm uses smallk::Algorithm numbering: MU=0, BPP=1, HALS=2, RANK2=3 (smallk.hpp:34-40) */
+int smk_api_nmf(unsigned k, int algorithm, const char* initfile_w, const char* initfile_h)
+{
+    return api_guard([&] {
+        smallk::Nmf(k, (smallk::Algorithm)algorithm, std::string(initfile_w ? initfile_w : ""),
+                    std::string(initfile_h ? initfile_h : ""));
+    });
+}
+const double* smk_api_locked_buffer_w(unsigned* ldim, unsigned* height, unsigned* width)
+{
+    return smallk::LockedBufferW(*ldim, *height, *width);
+}
+const double* smk_api_locked_buffer_h(unsigned* ldim, unsigned* height, unsigned* width)
+{
+    return smallk::LockedBufferH(*ldim, *height, *width);
+}
+int smk_api_hiernmf2(unsigned num_clusters) { return api_guard([&] { smallk::HierNmf2(num_clusters); }); }
+int smk_api_load_dictionary_file(const char* path) { return api_guard([&] { smallk::LoadDictionary(std::string(path ? path : "")); }); }
+
+}  // extern "C"

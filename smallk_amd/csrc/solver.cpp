@@ -1,0 +1,785 @@
+// smallk_amd/csrc/solver.cpp -- host side of the C ABI (include/smallk_amd.h):
+// device-resident A, the NmfSolve<> driver loop and the three per-iteration
+// schedules (MU / HALS / BPP) expressed as launches of the kernels in kernels.hip.
+//
+// Device data layout (all in HBM, fp64 unless noted):
+//   A   : m_pad x n_pad   bf16|f32, column-major, zero padded (rows to 128, cols to 128)
+//   At  : n_pad x m_pad   same dtype: the explicit transpose (the reference's BPP keeps one
+//         too, nmf_solver_bpp.hpp:319) so BOTH streaming products contract down the
+//         contiguous dimension
+//   H   : k x n  (ld k)     Wt : k x m (ld k)  -- W is kept transposed on the device
+//   Gw = W'W, Gh = HH' : KP x KP (KP = 8/16/32/64 padded)
+//   P1 : S1 slabs of n_pad x kpp fp32 = W'A partials,   P2 : S2 slabs of m_pad x kpp = (AH')' partials
+//   packW / packH : MFMA operand fragments of W' / H
+#include "common.h"
+#include "../../include/smallk_amd.h"
+
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+namespace smk {
+
+static std::string g_err;
+static bool g_init = false;
+static int g_cus = 256;
+static hipStream_t g_stream = nullptr;
+static bool g_own_stream = false;
+
+void set_error(const std::string& msg) { g_err = msg; }
+
+static inline double wall_us()
+{
+    using namespace std::chrono;
+    return (double)duration_cast<nanoseconds>(steady_clock::now().time_since_epoch()).count() * 1e-3;
+}
+
+template <typename T>
+static int dev_alloc(T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    SMK_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    return 0;
+}
+
+}  // namespace smk
+
+using namespace smk;
+
+struct smk_matrix {
+    i64 m = 0, n_global = 0, c0 = 0, n = 0;
+    int storage = SMK_STORE_F32;
+    void* A = nullptr;  i64 ldA = 0, colsA = 0;      // m_pad x n_pad
+    void* At = nullptr; i64 ldAt = 0, colsAt = 0;    // n_pad x m_pad
+};
+
+struct smk_solver {
+    smk_options o;
+    const smk_matrix* a = nullptr;
+    int k = 0, KP = 0, kpp = 0, nsplit = 3;
+    i64 m = 0, n = 0;
+    hipStream_t st = nullptr;
+    double *H = nullptr, *Wt = nullptr, *Gw = nullptr, *Gh = nullptr, *gram_scratch = nullptr;
+    double *Wprev = nullptr, *hals_scratch = nullptr, *pg_partials = nullptr, *scal = nullptr, *tmpW = nullptr;
+    double *Gh_own = nullptr, *scal_own = nullptr;
+    void *packW = nullptr, *packH = nullptr;
+    float *P1 = nullptr, *P2 = nullptr, *R2red = nullptr;
+    BigProdPlan pl1, pl2;
+    int* fail_flag = nullptr;
+    int iter = 0;
+    bool have_factors = false, inited = false, normalized = false;
+    double pg0 = 1.0, last_metric = 1.0;
+    size_t pg_half = 2048;
+    // comm
+    int rank = 0, world = 1;
+    smk_allreduce_fn ar = nullptr;
+    void* ar_user = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+    double acc_ms[2] = {0, 0};
+    int launches[2] = {0, 0};
+};
+
+static const int GRAM_BLOCKS = 256;
+
+extern "C" {
+
+int smk_initialize(int device_ordinal)
+{
+    if (device_ordinal >= 0) SMK_HIP(hipSetDevice(device_ordinal));
+    int dev = 0;
+    SMK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    SMK_HIP(hipGetDeviceProperties(&prop, dev));
+    g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (!g_stream) {
+        SMK_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        g_own_stream = true;
+    }
+    g_init = true;
+    return SMK_OK;
+}
+
+int smk_is_initialized(void) { return g_init ? SMK_INITIALIZED : SMK_NOTINITIALIZED; }
+
+void smk_finalize(void)
+{
+    if (g_own_stream && g_stream) (void)hipStreamDestroy(g_stream);
+    g_stream = nullptr;
+    g_own_stream = false;
+    g_init = false;
+}
+
+const char* smk_last_error(void) { return g_err.c_str(); }
+int smk_device_cu_count(void) { return g_cus; }
+
+int smk_set_stream(void* hip_stream)
+{
+    if (g_own_stream && g_stream) (void)hipStreamDestroy(g_stream);
+    g_stream = (hipStream_t)hip_stream;
+    g_own_stream = false;
+    return SMK_OK;
+}
+
+// IsValid, common/src/nmf_options.cpp:23-112 (same checks, same messages)
+int smk_is_valid(const smk_options* o, int validate_matrix)
+{
+    if (!o) return 0;
+    if (o->k <= 0) { fprintf(stderr, "nmflib error: k-value must be a positive integer\n"); return 0; }
+    if (validate_matrix) {
+        if (o->height <= 0) { fprintf(stderr, "nmflib error: matrix height must be a positive integer\n"); return 0; }
+        if (o->width <= 0) { fprintf(stderr, "nmflib error: matrix width must be a positive integer\n"); return 0; }
+        if (o->k > o->width) { fprintf(stderr, "nmflib error: k value cannot exceed the number of columns\n"); return 0; }
+    }
+    if (o->tol <= 0.0 || o->tol >= 1.0) { fprintf(stderr, "nmflib error: tolerance must be in the interval (0.0, 1.0)\n"); return 0; }
+    if (o->min_iter <= 0) { fprintf(stderr, "nmflib error: miniter must be a positive integer\n"); return 0; }
+    if (o->max_iter <= 0) { fprintf(stderr, "nmflib error: maxiter must be a positive integer\n"); return 0; }
+    if (o->tolcount <= 0) { fprintf(stderr, "nmflib error: tolcount must be a positive integer\n"); return 0; }
+    if (o->algorithm != SMK_ALG_MU && o->algorithm != SMK_ALG_HALS && o->algorithm != SMK_ALG_RANK2 &&
+        o->algorithm != SMK_ALG_BPP) {
+        fprintf(stderr, "nmflib error: unknown NMF algorithm specified\n");
+        return 0;
+    }
+    if (o->algorithm == SMK_ALG_RANK2 && o->k != 2) { fprintf(stderr, "nmflib error: RANK2 algorithm requires k == 2\n"); return 0; }
+    if (o->prog_est_algorithm != SMK_PROG_PG_RATIO && o->prog_est_algorithm != SMK_PROG_DELTA_FNORM) {
+        fprintf(stderr, "nmflib error: unknown stopping criterion specified\n");
+        return 0;
+    }
+    return 1;
+}
+
+// same generator as the device fill (kernels.hip) and the oracle, on the host
+static inline uint64_t h_mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void smk_uniform_fill_host(double* buf, int64_t ld, int64_t rows, int64_t cols, int64_t r0, int64_t c0,
+                           int64_t gheight, uint64_t seed, int quant)
+{
+    for (int64_t c = 0; c < cols; ++c)
+        for (int64_t r = 0; r < rows; ++r) {
+            uint64_t h = h_mix64(seed * 0xD1342543DE82EF95ull + (uint64_t)((c0 + c) * gheight + (r0 + r)));
+            float f = (float)(h >> 40) * (1.0f / 16777216.0f);
+            if (quant == 1) {
+                uint32_t b;
+                memcpy(&b, &f, 4);
+                b += 0x7FFFu + ((b >> 16) & 1u);
+                b &= 0xFFFF0000u;
+                memcpy(&f, &b, 4);
+            }
+            buf[c * ld + r] = (double)f;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// matrix
+// ------------------------------------------------------------------------------------------
+int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0, int64_t ncols_local,
+                      int storage)
+{
+    if (!out) return SMK_BAD_PARAM;
+    *out = nullptr;
+    if (!g_init) { set_error("smk_initialize() has not been called"); return SMK_NOTINITIALIZED; }
+    if (height <= 0 || width_global <= 0 || ncols_local <= 0 || col0 < 0 || col0 + ncols_local > width_global ||
+        (storage != SMK_STORE_F32 && storage != SMK_STORE_BF16))
+        return SMK_BAD_PARAM;
+    smk_matrix* a = new smk_matrix;
+    a->m = height; a->n_global = width_global; a->c0 = col0; a->n = ncols_local; a->storage = storage;
+    a->ldA = round_up(height, ROW_PAD);      a->colsA = round_up(ncols_local, COL_PAD);
+    a->ldAt = round_up(ncols_local, ROW_PAD); a->colsAt = round_up(height, COL_PAD);
+    const size_t es = (size_t)elem_size(storage);
+    hipError_t e1 = hipMalloc(&a->A, (size_t)a->ldA * a->colsA * es);
+    hipError_t e2 = (e1 == hipSuccess) ? hipMalloc(&a->At, (size_t)a->ldAt * a->colsAt * es) : e1;
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        set_error(std::string("hipMalloc(A): ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        if (a->A) (void)hipFree(a->A);
+        delete a;
+        return SMK_DEVICE_ERROR;
+    }
+    SMK_HIP(hipMemsetAsync(a->A, 0, (size_t)a->ldA * a->colsA * es, g_stream));
+    SMK_HIP(hipMemsetAsync(a->At, 0, (size_t)a->ldAt * a->colsAt * es, g_stream));
+    *out = a;
+    return SMK_OK;
+}
+
+static int matrix_make_transpose(smk_matrix* a)
+{
+    return launch_transpose_store(a->A, a->ldA, a->At, a->ldAt, a->storage, a->m, a->n, g_stream);
+}
+
+int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
+{
+    if (!a || !host || ld < a->m) return SMK_BAD_PARAM;
+    const size_t budget = (size_t)64 << 20;   // staging bytes
+    i64 chunk = (i64)(budget / ((size_t)a->m * sizeof(double)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > a->n) chunk = a->n;
+    double* stage = nullptr;
+    int rc = dev_alloc(&stage, (size_t)a->m * chunk);
+    if (rc) return rc;
+    const size_t es = (size_t)elem_size(a->storage);
+    for (i64 c = 0; c < a->n; c += chunk) {
+        const i64 nc = (a->n - c < chunk) ? (a->n - c) : chunk;
+        SMK_HIP(hipMemcpy2DAsync(stage, (size_t)a->m * sizeof(double), host + c * ld, (size_t)ld * sizeof(double),
+                                 (size_t)a->m * sizeof(double), (size_t)nc, hipMemcpyHostToDevice, g_stream));
+        rc = launch_convert_f64(stage, a->m, (unsigned char*)a->A + (size_t)c * a->ldA * es, a->storage, a->ldA,
+                                a->m, nc, g_stream);
+        if (rc) return rc;
+        SMK_HIP(hipStreamSynchronize(g_stream));
+    }
+    (void)hipFree(stage);
+    rc = matrix_make_transpose(a);
+    if (rc) return rc;
+    SMK_HIP(hipStreamSynchronize(g_stream));
+    return SMK_OK;
+}
+
+int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed)
+{
+    if (!a) return SMK_BAD_PARAM;
+    int rc = launch_fill_uniform(a->A, a->storage, a->ldA, a->m, a->n, a->ldA, a->colsA, 0, a->c0, a->m, seed,
+                                 a->storage == SMK_STORE_BF16 ? 1 : 0, g_stream);
+    if (rc) return rc;
+    rc = matrix_make_transpose(a);
+    if (rc) return rc;
+    SMK_HIP(hipStreamSynchronize(g_stream));
+    return SMK_OK;
+}
+
+int smk_matrix_download_f64(const smk_matrix* a, double* host, int64_t ld)
+{
+    if (!a || !host || ld < a->m) return SMK_BAD_PARAM;
+    const size_t es = (size_t)elem_size(a->storage);
+    std::vector<unsigned char> col((size_t)a->m * es);
+    SMK_HIP(hipStreamSynchronize(g_stream));
+    for (i64 c = 0; c < a->n; ++c) {
+        SMK_HIP(hipMemcpy(col.data(), (const unsigned char*)a->A + (size_t)c * a->ldA * es, (size_t)a->m * es,
+                          hipMemcpyDeviceToHost));
+        if (a->storage == SMK_STORE_BF16) {
+            const uint16_t* p = (const uint16_t*)col.data();
+            for (i64 r = 0; r < a->m; ++r) {
+                uint32_t b = ((uint32_t)p[r]) << 16;
+                float f;
+                memcpy(&f, &b, 4);
+                host[c * ld + r] = (double)f;
+            }
+        } else {
+            const float* p = (const float*)col.data();
+            for (i64 r = 0; r < a->m; ++r) host[c * ld + r] = (double)p[r];
+        }
+    }
+    return SMK_OK;
+}
+
+void smk_matrix_destroy(smk_matrix* a)
+{
+    if (!a) return;
+    if (a->A) (void)hipFree(a->A);
+    if (a->At) (void)hipFree(a->At);
+    delete a;
+}
+
+// ------------------------------------------------------------------------------------------
+// solver
+// ------------------------------------------------------------------------------------------
+static PartialView view1(const smk_solver* s)
+{
+    return PartialView{s->P1, s->pl1.S, (i64)s->pl1.ncols_pad * s->kpp, s->kpp};
+}
+static PartialView view2(const smk_solver* s)
+{
+    if (s->world > 1) return PartialView{s->R2red, 1, 0, s->kpp};
+    return PartialView{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp};
+}
+
+static size_t comm_bytes(const smk_solver* s)
+{
+    // [R2red: m_pad*kpp f32][Gh: KP*KP f64][scal: 8 f64]
+    size_t b = (size_t)s->pl2.ncols_pad * s->kpp * sizeof(float);
+    b = (b + 255) / 256 * 256;
+    b += (size_t)s->KP * s->KP * sizeof(double);
+    b = (b + 255) / 256 * 256;
+    b += 8 * sizeof(double);
+    return b;
+}
+
+int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matrix* a)
+{
+    if (!out) return SMK_BAD_PARAM;
+    *out = nullptr;
+    if (!g_init) { set_error("smk_initialize() has not been called"); return SMK_NOTINITIALIZED; }
+    if (!opts || !a) return SMK_BAD_PARAM;
+    if (!smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
+    if (opts->height != a->m || opts->width != a->n_global) { set_error("options/matrix dimension mismatch"); return SMK_BAD_PARAM; }
+    if (opts->algorithm == SMK_ALG_RANK2) { set_error("RANK2 is not built on the device path yet"); return SMK_UNSUPPORTED; }
+    if (opts->k > 64) { set_error("device path supports k <= 64"); return SMK_UNSUPPORTED; }
+    // W and H element counts must fit the reference's 32-bit index (nmf.cpp:194-210)
+    if ((uint64_t)a->m * (uint64_t)opts->k > 0x7FFFFFFFull) { fprintf(stderr, "W matrix size too large\n"); return SMK_SIZE_TOO_LARGE; }
+    if ((uint64_t)a->n_global * (uint64_t)opts->k > 0x7FFFFFFFull) { fprintf(stderr, "H matrix size too large\n"); return SMK_SIZE_TOO_LARGE; }
+
+    smk_solver* s = new smk_solver;
+    s->o = *opts;
+    s->a = a;
+    s->k = opts->k;
+    s->KP = kp_of(s->k);
+    s->kpp = kt_of(s->k) * 32;
+    s->m = a->m;
+    s->n = a->n;
+    s->st = g_stream;
+    const char* env = getenv("SMK_NSPLIT");
+    s->nsplit = env ? atoi(env) : 3;
+    if (s->nsplit < 1 || s->nsplit > 3) s->nsplit = 3;
+    s->pl1 = plan_bigprod(a->storage, s->k, s->m, s->n, s->nsplit, g_cus);
+    s->pl2 = plan_bigprod(a->storage, s->k, s->n, s->m, s->nsplit, g_cus);
+
+    int rc = 0;
+    const size_t kk = (size_t)s->KP * s->KP;
+    rc |= dev_alloc(&s->H, (size_t)s->k * s->n);
+    rc |= dev_alloc(&s->Wt, (size_t)s->k * s->m);
+    rc |= dev_alloc(&s->Gw, kk);
+    rc |= dev_alloc(&s->Gh_own, kk);
+    rc |= dev_alloc(&s->gram_scratch, gram_scratch_elems(s->k, GRAM_BLOCKS));
+    rc |= dev_alloc(&s->tmpW, (size_t)s->k * s->m);
+    s->pg_half = (size_t)((std::max(s->m, s->n) + 255) / 256) + 1024;
+    rc |= dev_alloc(&s->pg_partials, 2 * s->pg_half);
+    rc |= dev_alloc(&s->scal_own, (size_t)8);
+    rc |= dev_alloc(&s->fail_flag, (size_t)1);
+    rc |= dev_alloc((unsigned char**)&s->packW, packed_bytes(a->storage, s->k, s->m, s->nsplit));
+    rc |= dev_alloc((unsigned char**)&s->packH, packed_bytes(a->storage, s->k, s->n, s->nsplit));
+    rc |= dev_alloc(&s->P1, s->pl1.p_elems);
+    rc |= dev_alloc(&s->P2, s->pl2.p_elems);
+    if (opts->algorithm == SMK_ALG_HALS) rc |= dev_alloc(&s->hals_scratch, hals_w_scratch_elems(s->k, s->m));
+    if (opts->prog_est_algorithm == SMK_PROG_DELTA_FNORM) rc |= dev_alloc(&s->Wprev, (size_t)s->k * s->m);
+    if (rc) { smk_solver_destroy(s); return SMK_DEVICE_ERROR; }
+    s->Gh = s->Gh_own;
+    s->scal = s->scal_own;
+    *out = s;
+    return SMK_OK;
+}
+
+void smk_solver_destroy(smk_solver* s)
+{
+    if (!s) return;
+    void* ptrs[] = {s->H, s->Wt, s->Gw, s->Gh_own, s->gram_scratch, s->tmpW, s->pg_partials, s->scal_own,
+                    s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int w = 0; w < 2; ++w)
+        for (auto& e : s->ev[w]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete s;
+}
+
+int smk_solver_comm_workspace_bytes(const smk_solver* s, size_t* bytes)
+{
+    if (!s || !bytes) return SMK_BAD_PARAM;
+    *bytes = comm_bytes(s);
+    return SMK_OK;
+}
+
+int smk_solver_set_comm(smk_solver* s, int rank, int world, smk_allreduce_fn fn, void* user, void* workspace,
+                        size_t workspace_bytes)
+{
+    if (!s || world < 1 || rank < 0 || rank >= world) return SMK_BAD_PARAM;
+    if (world > 1 && (!fn || !workspace || workspace_bytes < comm_bytes(s))) return SMK_BAD_PARAM;
+    s->rank = rank; s->world = world; s->ar = fn; s->ar_user = user;
+    if (world > 1) {
+        unsigned char* p = (unsigned char*)workspace;
+        s->R2red = (float*)p;
+        size_t b = (size_t)s->pl2.ncols_pad * s->kpp * sizeof(float);
+        b = (b + 255) / 256 * 256;
+        s->Gh = (double*)(p + b);
+        b += (size_t)s->KP * s->KP * sizeof(double);
+        b = (b + 255) / 256 * 256;
+        s->scal = (double*)(p + b);
+    } else {
+        s->Gh = s->Gh_own;
+        s->scal = s->scal_own;
+    }
+    return SMK_OK;
+}
+
+int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const double* H0, int64_t ldH)
+{
+    if (!s || !W0 || !H0) return SMK_BAD_PARAM;
+    if (ldW < s->m || ldH < s->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
+    // W0 (m x k, host) -> tmpW (m x k, ld m) -> Wt (k x m)
+    SMK_HIP(hipMemcpy2DAsync(s->tmpW, (size_t)s->m * sizeof(double), W0, (size_t)ldW * sizeof(double),
+                             (size_t)s->m * sizeof(double), (size_t)s->k, hipMemcpyHostToDevice, s->st));
+    int rc = launch_transpose_f64(s->tmpW, s->m, s->Wt, s->k, s->m, s->k, s->st);
+    if (rc) return rc;
+    SMK_HIP(hipMemcpy2DAsync(s->H, (size_t)s->k * sizeof(double), H0, (size_t)ldH * sizeof(double),
+                             (size_t)s->k * sizeof(double), (size_t)s->n, hipMemcpyHostToDevice, s->st));
+    const int big = INT_MAX;
+    SMK_HIP(hipMemcpyAsync(s->fail_flag, &big, sizeof(int), hipMemcpyHostToDevice, s->st));
+    SMK_HIP(hipStreamSynchronize(s->st));
+    s->have_factors = true;
+    s->inited = false;
+    s->normalized = false;
+    s->iter = 0;
+    s->pg0 = 1.0;
+    s->last_metric = 1.0;
+    return SMK_OK;
+}
+
+// ---- building blocks -----------------------------------------------------------------------
+static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp,
+                         float* P)
+{
+    if (s->timing) {
+        hipEvent_t e0, e1;
+        SMK_HIP(hipEventCreate(&e0));
+        SMK_HIP(hipEventCreate(&e1));
+        SMK_HIP(hipEventRecord(e0, s->st));
+        int rc = launch_bigprod(pl, B, ldb, Xp, P, s->st);
+        if (rc) return rc;
+        SMK_HIP(hipEventRecord(e1, s->st));
+        s->ev[which].push_back({e0, e1});
+        return 0;
+    }
+    return launch_bigprod(pl, B, ldb, Xp, P, s->st);
+}
+
+// R1 = W'A  (k x n, local columns)
+static int prod1(smk_solver* s)
+{
+    int rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st);
+    if (rc) return rc;
+    return timed_bigprod(s, 0, s->pl1, s->a->A, s->a->ldA, s->packW, s->P1);
+}
+
+// R2 = H At = (A H')'  (k x m), summed over ranks when sharded
+static int prod2(smk_solver* s)
+{
+    int rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st);
+    if (rc) return rc;
+    rc = timed_bigprod(s, 1, s->pl2, s->a->At, s->a->ldAt, s->packH, s->P2);
+    if (rc) return rc;
+    if (s->world > 1) {
+        PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp};
+        rc = launch_reduce_partials(pv, s->k, s->pl2.ncols_pad, s->R2red, s->st);
+        if (rc) return rc;
+        if (s->ar(s->ar_user, s->R2red, (int64_t)s->pl2.ncols_pad * s->kpp, 0)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
+    }
+    return 0;
+}
+
+static int gram_w(smk_solver* s) { return launch_gram(s->Wt, s->k, s->m, s->Gw, s->gram_scratch, GRAM_BLOCKS, s->st); }
+
+static int gram_h(smk_solver* s)
+{
+    int rc = launch_gram(s->H, s->k, s->n, s->Gh, s->gram_scratch, GRAM_BLOCKS, s->st);
+    if (rc) return rc;
+    if (s->world > 1)
+        if (s->ar(s->ar_user, s->Gh, (int64_t)s->KP * s->KP, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
+    return 0;
+}
+
+// solver.Init (mu :98-114, hals :142-159, bpp :310-335) + progress_est->Init
+static int solver_init(smk_solver* s)
+{
+    int rc = 0;
+    if (s->o.algorithm == SMK_ALG_HALS) {
+        rc = gram_h(s);  if (rc) return rc;
+        rc = prod2(s);   if (rc) return rc;
+    } else {   // MU, BPP: WtA and WtW from W0
+        rc = prod1(s);   if (rc) return rc;
+        rc = gram_w(s);  if (rc) return rc;
+    }
+    if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM)
+        SMK_HIP(hipMemcpyAsync(s->Wprev, s->Wt, (size_t)s->k * s->m * sizeof(double), hipMemcpyDeviceToDevice, s->st));
+    s->inited = true;
+    return 0;
+}
+
+// one solver iteration (the body of `solver(A,W,H,gradW,gradH)`); gradients are formed on
+// demand by update_progress() from the same R1/R2/Gw/Gh the reference uses.
+static int solver_iteration(smk_solver* s)
+{
+    int rc = 0;
+    const PartialView r1 = view1(s), r2 = view2(s);
+    switch (s->o.algorithm) {
+        case SMK_ALG_MU:   // nmf_solver_mu.hpp:121-164
+            rc = launch_mu_update(s->H, s->k, s->n, r1, s->Gw, s->st);  if (rc) return rc;
+            rc = gram_h(s);   if (rc) return rc;
+            rc = prod2(s);    if (rc) return rc;
+            rc = launch_mu_update(s->Wt, s->k, s->m, r2, s->Gh, s->st); if (rc) return rc;
+            rc = prod1(s);    if (rc) return rc;
+            rc = gram_w(s);   if (rc) return rc;
+            break;
+        case SMK_ALG_HALS: // nmf_solver_hals.hpp:166-199
+            rc = launch_hals_w_update(s->Wt, s->k, s->m, r2, s->Gh, s->hals_scratch, s->st); if (rc) return rc;
+            rc = gram_w(s);   if (rc) return rc;
+            rc = prod1(s);    if (rc) return rc;
+            rc = launch_hals_sweep(s->H, s->k, s->n, r1, s->Gw, s->st); if (rc) return rc;
+            rc = gram_h(s);   if (rc) return rc;
+            rc = prod2(s);    if (rc) return rc;
+            break;
+        case SMK_ALG_BPP:  // nmf_solver_bpp.hpp:342-377
+            rc = launch_nnls_bpp(s->H, nullptr, s->k, s->n, r1, s->Gw, s->fail_flag, s->iter, s->st); if (rc) return rc;
+            rc = gram_h(s);   if (rc) return rc;
+            rc = prod2(s);    if (rc) return rc;
+            rc = launch_nnls_bpp(s->Wt, nullptr, s->k, s->m, r2, s->Gh, s->fail_flag, s->iter, s->st); if (rc) return rc;
+            rc = gram_w(s);   if (rc) return rc;
+            rc = prod1(s);    if (rc) return rc;
+            break;
+        default:
+            return SMK_UNSUPPORTED;
+    }
+    s->iter += 1;
+    return 0;
+}
+
+static int resolve_events(smk_solver* s)
+{
+    for (int w = 0; w < 2; ++w) {
+        for (auto& e : s->ev[w]) {
+            float ms = 0.f;
+            SMK_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+            s->acc_ms[w] += ms;
+            s->launches[w] += 1;
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        s->ev[w].clear();
+    }
+    return 0;
+}
+
+// wait for the stream; translate device-side failure flags into Result codes
+static int sync_and_check(smk_solver* s, int* fail_iter)
+{
+    int flag = INT_MAX;
+    SMK_HIP(hipMemcpyAsync(&flag, s->fail_flag, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    SMK_HIP(hipStreamSynchronize(s->st));
+    int rc = resolve_events(s);
+    if (rc) return rc;
+    if (fail_iter) *fail_iter = flag;
+    if (flag != INT_MAX) return SMK_FAILURE;
+    return SMK_OK;
+}
+
+// progress_est->Update(iter, W, H, gradW, gradH): returns the metric (synchronises)
+static int update_progress(smk_solver* s, int iter_index, double* metric)
+{
+    int rc = 0;
+    if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM) {
+        rc = launch_delta_fnorm(s->Wt, s->Wprev, (i64)s->k * s->m, s->pg_partials, s->scal + 2, s->st);
+        if (rc) return rc;
+    } else {
+        // gradW = W*HHt - AHt  (slot 0, replicated), gradH = WtW*H - WtA (slot 1, local shard)
+        rc = launch_grad_pg(s->Wt, s->k, s->m, view2(s), s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st);
+        if (rc) return rc;
+        rc = launch_grad_pg(s->H, s->k, s->n, view1(s), s->Gw, nullptr, s->pg_partials + s->pg_half, s->scal, 1, s->st);
+        if (rc) return rc;
+        if (s->world > 1)
+            if (s->ar(s->ar_user, s->scal + 1, 1, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
+    }
+    double h[4] = {0, 0, 0, 0};
+    SMK_HIP(hipMemcpyAsync(h, s->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    int fail_iter = INT_MAX;
+    rc = sync_and_check(s, &fail_iter);
+    if (rc) return rc;
+    if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM) {
+        *metric = std::sqrt(h[2]) / std::sqrt(h[3]);
+    } else {
+        const double pg = std::sqrt(h[0] + h[1]);
+        if (std::isnan(pg)) { set_error("ProjectedGradientNorm: NaN"); return SMK_FAILURE; }   // reference throws
+        if (iter_index == 0) { s->pg0 = pg; *metric = 1.0; }
+        else *metric = pg / s->pg0;
+    }
+    s->last_metric = *metric;
+    return SMK_OK;
+}
+
+static int normalize_device(smk_solver* s)
+{
+    if (s->normalized) return 0;
+    // nu_c^2 = (W'W)[c][c]; Gw is current in all three schedules after the last W update
+    int rc = launch_scale_rows(s->H, s->k, s->n, s->Gw, 0, s->fail_flag, s->st);
+    if (rc) return rc;
+    rc = launch_scale_rows(s->Wt, s->k, s->m, s->Gw, 1, s->fail_flag, s->st);
+    if (rc) return rc;
+    s->normalized = true;
+    return 0;
+}
+
+int smk_solver_iterate(smk_solver* s, int iters)
+{
+    if (!s || iters < 0) return SMK_BAD_PARAM;
+    if (!s->have_factors) { set_error("set_factors() first"); return SMK_BAD_PARAM; }
+    int rc = 0;
+    if (!s->inited) { rc = solver_init(s); if (rc) return rc; }
+    for (int i = 0; i < iters; ++i) {
+        rc = solver_iteration(s);
+        if (rc) return rc;
+    }
+    return SMK_OK;
+}
+
+int smk_solver_sync(smk_solver* s)
+{
+    if (!s) return SMK_BAD_PARAM;
+    return sync_and_check(s, nullptr);
+}
+
+int smk_solver_progress(smk_solver* s, double* metric)
+{
+    if (!s || !metric) return SMK_BAD_PARAM;
+    if (!s->inited) return SMK_BAD_PARAM;
+    return update_progress(s, s->iter > 0 ? s->iter - 1 : 0, metric);
+}
+
+int smk_solver_iteration_count(const smk_solver* s) { return s ? s->iter : 0; }
+
+// NmfSolve<>, common/include/nmf_solve_generic.hpp:34-140
+int smk_solver_run(smk_solver* s, smk_stats* stats)
+{
+    if (!s) return SMK_BAD_PARAM;
+    if (!s->have_factors) { set_error("set_factors() first"); return SMK_BAD_PARAM; }
+    const smk_options& o = s->o;
+    const double t0 = wall_us();
+    int rc = 0, result = SMK_OK;
+    bool success = false;
+    int iter = 0, success_count = 0, fail_iter = INT_MAX;
+
+    if (!s->inited) { rc = solver_init(s); if (rc) { result = rc; goto done; } }
+
+    for (iter = 0; iter < o.max_iter; ++iter) {
+        rc = solver_iteration(s);
+        if (rc) { result = rc; goto done; }
+
+        if (iter < o.min_iter) {
+            if (iter == 0) {
+                double metric;
+                rc = update_progress(s, 0, &metric);
+                if (rc) { result = rc; goto failed_check; }
+            }
+            if (o.verbose) printf("%d:\tprogress metric: \t(min_iter)\n", iter + 1);
+            continue;
+        }
+        {
+            double metric = 1.0;
+            rc = update_progress(s, iter, &metric);
+            if (rc) { result = rc; goto failed_check; }
+            if (o.verbose && ((iter + 1 < 10) || ((iter + 1) % 10 == 0)))
+                printf("%d:\tprogress metric:\t%g\n", iter + 1, metric);     // nmf_progress_estimation.hpp:22-33
+            if (metric <= o.tol) {
+                if (++success_count >= o.tolcount) {
+                    success = true;
+                    if (o.verbose) printf("\nSolution converged after %d iterations.\n\n", iter + 1);
+                    break;
+                }
+            } else {
+                success_count = 0;
+            }
+        }
+    }
+
+    if (o.normalize) { rc = normalize_device(s); if (rc) { result = rc; goto done; } }
+    rc = sync_and_check(s, &fail_iter);
+    if (rc) { result = rc; goto failed_check; }
+    if (!success && iter == o.max_iter) success = true;
+    result = success ? SMK_OK : SMK_FAILURE;
+    goto done;
+
+failed_check:
+    if (result == SMK_FAILURE) {
+        // which iteration set the device flag (BPP pivot limit / non-SPD / zero column norm)
+        int flag = INT_MAX;
+        (void)hipMemcpy(&flag, s->fail_flag, sizeof(int), hipMemcpyDeviceToHost);
+        if (flag != INT_MAX && flag >= 0) {
+            iter = flag;
+            fprintf(stderr, "\tNMF solver failure on iteration %d\n", iter + 1);
+        }
+    }
+done:
+    if (stats) {
+        stats->elapsed_us = (unsigned long long)(wall_us() - t0);
+        stats->iteration_count = iter;
+    }
+    return result;
+}
+
+int smk_solver_get_factors(smk_solver* s, int normalize, double* W, int64_t ldW, double* H, int64_t ldH)
+{
+    if (!s || !W || !H) return SMK_BAD_PARAM;
+    if (ldW < s->m || ldH < s->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
+    int rc = 0;
+    if (normalize) { rc = normalize_device(s); if (rc) return rc; }
+    rc = launch_transpose_f64(s->Wt, s->k, s->tmpW, s->m, s->k, s->m, s->st);
+    if (rc) return rc;
+    SMK_HIP(hipMemcpy2DAsync(W, (size_t)ldW * sizeof(double), s->tmpW, (size_t)s->m * sizeof(double),
+                             (size_t)s->m * sizeof(double), (size_t)s->k, hipMemcpyDeviceToHost, s->st));
+    SMK_HIP(hipMemcpy2DAsync(H, (size_t)ldH * sizeof(double), s->H, (size_t)s->k * sizeof(double),
+                             (size_t)s->k * sizeof(double), (size_t)s->n, hipMemcpyDeviceToHost, s->st));
+    return sync_and_check(s, nullptr);
+}
+
+int smk_solver_enable_timing(smk_solver* s, int on)
+{
+    if (!s) return SMK_BAD_PARAM;
+    s->timing = on != 0;
+    s->acc_ms[0] = s->acc_ms[1] = 0.0;
+    s->launches[0] = s->launches[1] = 0;
+    return SMK_OK;
+}
+
+int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* launches)
+{
+    if (!s || which < 0 || which > 1) return SMK_BAD_PARAM;
+    if (total_ms) *total_ms = s->acc_ms[which];
+    if (launches) *launches = s->launches[which];
+    return SMK_OK;
+}
+
+int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double* flops)
+{
+    if (!s || which < 0 || which > 1) return SMK_BAD_PARAM;
+    const double mn = (double)s->m * (double)s->n;
+    if (bytes) *bytes = mn * elem_size(s->a->storage);
+    if (flops) *flops = 2.0 * mn * s->k;
+    return SMK_OK;
+}
+
+// Result Nmf(...), common/src/nmf.cpp:173-229
+int smk_nmf_dense(const smk_options* opts, const double* A, int64_t ldA, double* W, int64_t ldW, double* H,
+                  int64_t ldH, smk_stats* stats, int storage)
+{
+    if (!g_init) {
+        fprintf(stderr, "nmflib error: nmf_initialize() must be called prior to any factorization routine\n\n");
+        return SMK_NOTINITIALIZED;
+    }
+    if (!opts || !smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
+    if (!A || !W || !H) return SMK_BAD_PARAM;
+    const int64_t m = opts->height, n = opts->width;
+    if (ldA < m || ldW < m || ldH < opts->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
+    smk_matrix* a = nullptr;
+    smk_solver* s = nullptr;
+    int rc = smk_matrix_create(&a, m, n, 0, n, storage);
+    if (rc == SMK_OK) rc = smk_matrix_upload_f64(a, A, ldA);
+    if (rc == SMK_OK) rc = smk_solver_create(&s, opts, a);
+    if (rc == SMK_OK) rc = smk_solver_set_factors(s, W, ldW, H, ldH);
+    int run_rc = SMK_OK;
+    if (rc == SMK_OK) {
+        run_rc = smk_solver_run(s, stats);
+        // like the reference, W/H hold the last iterate even when the solver reports failure
+        if (run_rc == SMK_OK || run_rc == SMK_FAILURE) (void)smk_solver_get_factors(s, 0, W, ldW, H, ldH);
+        rc = run_rc;
+    }
+    smk_solver_destroy(s);
+    smk_matrix_destroy(a);
+    return rc;
+}
+
+}  // extern "C"

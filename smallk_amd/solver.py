@@ -1,0 +1,211 @@
+"""Object wrappers over the C ABI: device-resident A and the NmfSolve<> solver.
+
+Host-side mirror of the reference's inner seam (common/include/nmf.hpp:77-81,
+common/include/nmf_solve_generic.hpp:34-140).  Numpy in/out, fp64, column-major.
+All compute happens in libsmallk_amd.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+ALGORITHMS = {"MU": L.ALG_MU, "HALS": L.ALG_HALS, "RANK2": L.ALG_RANK2, "BPP": L.ALG_BPP}
+STORAGE = {"f32": L.STORE_F32, "fp32": L.STORE_F32, "bf16": L.STORE_BF16}
+
+
+def _f(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def initialize(device: int = -1):
+    """NmfInitialize (nmf.hpp:71): select the GPU, create the stream.  Raises without a GPU."""
+    L.check(L.lib().smk_initialize(device), "smk_initialize")
+
+
+def is_initialized() -> bool:
+    return L.lib().smk_is_initialized() == L.INITIALIZED
+
+
+def finalize():
+    L.lib().smk_finalize()
+
+
+def set_stream(stream_ptr: int):
+    L.check(L.lib().smk_set_stream(C.c_void_p(stream_ptr)), "smk_set_stream")
+
+
+def uniform_host(rows, cols, seed, *, quant=0, r0=0, c0=0, gheight=None) -> np.ndarray:
+    """Counter-based uniform [0,1) matrix on the host (RandomMatrix stand-in)."""
+    out = np.empty((rows, cols), order="F")
+    L.lib().smk_uniform_fill_host(_p(out), rows, rows, cols, r0, c0, rows if gheight is None else gheight, seed, quant)
+    return out
+
+
+def make_options(m, n, k, algorithm, *, min_iter=5, max_iter=5000, tol=0.005, tolcount=1,
+                 prog_est=None, normalize=True, max_threads=1, verbose=False) -> L.Options:
+    alg = ALGORITHMS[algorithm] if isinstance(algorithm, str) else int(algorithm)
+    if prog_est is None:   # smallk::Nmf's rule (smallk/src/smallk.cpp:581-584)
+        prog_est = L.PROG_DELTA_FNORM if alg == L.ALG_MU else L.PROG_PG_RATIO
+    return L.Options(tol, alg, prog_est, m, n, k, min_iter, max_iter, tolcount, max_threads,
+                     int(verbose), int(normalize))
+
+
+class DenseMatrix:
+    """A (or the column shard [col0, col0+ncols) of it) resident in HBM with its transpose."""
+
+    def __init__(self, height, width_global, *, col0=0, ncols=None, storage="f32"):
+        self.height = int(height)
+        self.width_global = int(width_global)
+        self.col0 = int(col0)
+        self.ncols = int(width_global - col0 if ncols is None else ncols)
+        self.storage = STORAGE[storage] if isinstance(storage, str) else int(storage)
+        self._h = C.c_void_p()
+        L.check(L.lib().smk_matrix_create(C.byref(self._h), self.height, self.width_global, self.col0,
+                                          self.ncols, self.storage), "smk_matrix_create")
+
+    @classmethod
+    def from_host(cls, A, *, storage="f32"):
+        A = _f(A)
+        mat = cls(A.shape[0], A.shape[1], storage=storage)
+        mat.upload(A)
+        return mat
+
+    def upload(self, A_local):
+        A_local = _f(A_local)
+        assert A_local.shape == (self.height, self.ncols)
+        L.check(L.lib().smk_matrix_upload_f64(self._h, _p(A_local), A_local.shape[0]), "smk_matrix_upload_f64")
+
+    def fill_uniform(self, seed):
+        L.check(L.lib().smk_matrix_fill_uniform(self._h, seed), "smk_matrix_fill_uniform")
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.height, self.ncols), order="F")
+        L.check(L.lib().smk_matrix_download_f64(self._h, _p(out), self.height), "smk_matrix_download_f64")
+        return out
+
+    def close(self):
+        if self._h:
+            L.lib().smk_matrix_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class NmfResult:
+    result: int
+    W: np.ndarray
+    H: np.ndarray
+    iteration_count: int
+    elapsed_us: int
+
+
+class NmfSolver:
+    """One NmfSolve<> instance bound to a DenseMatrix."""
+
+    def __init__(self, A: DenseMatrix, options: L.Options):
+        self.A = A
+        self.options = options
+        self.k = options.k
+        self._h = C.c_void_p()
+        self._cb = None
+        L.check(L.lib().smk_solver_create(C.byref(self._h), C.byref(options), A._h), "smk_solver_create")
+
+    def set_factors(self, W0, H0_local):
+        W0, H0 = _f(W0), _f(H0_local)
+        assert W0.shape == (self.A.height, self.k) and H0.shape == (self.k, self.A.ncols)
+        L.check(L.lib().smk_solver_set_factors(self._h, _p(W0), W0.shape[0], _p(H0), H0.shape[0]),
+                "smk_solver_set_factors")
+
+    def run(self):
+        st = L.Stats()
+        rc = L.lib().smk_solver_run(self._h, C.byref(st))
+        return rc, st.iteration_count, st.elapsed_us
+
+    def iterate(self, iters):
+        L.check(L.lib().smk_solver_iterate(self._h, iters), "smk_solver_iterate")
+
+    def sync(self):
+        return L.lib().smk_solver_sync(self._h)
+
+    def progress(self) -> float:
+        v = C.c_double(0)
+        L.check(L.lib().smk_solver_progress(self._h, C.byref(v)), "smk_solver_progress")
+        return v.value
+
+    def factors(self, normalize=False):
+        W = np.empty((self.A.height, self.k), order="F")
+        H = np.empty((self.k, self.A.ncols), order="F")
+        rc = L.lib().smk_solver_get_factors(self._h, int(normalize), _p(W), W.shape[0], _p(H), H.shape[0])
+        if rc not in (L.OK, L.FAILURE):
+            L.check(rc, "smk_solver_get_factors")
+        return W, H
+
+    def enable_timing(self, on=True):
+        L.check(L.lib().smk_solver_enable_timing(self._h, int(on)), "smk_solver_enable_timing")
+
+    def kernel_time(self, which):
+        ms, cnt = C.c_double(0), C.c_int(0)
+        L.check(L.lib().smk_solver_kernel_time(self._h, which, C.byref(ms), C.byref(cnt)), "smk_solver_kernel_time")
+        return ms.value, cnt.value
+
+    def kernel_work(self, which):
+        b, f = C.c_double(0), C.c_double(0)
+        L.check(L.lib().smk_solver_kernel_work(self._h, which, C.byref(b), C.byref(f)), "smk_solver_kernel_work")
+        return b.value, f.value
+
+    def comm_workspace_bytes(self) -> int:
+        n = C.c_size_t(0)
+        L.check(L.lib().smk_solver_comm_workspace_bytes(self._h, C.byref(n)), "smk_solver_comm_workspace_bytes")
+        return n.value
+
+    def set_comm(self, rank, world, callback, workspace_ptr, workspace_bytes):
+        """callback(ptr:int, count:int, dtype:int) -> 0 on success; kept alive by this object."""
+        def _tramp(_user, ptr, count, dtype):
+            try:
+                return int(callback(ptr, count, dtype) or 0)
+            except Exception as e:  # never let an exception cross the C boundary
+                print("all-reduce callback failed:", e, flush=True)
+                return 1
+        self._cb = L.ALLREDUCE_FN(_tramp)
+        L.check(L.lib().smk_solver_set_comm(self._h, rank, world, self._cb, None, C.c_void_p(workspace_ptr),
+                                            workspace_bytes), "smk_solver_set_comm")
+
+    def close(self):
+        if self._h:
+            L.lib().smk_solver_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def nmf(A, W0, H0, algorithm, *, storage="f32", **kw) -> NmfResult:
+    """One-shot dense NMF = ``Nmf(NmfOptions, A, W, H, stats)`` (common/src/nmf.cpp:173-229)."""
+    A = _f(A)
+    W = _f(W0).copy(order="F")
+    H = _f(H0).copy(order="F")
+    m, n = A.shape
+    k = W.shape[1]
+    o = make_options(m, n, k, algorithm, **kw)
+    st = L.Stats()
+    stg = STORAGE[storage] if isinstance(storage, str) else int(storage)
+    rc = L.lib().smk_nmf_dense(C.byref(o), _p(A), m, _p(W), m, _p(H), k, C.byref(st), stg)
+    if rc not in (L.OK, L.FAILURE, L.BAD_PARAM, L.NOTINITIALIZED, L.SIZE_TOO_LARGE):
+        L.check(rc, "smk_nmf_dense")
+    return NmfResult(rc, W, H, st.iteration_count, st.elapsed_us)

@@ -1,0 +1,189 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same inputs.  Tolerance: relative Frobenius error of W and H <= 1e-4 after equal iterations
+(BASELINE.json north_star); the reference computes in fp64, the device stores A in fp32/bf16
+(the oracle is fed the same quantised A), keeps W/H/Gram in fp64 and accumulates the two big
+products in fp32 MFMA."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import make_golden as mg
+import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("storage,quant", [("f32", 0), ("bf16", 1)])
+def test_device_fill_is_bit_identical_to_oracle(gpu, storage, quant):
+    for (m, n) in [(300, 200), (64, 16), (1000, 77)]:
+        A = gpu.DenseMatrix(m, n, storage=storage)
+        A.fill_uniform(42)
+        assert np.array_equal(A.download(), oracle.fill_uniform(m, n, 42, quant=quant))
+    # a column shard reproduces the corresponding block of the whole matrix
+    S = gpu.DenseMatrix(300, 200, col0=50, ncols=70, storage=storage)
+    S.fill_uniform(42)
+    assert np.array_equal(S.download(), oracle.fill_uniform(300, 200, 42, quant=quant)[:, 50:120])
+
+
+@pytest.mark.parametrize("storage,quant", [("f32", 0), ("bf16", 1)])
+def test_upload_rounds_like_the_oracle(gpu, storage, quant):
+    rng = np.random.default_rng(1)
+    A = np.asfortranarray(rng.random((257, 131)) * 3.0)
+    D = gpu.DenseMatrix.from_host(A, storage=storage)
+    assert np.array_equal(D.download(), oracle.quantize(A, quant))
+
+
+CASES = [(m, n, k, pl, q, alg, it)
+         for (m, n, k, pl) in mg.CASES for q in (0, 1) for alg in ("MU", "HALS", "BPP")
+         for it in ((1, 5, 20) if q == 0 else (5,))]
+
+
+@pytest.mark.parametrize("m,n,k,planted,quant,alg,iters", CASES)
+def test_nmf_matches_oracle_and_golden(gpu, golden, m, n, k, planted, quant, alg, iters):
+    A = mg.make_A(m, n, k, planted, quant)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters)
+    got = gpu.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, storage="bf16" if quant else "f32")
+    assert got.result == 0 and got.iteration_count == iters
+    assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL
+    key = f"{alg}_{m}x{n}_k{k}_it{iters}_q{quant}"
+    assert rel(got.W, golden[key + "_W"]) < TOL and rel(got.H, golden[key + "_H"]) < TOL
+    assert (got.W >= 0).all() and (got.H >= 0).all()
+    assert np.allclose(np.linalg.norm(got.W, axis=0), 1.0, atol=1e-9)
+
+
+@pytest.mark.parametrize("alg", ["MU", "HALS", "BPP"])
+def test_unnormalized_and_leading_dimensions(gpu, alg):
+    """normalize=false and ldim > height (views into larger buffers, nmf.cpp:224-226)."""
+    m, n, k, it = 130, 70, 6, 4
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=it, max_iter=it, normalize=False)
+    L = gpu._lib
+    Ab = np.zeros((m + 5, n), order="F"); Ab[:m] = A
+    Wb = np.zeros((m + 3, k), order="F"); Wb[:m] = W0
+    Hb = np.zeros((k + 2, n), order="F"); Hb[:k] = H0
+    o = gpu.make_options(m, n, k, alg, min_iter=it, max_iter=it, normalize=False)
+    st = L.Stats()
+    dp = C.POINTER(C.c_double)
+    rc = L.lib().smk_nmf_dense(C.byref(o), Ab.ctypes.data_as(dp), m + 5, Wb.ctypes.data_as(dp), m + 3,
+                               Hb.ctypes.data_as(dp), k + 2, C.byref(st), L.STORE_F32)
+    assert rc == 0
+    assert rel(Wb[:m], ref.W) < TOL and rel(Hb[:k], ref.H) < TOL
+    assert not Wb[m:].any() and not Hb[k:].any()          # padding rows untouched
+
+
+@pytest.mark.parametrize("alg,tol", [("BPP", 0.05), ("HALS", 0.05), ("MU", 0.01)])
+def test_stopping_rule_matches_oracle(gpu, alg, tol):
+    """tolerance-based exit: same iteration count and factors as the oracle
+    (nmf_solve_generic.hpp:98-121; PG_RATIO / DELTA_FNORM estimators)."""
+    m, n, k = 512, 256, 8
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=3, max_iter=300, tol=tol)
+    got = gpu.nmf(A, W0, H0, alg, min_iter=3, max_iter=300, tol=tol)
+    assert ref.result == 0 and got.result == 0
+    assert got.iteration_count == ref.iteration_count
+    assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL
+
+
+def test_solver_object_iterate_progress(gpu):
+    m, n, k = 512, 256, 8
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    D = gpu.DenseMatrix.from_host(A)
+    s = gpu.NmfSolver(D, gpu.make_options(m, n, k, "HALS", min_iter=7, max_iter=7))
+    s.set_factors(W0, H0)
+    s.enable_timing(True)
+    s.iterate(3)
+    s.iterate(4)
+    assert s.sync() == 0
+    W, H = s.factors(normalize=True)
+    ref = oracle.nmf(A, W0, H0, "HALS", min_iter=7, max_iter=7)
+    assert rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
+    ms0, c0 = s.kernel_time(0)
+    ms1, c1 = s.kernel_time(1)
+    assert c0 == 7 and c1 == 8 and ms0 > 0 and ms1 > 0       # pass 2 also runs once in Init
+    b, f = s.kernel_work(0)
+    assert b == m * n * 4 and f == 2.0 * m * n * k
+
+
+def test_failure_and_bad_params(gpu):
+    L = gpu._lib
+    A = np.ones((12, 6))
+    r = gpu.nmf(A, np.ones((12, 3)), np.ones((3, 6)), "BPP", min_iter=1, max_iter=2)
+    assert r.result == L.FAILURE                               # rank-deficient Gram (normal_eq.hpp:35-50)
+    assert gpu.nmf(A, np.ones((12, 3)), np.ones((3, 6)), "MU", tol=2.0).result == L.BAD_PARAM
+    assert gpu.nmf(A[:, :2], np.ones((12, 3)), np.ones((3, 2)), "MU").result == L.BAD_PARAM   # k > n
+    with pytest.raises(L.SmallkError):
+        gpu.nmf(np.ones((200, 100)), np.ones((200, 65)), np.ones((65, 100)), "MU")            # k > 64
+
+
+@pytest.mark.parametrize("alg,storage,quant,m,n,k,iters", [
+    ("HALS", "bf16", 1, 4096, 2048, 32, 10),
+    ("BPP", "f32", 0, 2048, 1024, 16, 6),
+    ("MU", "bf16", 1, 3000, 1100, 20, 10),
+    ("BPP", "bf16", 1, 1024, 2048, 64, 4),
+])
+def test_medium_sizes_against_oracle(gpu, alg, storage, quant, m, n, k, iters):
+    """sizes where the row-split / multi-tile paths of the streaming kernel are exercised"""
+    A = oracle.fill_uniform(m, n, 42, quant=quant)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters)
+    D = gpu.DenseMatrix(m, n, storage=storage)
+    D.fill_uniform(42)
+    s = gpu.NmfSolver(D, gpu.make_options(m, n, k, alg, min_iter=iters, max_iter=iters))
+    s.set_factors(W0, H0)
+    rc, it, _ = s.run()
+    assert rc == 0 and it == iters
+    W, H = s.factors()
+    print(f"\n{alg} {storage} {m}x{n} k={k}: relW={rel(W, ref.W):.2e} relH={rel(H, ref.H):.2e}")
+    assert rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
+
+
+def test_smallkapi_mirror(gpu, tmp_path):
+    """pysmallk surface: load_matrix(matrix=...), nmf with init files, get_W/get_H, w.csv/h.csv
+    (reference flow: pysmallk/tests/smallkapi_inmem.py:57-109, tests/scripts/test_smallk.sh:23-35)."""
+    m, n, k = 96, 64, 5
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    l = gpu._lib.lib()
+    dp = C.POINTER(C.c_double)
+    fw, fh = str(tmp_path / "w0.csv"), str(tmp_path / "h0.csv")
+    assert l.smk_write_csv(W0.ctypes.data_as(dp), m, m, k, fw.encode(), 17) == 1
+    assert l.smk_write_csv(H0.ctypes.data_as(dp), k, k, n, fh.encode(), 17) == 1
+    api = gpu.SmallkAPI()
+    api.load_matrix(matrix=A, column_major=True)
+    assert api.is_matrix_loaded()
+    api.nmf(k, "BPP", infile_W=fw, infile_H=fh, precision=6, min_iter=1, max_iter=5000, tol=0.005,
+            outdir=str(tmp_path))
+    inputs = api.get_inputs()
+    assert inputs["precision"] == 6 and inputs["min_iter"] == 1 and inputs["max_iter"] == 5000
+    assert inputs["tol"] == 0.005 and inputs["outdir"] == str(tmp_path) + "/"
+    ref = oracle.nmf(A, W0, H0, "BPP", min_iter=1, max_iter=5000, tol=0.005)
+    W, H = api.get_W(), api.get_H()
+    assert W.shape == (m, k) and H.shape == (k, n)
+    assert api.get_iteration_count() == ref.iteration_count
+    assert rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
+    Wf = np.loadtxt(tmp_path / "w.csv", delimiter=",")
+    Hf = np.loadtxt(tmp_path / "h.csv", delimiter=",")
+    assert np.allclose(Wf, W, rtol=1e-5, atol=1e-12) and np.allclose(Hf, H, rtol=1e-5, atol=1e-12)
+    # MU uses the delta-Fnorm rule, HALS the PG ratio (smallk.cpp:581-584)
+    for alg in ("MU", "HALS"):
+        api.nmf(k, alg, infile_W=fw, infile_H=fh, min_iter=2, max_iter=40, tol=0.01, outdir=str(tmp_path))
+        ref = oracle.nmf(A, W0, H0, alg, min_iter=2, max_iter=40, tol=0.01)
+        assert api.get_iteration_count() == ref.iteration_count
+        assert rel(api.get_W(), ref.W) < TOL and rel(api.get_H(), ref.H) < TOL
