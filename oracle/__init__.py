@@ -78,6 +78,10 @@ def lib():
         _lib.orc_gemm.restype = None
         _lib.orc_gemm.argtypes = [C.c_int, C.c_int, i64, i64, i64, C.c_double, dp, i64, dp, i64, C.c_double, dp, i64]
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_set_num_threads.restype = None
+        _lib.orc_set_num_threads.argtypes = [C.c_int]
+        # hosts with hundreds of cores: an OpenMP team per tiny loop is pathological
+        _lib.orc_set_num_threads(int(os.environ.get("ORACLE_THREADS", min(os.cpu_count() or 1, 16))))
     return _lib
 
 
@@ -155,3 +159,7 @@ def projected_gradient_norm(gradW, gradH, W, H) -> float:
 
 def num_threads() -> int:
     return lib().orc_num_threads()
+
+
+def set_num_threads(n: int) -> None:
+    lib().orc_set_num_threads(int(n))

@@ -42,13 +42,14 @@ void set_error(const std::string& msg);
 // kernel launchers (kernels.hip).  All asynchronous on `st`.
 // X-side matrices are fp64, column-major k x N with leading dimension k
 // ("H layout"; W is kept transposed as Wt, k x m).
-// P = fp32 partial products from the streaming kernel: [S][ncols_pad][KPP].
+// P = fp64 partial products from the streaming kernel: [S][ncols_pad][KPP].
 // ---------------------------------------------------------------------------
 struct PartialView {
-    const float* p;   // base
+    const void* p;    // base: doubles (kernel output) or floats (after the cross-GPU all-reduce)
     int S;            // number of partial slabs to sum
     i64 slab;         // elements between slabs (= ncols_pad * kpp)
     int kpp;          // padded k of a column in P (multiple of 32)
+    int f64;          // element type of p
 };
 
 int launch_fill_uniform(void* buf, int storage, i64 ld, i64 rows, i64 cols, i64 rows_pad, i64 cols_pad,
@@ -71,10 +72,10 @@ struct BigProdPlan {
     i64 tiles;      // column tiles of 128
     int kt, nsplit, storage;
     i64 ncols_pad;
-    size_t p_elems; // floats needed for P
+    size_t p_elems; // doubles needed for P
 };
 BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus);
-int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, float* P, hipStream_t st);
+int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st);
 const void* bigprod_kernel_ptr(const BigProdPlan& pl);
 
 int launch_reduce_partials(PartialView pv, int k, i64 N, float* out /* [N][kpp] */, hipStream_t st);

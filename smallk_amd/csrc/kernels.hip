@@ -217,7 +217,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 template <int EBYTES, int KT, int NSPLIT>
 __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                          const unsigned char* __restrict__ Xp,
-                                                         float* __restrict__ P, i64 stages, i64 nst,
+                                                         double* __restrict__ P, i64 stages, i64 nst,
                                                          i64 tiles, i64 ncols_pad, int S, int logS)
 {
     using C = BPCfg<EBYTES, KT, NSPLIT>;
@@ -283,13 +283,25 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
         }
     };
 
-    f32x16_t acc[NSPLIT][KT];
+    // Accumulators.  The leading (hi) term is accumulated in fp32 by the MFMA for ONE stage
+    // (64 rows = 4 dependent MFMAs) and then added into fp64 running sums by the VALU while the
+    // next stage's MFMAs run into the other fp32 set (accA/accB ping-pong): the fp32 rounding
+    // chain never exceeds one stage.  The mid/lo split terms are 2^-8 / 2^-16 smaller and stay
+    // in fp32 for the whole split.
+    f32x16_t accA[KT], accB[KT];
+    f32x16_t accs[NSPLIT > 1 ? NSPLIT - 1 : 1][KT];
+    double dacc[KT][16];
 #pragma unroll
-    for (int s = 0; s < NSPLIT; ++s)
+    for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int r = 0; r < 16; ++r) {
+            accA[kt][r] = 0.f;
+            accB[kt][r] = 0.f;
+            dacc[kt][r] = 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[s][kt][r] = 0.f;
+            for (int s = 0; s < (NSPLIT > 1 ? NSPLIT - 1 : 1); ++s) accs[s][kt][r] = 0.f;
+        }
+    }
 
     // fragment read addresses
     const int jl = wave * 32 + (lane & 31);
@@ -297,10 +309,19 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
     const int swz_r = (C::CPC == 8) ? ((jl >> 1) & 7) : (jl & 15);
     const int bfrag_base = jl * C::CPC * 16;
 
-    if (my_nst > 0) issue(0);
-    if (my_nst > 1) issue(1);
+    auto flush = [&](f32x16_t (&a)[KT]) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dacc[kt][r] += (double)a[kt][r];
+                a[kt][r] = 0.f;
+            }
+    };
 
-    for (int t = 0; t < my_nst; ++t) {
+    // one stage: wait for its data, release the ring slot two stages ahead, MFMAs into `cur`;
+    // the previous stage's fp32 sums (`prev`) are folded into fp64 right after the first step.
+    auto stage_body = [&](int t, f32x16_t (&cur)[KT], f32x16_t (&prev)[KT], bool flush_prev) {
         if (t + 1 < my_nst) wait_vmcnt<C::LPS>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -319,8 +340,9 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
                         const u32x4_t araw = *(const u32x4_t*)(sx + ((q * NSPLIT + s) * KT + kt) * 1024 + lane * 16);
-                        acc[s][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, araw), bfr,
-                                                                             acc[s][kt], 0, 0, 0);
+                        const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, araw);
+                        if (s == 0) cur[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, cur[kt], 0, 0, 0);
+                        else accs[s - 1][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, accs[s - 1][kt], 0, 0, 0);
                     }
             } else {
                 const f32x4_t bfr = __builtin_bit_cast(f32x4_t, braw);
@@ -329,29 +351,52 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
                     const f32x4_t afr = *(const f32x4_t*)(sx + (q * KT + kt) * 1024 + lane * 16);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        acc[0][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[e], bfr[e], acc[0][kt], 0, 0, 0);
+                        cur[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[e], bfr[e], cur[kt], 0, 0, 0);
                 }
             }
+            if (q == 0 && flush_prev) flush(prev);
         }
+    };
+
+    if (my_nst > 0) issue(0);
+    if (my_nst > 1) issue(1);
+
+    int t = 0;
+    for (; t + 1 < my_nst; t += 2) {
+        stage_body(t, accA, accB, t > 0);
+        stage_body(t + 1, accB, accA, true);
+    }
+    if (t < my_nst) {
+        stage_body(t, accA, accB, t > 0);
+        flush(accA);
+    } else if (my_nst > 0) {
+        flush(accB);
     }
 
-    // epilogue: combine split-term accumulators (small terms first), store k-contiguous.
+    // epilogue: fp64 totals (+ the small split terms), stored k-contiguous as doubles.
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     const i64 jg = col0 + jl;
-    float* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32);
+    double* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32);
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4_t v;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float tsum = acc[NSPLIT - 1][kt][4 * g + i];
+            for (int i = 0; i < 4; i += 2) {
+                f64x2_t v;
 #pragma unroll
-                for (int s = NSPLIT - 2; s >= 0; --s) tsum += acc[s][kt][4 * g + i];
-                v[i] = tsum;
+                for (int u = 0; u < 2; ++u) {
+                    double tsum = dacc[kt][4 * g + i + u];
+                    if constexpr (NSPLIT > 1) {
+                        float small = accs[NSPLIT - 2][kt][4 * g + i + u];
+#pragma unroll
+                        for (int s = NSPLIT - 3; s >= 0; --s) small += accs[s][kt][4 * g + i + u];
+                        tsum += (double)small;
+                    }
+                    v[u] = tsum;
+                }
+                *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
             }
-            *(f32x4_t*)(pout + kt * 32 + 8 * g + 4 * h) = v;
         }
     }
 }
@@ -449,12 +494,12 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     while (pl.tiles * S < 4 * (i64)num_cus && S < 64 && pl.stages / (2 * S) >= 8) S *= 2;
     pl.S = S;
     pl.nst = (pl.stages + S - 1) / S;
-    pl.p_elems = (size_t)S * pl.ncols_pad * pl.kt * 32;
+    pl.p_elems = (size_t)S * pl.ncols_pad * pl.kt * 32;   // doubles
     return pl;
 }
 
 template <int EBYTES, int KT, int NSPLIT>
-static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, float* P, hipStream_t st)
+static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
     using C = BPCfg<EBYTES, KT, NSPLIT>;
     constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
@@ -479,7 +524,7 @@ static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const
     return 0;
 }
 
-int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, float* P, hipStream_t st)
+int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
     if (pl.storage == STORE_BF16) {
         if (pl.kt == 1) {
@@ -498,12 +543,12 @@ int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp
 }
 
 // sum the S slabs into one fp32 slab (used before a cross-GPU all-reduce)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ p, int S, i64 slab, i64 count,
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ p, int S, i64 slab, i64 count,
                                                               float* __restrict__ out)
 {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (i64)gridDim.x * blockDim.x) {
         double s = 0.0;
-        for (int t = 0; t < S; ++t) s += (double)p[t * slab + i];
+        for (int t = 0; t < S; ++t) s += p[t * slab + i];
         out[i] = (float)s;
     }
 }
@@ -513,7 +558,7 @@ int launch_reduce_partials(PartialView pv, int k, i64 N, float* out, hipStream_t
     i64 count = N * pv.kpp;
     if (count == 0) return 0;
     int grid = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
-    reduce_partials_kernel<<<grid, 256, 0, st>>>(pv.p, pv.S, pv.slab, count, out);
+    reduce_partials_kernel<<<grid, 256, 0, st>>>((const double*)pv.p, pv.S, pv.slab, count, out);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -631,12 +676,33 @@ __device__ __forceinline__ void load_rhs(const PartialView& R, int k, i64 j, dou
 {
 #pragma unroll
     for (int r = 0; r < KP; ++r) b[r] = 0.0;
-    for (int s = 0; s < R.S; ++s) {
-        const float* p = R.p + s * R.slab + j * R.kpp;
+    if (R.f64) {
+        for (int s = 0; s < R.S; ++s) {
+            const double* p = (const double*)R.p + s * R.slab + j * R.kpp;
 #pragma unroll
-        for (int r = 0; r < KP; ++r)
-            if (r < k) b[r] += (double)p[r];
+            for (int r = 0; r < KP; ++r)
+                if (r < k) b[r] += p[r];
+        }
+    } else {
+        for (int s = 0; s < R.S; ++s) {
+            const float* p = (const float*)R.p + s * R.slab + j * R.kpp;
+#pragma unroll
+            for (int r = 0; r < KP; ++r)
+                if (r < k) b[r] += (double)p[r];
+        }
     }
+}
+
+// one element (row i of column j) of the summed partial product
+__device__ __forceinline__ double rhs_elem(const PartialView& R, i64 j, int i)
+{
+    double v = 0.0;
+    if (R.f64) {
+        for (int s = 0; s < R.S; ++s) v += ((const double*)R.p)[s * R.slab + j * R.kpp + i];
+    } else {
+        for (int s = 0; s < R.S; ++s) v += (double)((const float*)R.p)[s * R.slab + j * R.kpp + i];
+    }
+    return v;
 }
 
 // block-wide sum of one double; result valid in thread 0
@@ -879,8 +945,7 @@ __global__ __launch_bounds__(256) void hals_w_col_kernel(double* __restrict__ Wt
                 acc += w[r] * gcol[r];
                 if (r == c) wc = w[r];
             }
-            double rhs = 0.0;
-            for (int s = 0; s < R.S; ++s) rhs += (double)R.p[s * R.slab + i * R.kpp + c];
+            const double rhs = rhs_elem(R, i, c);
             double v = wc + (rhs - acc) / gcol[c];
             if (isnan(v) || v < 0.0) { v = 0.0; zero = 1.0; }
             pw[c] = v;
@@ -974,7 +1039,7 @@ __global__ __launch_bounds__(256) void nnls_bpp_kernel(double* __restrict__ X, d
 
     double rhs = 0.0, x = 0.0, y = 0.0;
     if (comp_ok) {
-        for (int s = 0; s < R.S; ++s) rhs += (double)R.p[s * R.slab + cc * R.kpp + i];
+        rhs = rhs_elem(R, cc, i);
         x = X[cc * k + i];
     }
     bool passive = comp_ok && (x > 0.0);            // passive_set = (X > 0), nnls.hpp:157

@@ -9,7 +9,7 @@
 //         contiguous dimension
 //   H   : k x n  (ld k)     Wt : k x m (ld k)  -- W is kept transposed on the device
 //   Gw = W'W, Gh = HH' : KP x KP (KP = 8/16/32/64 padded)
-//   P1 : S1 slabs of n_pad x kpp fp32 = W'A partials,   P2 : S2 slabs of m_pad x kpp = (AH')' partials
+//   P1 : S1 slabs of n_pad x kpp fp64 = W'A partials,   P2 : S2 slabs of m_pad x kpp = (AH')' partials
 //   packW / packH : MFMA operand fragments of W' / H
 #include "common.h"
 #include "../../include/smallk_amd.h"
@@ -69,7 +69,8 @@ struct smk_solver {
     double *Wprev = nullptr, *hals_scratch = nullptr, *pg_partials = nullptr, *scal = nullptr, *tmpW = nullptr;
     double *Gh_own = nullptr, *scal_own = nullptr;
     void *packW = nullptr, *packH = nullptr;
-    float *P1 = nullptr, *P2 = nullptr, *R2red = nullptr;
+    double *P1 = nullptr, *P2 = nullptr;
+    float* R2red = nullptr;
     BigProdPlan pl1, pl2;
     int* fail_flag = nullptr;
     int iter = 0;
@@ -295,12 +296,12 @@ void smk_matrix_destroy(smk_matrix* a)
 // ------------------------------------------------------------------------------------------
 static PartialView view1(const smk_solver* s)
 {
-    return PartialView{s->P1, s->pl1.S, (i64)s->pl1.ncols_pad * s->kpp, s->kpp};
+    return PartialView{s->P1, s->pl1.S, (i64)s->pl1.ncols_pad * s->kpp, s->kpp, 1};
 }
 static PartialView view2(const smk_solver* s)
 {
-    if (s->world > 1) return PartialView{s->R2red, 1, 0, s->kpp};
-    return PartialView{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp};
+    if (s->world > 1) return PartialView{s->R2red, 1, 0, s->kpp, 0};
+    return PartialView{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
 }
 
 static size_t comm_bytes(const smk_solver* s)
@@ -434,7 +435,7 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
 
 // ---- building blocks -----------------------------------------------------------------------
 static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp,
-                         float* P)
+                         double* P)
 {
     if (s->timing) {
         hipEvent_t e0, e1;
@@ -466,7 +467,7 @@ static int prod2(smk_solver* s)
     rc = timed_bigprod(s, 1, s->pl2, s->a->At, s->a->ldAt, s->packH, s->P2);
     if (rc) return rc;
     if (s->world > 1) {
-        PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp};
+        PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
         rc = launch_reduce_partials(pv, s->k, s->pl2.ncols_pad, s->R2red, s->st);
         if (rc) return rc;
         if (s->ar(s->ar_user, s->R2red, (int64_t)s->pl2.ncols_pad * s->kpp, 0)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
