@@ -18,7 +18,7 @@ inline int elem_size(int storage) { return storage == STORE_BF16 ? 2 : 4; }
 // kernel read whole 64/128-row stages without bounds checks.
 constexpr i64 ROW_PAD = 128;
 // Column padding = columns per workgroup tile of the streaming kernel.
-constexpr i64 COL_PAD = 128;
+constexpr i64 COL_PAD = 256;
 
 inline i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
 
@@ -70,7 +70,7 @@ struct BigProdPlan {
     i64 stages;     // total stages = ceil(len / MB)
     i64 nst;        // stages per split
     i64 tiles;      // column tiles of 128
-    int kt, nsplit, storage;
+    int kt, nsplit, storage, variant;
     i64 ncols_pad;
     size_t p_elems; // doubles needed for P
 };
@@ -92,7 +92,8 @@ int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G
 int launch_pg_from_grad(const double* X, const double* Y, int k, i64 N, double* pg_partials, double* pg_accum,
                         int slot, hipStream_t st);
 // HALS W update (all k columns, k+1 launches); norms scratch: [k][nblocks] + ...
-int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, hipStream_t st);
+int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, int num_cus,
+                         int* fail_flag, hipStream_t st);
 size_t hals_w_scratch_elems(int k, i64 M);
 // BPP / NNLS block principal pivoting over all columns
 int launch_nnls_bpp(double* X, double* Y, int k, i64 N, PartialView R, const double* G, int* fail_flag,

@@ -18,6 +18,8 @@
 //   delta_fnorm_kernel  ProgEstGenericDeltaW::Compute    (progress_estimator_generic.hpp:58-69)
 #include "common.h"
 #include <cfloat>
+#include <cstdlib>
+#include <utility>
 
 namespace smk {
 
@@ -193,20 +195,24 @@ int launch_zero_f64(double* p, i64 n, hipStream_t st)
 //   2q+h) -- identical on both operands, so the result is the plain dot product.
 //   HBM-bound: algorithmic bytes = len*ncols*sizeof(B elt) per launch.
 // ==========================================================================
-template <int EBYTES, int KT, int NSPLIT>
+template <int EBYTES, int KT, int NSPLIT, int MB_, int NSTAGE_, int CW_>
 struct BPCfg {
-    static constexpr int MB = 64;
+    static constexpr int MB = MB_;          // rows per stage
+    static constexpr int CW = CW_;          // 32-column MFMA tiles per wave
     static constexpr int E = 16 / EBYTES;
     static constexpr int CPC = MB / E;      // 16-B chunks per column per stage
     static constexpr int QS = CPC / 2;      // chunk-pair steps per stage
-    static constexpr int NB = 128;
+    static constexpr int NB = 128 * CW;     // columns per workgroup
     static constexpr int B_BYTES = NB * MB * EBYTES;
     static constexpr int X_BYTES = QS * NSPLIT * KT * 1024;
     static constexpr int STAGE_BYTES = B_BYTES + X_BYTES;
-    static constexpr int NSTAGE = 3;
+    static constexpr int NSTAGE = NSTAGE_;
+    static constexpr int PD = NSTAGE_ - 1;          // stages in flight ahead of the consumer
     static constexpr int TI = STAGE_BYTES / 1024;   // wave-level 1-KiB loads per stage
     static constexpr int LPS = TI / 4;              // per wave
     static_assert(TI % 4 == 0, "loads per stage must split evenly over 4 waves");
+    static_assert(LPS * PD <= 63, "vmcnt is a 6-bit counter");
+    static_assert(STAGE_BYTES * NSTAGE <= 160 * 1024, "LDS ring exceeds 160 KiB");
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt()
@@ -214,13 +220,23 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EBYTES, int KT, int NSPLIT>
+// wait until at most `ahead` younger stages (LPS loads each) are still in flight
+template <int LPS, int PD> __device__ __forceinline__ void wait_stage(int ahead)
+{
+    if constexpr (PD >= 4) { if (ahead >= 4) { wait_vmcnt<4 * LPS>(); return; } }
+    if constexpr (PD >= 3) { if (ahead == 3) { wait_vmcnt<3 * LPS>(); return; } }
+    if constexpr (PD >= 2) { if (ahead == 2) { wait_vmcnt<2 * LPS>(); return; } }
+    if (ahead == 1) { wait_vmcnt<LPS>(); return; }
+    wait_vmcnt<0>();
+}
+
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW>
 __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                          const unsigned char* __restrict__ Xp,
                                                          double* __restrict__ P, i64 stages, i64 nst,
                                                          i64 tiles, i64 ncols_pad, int S, int logS)
 {
-    using C = BPCfg<EBYTES, KT, NSPLIT>;
+    using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // ---- XCD-aware block -> (tile, split): all blocks of one split share an XCD's L2
@@ -249,9 +265,9 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
     if (st1 > stages) st1 = stages;
     const int my_nst = (st1 > st0) ? (int)(st1 - st0) : 0;
 
-    // per-lane source offsets for this wave's B loads (constant across stages)
+    // per-lane source offsets for this wave's loads (constant across stages)
     const i64 col0 = tile * C::NB;
-    i64 b_off[C::LPS];     // byte offset of the lane's 16-B chunk relative to stage row 0
+    i64 src_off[C::LPS];
     int is_b[C::LPS];
 #pragma unroll
     for (int i = 0; i < C::LPS; ++i) {
@@ -262,10 +278,10 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
             const int pc = p % C::CPC;
             const int swz = (C::CPC == 8) ? ((j >> 1) & 7) : (j & 15);
             const int lc = pc ^ swz;
-            b_off[i] = (col0 + j) * ldb_bytes + (i64)lc * 16;
+            src_off[i] = (col0 + j) * ldb_bytes + (i64)lc * 16;
             is_b[i] = 1;
         } else {
-            b_off[i] = (i64)(t * 1024 - C::B_BYTES) + lane * 16;   // offset inside the X stage block
+            src_off[i] = (i64)(t * 1024 - C::B_BYTES) + lane * 16;   // offset inside the X stage block
             is_b[i] = 0;
         }
     }
@@ -277,89 +293,106 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
 #pragma unroll
         for (int i = 0; i < C::LPS; ++i) {
             const int t = wave + 4 * i;
-            const unsigned char* g = is_b[i] ? (B + b_off[i] + stage * (C::MB * EBYTES))
-                                             : (Xp + stage * C::X_BYTES + b_off[i]);
+            const unsigned char* g = is_b[i] ? (B + src_off[i] + stage * (C::MB * EBYTES))
+                                             : (Xp + stage * C::X_BYTES + src_off[i]);
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
         }
     };
 
-    // Accumulators.  The leading (hi) term is accumulated in fp32 by the MFMA for ONE stage
-    // (64 rows = 4 dependent MFMAs) and then added into fp64 running sums by the VALU while the
-    // next stage's MFMAs run into the other fp32 set (accA/accB ping-pong): the fp32 rounding
-    // chain never exceeds one stage.  The mid/lo split terms are 2^-8 / 2^-16 smaller and stay
-    // in fp32 for the whole split.
-    f32x16_t accA[KT], accB[KT];
-    f32x16_t accs[NSPLIT > 1 ? NSPLIT - 1 : 1][KT];
-    double dacc[KT][16];
+    // Accumulators.  The leading (hi) term is accumulated in fp32 by the MFMA for ONE stage and
+    // then added into fp64 running sums by the VALU while the next stage's MFMAs run into the
+    // other fp32 set (accA/accB ping-pong): the fp32 rounding chain never exceeds one stage.
+    // The mid/lo split terms are 2^-8 / 2^-16 smaller and stay in fp32 for the whole split.
+    constexpr int NT = CW * KT;                    // 32x32 output tiles per wave
+    constexpr int NS1 = (NSPLIT > 1) ? NSPLIT - 1 : 1;
+    f32x16_t accA[NT], accB[NT];
+    f32x16_t accs[NS1][NT];
+    double dacc[NT][16];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int n = 0; n < NT; ++n) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            accA[kt][r] = 0.f;
-            accB[kt][r] = 0.f;
-            dacc[kt][r] = 0.0;
+            accA[n][r] = 0.f;
+            accB[n][r] = 0.f;
+            dacc[n][r] = 0.0;
 #pragma unroll
-            for (int s = 0; s < (NSPLIT > 1 ? NSPLIT - 1 : 1); ++s) accs[s][kt][r] = 0.f;
+            for (int s = 0; s < NS1; ++s) accs[s][n][r] = 0.f;
         }
     }
 
-    // fragment read addresses
-    const int jl = wave * 32 + (lane & 31);
+    // fragment read addresses: this wave owns columns [wave*32*CW, +32*CW) of the tile
     const int h = lane >> 5;
-    const int swz_r = (C::CPC == 8) ? ((jl >> 1) & 7) : (jl & 15);
-    const int bfrag_base = jl * C::CPC * 16;
-
-    auto flush = [&](f32x16_t (&a)[KT]) {
+    int bfrag_base[CW], swz_r[CW];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+    for (int c = 0; c < CW; ++c) {
+        const int jl = (wave * CW + c) * 32 + (lane & 31);
+        swz_r[c] = (C::CPC == 8) ? ((jl >> 1) & 7) : (jl & 15);
+        bfrag_base[c] = jl * C::CPC * 16;
+    }
+
+    auto flush = [&](f32x16_t (&a)[NT]) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                dacc[kt][r] += (double)a[kt][r];
-                a[kt][r] = 0.f;
+                dacc[n][r] += (double)a[n][r];
+                a[n][r] = 0.f;
             }
     };
 
-    // one stage: wait for its data, release the ring slot two stages ahead, MFMAs into `cur`;
-    // the previous stage's fp32 sums (`prev`) are folded into fp64 right after the first step.
-    auto stage_body = [&](int t, f32x16_t (&cur)[KT], f32x16_t (&prev)[KT], bool flush_prev) {
-        if (t + 1 < my_nst) wait_vmcnt<C::LPS>();
-        else wait_vmcnt<0>();
+    // one stage: wait for its data, refill the ring slot freed by the previous stage, MFMAs into
+    // `cur`; the previous stage's fp32 sums (`prev`) are folded into fp64 after the first step.
+    auto stage_body = [&](int t, f32x16_t (&cur)[NT], f32x16_t (&prev)[NT], bool flush_prev) {
+        int ahead = my_nst - 1 - t;
+        if (ahead > C::PD - 1) ahead = C::PD - 1;
+        wait_stage<C::LPS, C::PD>(ahead);
         __builtin_amdgcn_s_barrier();
-        if (t + 2 < my_nst) issue(t + 2);
+        if (t + C::PD < my_nst) issue(t + C::PD);
 
         const unsigned char* sb = smem + (t % C::NSTAGE) * C::STAGE_BYTES;
         const unsigned char* sx = sb + C::B_BYTES;
 #pragma unroll
         for (int q = 0; q < C::QS; ++q) {
             const int lc = 2 * q + h;
-            const u32x4_t braw = *(const u32x4_t*)(sb + bfrag_base + ((lc ^ swz_r) << 4));
+            u32x4_t braw[CW];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) braw[c] = *(const u32x4_t*)(sb + bfrag_base[c] + ((lc ^ swz_r[c]) << 4));
             if constexpr (EBYTES == 2) {
-                const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, braw);
 #pragma unroll
                 for (int s = 0; s < NSPLIT; ++s)
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
                         const u32x4_t araw = *(const u32x4_t*)(sx + ((q * NSPLIT + s) * KT + kt) * 1024 + lane * 16);
                         const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, araw);
-                        if (s == 0) cur[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, cur[kt], 0, 0, 0);
-                        else accs[s - 1][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, accs[s - 1][kt], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) {
+                            const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, braw[c]);
+                            const int n = c * KT + kt;
+                            if (s == 0) cur[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, cur[n], 0, 0, 0);
+                            else accs[s - 1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, accs[s - 1][n], 0, 0, 0);
+                        }
                     }
             } else {
-                const f32x4_t bfr = __builtin_bit_cast(f32x4_t, braw);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
                     const f32x4_t afr = *(const f32x4_t*)(sx + (q * KT + kt) * 1024 + lane * 16);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        cur[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[e], bfr[e], cur[kt], 0, 0, 0);
+                    for (int c = 0; c < CW; ++c) {
+                        const f32x4_t bfr = __builtin_bit_cast(f32x4_t, braw[c]);
+                        const int n = c * KT + kt;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            cur[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[e], bfr[e], cur[n], 0, 0, 0);
+                    }
                 }
             }
             if (q == 0 && flush_prev) flush(prev);
         }
     };
 
-    if (my_nst > 0) issue(0);
-    if (my_nst > 1) issue(1);
+#pragma unroll
+    for (int i = 0; i < C::PD; ++i)
+        if (i < my_nst) issue(i);
 
     int t = 0;
     for (; t + 1 < my_nst; t += 2) {
@@ -375,27 +408,31 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
 
     // epilogue: fp64 totals (+ the small split terms), stored k-contiguous as doubles.
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    const i64 jg = col0 + jl;
-    double* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32);
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int c = 0; c < CW; ++c) {
+        const i64 jg = col0 + (wave * CW + c) * 32 + (lane & 31);
+        double* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int kt = 0; kt < KT; ++kt) {
+            const int n = c * KT + kt;
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                f64x2_t v;
+            for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    double tsum = dacc[kt][4 * g + i + u];
-                    if constexpr (NSPLIT > 1) {
-                        float small = accs[NSPLIT - 2][kt][4 * g + i + u];
+                for (int i = 0; i < 4; i += 2) {
+                    f64x2_t v;
 #pragma unroll
-                        for (int s = NSPLIT - 3; s >= 0; --s) small += accs[s][kt][4 * g + i + u];
-                        tsum += (double)small;
+                    for (int u = 0; u < 2; ++u) {
+                        double tsum = dacc[n][4 * g + i + u];
+                        if constexpr (NSPLIT > 1) {
+                            float small = accs[NSPLIT - 2][n][4 * g + i + u];
+#pragma unroll
+                            for (int s = NSPLIT - 3; s >= 0; --s) small += accs[s][n][4 * g + i + u];
+                            tsum += (double)small;
+                        }
+                        v[u] = tsum;
                     }
-                    v[u] = tsum;
+                    *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
                 }
-                *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
             }
         }
     }
@@ -405,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
 // out layout: [q][s][kt][lane = (r, h)][16 B], chunk = 2q + h covers rows chunk*E .. +E-1,
 // r = k index inside tile kt.  bf16: hi = bf16(x), mid = bf16(x-hi), lo = bf16(x-hi-mid).
 template <int EBYTES, int NSPLIT>
-__global__ __launch_bounds__(256) void pack_kernel(const double* __restrict__ X, int k, i64 N, int KT, i64 nq,
+__global__ __launch_bounds__(256) void pack_kernel(const double* __restrict__ X, int k, int ldx, i64 N, int KT, i64 nq,
                                                    unsigned char* __restrict__ out)
 {
     constexpr int E = 16 / EBYTES;
@@ -421,7 +458,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const double* __restrict__ X,
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const i64 row = row0 + e;
-        v[e] = (row < N && r < k) ? X[row * k + r] : 0.0;
+        v[e] = (row < N && r < k) ? X[row * ldx + r] : 0.0;
     }
     if constexpr (EBYTES == 2) {
         double res[E];
@@ -448,12 +485,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const double* __restrict__ X,
     }
 }
 
+// The packed operand layout does not depend on the stage height: it is a sequence of 1-KiB
+// blocks indexed by the global chunk-pair q; rows are padded to a multiple of 128.
 static inline i64 pack_nq(int storage, i64 N)
 {
-    const i64 MB = 64;
     const i64 E = storage == STORE_BF16 ? 8 : 4;
-    i64 stages = (N + MB - 1) / MB;
-    return stages * (MB / E / 2);
+    return round_up(N, ROW_PAD) / (2 * E);
 }
 
 size_t packed_bytes(int storage, int k, i64 N, int nsplit)
@@ -470,15 +507,29 @@ int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* ou
     const int grid = (int)((threads + 255) / 256);
     if (grid == 0) return 0;
     if (storage == STORE_BF16) {
-        if (nsplit == 3) pack_kernel<2, 3><<<grid, 256, 0, st>>>(X, k, N, KT, nq, (unsigned char*)out);
-        else if (nsplit == 2) pack_kernel<2, 2><<<grid, 256, 0, st>>>(X, k, N, KT, nq, (unsigned char*)out);
-        else pack_kernel<2, 1><<<grid, 256, 0, st>>>(X, k, N, KT, nq, (unsigned char*)out);
+        if (nsplit == 3) pack_kernel<2, 3><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
+        else if (nsplit == 2) pack_kernel<2, 2><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
+        else pack_kernel<2, 1><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
     } else {
-        pack_kernel<4, 1><<<grid, 256, 0, st>>>(X, k, N, KT, nq, (unsigned char*)out);
+        pack_kernel<4, 1><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
     }
     SMK_HIP(hipGetLastError());
     return 0;
 }
+
+constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw);
+// ---- kernel variants (tile shape / pipeline depth); chosen per plan, SMK_BP_VARIANT overrides ----
+struct BPVariant { int mb, nstage, cw; };
+static const BPVariant kVariants[] = {
+    {64, 3, 1},    // 0: 128 cols x 64 rows, 3-deep ring
+    {64, 4, 1},    // 1
+    {64, 5, 1},    // 2
+    {128, 2, 1},   // 3
+    {128, 3, 1},   // 4 (bf16 only: LDS)
+    {64, 3, 2},    // 5: 256 cols per workgroup
+    {64, 2, 1},    // 6
+};
+static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
 BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus)
 {
@@ -486,25 +537,36 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     pl.storage = storage;
     pl.kt = kt_of(k);
     pl.nsplit = storage == STORE_BF16 ? nsplit : 1;
-    pl.stages = (len + 63) / 64;
-    pl.tiles = (ncols + 127) / 128;
-    pl.ncols_pad = pl.tiles * 128;
+    int v = 6;   // measured best on MI355X (C3: 5.98 TB/s): 2 workgroups per CU beat a deeper ring
+    const char* env = getenv("SMK_BP_VARIANT");
+    if (env) v = atoi(env);
+    if (v < 0 || v >= kNumVariants) v = 6;
+    // variants that do not fit the 160 KiB LDS for this dtype / k fall back to variant 0
+    if (!bp_fits(storage == STORE_BF16 ? 2 : 4, pl.kt, pl.nsplit, kVariants[v].mb, kVariants[v].nstage, kVariants[v].cw)) v = 0;
+    pl.variant = v;
+    const int MB = kVariants[v].mb;
+    const int NB = 128 * kVariants[v].cw;
+    pl.stages = (len + MB - 1) / MB;
+    pl.tiles = (ncols + NB - 1) / NB;
+    pl.ncols_pad = round_up(ncols, COL_PAD);
     // enough workgroups for >= 4 rounds over the CUs, but keep >= 8 stages per split
     int S = 1;
-    while (pl.tiles * S < 4 * (i64)num_cus && S < 64 && pl.stages / (2 * S) >= 8) S *= 2;
+    while (pl.tiles * S < 2 * (i64)num_cus && S < 64 && pl.stages / (2 * S) >= 8) S *= 2;
+    const char* envS = getenv("SMK_BP_SPLITS");
+    if (envS && atoi(envS) > 0) { S = 1; while (S < atoi(envS) && S < 64) S *= 2; }
     pl.S = S;
     pl.nst = (pl.stages + S - 1) / S;
     pl.p_elems = (size_t)S * pl.ncols_pad * pl.kt * 32;   // doubles
     return pl;
 }
 
-template <int EBYTES, int KT, int NSPLIT>
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW>
 static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
-    using C = BPCfg<EBYTES, KT, NSPLIT>;
+    using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW>;
     constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
     static bool attr_set = false;
-    auto kern = bigprod_kernel<EBYTES, KT, NSPLIT>;
+    auto kern = bigprod_kernel<EBYTES, KT, NSPLIT, MB, NSTAGE, CW>;
     if (!attr_set) {
         SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -524,21 +586,55 @@ static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const
     return 0;
 }
 
+constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw)
+{
+    const int cpc = mb / (16 / ebytes);
+    const int stage = 128 * cw * mb * ebytes + (cpc / 2) * nsplit * kt * 1024;
+    const int ti = stage / 1024;
+    return (ti % 4 == 0) && (ti / 4 * (nstage - 1) <= 63) && (stage * nstage <= 160 * 1024);
+}
+
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW>
+static int launch_bigprod_if(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
+{
+    if constexpr (bp_fits(EBYTES, KT, NSPLIT, MB, NSTAGE, CW))
+        return launch_bigprod_t<EBYTES, KT, NSPLIT, MB, NSTAGE, CW>(pl, B, ldb, Xp, P, st);
+    else {
+        set_error("bigprod variant does not fit LDS");
+        return -100;
+    }
+}
+
+template <int EBYTES, int KT, int NSPLIT>
+static int launch_bigprod_v(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
+{
+    switch (pl.variant) {
+        case 1: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 4, 1>(pl, B, ldb, Xp, P, st);
+        case 2: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 5, 1>(pl, B, ldb, Xp, P, st);
+        case 3: return launch_bigprod_if<EBYTES, KT, NSPLIT, 128, 2, 1>(pl, B, ldb, Xp, P, st);
+        case 4: return launch_bigprod_if<EBYTES, KT, NSPLIT, 128, 3, 1>(pl, B, ldb, Xp, P, st);
+        case 5: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 2>(pl, B, ldb, Xp, P, st);
+        case 6: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 2, 1>(pl, B, ldb, Xp, P, st);
+        default: break;
+    }
+    return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 1>(pl, B, ldb, Xp, P, st);
+}
+
 int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
     if (pl.storage == STORE_BF16) {
         if (pl.kt == 1) {
-            if (pl.nsplit == 3) return launch_bigprod_t<2, 1, 3>(pl, B, ldb, Xp, P, st);
-            if (pl.nsplit == 2) return launch_bigprod_t<2, 1, 2>(pl, B, ldb, Xp, P, st);
-            return launch_bigprod_t<2, 1, 1>(pl, B, ldb, Xp, P, st);
+            if (pl.nsplit == 3) return launch_bigprod_v<2, 1, 3>(pl, B, ldb, Xp, P, st);
+            if (pl.nsplit == 2) return launch_bigprod_v<2, 1, 2>(pl, B, ldb, Xp, P, st);
+            return launch_bigprod_v<2, 1, 1>(pl, B, ldb, Xp, P, st);
         } else {
-            if (pl.nsplit == 3) return launch_bigprod_t<2, 2, 3>(pl, B, ldb, Xp, P, st);
-            if (pl.nsplit == 2) return launch_bigprod_t<2, 2, 2>(pl, B, ldb, Xp, P, st);
-            return launch_bigprod_t<2, 2, 1>(pl, B, ldb, Xp, P, st);
+            if (pl.nsplit == 3) return launch_bigprod_v<2, 2, 3>(pl, B, ldb, Xp, P, st);
+            if (pl.nsplit == 2) return launch_bigprod_v<2, 2, 2>(pl, B, ldb, Xp, P, st);
+            return launch_bigprod_v<2, 2, 1>(pl, B, ldb, Xp, P, st);
         }
     } else {
-        if (pl.kt == 1) return launch_bigprod_t<4, 1, 1>(pl, B, ldb, Xp, P, st);
-        return launch_bigprod_t<4, 2, 1>(pl, B, ldb, Xp, P, st);
+        if (pl.kt == 1) return launch_bigprod_v<4, 1, 1>(pl, B, ldb, Xp, P, st);
+        return launch_bigprod_v<4, 2, 1>(pl, B, ldb, Xp, P, st);
     }
 }
 
@@ -564,131 +660,62 @@ int launch_reduce_partials(PartialView pv, int k, i64 N, float* out, hipStream_t
 }
 
 // ==========================================================================
-// Gram matrix  G(KP x KP, ld KP) = X X'   (X: k x N fp64), deterministic two stage
+// Layout of the factor-side matrices: fp64, column-major KP x N with leading
+// dimension KP (k padded to 8/16/32/64, pad rows are zero and stay zero).
+// "Column tile" kernels give each column to LPC = KP/4 adjacent lanes, 4
+// consecutive values (32 B) per lane, so a wave reads 2 KiB contiguous.
+// Dot products over the column are summed across the lane group with DPP
+// moves (no LDS traffic).
 // ==========================================================================
-template <int KP>
-__global__ __launch_bounds__(256) void gram_partial_kernel(const double* __restrict__ X, int k, i64 N,
-                                                           i64 cols_per_block, double* __restrict__ Gp)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
 {
-    constexpr int CB = 32;                       // columns per LDS chunk
-    constexpr int T = (KP >= 16) ? KP / 16 : 1;  // per-thread tile edge
-    constexpr int GRID = (KP >= 16) ? 16 : KP;   // threads per tile edge
-    __shared__ double xs[CB][KP + 1];
-    const int tid = threadIdx.x;
-    const int ti = tid / GRID, tj = tid % GRID;
-    const bool active = tid < GRID * GRID;
-    double acc[T][T];
-#pragma unroll
-    for (int a = 0; a < T; ++a)
-#pragma unroll
-        for (int b = 0; b < T; ++b) acc[a][b] = 0.0;
-
-    const i64 c_begin = (i64)blockIdx.x * cols_per_block;
-    i64 c_end = c_begin + cols_per_block;
-    if (c_end > N) c_end = N;
-    for (i64 c0 = c_begin; c0 < c_end; c0 += CB) {
-        const int nc = (int)((c_end - c0 < CB) ? (c_end - c0) : CB);
-        // coalesced: the chunk is nc*k contiguous doubles
-        for (int idx = tid; idx < CB * KP; idx += 256) {
-            const int cc = idx / KP, r = idx % KP;
-            double v = 0.0;
-            if (cc < nc && r < k) v = X[(c0 + cc) * k + r];
-            xs[cc][r] = v;
-        }
-        __syncthreads();
-        if (active) {
-#pragma unroll 4
-            for (int cc = 0; cc < CB; ++cc) {
-                double xa[T], xb[T];
-#pragma unroll
-                for (int a = 0; a < T; ++a) xa[a] = xs[cc][ti * T + a];
-#pragma unroll
-                for (int b = 0; b < T; ++b) xb[b] = xs[cc][tj * T + b];
-#pragma unroll
-                for (int a = 0; a < T; ++a)
-#pragma unroll
-                    for (int b = 0; b < T; ++b) acc[a][b] += xa[a] * xb[b];
-            }
-        }
-        __syncthreads();
-    }
-    if (active) {
-        double* out = Gp + (i64)blockIdx.x * KP * KP;
-#pragma unroll
-        for (int a = 0; a < T; ++a)
-#pragma unroll
-            for (int b = 0; b < T; ++b) out[(tj * T + b) * KP + (ti * T + a)] = acc[a][b];
-    }
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ Gp, int nblk, int elems,
-                                                          double* __restrict__ G)
+// sum over the LPC (2/4/8/16) adjacent lanes of a group; every lane gets the total
+template <int LPC>
+__device__ __forceinline__ double group_sum(double v)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= elems) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += Gp[(i64)b * elems + i];
-    G[i] = s;
+    if constexpr (LPC >= 2) v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    if constexpr (LPC >= 4) v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    if constexpr (LPC >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
+    if constexpr (LPC >= 16) v += dpp_f64<0x140>(v);  // row_mirror
+    return v;
 }
 
-size_t gram_scratch_elems(int k, int max_blocks)
+// the 4 values of column j owned by sub-lane s
+__device__ __forceinline__ void load4(const double* __restrict__ p, double (&x)[4])
 {
-    int KP = kp_of(k);
-    return (size_t)max_blocks * KP * KP;
+    const f64x2_t a = *(const f64x2_t*)p, b = *(const f64x2_t*)(p + 2);
+    x[0] = a[0]; x[1] = a[1]; x[2] = b[0]; x[3] = b[1];
+}
+__device__ __forceinline__ void store4(double* __restrict__ p, const double (&x)[4])
+{
+    f64x2_t a, b;
+    a[0] = x[0]; a[1] = x[1]; b[0] = x[2]; b[1] = x[3];
+    *(f64x2_t*)p = a;
+    *(f64x2_t*)(p + 2) = b;
 }
 
-int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, hipStream_t st)
+// the same 4 entries of the summed partial product (zero beyond kpp)
+__device__ __forceinline__ void load_rhs4(const PartialView& R, i64 j, int e0, double (&b)[4])
 {
-    const int KP = kp_of(k);
-    int nblk = (int)((N + 127) / 128);
-    if (nblk > max_blocks) nblk = max_blocks;
-    if (nblk < 1) nblk = 1;
-    i64 cpb = (N + nblk - 1) / nblk;
-    cpb = (cpb + 31) / 32 * 32;
-    nblk = (int)((N + cpb - 1) / cpb);
-    if (nblk < 1) nblk = 1;
-    switch (KP) {
-        case 8: gram_partial_kernel<8><<<nblk, 256, 0, st>>>(X, k, N, cpb, scratch); break;
-        case 16: gram_partial_kernel<16><<<nblk, 256, 0, st>>>(X, k, N, cpb, scratch); break;
-        case 32: gram_partial_kernel<32><<<nblk, 256, 0, st>>>(X, k, N, cpb, scratch); break;
-        default: gram_partial_kernel<64><<<nblk, 256, 0, st>>>(X, k, N, cpb, scratch); break;
-    }
-    SMK_HIP(hipGetLastError());
-    const int elems = KP * KP;
-    gram_reduce_kernel<<<(elems + 255) / 256, 256, 0, st>>>(scratch, nblk, elems, G);
-    SMK_HIP(hipGetLastError());
-    return 0;
-}
-
-// ==========================================================================
-// column-per-thread helpers
-// ==========================================================================
-template <int KP>
-__device__ __forceinline__ void load_col(const double* __restrict__ X, int k, i64 j, double (&x)[KP])
-{
-    const double* p = X + j * k;
-#pragma unroll
-    for (int r = 0; r < KP; ++r) x[r] = (r < k) ? p[r] : 0.0;
-}
-
-template <int KP>
-__device__ __forceinline__ void load_rhs(const PartialView& R, int k, i64 j, double (&b)[KP])
-{
-#pragma unroll
-    for (int r = 0; r < KP; ++r) b[r] = 0.0;
+    b[0] = b[1] = b[2] = b[3] = 0.0;
+    if (e0 >= R.kpp) return;
     if (R.f64) {
         for (int s = 0; s < R.S; ++s) {
-            const double* p = (const double*)R.p + s * R.slab + j * R.kpp;
-#pragma unroll
-            for (int r = 0; r < KP; ++r)
-                if (r < k) b[r] += p[r];
+            double t[4];
+            load4((const double*)R.p + s * R.slab + j * R.kpp + e0, t);
+            b[0] += t[0]; b[1] += t[1]; b[2] += t[2]; b[3] += t[3];
         }
     } else {
         for (int s = 0; s < R.S; ++s) {
-            const float* p = (const float*)R.p + s * R.slab + j * R.kpp;
-#pragma unroll
-            for (int r = 0; r < KP; ++r)
-                if (r < k) b[r] += (double)p[r];
+            const f32x4_t t = *(const f32x4_t*)((const float*)R.p + s * R.slab + j * R.kpp + e0);
+            b[0] += (double)t[0]; b[1] += (double)t[1]; b[2] += (double)t[2]; b[3] += (double)t[3];
         }
     }
 }
@@ -742,29 +769,150 @@ __global__ void sum_partials_kernel(const double* __restrict__ partials, int n, 
     if (threadIdx.x == 0) *out = t;
 }
 
+// ==========================================================================
+// Gram matrix  G(KP x KP, ld KP) = X X'   (X: KP x N fp64), deterministic two stage
+// ==========================================================================
+template <int KP>
+__global__ __launch_bounds__(256) void gram_partial_kernel(const double* __restrict__ X, i64 N,
+                                                           i64 cols_per_block, double* __restrict__ Gp)
+{
+    constexpr int CB = 32;                       // columns per LDS chunk
+    constexpr int T = (KP >= 16) ? KP / 16 : 1;  // per-thread tile edge
+    constexpr int GRID = (KP >= 16) ? 16 : KP;   // threads per tile edge
+    __shared__ double xs[CB][KP + 1];
+    const int tid = threadIdx.x;
+    const int ti = tid / GRID, tj = tid % GRID;
+    const bool active = tid < GRID * GRID;
+    double acc[T][T];
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b) acc[a][b] = 0.0;
+
+    const i64 c_begin = (i64)blockIdx.x * cols_per_block;
+    i64 c_end = c_begin + cols_per_block;
+    if (c_end > N) c_end = N;
+    for (i64 c0 = c_begin; c0 < c_end; c0 += CB) {
+        const int nc = (int)((c_end - c0 < CB) ? (c_end - c0) : CB);
+        // coalesced: the chunk is nc*KP contiguous doubles
+        for (int idx = tid; idx < CB * KP; idx += 256) {
+            const int cc = idx / KP, r = idx % KP;
+            xs[cc][r] = (cc < nc) ? X[(c0 + cc) * KP + r] : 0.0;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll 4
+            for (int cc = 0; cc < CB; ++cc) {
+                double xa[T], xb[T];
+#pragma unroll
+                for (int a = 0; a < T; ++a) xa[a] = xs[cc][ti * T + a];
+#pragma unroll
+                for (int b = 0; b < T; ++b) xb[b] = xs[cc][tj * T + b];
+#pragma unroll
+                for (int a = 0; a < T; ++a)
+#pragma unroll
+                    for (int b = 0; b < T; ++b) acc[a][b] += xa[a] * xb[b];
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        double* out = Gp + (i64)blockIdx.x * KP * KP;
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+            for (int b = 0; b < T; ++b) out[(tj * T + b) * KP + (ti * T + a)] = acc[a][b];
+    }
+}
+
+// G[e] = sum_b Gp[b][e]: 64 elements per block, 4 thread groups stride the partials, fixed order
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ Gp, int nblk, int elems,
+                                                          double* __restrict__ G)
+{
+    __shared__ double sh[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    double s = 0.0;
+    if (e < elems)
+        for (int b = g; b < nblk; b += 4) s += Gp[(i64)b * elems + e];
+    sh[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && e < elems) G[e] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+size_t gram_scratch_elems(int k, int max_blocks)
+{
+    int KP = kp_of(k);
+    return (size_t)max_blocks * KP * KP;
+}
+
+int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, hipStream_t st)
+{
+    const int KP = kp_of(k);
+    int nblk = (int)((N + 127) / 128);
+    if (nblk > max_blocks) nblk = max_blocks;
+    if (nblk < 1) nblk = 1;
+    i64 cpb = (N + nblk - 1) / nblk;
+    cpb = (cpb + 31) / 32 * 32;
+    nblk = (int)((N + cpb - 1) / cpb);
+    if (nblk < 1) nblk = 1;
+    switch (KP) {
+        case 8: gram_partial_kernel<8><<<nblk, 256, 0, st>>>(X, N, cpb, scratch); break;
+        case 16: gram_partial_kernel<16><<<nblk, 256, 0, st>>>(X, N, cpb, scratch); break;
+        case 32: gram_partial_kernel<32><<<nblk, 256, 0, st>>>(X, N, cpb, scratch); break;
+        default: gram_partial_kernel<64><<<nblk, 256, 0, st>>>(X, N, cpb, scratch); break;
+    }
+    SMK_HIP(hipGetLastError());
+    const int elems = KP * KP;
+    gram_reduce_kernel<<<(elems + 63) / 64, 256, 0, st>>>(scratch, nblk, elems, G);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ==========================================================================
+// column-tile kernels.  Thread (column j, sub-lane s) owns X[4s..4s+3, j].
+// G is symmetric, so row r of G at "my" columns is gs[r*KP + 4s .. +3]: one
+// 32-byte LDS read, identical addresses across the columns of a wave.
+// ==========================================================================
+#define COLTILE_PROLOGUE(KP)                                                          \
+    constexpr int LPC = KP / 4;                                                       \
+    __shared__ __attribute__((aligned(16))) double gs[KP * KP];                       \
+    for (int i_ = threadIdx.x; i_ < KP * KP; i_ += blockDim.x) gs[i_] = G[i_];        \
+    __syncthreads();                                                                  \
+    const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;                      \
+    const i64 j = gtid / LPC;                                                         \
+    const int s = (int)(gtid % LPC);                                                  \
+    const bool valid = j < N;                                                         \
+    const i64 jc = valid ? j : (N - 1);
+
+template <int KP>
+__device__ __forceinline__ double dot_row(const double* gs, int r, int s, const double (&x)[4])
+{
+    double g[4];
+    load4(gs + r * KP + 4 * s, g);
+    return (g[0] * x[0] + g[1] * x[1]) + (g[2] * x[2] + g[3] * x[3]);
+}
+
 // ---- MU: x <- x .* R ./ (G x + 1e-13)      (nmf_solver_mu.hpp:22, :27-71) -------------
 template <int KP>
 __global__ __launch_bounds__(256) void mu_update_kernel(double* __restrict__ X, int k, i64 N, PartialView R,
                                                         const double* __restrict__ G)
 {
-    __shared__ double gs[KP * KP];
-    for (int i = threadIdx.x; i < KP * KP; i += blockDim.x) gs[i] = G[i];
-    __syncthreads();
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    double x[KP], b[KP];
-    load_col<KP>(X, k, j, x);
-    load_rhs<KP>(R, k, j, b);
-    double* px = X + j * k;
+    COLTILE_PROLOGUE(KP)
+    double x[4], b[4], d[4] = {0, 0, 0, 0};
+    load4(X + jc * KP + 4 * s, x);
+    load_rhs4(R, jc, 4 * s, b);
 #pragma unroll
     for (int r = 0; r < KP; ++r) {
         if (r < k) {
-            double acc = 0.0;
-#pragma unroll
-            for (int q = 0; q < KP; ++q) acc += gs[q * KP + r] * x[q];
-            px[r] = x[r] * (b[r] / (acc + 1.0e-13));
+            const double dot = group_sum<LPC>(dot_row<KP>(gs, r, s, x));
+            if (s == r / 4) d[r % 4] = dot;
         }
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (4 * s + e < k) x[e] = x[e] * (b[e] / (d[e] + 1.0e-13));
+    if (valid) store4(X + j * KP + 4 * s, x);
 }
 
 // ---- HALS H sweep: rows r = 0..k-1 in order, Gauss-Seidel inside the column ----------
@@ -773,29 +921,22 @@ template <int KP>
 __global__ __launch_bounds__(256) void hals_sweep_kernel(double* __restrict__ X, int k, i64 N, PartialView R,
                                                          const double* __restrict__ G)
 {
-    __shared__ double gs[KP * KP];
-    for (int i = threadIdx.x; i < KP * KP; i += blockDim.x) gs[i] = G[i];
-    __syncthreads();
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    double x[KP], b[KP];
-    load_col<KP>(X, k, j, x);
-    load_rhs<KP>(R, k, j, b);
+    COLTILE_PROLOGUE(KP)
+    double x[4], b[4];
+    load4(X + jc * KP + 4 * s, x);
+    load_rhs4(R, jc, 4 * s, b);
 #pragma unroll
     for (int r = 0; r < KP; ++r) {
         if (r < k) {
-            double acc = 0.0;
-#pragma unroll
-            for (int q = 0; q < KP; ++q) acc += gs[q * KP + r] * x[q];
-            double v = x[r] + (b[r] - acc) / gs[r * KP + r];
-            if (isnan(v) || v < 0.0) v = 0.0;
-            x[r] = v;
+            const double dot = group_sum<LPC>(dot_row<KP>(gs, r, s, x));
+            if (s == r / 4) {
+                double v = x[r % 4] + (b[r % 4] - dot) / gs[r * KP + r];
+                if (isnan(v) || v < 0.0) v = 0.0;
+                x[r % 4] = v;
+            }
         }
     }
-    double* px = X + j * k;
-#pragma unroll
-    for (int r = 0; r < KP; ++r)
-        if (r < k) px[r] = x[r];
+    if (valid) store4(X + j * KP + 4 * s, x);
 }
 
 // ---- gradient g = G x - R, projected-gradient partial sums ---------------------------
@@ -805,27 +946,24 @@ __global__ __launch_bounds__(256) void grad_pg_kernel(const double* __restrict__
                                                       const double* __restrict__ G, double* __restrict__ grad_out,
                                                       double* __restrict__ partials)
 {
-    __shared__ double gs[KP * KP];
     __shared__ double sh[16];
-    for (int i = threadIdx.x; i < KP * KP; i += blockDim.x) gs[i] = G[i];
-    __syncthreads();
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    double sum = 0.0;
-    if (j < N) {
-        double x[KP], b[KP];
-        load_col<KP>(X, k, j, x);
-        load_rhs<KP>(R, k, j, b);
+    COLTILE_PROLOGUE(KP)
+    double x[4], b[4], g[4] = {0, 0, 0, 0};
+    load4(X + jc * KP + 4 * s, x);
+    load_rhs4(R, jc, 4 * s, b);
 #pragma unroll
-        for (int r = 0; r < KP; ++r) {
-            if (r < k) {
-                double acc = 0.0;
-#pragma unroll
-                for (int q = 0; q < KP; ++q) acc += gs[q * KP + r] * x[q];
-                const double g = acc - b[r];
-                if (grad_out) grad_out[j * k + r] = g;
-                if (g < 0.0 || x[r] > 0.0) sum += g * g;
-            }
+    for (int r = 0; r < KP; ++r) {
+        if (r < k) {
+            const double dot = group_sum<LPC>(dot_row<KP>(gs, r, s, x));
+            if (s == r / 4) g[r % 4] = dot - b[r % 4];
         }
+    }
+    double sum = 0.0;
+    if (valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * s + e < k && (g[e] < 0.0 || x[e] > 0.0)) sum += g[e] * g[e];
+        if (grad_out) store4(grad_out + j * KP + 4 * s, g);
     }
     const double t = block_sum(sum, sh);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
@@ -852,18 +990,20 @@ __global__ __launch_bounds__(256) void pg_from_grad_kernel(const double* __restr
         default: { constexpr int KP = 64; CALL; } break; \
     }
 
+static inline int coltile_grid(int KP, i64 N) { return (int)((N * (KP / 4) + 255) / 256); }
+
 int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st)
 {
-    const int grid = (int)((N + 255) / 256);
-    KP_DISPATCH(kp_of(k), (mu_update_kernel<KP><<<grid, 256, 0, st>>>(X, k, N, R, G)));
+    const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
+    KP_DISPATCH(KPv, (mu_update_kernel<KP><<<grid, 256, 0, st>>>(X, k, N, R, G)));
     SMK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st)
 {
-    const int grid = (int)((N + 255) / 256);
-    KP_DISPATCH(kp_of(k), (hals_sweep_kernel<KP><<<grid, 256, 0, st>>>(X, k, N, R, G)));
+    const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
+    KP_DISPATCH(KPv, (hals_sweep_kernel<KP><<<grid, 256, 0, st>>>(X, k, N, R, G)));
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -871,8 +1011,8 @@ int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, h
 int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
                    double* pg_partials, double* pg_accum, int slot, hipStream_t st)
 {
-    const int grid = (int)((N + 255) / 256);
-    KP_DISPATCH(kp_of(k), (grad_pg_kernel<KP><<<grid, 256, 0, st>>>(X, k, N, R, G, grad_out, pg_partials)));
+    const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
+    KP_DISPATCH(KPv, (grad_pg_kernel<KP><<<grid, 256, 0, st>>>(X, k, N, R, G, grad_out, pg_partials)));
     SMK_HIP(hipGetLastError());
     sum_partials_kernel<<<1, 256, 0, st>>>(pg_partials, grid, pg_accum + slot);
     SMK_HIP(hipGetLastError());
@@ -882,7 +1022,7 @@ int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G
 int launch_pg_from_grad(const double* X, const double* Y, int k, i64 N, double* pg_partials, double* pg_accum,
                         int slot, hipStream_t st)
 {
-    const i64 count = N * k;
+    const i64 count = N * kp_of(k);
     int grid = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
     if (grid < 1) grid = 1;
     pg_from_grad_kernel<<<grid, 256, 0, st>>>(X, Y, count, pg_partials);
@@ -893,25 +1033,71 @@ int launch_pg_from_grad(const double* X, const double* Y, int k, i64 N, double* 
 }
 
 // ==========================================================================
-// HALS W update (nmf_solver_hals.hpp:66-117) on Wt (k x M): one launch per
+// HALS W update (nmf_solver_hals.hpp:66-117) on Wt (KP x M): one launch per
 // column c (k sequential grid-wide reductions are inherent: column c's L2 norm
-// feeds every later column).  Kernel c first applies the pending normalisation
-// of column c-1, then updates column c un-normalised and emits per-block
-// partial sums of squares / zero counts; kernel boundaries are the grid sync.
+// feeds every later column; a dependent kernel boundary, ~1.5 us, is the
+// cheapest grid-wide sync on this chip).  Kernel c first applies the pending
+// normalisation of column c-1, then updates column c un-normalised and emits
+// per-block partial sums of squares / zero counts.
 //   scratch: ss[k][nblk], nz[k][nblk]
 // ==========================================================================
-template <int KP>
-__global__ __launch_bounds__(256) void hals_w_col_kernel(double* __restrict__ Wt, int k, i64 M, PartialView R,
-                                                         const double* __restrict__ G, int c, int nblk,
-                                                         double* __restrict__ ss, double* __restrict__ nz)
+// two block-wide sums at once (1024-thread blocks); results broadcast to every thread
+__device__ __forceinline__ void block_sum2_bcast(double& a, double& b, double* sh /* >= 34 doubles */)
 {
-    __shared__ double sh[16];
-    __shared__ double gcol[KP];
-    if (threadIdx.x < KP) gcol[threadIdx.x] = (c < k) ? G[c * KP + threadIdx.x] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) { sh[w] = a; sh[16 + w] = b; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+    for (int i = 0; i < nw; ++i) { ta += sh[i]; tb += sh[16 + i]; }     // same order in every thread
+    __syncthreads();
+    a = ta;
+    b = tb;
+}
+
+template <int KP>
+__global__ __launch_bounds__(1024) void hals_w_col_kernel(double* __restrict__ Wt, int k, i64 M, PartialView R,
+                                                          const double* __restrict__ G, int c, int nblk,
+                                                          double* __restrict__ ss, double* __restrict__ nz)
+{
+    constexpr int LPC = KP / 4;
+    constexpr int RPB = 1024 / LPC;                // rows per block pass
+    __shared__ double sh[34];
+    const int s = threadIdx.x % LPC;
+    const int own_c = (c < k && s == c / 4) ? (c % 4) : -1;            // which of my 4 slots is column c
+    const int own_p = (c > 0 && s == (c - 1) / 4) ? ((c - 1) % 4) : -1;
+    const i64 rows_per_block = (M + nblk - 1) / nblk;
+    const i64 r_begin = (i64)blockIdx.x * rows_per_block;
+    i64 r_end = r_begin + rows_per_block;
+    if (r_end > M) r_end = M;
+
+    // ---- issue every load of the first pass before touching the previous column's norm
+    i64 i = r_begin + threadIdx.x / LPC;
+    bool valid = i < r_end;
+    i64 ic = valid ? i : (r_end > r_begin ? r_end - 1 : 0);
+    double w[4], gc[4] = {0, 0, 0, 0};
+    double gcc = 1.0, rhs = 0.0;
+    load4(Wt + ic * KP + 4 * s, w);
+    if (c < k) {
+        load4(G + (i64)c * KP + 4 * s, gc);         // HHt(4s.., c) (symmetric)
+        gcc = G[(i64)c * KP + c];
+        if (own_c >= 0) rhs = rhs_elem(R, ic, c);
+    }
+
+    // ---- norm of the previous column from the per-block partials of the previous launch
     double scale_prev = 1.0, fill_prev = -1.0;
     if (c > 0) {
-        const double s2 = block_sum_array(ss + (i64)(c - 1) * nblk, nblk, sh);
-        const double zc = block_sum_array(nz + (i64)(c - 1) * nblk, nblk, sh);
+        double s2 = 0.0, zc = 0.0;
+        for (int t = threadIdx.x; t < nblk; t += blockDim.x) {
+            s2 += ss[(i64)(c - 1) * nblk + t];
+            zc += nz[(i64)(c - 1) * nblk + t];
+        }
+        block_sum2_bcast(s2, zc, sh);
         if (zc >= (double)M) {                      // all-zero column guard (:105-111)
             const double eps = DBL_EPSILON;
             const double nrm = sqrt((double)M * eps * eps);
@@ -920,62 +1106,229 @@ __global__ __launch_bounds__(256) void hals_w_col_kernel(double* __restrict__ Wt
             scale_prev = 1.0 / sqrt(s2);
         }
     }
-    __syncthreads();
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+
     double v2 = 0.0, zero = 0.0;
-    if (i < M) {
-        double w[KP];
-        load_col<KP>(Wt, k, i, w);
-        double* pw = Wt + i * k;
-        if (c > 0) {
-            double wp = 0.0;
+    for (i64 i0 = r_begin; i0 < r_end; i0 += RPB) {
+        if (i0 != r_begin) {                        // later passes (M > nblk * RPB)
+            i = i0 + threadIdx.x / LPC;
+            valid = i < r_end;
+            ic = valid ? i : (r_end - 1);
+            load4(Wt + ic * KP + 4 * s, w);
+            if (own_c >= 0) rhs = rhs_elem(R, ic, c);
+        }
+        double* pw = Wt + ic * KP + 4 * s;
+        if (own_p >= 0) {
 #pragma unroll
-            for (int r = 0; r < KP; ++r)
-                if (r == c - 1) wp = w[r];
-            wp = (fill_prev >= 0.0) ? fill_prev : wp * scale_prev;
-#pragma unroll
-            for (int r = 0; r < KP; ++r)
-                if (r == c - 1) w[r] = wp;
-            pw[c - 1] = wp;
+            for (int e = 0; e < 4; ++e)
+                if (e == own_p) {
+                    w[e] = (fill_prev >= 0.0) ? fill_prev : w[e] * scale_prev;
+                    if (valid) pw[e] = w[e];
+                }
         }
         if (c < k) {
-            double acc = 0.0, wc = 0.0;
+            const double dot = group_sum<LPC>((gc[0] * w[0] + gc[1] * w[1]) + (gc[2] * w[2] + gc[3] * w[3]));
+            if (own_c >= 0 && valid) {
+                double wc = 0.0;
 #pragma unroll
-            for (int r = 0; r < KP; ++r) {
-                acc += w[r] * gcol[r];
-                if (r == c) wc = w[r];
+                for (int e = 0; e < 4; ++e)
+                    if (e == own_c) wc = w[e];
+                double v = wc + (rhs - dot) / gcc;
+                if (isnan(v) || v < 0.0) { v = 0.0; zero += 1.0; }
+                pw[own_c] = v;
+                v2 += v * v;
             }
-            const double rhs = rhs_elem(R, i, c);
-            double v = wc + (rhs - acc) / gcol[c];
-            if (isnan(v) || v < 0.0) { v = 0.0; zero = 1.0; }
-            pw[c] = v;
-            v2 = v * v;
         }
     }
     if (c < k) {
-        const double t2 = block_sum(v2, sh);
-        const double tz = block_sum(zero, sh);
+        block_sum2_bcast(v2, zero, sh);
         if (threadIdx.x == 0) {
-            ss[(i64)c * nblk + blockIdx.x] = t2;
-            nz[(i64)c * nblk + blockIdx.x] = tz;
+            ss[(i64)c * nblk + blockIdx.x] = v2;
+            nz[(i64)c * nblk + blockIdx.x] = zero;
+        }
+    }
+}
+
+static inline int hals_w_blocks(int KP, i64 M)
+{
+    const i64 rpb = 1024 / (KP / 4);
+    i64 nblk = (M + rpb - 1) / rpb;
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    return (int)nblk;
+}
+
+// --------------------------------------------------------------------------
+// Fused HALS W update: ONE persistent launch, every row of W lives in the
+// registers of one thread for the whole sweep; the k column norms are exchanged
+// between workgroups through self-validating 8-byte granules (the partial sum
+// of squares IS the flag: slots are pre-set to an all-ones NaN pattern, a
+// relaxed agent-scope (sc1) store publishes, relaxed agent-scope loads poll).
+// Every workgroup sums the same slots in the same order, so all of them derive
+// bit-identical norms.  At most one workgroup per CU (grid <= CU count): all
+// resident by construction; every spin is bounded and reports through
+// fail_flag instead of hanging.
+// --------------------------------------------------------------------------
+constexpr unsigned long long kSlotEmpty = ~0ull;
+
+// one column step of the fused sweep; C is a compile-time column index so that w[] stays in VGPRs
+template <int KP, int NT, int C>
+__device__ __forceinline__ void hals_w_fused_step(double (&w)[KP], double& rhs, bool& dead, const double* gs,
+                                                  double* sh, int k, i64 M, i64 row, bool valid,
+                                                  const PartialView& R, unsigned long long* __restrict__ slots,
+                                                  int nblk, int lane, int wave)
+{
+    constexpr int NW = NT / 64;
+    if (C >= k || dead) return;                     // uniform
+    const double gcc = gs[C * KP + C];
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < KP; j += 2) {
+        d0 += w[j] * gs[C * KP + j];
+        d1 += w[j + 1] * gs[C * KP + j + 1];
+    }
+    double v = w[C] + (rhs - (d0 + d1)) / gcc;
+    if (isnan(v) || v < 0.0) v = 0.0;
+    if (!valid) v = 0.0;
+    double v2 = v * v;
+    // prefetch next column's right-hand side while the norm is being exchanged
+    const double rhs_next = (C + 1 < k && valid) ? rhs_elem(R, row, C + 1) : 0.0;
+
+    // block partial -> slot
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v2 += __shfl_down(v2, off, 64);
+    if (lane == 0) sh[wave] = v2;
+    __syncthreads();
+    if (wave == 0) {
+        double t = (lane < NW) ? sh[lane] : 0.0;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        unsigned long long* col_slots = slots + (i64)C * nblk;
+        if (lane == 0)
+            __hip_atomic_store(col_slots + blockIdx.x, (unsigned long long)__double_as_longlong(t),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // gather every workgroup's partial (bounded spin)
+        double acc = 0.0;
+        bool ok = true;
+        for (int b = lane; b < nblk; b += 64) {
+            unsigned long long bits = kSlotEmpty;
+            for (unsigned spin = 0; spin < (1u << 24); ++spin) {
+                bits = __hip_atomic_load(col_slots + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bits != kSlotEmpty) break;
+            }
+            if (bits == kSlotEmpty) { ok = false; bits = 0; }
+            acc += __longlong_as_double((long long)bits);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        const bool all_ok = __all(ok);
+        if (lane == 0) { sh[16] = acc; sh[17] = all_ok ? 0.0 : 1.0; }
+    }
+    __syncthreads();
+    const double nu2 = sh[16];
+    if (sh[17] != 0.0) dead = true;
+    if (nu2 == 0.0) {                               // whole column clamped to zero (:105-111)
+        const double eps = DBL_EPSILON;
+        v = eps * (1.0 / sqrt((double)M * eps * eps));
+    } else {
+        v = v * (1.0 / sqrt(nu2));
+    }
+    w[C] = v;
+    rhs = rhs_next;
+    __syncthreads();                                // sh[] is reused by the next column
+}
+
+template <int KP, int NT, int... Cs>
+__device__ __forceinline__ void hals_w_fused_all(std::integer_sequence<int, Cs...>, double (&w)[KP], double& rhs,
+                                                 bool& dead, const double* gs, double* sh, int k, i64 M, i64 row,
+                                                 bool valid, const PartialView& R,
+                                                 unsigned long long* __restrict__ slots, int nblk, int lane, int wave)
+{
+    (hals_w_fused_step<KP, NT, Cs>(w, rhs, dead, gs, sh, k, M, row, valid, R, slots, nblk, lane, wave), ...);
+}
+
+template <int KP, int NT>
+__global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ Wt, int k, i64 M, PartialView R,
+                                                          const double* __restrict__ G,
+                                                          unsigned long long* __restrict__ slots, int nblk,
+                                                          int* __restrict__ fail_flag)
+{
+    __shared__ __attribute__((aligned(16))) double gs[KP * KP];
+    __shared__ double sh[24];
+    for (int t = threadIdx.x; t < KP * KP; t += NT) gs[t] = G[t];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 row = (i64)blockIdx.x * NT + threadIdx.x;
+    const bool valid = row < M;
+    double w[KP];
+    {
+        const double* p = Wt + (valid ? row : 0) * KP;
+#pragma unroll
+        for (int j = 0; j < KP; j += 2) {
+            const f64x2_t v = *(const f64x2_t*)(p + j);
+            w[j] = valid ? v[0] : 0.0;
+            w[j + 1] = valid ? v[1] : 0.0;
+        }
+    }
+    double rhs = valid ? rhs_elem(R, row, 0) : 0.0;
+    __syncthreads();
+
+    bool dead = false;
+    hals_w_fused_all<KP, NT>(std::make_integer_sequence<int, KP>{}, w, rhs, dead, gs, sh, k, M, row, valid, R, slots,
+                             nblk, lane, wave);
+    if (dead) {
+        if (threadIdx.x == 0) atomicMin(fail_flag, -3);
+        return;
+    }
+    if (valid) {
+        double* p = Wt + row * KP;
+#pragma unroll
+        for (int j = 0; j < KP; j += 2) {
+            f64x2_t v;
+            v[0] = w[j];
+            v[1] = w[j + 1];
+            *(f64x2_t*)(p + j) = v;
         }
     }
 }
 
 size_t hals_w_scratch_elems(int k, i64 M)
 {
-    i64 nblk = (M + 255) / 256;
-    return (size_t)(2 * (i64)k * nblk);
+    const size_t multi = (size_t)(2 * (i64)k * hals_w_blocks(kp_of(k), M));
+    const size_t fused = (size_t)k * 1024;          // slots (8 bytes each), generous
+    return multi > fused ? multi : fused;
 }
 
-int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, hipStream_t st)
+int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, int num_cus,
+                         int* fail_flag, hipStream_t st)
 {
-    const int nblk = (int)((M + 255) / 256);
+    const int KPv = kp_of(k);
+    static int mode = -1;                            // SMK_HALS_W=multi forces the one-launch-per-column path
+    if (mode < 0) {
+        const char* env = getenv("SMK_HALS_W");
+        mode = (env && env[0] == 'm') ? 0 : 1;
+    }
+    // fused path: at most one workgroup per CU so that all of them are resident by construction.
+    // Threads per workgroup are chosen so a whole W row (KP doubles) fits the register budget.
+    const int nt = (KPv == 64) ? 256 : (KPv == 32) ? 512 : 1024;
+    const i64 nblk_f = (M + nt - 1) / nt;
+    if (mode == 1 && nblk_f <= (i64)num_cus && nblk_f <= 1024) {
+        unsigned long long* slots = (unsigned long long*)scratch;
+        SMK_HIP(hipMemsetAsync(slots, 0xFF, (size_t)k * nblk_f * sizeof(unsigned long long), st));
+        const int nb = (int)nblk_f;
+        switch (KPv) {
+            case 8: hals_w_fused_kernel<8, 1024><<<nb, 1024, 0, st>>>(Wt, k, M, R, G, slots, nb, fail_flag); break;
+            case 16: hals_w_fused_kernel<16, 1024><<<nb, 1024, 0, st>>>(Wt, k, M, R, G, slots, nb, fail_flag); break;
+            case 32: hals_w_fused_kernel<32, 512><<<nb, 512, 0, st>>>(Wt, k, M, R, G, slots, nb, fail_flag); break;
+            default: hals_w_fused_kernel<64, 256><<<nb, 256, 0, st>>>(Wt, k, M, R, G, slots, nb, fail_flag); break;
+        }
+        SMK_HIP(hipGetLastError());
+        return 0;
+    }
+    const int nblk = hals_w_blocks(KPv, M);
     double* ss = scratch;
     double* nz = scratch + (i64)k * nblk;
-    const int KPv = kp_of(k);
     for (int c = 0; c <= k; ++c) {
-        KP_DISPATCH(KPv, (hals_w_col_kernel<KP><<<nblk, 256, 0, st>>>(Wt, k, M, R, G, c, nblk, ss, nz)));
+        KP_DISPATCH(KPv, (hals_w_col_kernel<KP><<<nblk, 1024, 0, st>>>(Wt, k, M, R, G, c, nblk, ss, nz)));
     }
     SMK_HIP(hipGetLastError());
     return 0;
@@ -1040,7 +1393,7 @@ __global__ __launch_bounds__(256) void nnls_bpp_kernel(double* __restrict__ X, d
     double rhs = 0.0, x = 0.0, y = 0.0;
     if (comp_ok) {
         rhs = rhs_elem(R, cc, i);
-        x = X[cc * k + i];
+        x = X[cc * KP + i];
     }
     bool passive = comp_ok && (x > 0.0);            // passive_set = (X > 0), nnls.hpp:157
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
@@ -1128,8 +1481,8 @@ __global__ __launch_bounds__(256) void nnls_bpp_kernel(double* __restrict__ X, d
     }
 
     if (col_ok && comp_ok) {
-        X[col * k + i] = x;
-        if (Y) Y[col * k + i] = y;
+        X[col * KP + i] = x;
+        if (Y) Y[col * KP + i] = y;
     }
     if (failed && col_ok) atomicMin(fail_flag, iter_tag);
 }
@@ -1153,9 +1506,10 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(double* __restrict__ X,
                                                          const double* __restrict__ G, int KP, int invert,
                                                          int* __restrict__ fail_flag)
 {
-    const i64 total = N * k;
+    const i64 total = N * KP;
     for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (i64)gridDim.x * blockDim.x) {
-        const int r = (int)(idx % k);
+        const int r = (int)(idx % KP);
+        if (r >= k) continue;
         const double nu = sqrt(G[r * KP + r]);
         if (fabs(nu) < DBL_EPSILON) {               // reference throws (normalize.hpp:41-42)
             if (invert) atomicMin(fail_flag, -2);
@@ -1167,7 +1521,7 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(double* __restrict__ X,
 
 int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int* fail_flag, hipStream_t st)
 {
-    const i64 total = N * k;
+    const i64 total = N * kp_of(k);
     int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     if (grid < 1) grid = 1;
     scale_rows_kernel<<<grid, 256, 0, st>>>(X, k, N, G, kp_of(k), invert, fail_flag);

@@ -7,7 +7,8 @@
 //   At  : n_pad x m_pad   same dtype: the explicit transpose (the reference's BPP keeps one
 //         too, nmf_solver_bpp.hpp:319) so BOTH streaming products contract down the
 //         contiguous dimension
-//   H   : k x n  (ld k)     Wt : k x m (ld k)  -- W is kept transposed on the device
+//   H   : KP x n (ld KP)    Wt : KP x m (ld KP) -- W is kept transposed on the device; KP = k padded
+//         to 8/16/32/64, pad rows are zero
 //   Gw = W'W, Gh = HH' : KP x KP (KP = 8/16/32/64 padded)
 //   P1 : S1 slabs of n_pad x kpp fp64 = W'A partials,   P2 : S2 slabs of m_pad x kpp = (AH')' partials
 //   packW / packH : MFMA operand fragments of W' / H
@@ -346,12 +347,12 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
 
     int rc = 0;
     const size_t kk = (size_t)s->KP * s->KP;
-    rc |= dev_alloc(&s->H, (size_t)s->k * s->n);
-    rc |= dev_alloc(&s->Wt, (size_t)s->k * s->m);
+    rc |= dev_alloc(&s->H, (size_t)s->KP * s->n);
+    rc |= dev_alloc(&s->Wt, (size_t)s->KP * s->m);
     rc |= dev_alloc(&s->Gw, kk);
     rc |= dev_alloc(&s->Gh_own, kk);
     rc |= dev_alloc(&s->gram_scratch, gram_scratch_elems(s->k, GRAM_BLOCKS));
-    rc |= dev_alloc(&s->tmpW, (size_t)s->k * s->m);
+    rc |= dev_alloc(&s->tmpW, (size_t)s->KP * s->m);
     s->pg_half = (size_t)((std::max(s->m, s->n) + 255) / 256) + 1024;
     rc |= dev_alloc(&s->pg_partials, 2 * s->pg_half);
     rc |= dev_alloc(&s->scal_own, (size_t)8);
@@ -361,7 +362,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     rc |= dev_alloc(&s->P1, s->pl1.p_elems);
     rc |= dev_alloc(&s->P2, s->pl2.p_elems);
     if (opts->algorithm == SMK_ALG_HALS) rc |= dev_alloc(&s->hals_scratch, hals_w_scratch_elems(s->k, s->m));
-    if (opts->prog_est_algorithm == SMK_PROG_DELTA_FNORM) rc |= dev_alloc(&s->Wprev, (size_t)s->k * s->m);
+    if (opts->prog_est_algorithm == SMK_PROG_DELTA_FNORM) rc |= dev_alloc(&s->Wprev, (size_t)s->KP * s->m);
     if (rc) { smk_solver_destroy(s); return SMK_DEVICE_ERROR; }
     s->Gh = s->Gh_own;
     s->scal = s->scal_own;
@@ -414,12 +415,15 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
 {
     if (!s || !W0 || !H0) return SMK_BAD_PARAM;
     if (ldW < s->m || ldH < s->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
-    // W0 (m x k, host) -> tmpW (m x k, ld m) -> Wt (k x m)
+    // pad rows of the KP x N device layout must be (and stay) zero
+    SMK_HIP(hipMemsetAsync(s->Wt, 0, (size_t)s->KP * s->m * sizeof(double), s->st));
+    SMK_HIP(hipMemsetAsync(s->H, 0, (size_t)s->KP * s->n * sizeof(double), s->st));
+    // W0 (m x k, host) -> tmpW (m x k, ld m) -> Wt (KP x m)
     SMK_HIP(hipMemcpy2DAsync(s->tmpW, (size_t)s->m * sizeof(double), W0, (size_t)ldW * sizeof(double),
                              (size_t)s->m * sizeof(double), (size_t)s->k, hipMemcpyHostToDevice, s->st));
-    int rc = launch_transpose_f64(s->tmpW, s->m, s->Wt, s->k, s->m, s->k, s->st);
+    int rc = launch_transpose_f64(s->tmpW, s->m, s->Wt, s->KP, s->m, s->k, s->st);
     if (rc) return rc;
-    SMK_HIP(hipMemcpy2DAsync(s->H, (size_t)s->k * sizeof(double), H0, (size_t)ldH * sizeof(double),
+    SMK_HIP(hipMemcpy2DAsync(s->H, (size_t)s->KP * sizeof(double), H0, (size_t)ldH * sizeof(double),
                              (size_t)s->k * sizeof(double), (size_t)s->n, hipMemcpyHostToDevice, s->st));
     const int big = INT_MAX;
     SMK_HIP(hipMemcpyAsync(s->fail_flag, &big, sizeof(int), hipMemcpyHostToDevice, s->st));
@@ -498,7 +502,7 @@ static int solver_init(smk_solver* s)
         rc = gram_w(s);  if (rc) return rc;
     }
     if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM)
-        SMK_HIP(hipMemcpyAsync(s->Wprev, s->Wt, (size_t)s->k * s->m * sizeof(double), hipMemcpyDeviceToDevice, s->st));
+        SMK_HIP(hipMemcpyAsync(s->Wprev, s->Wt, (size_t)s->KP * s->m * sizeof(double), hipMemcpyDeviceToDevice, s->st));
     s->inited = true;
     return 0;
 }
@@ -519,7 +523,7 @@ static int solver_iteration(smk_solver* s)
             rc = gram_w(s);   if (rc) return rc;
             break;
         case SMK_ALG_HALS: // nmf_solver_hals.hpp:166-199
-            rc = launch_hals_w_update(s->Wt, s->k, s->m, r2, s->Gh, s->hals_scratch, s->st); if (rc) return rc;
+            rc = launch_hals_w_update(s->Wt, s->k, s->m, r2, s->Gh, s->hals_scratch, g_cus, s->fail_flag, s->st); if (rc) return rc;
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
             rc = launch_hals_sweep(s->H, s->k, s->n, r1, s->Gw, s->st); if (rc) return rc;
@@ -575,7 +579,7 @@ static int update_progress(smk_solver* s, int iter_index, double* metric)
 {
     int rc = 0;
     if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM) {
-        rc = launch_delta_fnorm(s->Wt, s->Wprev, (i64)s->k * s->m, s->pg_partials, s->scal + 2, s->st);
+        rc = launch_delta_fnorm(s->Wt, s->Wprev, (i64)s->KP * s->m, s->pg_partials, s->scal + 2, s->st);
         if (rc) return rc;
     } else {
         // gradW = W*HHt - AHt  (slot 0, replicated), gradH = WtW*H - WtA (slot 1, local shard)
@@ -718,11 +722,11 @@ int smk_solver_get_factors(smk_solver* s, int normalize, double* W, int64_t ldW,
     if (ldW < s->m || ldH < s->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
     int rc = 0;
     if (normalize) { rc = normalize_device(s); if (rc) return rc; }
-    rc = launch_transpose_f64(s->Wt, s->k, s->tmpW, s->m, s->k, s->m, s->st);
+    rc = launch_transpose_f64(s->Wt, s->KP, s->tmpW, s->m, s->k, s->m, s->st);
     if (rc) return rc;
     SMK_HIP(hipMemcpy2DAsync(W, (size_t)ldW * sizeof(double), s->tmpW, (size_t)s->m * sizeof(double),
                              (size_t)s->m * sizeof(double), (size_t)s->k, hipMemcpyDeviceToHost, s->st));
-    SMK_HIP(hipMemcpy2DAsync(H, (size_t)ldH * sizeof(double), s->H, (size_t)s->k * sizeof(double),
+    SMK_HIP(hipMemcpy2DAsync(H, (size_t)ldH * sizeof(double), s->H, (size_t)s->KP * sizeof(double),
                              (size_t)s->k * sizeof(double), (size_t)s->n, hipMemcpyDeviceToHost, s->st));
     return sync_and_check(s, nullptr);
 }
