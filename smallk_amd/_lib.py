@@ -119,6 +119,28 @@ SYMBOLS = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """A process must not end up with two HIP runtimes.  PyTorch-ROCm wheels bundle their own
+    libamdhip64/libhsa-runtime64; if torch is installed, load those first (RTLD_GLOBAL) so that
+    libsmallk_amd.so binds to the same runtime no matter which of the two is imported first.
+    Without torch the system runtime under /opt/rocm is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if not spec or not spec.origin:
+        return
+    d = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(d, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 class SmallkError(RuntimeError):
     def __init__(self, code, where, detail=""):
         self.code = code
@@ -133,6 +155,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C smallk_amd/csrc`.  There is no CPU fallback.")
+        _preload_torch_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)

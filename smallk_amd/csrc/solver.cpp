@@ -301,7 +301,7 @@ static PartialView view1(const smk_solver* s)
 }
 static PartialView view2(const smk_solver* s)
 {
-    if (s->world > 1) return PartialView{s->R2red, 1, 0, s->kpp, 0};
+    if (s->ar) return PartialView{s->R2red, 1, 0, s->kpp, 0};
     return PartialView{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
 }
 
@@ -393,9 +393,10 @@ int smk_solver_set_comm(smk_solver* s, int rank, int world, smk_allreduce_fn fn,
                         size_t workspace_bytes)
 {
     if (!s || world < 1 || rank < 0 || rank >= world) return SMK_BAD_PARAM;
-    if (world > 1 && (!fn || !workspace || workspace_bytes < comm_bytes(s))) return SMK_BAD_PARAM;
+    if (world > 1 && !fn) return SMK_BAD_PARAM;
+    if (fn && (!workspace || workspace_bytes < comm_bytes(s))) return SMK_BAD_PARAM;
     s->rank = rank; s->world = world; s->ar = fn; s->ar_user = user;
-    if (world > 1) {
+    if (fn) {
         unsigned char* p = (unsigned char*)workspace;
         s->R2red = (float*)p;
         size_t b = (size_t)s->pl2.ncols_pad * s->kpp * sizeof(float);
@@ -470,7 +471,7 @@ static int prod2(smk_solver* s)
     if (rc) return rc;
     rc = timed_bigprod(s, 1, s->pl2, s->a->At, s->a->ldAt, s->packH, s->P2);
     if (rc) return rc;
-    if (s->world > 1) {
+    if (s->ar) {
         PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
         rc = launch_reduce_partials(pv, s->k, s->pl2.ncols_pad, s->R2red, s->st);
         if (rc) return rc;
@@ -485,7 +486,7 @@ static int gram_h(smk_solver* s)
 {
     int rc = launch_gram(s->H, s->k, s->n, s->Gh, s->gram_scratch, GRAM_BLOCKS, s->st);
     if (rc) return rc;
-    if (s->world > 1)
+    if (s->ar)
         if (s->ar(s->ar_user, s->Gh, (int64_t)s->KP * s->KP, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
     return 0;
 }
@@ -587,7 +588,7 @@ static int update_progress(smk_solver* s, int iter_index, double* metric)
         if (rc) return rc;
         rc = launch_grad_pg(s->H, s->k, s->n, view1(s), s->Gw, nullptr, s->pg_partials + s->pg_half, s->scal, 1, s->st);
         if (rc) return rc;
-        if (s->world > 1)
+        if (s->ar)
             if (s->ar(s->ar_user, s->scal + 1, 1, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
     }
     double h[4] = {0, 0, 0, 0};

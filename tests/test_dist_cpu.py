@@ -1,0 +1,84 @@
+"""CPU tests of the N > 1 path (world_size 2, gloo): the column-sharded algorithm with
+all-reduces of HH', AH' (and nothing else) equals the unsharded oracle; shard bookkeeping."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle
+from smallk_amd import dist as sdist
+
+
+def test_shard_columns_partition():
+    for n in (1, 7, 16, 100, 16384, 65537):
+        for world in (1, 2, 3, 8):
+            ranges = [sdist.shard_columns(n, world, r) for r in range(world)]
+            assert ranges[0][0] == 0
+            assert sum(nc for _, nc in ranges) == n
+            for (c0, nc), (c1, _) in zip(ranges, ranges[1:]):
+                assert c0 + nc == c1
+            assert max(nc for _, nc in ranges) - min(nc for _, nc in ranges) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, m, n, k, iters, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c0, nc = sdist.shard_columns(n, world, rank)
+        # every rank regenerates its own shard from the counter-based generator
+        A_loc = oracle.fill_uniform(m, nc, 42, c0=c0, gheight=m)
+        W0 = oracle.fill_uniform(m, k, 43)
+        H_loc = oracle.fill_uniform(k, nc, 44, c0=c0, gheight=k)
+
+        calls = []
+
+        def allreduce(x):
+            t = torch.from_numpy(np.ascontiguousarray(x))
+            dist.all_reduce(t)
+            calls.append(x.shape)
+            return t.numpy()
+
+        W, H = sdist.sharded_hals_reference(A_loc, W0, H_loc, iters, allreduce)
+        q.put((rank, c0, nc, W, H, calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_hals_equals_unsharded_oracle(world):
+    import torch.multiprocessing as mp
+    m, n, k, iters = 96, 50, 5, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, m, n, k, iters, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    ref = oracle.nmf(A, W0, H0, "HALS", min_iter=iters, max_iter=iters, normalize=False)
+    H = np.concatenate([r[4] for r in results], axis=1)
+    for r in results:                                   # W is replicated and identical on every rank
+        assert np.allclose(r[3], ref.W, rtol=1e-10, atol=1e-13)
+    assert np.allclose(H, ref.H, rtol=1e-10, atol=1e-13)
+    # the only exchanged objects are k x k and m x k
+    shapes = set(results[0][5])
+    assert shapes == {(k, k), (m, k)}
+    assert len(results[0][5]) == 2 * (iters + 1)

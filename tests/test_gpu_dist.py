@@ -1,0 +1,114 @@
+"""GPU tests of the sharded path on ONE GPU:
+ * two column shards driven by two host threads whose all-reduce callback sums the two device
+   buffers -- the real sharded device path, checked against the unsharded oracle;
+ * the torch.distributed (NCCL = RCCL) glue with a world of one rank."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("alg,storage,quant", [("HALS", "bf16", 1), ("MU", "f32", 0), ("BPP", "f32", 0)])
+def test_two_shards_on_one_gpu(gpu, alg, storage, quant):
+    import torch
+    from smallk_amd import dist as sdist
+    m, n, k, iters, world = 1500, 700, 12, 6, 2
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda", 0)
+    A = oracle.fill_uniform(m, n, 42, quant=quant)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, tol=1e-9)
+
+    barrier = threading.Barrier(world)
+    views = [None] * world
+    out = [None] * world
+    errors = []
+
+    def make_cb(rank, ar):
+        def cb(ptr, count, dtype):
+            esz = 4 if dtype == 0 else 8
+            off = ptr - ar.base
+            views[rank] = ar.ws[off:off + count * esz].view(torch.float32 if dtype == 0 else torch.float64)
+            barrier.wait(timeout=60)
+            if rank == 0:
+                total = views[0] + views[1]
+                views[0].copy_(total)
+                views[1].copy_(total)
+                torch.cuda.synchronize()
+            barrier.wait(timeout=60)
+            return 0
+        return cb
+
+    def run(rank):
+        try:
+            c0, nc = sdist.shard_columns(n, world, rank)
+            D = gpu.DenseMatrix(m, n, col0=c0, ncols=nc, storage=storage)
+            D.fill_uniform(42)
+            s = gpu.NmfSolver(D, gpu.make_options(m, n, k, alg, min_iter=iters, max_iter=iters, tol=1e-9))
+            ar = sdist.TorchAllReduce(s.comm_workspace_bytes(), dev)
+            s.set_comm(rank, world, make_cb(rank, ar), ar.ptr, ar.nbytes)
+            s._keep = ar
+            s.set_factors(W0, H0[:, c0:c0 + nc])
+            rc, it, _ = s.run()
+            W, H = s.factors()
+            out[rank] = (rc, it, c0, nc, W, H)
+        except Exception as e:     # pragma: no cover
+            errors.append(e)
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    H = np.concatenate([o[5] for o in out], axis=1)
+    for o in out:
+        assert o[0] == 0 and o[1] == iters
+        assert rel(o[4], ref.W) < TOL
+    assert rel(out[0][4], out[1][4]) < 1e-12          # replicated W identical on both ranks
+    assert rel(H, ref.H) < TOL
+
+
+def test_torch_nccl_world_of_one(gpu):
+    """the production glue: torch.distributed all_reduce on views of the comm workspace"""
+    import torch
+    import torch.distributed as dist
+    from smallk_amd import dist as sdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+        m, n, k, iters = 2048, 1024, 32, 5
+        A = oracle.fill_uniform(m, n, 42, quant=1)
+        W0 = oracle.fill_uniform(m, k, 43)
+        H0 = oracle.fill_uniform(k, n, 44)
+        ref = oracle.nmf(A, W0, H0, "HALS", min_iter=iters, max_iter=iters)
+        D = gpu.DenseMatrix(m, n, storage="bf16")
+        D.fill_uniform(42)
+        s = gpu.NmfSolver(D, gpu.make_options(m, n, k, "HALS", min_iter=iters, max_iter=iters))
+        sdist.attach(s, 0, 1, dev)
+        s.set_factors(W0, H0)
+        rc, it, _ = s.run()
+        W, H = s.factors()
+        assert rc == 0 and it == iters
+        assert rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
+    finally:
+        dist.destroy_process_group()
