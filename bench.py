@@ -31,6 +31,10 @@ WORKLOADS = {
     "c2": (8192, 4096, 16, "BPP", "f32", "C2 dense 8192x4096 k=16 BPP fp32"),
     "c3": (65536, 16384, 32, "HALS", "bf16", "C3 dense 65536x16384 k=32 HALS bf16 (MFMA roofline run)"),
     "c4": (262144, 65536, 64, "BPP", "f32", "C4 dense 262144x65536 k=64 BPP fp32"),
+    # experiments (not BASELINE configs)
+    "c4t": (65536, 262144, 64, "BPP", "f32", "EXPERIMENT transposed C4 shape 65536x262144 k=64 BPP fp32"),
+    "c4s": (262144, 8192, 64, "BPP", "f32", "EXPERIMENT one 1/8 column shard of C4: 262144x8192 k=64 BPP fp32"),
+    "c4b": (262144, 65536, 64, "BPP", "bf16", "EXPERIMENT C4 with A held as bf16"),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
@@ -162,6 +166,7 @@ def main():
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_ms": avg_ms, "launches": c0 + c1,
+                "pass_WtA_ms": ms0 / max(c0, 1), "pass_HAt_ms": ms1 / max(c1, 1),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
             },
         }

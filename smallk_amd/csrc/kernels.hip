@@ -26,6 +26,7 @@ namespace smk {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((ext_vector_type(2))) double f64x2_t;
 
@@ -195,13 +196,24 @@ int launch_zero_f64(double* p, i64 n, hipStream_t st)
 //   2q+h) -- identical on both operands, so the result is the plain dot product.
 //   HBM-bound: algorithmic bytes = len*ncols*sizeof(B elt) per launch.
 // ==========================================================================
-template <int EBYTES, int KT, int NSPLIT, int MB_, int NSTAGE_, int CW_>
+template <int EBYTES, int KT, int NSPLIT, int MB_, int NSTAGE_, int CW_, int WK_>
 struct BPCfg {
     static constexpr int MB = MB_;          // rows per stage
     static constexpr int CW = CW_;          // 32-column MFMA tiles per wave
+    static constexpr int WK = WK_;          // wave groups along k: waves = 4*WK, each owns KT/WK k-tiles
+    static constexpr int KTW = KT / WK_;
+    static constexpr int NW = 4 * WK_;      // waves per workgroup
     static constexpr int E = 16 / EBYTES;
     static constexpr int CPC = MB / E;      // 16-B chunks per column per stage
-    static constexpr int QS = CPC / 2;      // chunk-pair steps per stage
+    // XOR swizzle of the chunk index so that 16 lanes reading 16 different columns hit 16 distinct
+    // 16-byte slots of the 256-byte LDS bank row (column pitch = CPC*16 bytes)
+    static constexpr int SWZ_SH = (CPC >= 16) ? 0 : (CPC == 8) ? 1 : (CPC == 4) ? 2 : 3;
+    static constexpr int SWZ_MASK = (CPC >= 16 ? 16 : CPC) - 1;
+    // fp32 B with a 3-term X operand = "bf16x3" emulation: the fp32 tile is split into bf16
+    // hi/mid/lo in registers and multiplied on the bf16 MFMA (6 products of significance <= 2^-16),
+    // 2.7x less matrix-core time than v_mfma_f32_32x32x2_f32 and a 16x shorter rounding chain.
+    static constexpr bool EMU = (EBYTES == 4 && NSPLIT == 3);
+    static constexpr int QS = (EBYTES == 2 || EMU) ? MB / 16 : CPC / 2;   // MFMA steps per stage
     static constexpr int NB = 128 * CW;     // columns per workgroup
     static constexpr int B_BYTES = NB * MB * EBYTES;
     static constexpr int X_BYTES = QS * NSPLIT * KT * 1024;
@@ -209,8 +221,9 @@ struct BPCfg {
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PD = NSTAGE_ - 1;          // stages in flight ahead of the consumer
     static constexpr int TI = STAGE_BYTES / 1024;   // wave-level 1-KiB loads per stage
-    static constexpr int LPS = TI / 4;              // per wave
-    static_assert(TI % 4 == 0, "loads per stage must split evenly over 4 waves");
+    static constexpr int LPS = TI / NW;             // per wave
+    static_assert(TI % NW == 0, "loads per stage must split evenly over the waves");
+    static_assert(KT % WK_ == 0, "k tiles must split evenly over the wave groups");
     static_assert(LPS * PD <= 63, "vmcnt is a 6-bit counter");
     static_assert(STAGE_BYTES * NSTAGE <= 160 * 1024, "LDS ring exceeds 160 KiB");
 };
@@ -230,13 +243,14 @@ template <int LPS, int PD> __device__ __forceinline__ void wait_stage(int ahead)
     wait_vmcnt<0>();
 }
 
-template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW>
-__global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK>
+__global__ __launch_bounds__(256 * WK, 1) void bigprod_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                          const unsigned char* __restrict__ Xp,
                                                          double* __restrict__ P, i64 stages, i64 nst,
                                                          i64 tiles, i64 ncols_pad, int S, int logS)
 {
-    using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW>;
+    using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK>;
+    constexpr int KTW = C::KTW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // ---- XCD-aware block -> (tile, split): all blocks of one split share an XCD's L2
@@ -271,12 +285,12 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
     int is_b[C::LPS];
 #pragma unroll
     for (int i = 0; i < C::LPS; ++i) {
-        const int t = wave + 4 * i;                // wave-level load index within the stage
+        const int t = wave + C::NW * i;            // wave-level load index within the stage
         if (t * 1024 < C::B_BYTES) {
             const int p = t * 64 + lane;           // chunk position inside the LDS B tile
             const int j = p / C::CPC;
             const int pc = p % C::CPC;
-            const int swz = (C::CPC == 8) ? ((j >> 1) & 7) : (j & 15);
+            const int swz = (j >> C::SWZ_SH) & C::SWZ_MASK;
             const int lc = pc ^ swz;
             src_off[i] = (col0 + j) * ldb_bytes + (i64)lc * 16;
             is_b[i] = 1;
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
         unsigned char* lbase = smem + buf * C::STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < C::LPS; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + C::NW * i;
             const unsigned char* g = is_b[i] ? (B + src_off[i] + stage * (C::MB * EBYTES))
                                              : (Xp + stage * C::X_BYTES + src_off[i]);
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
@@ -303,7 +317,9 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
     // then added into fp64 running sums by the VALU while the next stage's MFMAs run into the
     // other fp32 set (accA/accB ping-pong): the fp32 rounding chain never exceeds one stage.
     // The mid/lo split terms are 2^-8 / 2^-16 smaller and stay in fp32 for the whole split.
-    constexpr int NT = CW * KT;                    // 32x32 output tiles per wave
+    constexpr int NT = CW * KTW;                   // 32x32 output tiles per wave
+    const int cwv = wave & 3;                      // column group of this wave
+    const int kw = wave >> 2;                      // k-tile group of this wave
     constexpr int NS1 = (NSPLIT > 1) ? NSPLIT - 1 : 1;
     f32x16_t accA[NT], accB[NT];
     f32x16_t accs[NS1][NT];
@@ -325,8 +341,8 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
     int bfrag_base[CW], swz_r[CW];
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-        const int jl = (wave * CW + c) * 32 + (lane & 31);
-        swz_r[c] = (C::CPC == 8) ? ((jl >> 1) & 7) : (jl & 15);
+        const int jl = (cwv * CW + c) * 32 + (lane & 31);
+        swz_r[c] = (jl >> C::SWZ_SH) & C::SWZ_MASK;
         bfrag_base[c] = jl * C::CPC * 16;
     }
 
@@ -351,40 +367,100 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
 
         const unsigned char* sb = smem + (t % C::NSTAGE) * C::STAGE_BYTES;
         const unsigned char* sx = sb + C::B_BYTES;
+        u32x4_t bq[2][CW];
+        u32x4_t aq[2][NSPLIT][KTW];
 #pragma unroll
         for (int q = 0; q < C::QS; ++q) {
-            const int lc = 2 * q + h;
-            u32x4_t braw[CW];
+            if constexpr (C::EMU) {
+                // 16 rows per step: this lane half owns rows 16q + 8h .. +7 = fp32 chunks 4q+2h, 4q+2h+1
+                bf16x8_t bhi[CW], bmid[CW], blo[CW];
 #pragma unroll
-            for (int c = 0; c < CW; ++c) braw[c] = *(const u32x4_t*)(sb + bfrag_base[c] + ((lc ^ swz_r[c]) << 4));
+                for (int c = 0; c < CW; ++c) {
+                    const int lc0 = 4 * q + 2 * h;
+                    const f32x4_t f0 = *(const f32x4_t*)(sb + bfrag_base[c] + (((lc0) ^ swz_r[c]) << 4));
+                    const f32x4_t f1 = *(const f32x4_t*)(sb + bfrag_base[c] + (((lc0 + 1) ^ swz_r[c]) << 4));
+                    f32x8_t x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x[e] = f0[e]; x[4 + e] = f1[e]; }
+                    bhi[c] = __builtin_convertvector(x, bf16x8_t);
+                    x -= __builtin_convertvector(bhi[c], f32x8_t);
+                    bmid[c] = __builtin_convertvector(x, bf16x8_t);
+                    x -= __builtin_convertvector(bmid[c], f32x8_t);
+                    blo[c] = __builtin_convertvector(x, bf16x8_t);
+                }
+#pragma unroll
+                for (int kt = 0; kt < KTW; ++kt) {
+                    bf16x8_t a[3];
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        a[s] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(sx + ((q * 3 + s) * KT + kw * KTW + kt) * 1024 + lane * 16));
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) {
+                        const int n = c * KTW + kt;
+                        cur[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bhi[c], cur[n], 0, 0, 0);
+                        accs[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bmid[c], accs[0][n], 0, 0, 0);
+                        accs[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bhi[c], accs[0][n], 0, 0, 0);
+                        accs[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], blo[c], accs[1][n], 0, 0, 0);
+                        accs[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bmid[c], accs[1][n], 0, 0, 0);
+                        accs[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bhi[c], accs[1][n], 0, 0, 0);
+                    }
+                }
+            } else {
+            const int lc = 2 * q + h;
             if constexpr (EBYTES == 2) {
+                // software-pipelined fragment reads: the ds_reads of step q+1 are issued before the
+                // MFMAs of step q so that LDS latency hides behind the matrix pipe
+                if (q == 0) {
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) bq[0][c] = *(const u32x4_t*)(sb + bfrag_base[c] + ((lc ^ swz_r[c]) << 4));
+#pragma unroll
+                    for (int s = 0; s < NSPLIT; ++s)
+#pragma unroll
+                        for (int kt = 0; kt < KTW; ++kt)
+                            aq[0][s][kt] = *(const u32x4_t*)(sx + ((0 * NSPLIT + s) * KT + kw * KTW + kt) * 1024 + lane * 16);
+                }
+                if (q + 1 < C::QS) {
+                    const int lcn = 2 * (q + 1) + h;
+#pragma unroll
+                    for (int c = 0; c < CW; ++c)
+                        bq[(q + 1) & 1][c] = *(const u32x4_t*)(sb + bfrag_base[c] + ((lcn ^ swz_r[c]) << 4));
+#pragma unroll
+                    for (int s = 0; s < NSPLIT; ++s)
+#pragma unroll
+                        for (int kt = 0; kt < KTW; ++kt)
+                            aq[(q + 1) & 1][s][kt] =
+                                *(const u32x4_t*)(sx + (((q + 1) * NSPLIT + s) * KT + kw * KTW + kt) * 1024 + lane * 16);
+                }
 #pragma unroll
                 for (int s = 0; s < NSPLIT; ++s)
 #pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) {
-                        const u32x4_t araw = *(const u32x4_t*)(sx + ((q * NSPLIT + s) * KT + kt) * 1024 + lane * 16);
-                        const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, araw);
+                    for (int kt = 0; kt < KTW; ++kt) {
+                        const bf16x8_t afr = __builtin_bit_cast(bf16x8_t, aq[q & 1][s][kt]);
 #pragma unroll
                         for (int c = 0; c < CW; ++c) {
-                            const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, braw[c]);
-                            const int n = c * KT + kt;
+                            const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, bq[q & 1][c]);
+                            const int n = c * KTW + kt;
                             if (s == 0) cur[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, cur[n], 0, 0, 0);
                             else accs[s - 1][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, accs[s - 1][n], 0, 0, 0);
                         }
                     }
             } else {
+                u32x4_t braw[CW];
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    const f32x4_t afr = *(const f32x4_t*)(sx + (q * KT + kt) * 1024 + lane * 16);
+                for (int c = 0; c < CW; ++c) braw[c] = *(const u32x4_t*)(sb + bfrag_base[c] + ((lc ^ swz_r[c]) << 4));
+#pragma unroll
+                for (int kt = 0; kt < KTW; ++kt) {
+                    const f32x4_t afr = *(const f32x4_t*)(sx + (q * KT + kw * KTW + kt) * 1024 + lane * 16);
 #pragma unroll
                     for (int c = 0; c < CW; ++c) {
                         const f32x4_t bfr = __builtin_bit_cast(f32x4_t, braw[c]);
-                        const int n = c * KT + kt;
+                        const int n = c * KTW + kt;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             cur[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[e], bfr[e], cur[n], 0, 0, 0);
                     }
                 }
+            }
             }
             if (q == 0 && flush_prev) flush(prev);
         }
@@ -410,11 +486,11 @@ __global__ __launch_bounds__(256, 1) void bigprod_kernel(const unsigned char* __
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-        const i64 jg = col0 + (wave * CW + c) * 32 + (lane & 31);
-        double* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32);
+        const i64 jg = col0 + (cwv * CW + c) * 32 + (lane & 31);
+        double* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32) + kw * KTW * 32;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const int n = c * KT + kt;
+        for (int kt = 0; kt < KTW; ++kt) {
+            const int n = c * KTW + kt;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -487,26 +563,30 @@ __global__ __launch_bounds__(256) void pack_kernel(const double* __restrict__ X,
 
 // The packed operand layout does not depend on the stage height: it is a sequence of 1-KiB
 // blocks indexed by the global chunk-pair q; rows are padded to a multiple of 128.
-static inline i64 pack_nq(int storage, i64 N)
+// operand format: bf16 fragments (E = 8) for bf16 storage and for the fp32 "bf16x3" emulation
+// (nsplit == 3); native fp32 fragments (E = 4, one term) otherwise
+static inline bool pack_is_bf16(int storage, int nsplit) { return storage == STORE_BF16 || nsplit == 3; }
+
+static inline i64 pack_nq(int storage, int nsplit, i64 N)
 {
-    const i64 E = storage == STORE_BF16 ? 8 : 4;
+    const i64 E = pack_is_bf16(storage, nsplit) ? 8 : 4;
     return round_up(N, ROW_PAD) / (2 * E);
 }
 
 size_t packed_bytes(int storage, int k, i64 N, int nsplit)
 {
-    if (storage != STORE_BF16) nsplit = 1;
-    return (size_t)pack_nq(storage, N) * nsplit * kt_of(k) * 1024;
+    if (!pack_is_bf16(storage, nsplit)) nsplit = 1;
+    return (size_t)pack_nq(storage, nsplit, N) * nsplit * kt_of(k) * 1024;
 }
 
 int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st)
 {
     const int KT = kt_of(k);
-    const i64 nq = pack_nq(storage, N);
+    const i64 nq = pack_nq(storage, nsplit, N);
     const i64 threads = nq * KT * 64;
     const int grid = (int)((threads + 255) / 256);
     if (grid == 0) return 0;
-    if (storage == STORE_BF16) {
+    if (pack_is_bf16(storage, nsplit)) {
         if (nsplit == 3) pack_kernel<2, 3><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
         else if (nsplit == 2) pack_kernel<2, 2><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
         else pack_kernel<2, 1><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
@@ -517,17 +597,24 @@ int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* ou
     return 0;
 }
 
-constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw);
+constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw, int wk);
 // ---- kernel variants (tile shape / pipeline depth); chosen per plan, SMK_BP_VARIANT overrides ----
-struct BPVariant { int mb, nstage, cw; };
+struct BPVariant { int mb, nstage, cw, wk; };
 static const BPVariant kVariants[] = {
-    {64, 3, 1},    // 0: 128 cols x 64 rows, 3-deep ring
-    {64, 4, 1},    // 1
-    {64, 5, 1},    // 2
-    {128, 2, 1},   // 3
-    {128, 3, 1},   // 4 (bf16 only: LDS)
-    {64, 3, 2},    // 5: 256 cols per workgroup
-    {64, 2, 1},    // 6
+    {64, 3, 1, 1},    // 0: 128 cols x 64 rows, 3-deep ring
+    {64, 4, 1, 1},    // 1
+    {64, 5, 1, 1},    // 2
+    {128, 2, 1, 1},   // 3
+    {128, 3, 1, 1},   // 4
+    {64, 3, 2, 1},    // 5: 256 cols per workgroup
+    {64, 2, 1, 1},    // 6: two workgroups per CU (bf16, k <= 32 default)
+    {32, 2, 1, 1},    // 7: 32-row stages (fp32: one 128-B line per column per stage)
+    {32, 3, 1, 1},    // 8
+    {32, 4, 1, 1},    // 9
+    {64, 2, 1, 2},    // 10: k in (32,64]: 8 waves, the two k tiles on different waves
+    {64, 3, 1, 2},    // 11
+    {64, 4, 1, 2},    // 12
+    {32, 4, 1, 2},    // 13
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -536,13 +623,22 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     BigProdPlan pl;
     pl.storage = storage;
     pl.kt = kt_of(k);
-    pl.nsplit = storage == STORE_BF16 ? nsplit : 1;
-    int v = 6;   // measured best on MI355X (C3: 5.98 TB/s): 2 workgroups per CU beat a deeper ring
+    // fp32 storage: nsplit 3 selects the bf16x3 emulation (default), 1 the native fp32 MFMA
+    pl.nsplit = storage == STORE_BF16 ? nsplit : (nsplit == 3 ? 3 : 1);
+    // measured best on MI355X: bf16 -> 64-row stages, 2-deep ring, 2 workgroups per CU (C3: 5.98 TB/s)
+    int v = (storage == STORE_BF16) ? 6 : 7;
+    if (pl.kt == 2) v = 11;
     const char* env = getenv("SMK_BP_VARIANT");
     if (env) v = atoi(env);
     if (v < 0 || v >= kNumVariants) v = 6;
     // variants that do not fit the 160 KiB LDS for this dtype / k fall back to variant 0
-    if (!bp_fits(storage == STORE_BF16 ? 2 : 4, pl.kt, pl.nsplit, kVariants[v].mb, kVariants[v].nstage, kVariants[v].cw)) v = 0;
+    auto fits = [&](int vv) {
+        return bp_fits(storage == STORE_BF16 ? 2 : 4, pl.kt, pl.nsplit, kVariants[vv].mb, kVariants[vv].nstage,
+                       kVariants[vv].cw, kVariants[vv].wk);
+    };
+    if (!fits(v)) v = (pl.kt == 2) ? 11 : 0;
+    if (!fits(v)) v = 0;
+    if (!fits(v)) v = 7;
     pl.variant = v;
     const int MB = kVariants[v].mb;
     const int NB = 128 * kVariants[v].cw;
@@ -560,13 +656,13 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     return pl;
 }
 
-template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW>
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK>
 static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
-    using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW>;
+    using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK>;
     constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
     static bool attr_set = false;
-    auto kern = bigprod_kernel<EBYTES, KT, NSPLIT, MB, NSTAGE, CW>;
+    auto kern = bigprod_kernel<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK>;
     if (!attr_set) {
         SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -580,25 +676,29 @@ static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const
     } else {
         grid = pl.tiles * pl.S;
     }
-    kern<<<(unsigned)grid, 256, lds, st>>>((const unsigned char*)B, ldb * EBYTES, (const unsigned char*)Xp, P,
+    kern<<<(unsigned)grid, 256 * WK, lds, st>>>((const unsigned char*)B, ldb * EBYTES, (const unsigned char*)Xp, P,
                                            pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS);
     SMK_HIP(hipGetLastError());
     return 0;
 }
 
-constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw)
+constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw, int wk)
 {
+    if (kt % wk != 0) return false;
     const int cpc = mb / (16 / ebytes);
-    const int stage = 128 * cw * mb * ebytes + (cpc / 2) * nsplit * kt * 1024;
+    const int qs = (ebytes == 2 || nsplit == 3) ? mb / 16 : cpc / 2;
+    if (qs < 1) return false;
+    const int stage = 128 * cw * mb * ebytes + qs * nsplit * kt * 1024;
     const int ti = stage / 1024;
-    return (ti % 4 == 0) && (ti / 4 * (nstage - 1) <= 63) && (stage * nstage <= 160 * 1024);
+    const int nw = 4 * wk;
+    return (ti % nw == 0) && (ti / nw * (nstage - 1) <= 63) && (stage * nstage <= 160 * 1024);
 }
 
-template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW>
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK>
 static int launch_bigprod_if(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
-    if constexpr (bp_fits(EBYTES, KT, NSPLIT, MB, NSTAGE, CW))
-        return launch_bigprod_t<EBYTES, KT, NSPLIT, MB, NSTAGE, CW>(pl, B, ldb, Xp, P, st);
+    if constexpr (bp_fits(EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK))
+        return launch_bigprod_t<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK>(pl, B, ldb, Xp, P, st);
     else {
         set_error("bigprod variant does not fit LDS");
         return -100;
@@ -609,15 +709,22 @@ template <int EBYTES, int KT, int NSPLIT>
 static int launch_bigprod_v(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
     switch (pl.variant) {
-        case 1: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 4, 1>(pl, B, ldb, Xp, P, st);
-        case 2: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 5, 1>(pl, B, ldb, Xp, P, st);
-        case 3: return launch_bigprod_if<EBYTES, KT, NSPLIT, 128, 2, 1>(pl, B, ldb, Xp, P, st);
-        case 4: return launch_bigprod_if<EBYTES, KT, NSPLIT, 128, 3, 1>(pl, B, ldb, Xp, P, st);
-        case 5: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 2>(pl, B, ldb, Xp, P, st);
-        case 6: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 2, 1>(pl, B, ldb, Xp, P, st);
+        case 1: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 4, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 2: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 5, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 3: return launch_bigprod_if<EBYTES, KT, NSPLIT, 128, 2, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 4: return launch_bigprod_if<EBYTES, KT, NSPLIT, 128, 3, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 5: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 2, 1>(pl, B, ldb, Xp, P, st);
+        case 6: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 2, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 7: return launch_bigprod_if<EBYTES, KT, NSPLIT, 32, 2, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 8: return launch_bigprod_if<EBYTES, KT, NSPLIT, 32, 3, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 9: return launch_bigprod_if<EBYTES, KT, NSPLIT, 32, 4, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 10: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 2, 1, 2>(pl, B, ldb, Xp, P, st);
+        case 11: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 1, 2>(pl, B, ldb, Xp, P, st);
+        case 12: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 4, 1, 2>(pl, B, ldb, Xp, P, st);
+        case 13: return launch_bigprod_if<EBYTES, KT, NSPLIT, 32, 4, 1, 2>(pl, B, ldb, Xp, P, st);
         default: break;
     }
-    return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 1>(pl, B, ldb, Xp, P, st);
+    return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 1, 1>(pl, B, ldb, Xp, P, st);
 }
 
 int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
@@ -633,6 +740,10 @@ int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp
             return launch_bigprod_v<2, 2, 1>(pl, B, ldb, Xp, P, st);
         }
     } else {
+        if (pl.nsplit == 3) {
+            if (pl.kt == 1) return launch_bigprod_v<4, 1, 3>(pl, B, ldb, Xp, P, st);
+            return launch_bigprod_v<4, 2, 3>(pl, B, ldb, Xp, P, st);
+        }
         if (pl.kt == 1) return launch_bigprod_v<4, 1, 1>(pl, B, ldb, Xp, P, st);
         return launch_bigprod_v<4, 2, 1>(pl, B, ldb, Xp, P, st);
     }
@@ -685,6 +796,21 @@ __device__ __forceinline__ double group_sum(double v)
     if constexpr (LPC >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
     if constexpr (LPC >= 16) v += dpp_f64<0x140>(v);  // row_mirror
     return v;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes of a wave, result in every lane: DPP row reductions + 4 readlanes
+// (no LDS-crossbar permutes, fixed order)
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = group_sum<16>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 // the 4 values of column j owned by sub-lane s
@@ -825,19 +951,80 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const double* __restr
     }
 }
 
-// G[e] = sum_b Gp[b][e]: 64 elements per block, 4 thread groups stride the partials, fixed order
+// fp64 matrix-core version (KP >= 16): v_mfma_f64_16x16x4_f64, 4 columns of X per instruction.
+// A operand lane l: X[16*ti + (l&15)][c0 + (l>>4)], B operand the same with tj -- the Gram matrix
+// needs no second operand load.  D: col = lane&15, row = (lane>>4) + 4*reg (f64 layout).
+typedef __attribute__((ext_vector_type(4))) double f64x4_t;
+
+template <int KP>
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ X, i64 N, i64 cols_per_wave,
+                                                        double* __restrict__ Gp)
+{
+    constexpr int T = KP / 16;
+    __shared__ double red[KP * KP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 wg = (i64)blockIdx.x * 4 + wave;
+    const i64 c_begin = wg * cols_per_wave;
+    i64 c_end = c_begin + cols_per_wave;
+    if (c_end > N) c_end = N;
+    f64x4_t acc[T][T];
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b) acc[a][b] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const int kc = lane >> 4, r16 = lane & 15;
+    for (i64 c0 = c_begin; c0 < c_end; c0 += 4) {
+        const i64 col = c0 + kc;
+        const bool ok = col < c_end;
+        double f[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) f[t] = ok ? X[col * KP + 16 * t + r16] : 0.0;
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+            for (int b = 0; b < T; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], acc[a][b], 0, 0, 0);
+    }
+    // deterministic in-block sum of the 4 waves
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int b = 0; b < T; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * a + kc + 4 * r, colm = 16 * b + r16;
+                        const int idx = colm * KP + row;
+                        red[idx] = (w == 0) ? acc[a][b][r] : red[idx] + acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    double* out = Gp + (i64)blockIdx.x * KP * KP;
+    for (int i = threadIdx.x; i < KP * KP; i += 256) out[i] = red[i];
+}
+
+// G[e] = sum_b Gp[b][e]: 16 elements per block, 16 thread groups stride the partials, fixed order
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ Gp, int nblk, int elems,
                                                           double* __restrict__ G)
 {
-    __shared__ double sh[4][64];
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int g = threadIdx.x >> 6;
+    __shared__ double sh[16][17];
+    const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
     double s = 0.0;
-    if (e < elems)
-        for (int b = g; b < nblk; b += 4) s += Gp[(i64)b * elems + e];
-    sh[g][threadIdx.x & 63] = s;
+    if (e < elems) {
+#pragma unroll 8
+        for (int b = g; b < nblk; b += 16) s += Gp[(i64)b * elems + e];
+    }
+    sh[g][el] = s;
     __syncthreads();
-    if (g == 0 && e < elems) G[e] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (g == 0 && e < elems) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sh[i][el];
+        G[e] = t;
+    }
 }
 
 size_t gram_scratch_elems(int k, int max_blocks)
@@ -849,22 +1036,31 @@ size_t gram_scratch_elems(int k, int max_blocks)
 int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, hipStream_t st)
 {
     const int KP = kp_of(k);
-    int nblk = (int)((N + 127) / 128);
-    if (nblk > max_blocks) nblk = max_blocks;
-    if (nblk < 1) nblk = 1;
-    i64 cpb = (N + nblk - 1) / nblk;
-    cpb = (cpb + 31) / 32 * 32;
-    nblk = (int)((N + cpb - 1) / cpb);
-    if (nblk < 1) nblk = 1;
-    switch (KP) {
-        case 8: gram_partial_kernel<8><<<nblk, 256, 0, st>>>(X, N, cpb, scratch); break;
-        case 16: gram_partial_kernel<16><<<nblk, 256, 0, st>>>(X, N, cpb, scratch); break;
-        case 32: gram_partial_kernel<32><<<nblk, 256, 0, st>>>(X, N, cpb, scratch); break;
-        default: gram_partial_kernel<64><<<nblk, 256, 0, st>>>(X, N, cpb, scratch); break;
+    const int elems = KP * KP;
+    int nblk;
+    if (KP >= 16) {
+        nblk = (int)((N + 255) / 256);               // >= 64 columns per wave
+        if (nblk > max_blocks) nblk = max_blocks;
+        if (nblk < 1) nblk = 1;
+        i64 cpw = (N + (i64)nblk * 4 - 1) / ((i64)nblk * 4);
+        cpw = (cpw + 3) / 4 * 4;
+        switch (KP) {
+            case 16: gram_mfma_kernel<16><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
+            case 32: gram_mfma_kernel<32><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
+            default: gram_mfma_kernel<64><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
+        }
+    } else {
+        nblk = (int)((N + 127) / 128);
+        if (nblk > max_blocks) nblk = max_blocks;
+        if (nblk < 1) nblk = 1;
+        i64 cpb = (N + nblk - 1) / nblk;
+        cpb = (cpb + 31) / 32 * 32;
+        nblk = (int)((N + cpb - 1) / cpb);
+        if (nblk < 1) nblk = 1;
+        gram_partial_kernel<8><<<nblk, 256, 0, st>>>(X, N, cpb, scratch);
     }
     SMK_HIP(hipGetLastError());
-    const int elems = KP * KP;
-    gram_reduce_kernel<<<(elems + 63) / 64, 256, 0, st>>>(scratch, nblk, elems, G);
+    gram_reduce_kernel<<<(elems + 15) / 16, 256, 0, st>>>(scratch, nblk, elems, G);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -1193,39 +1389,49 @@ __device__ __forceinline__ void hals_w_fused_step(double (&w)[KP], double& rhs, 
     // prefetch next column's right-hand side while the norm is being exchanged
     const double rhs_next = (C + 1 < k && valid) ? rhs_elem(R, row, C + 1) : 0.0;
 
-    // block partial -> slot
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v2 += __shfl_down(v2, off, 64);
-    if (lane == 0) sh[wave] = v2;
+    // block partial -> slot.  sh[] is double buffered by column parity (one barrier less).
+    double* shc = sh + (C & 1) * 20;
+    v2 = wave_sum(v2);
+    if (lane == 0) shc[wave] = v2;
     __syncthreads();
     if (wave == 0) {
-        double t = (lane < NW) ? sh[lane] : 0.0;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        double t = (lane < NW) ? shc[lane] : 0.0;
+        t = wave_sum(t);
         unsigned long long* col_slots = slots + (i64)C * nblk;
         if (lane == 0)
             __hip_atomic_store(col_slots + blockIdx.x, (unsigned long long)__double_as_longlong(t),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // gather every workgroup's partial (bounded spin)
+        // gather every workgroup's partial: up to 4 slots per lane polled together (bounded spin)
         double acc = 0.0;
         bool ok = true;
-        for (int b = lane; b < nblk; b += 64) {
-            unsigned long long bits = kSlotEmpty;
-            for (unsigned spin = 0; spin < (1u << 24); ++spin) {
-                bits = __hip_atomic_load(col_slots + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (bits != kSlotEmpty) break;
-            }
-            if (bits == kSlotEmpty) { ok = false; bits = 0; }
-            acc += __longlong_as_double((long long)bits);
-        }
+        for (int b0 = 0; b0 < nblk; b0 += 256) {
+            unsigned long long bits[4];
+            bool have[4];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+            for (int u = 0; u < 4; ++u) { have[u] = (b0 + u * 64 + lane) < nblk; bits[u] = have[u] ? kSlotEmpty : 0ull; }
+            for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+                bool pending = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (have[u] && bits[u] == kSlotEmpty) {
+                        bits[u] = __hip_atomic_load(col_slots + b0 + u * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pending |= (bits[u] == kSlotEmpty);
+                    }
+                if (!__any(pending)) break;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (have[u] && bits[u] == kSlotEmpty) { ok = false; bits[u] = 0ull; }
+                acc += __longlong_as_double((long long)bits[u]);
+            }
+        }
+        acc = wave_sum(acc);
         const bool all_ok = __all(ok);
-        if (lane == 0) { sh[16] = acc; sh[17] = all_ok ? 0.0 : 1.0; }
+        if (lane == 0) { shc[16] = acc; shc[17] = all_ok ? 0.0 : 1.0; }
     }
     __syncthreads();
-    const double nu2 = sh[16];
-    if (sh[17] != 0.0) dead = true;
+    const double nu2 = shc[16];
+    if (shc[17] != 0.0) dead = true;
     if (nu2 == 0.0) {                               // whole column clamped to zero (:105-111)
         const double eps = DBL_EPSILON;
         v = eps * (1.0 / sqrt((double)M * eps * eps));
@@ -1234,7 +1440,6 @@ __device__ __forceinline__ void hals_w_fused_step(double (&w)[KP], double& rhs, 
     }
     w[C] = v;
     rhs = rhs_next;
-    __syncthreads();                                // sh[] is reused by the next column
 }
 
 template <int KP, int NT, int... Cs>
@@ -1253,7 +1458,7 @@ __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ W
                                                           int* __restrict__ fail_flag)
 {
     __shared__ __attribute__((aligned(16))) double gs[KP * KP];
-    __shared__ double sh[24];
+    __shared__ double sh[40];
     for (int t = threadIdx.x; t < KP * KP; t += NT) gs[t] = G[t];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
