@@ -763,6 +763,107 @@ static int bpp_iter(solver_ws* s, double* W, i64 ldw, double* H, i64 ldh,
     return 1;
 }
 
+/* ---- RANK2: nmf_solver_rank2.hpp:25-135 (SystemSolveH), :139-212 (SystemSolveW), -------- */
+/*      :216-318 (OptimalActiveSetH/W), :323-461 (Init / iteration)                       */
+/* side 0: solve G * x = b for every column of B (2 x n), X is 2 x n (ld ldx)              */
+/* side 1: solve x' * G = b' for every row; stored here as columns too (X, B are 2 x m)    */
+static int rank2_system_solve(int side, i64 N, double* X, i64 ldx, const double* G /*2x2, ld 2*/,
+                              const double* B, i64 ldb)
+{
+    const double eps = DBL_EPSILON;
+    const double a00 = G[0], a10 = G[1], a01 = G[2], a11 = G[3];
+    if (fabs(a00) < eps && fabs(a01) < eps) { fprintf(stderr, "SystemSolve%c: singular matrix\n", side ? 'W' : 'H'); return 0; }
+    double a2, b2, d2, t;
+    const int cosine = fabs(a00) >= fabs(a01);
+    if (side == 0) {
+        if (cosine) { t = -a10 / a00; a2 = a00 - t * a10; b2 = a01 - t * a11; d2 = a11 + t * a01; }
+        else        { t = -a00 / a10; a2 = -a10 + t * a00; b2 = -a11 + t * a01; d2 = a01 + t * a11; }
+    } else {
+        if (cosine) { t = a01 / a00; a2 = a00 + t * a01; b2 = a10 + t * a11; d2 = a11 - t * a10; }
+        else        { t = a00 / a01; a2 = -a01 - t * a00; b2 = -a11 - t * a10; d2 = a10 - t * a11; }
+    }
+    const double inv_a2 = 1.0 / a2, inv_d2 = 1.0 / d2;
+    if (fabs(d2 / a2) < eps) return 0;
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < N; ++i) {
+        const double b0 = AT(B, ldb, 0, i), b1 = AT(B, ldb, 1, i);
+        double e2, f2;
+        if (side == 0) {
+            if (cosine) { e2 = b0 - t * b1; f2 = b1 + t * b0; }
+            else        { e2 = -b1 + t * b0; f2 = b0 + t * b1; }
+        } else {
+            if (cosine) { e2 = b0 + t * b1; f2 = b1 - t * b0; }
+            else        { e2 = -b1 - t * b0; f2 = b0 - t * b1; }
+        }
+        const double x1 = f2 * inv_d2;
+        AT(X, ldx, 1, i) = x1;
+        AT(X, ldx, 0, i) = (e2 - b2 * x1) * inv_a2;
+    }
+    return 1;
+}
+
+/* OptimalActiveSetH / W (:216-318): columns whose unconstrained solution has a non-positive
+ * entry are replaced by the better of the two single-variable solutions */
+static void rank2_optimal_active_set(i64 N, double* X, i64 ldx, const double* G, const double* B, i64 ldb)
+{
+    const double g00 = G[0], g11 = G[3];
+    const double inv0 = 1.0 / g00, inv1 = 1.0 / g11, sq0 = sqrt(g00), sq1 = sqrt(g11);
+#pragma omp parallel for schedule(static)
+    for (i64 i = 0; i < N; ++i) {
+        double v1 = AT(B, ldb, 0, i) * inv0, v2 = AT(B, ldb, 1, i) * inv1;
+        const double vv1 = v1 * sq0, vv2 = v2 * sq1;
+        if (vv1 >= vv2) v2 = 0.0; else v1 = 0.0;
+        if (AT(X, ldx, 0, i) <= 0.0 || AT(X, ldx, 1, i) <= 0.0) { AT(X, ldx, 0, i) = v1; AT(X, ldx, 1, i) = v2; }
+    }
+}
+
+static void rank2_init(solver_ws* s, const double* W, i64 ldw)
+{
+    orc_gemm(1, 0, 2, 2, s->m, 1.0, W, ldw, W, ldw, 0.0, s->WtW, 2);
+    orc_gemm(1, 0, 2, s->n, s->m, 1.0, W, ldw, s->A, s->lda, 0.0, s->WtA, 2);
+}
+
+static int rank2_iter(solver_ws* s, double* W, i64 ldw, double* H, i64 ldh, double* gradW, double* gradH)
+{
+    const i64 m = s->m, n = s->n;
+    if (!rank2_system_solve(0, n, H, ldh, s->WtW, s->WtA, 2)) return 0;
+    rank2_optimal_active_set(n, H, ldh, s->WtW, s->WtA, 2);
+    orc_gemm(0, 1, 2, 2, n, 1.0, H, ldh, H, ldh, 0.0, s->HHt, 2);
+    orc_gemm(0, 1, m, 2, n, 1.0, s->A, s->lda, H, ldh, 0.0, s->AHt, m);
+    /* W side works on rows of W; reuse the column routines on W' (2 x m) */
+    double* Wt = s->T1;        /* 2 x m scratch (T1 has k*n >= ? doubles: allocated max(k*n, k*m) below) */
+    double* Bt = s->T2;        /* 2 x m */
+    mat_transpose(m, 2, s->AHt, m, Bt, 2);
+    if (!rank2_system_solve(1, m, Wt, 2, s->HHt, Bt, 2)) return 0;
+    /* OptimalActiveSetW tests the freshly solved W */
+    rank2_optimal_active_set(m, Wt, 2, s->HHt, Bt, 2);
+    mat_transpose(2, m, Wt, 2, W, ldw);
+    /* NormalizeAndScale(W, H, ScaleFactors) every iteration (:418) */
+    double sf[2];
+    for (int c = 0; c < 2; ++c) {
+        double ss = 0.0;
+        for (i64 r = 0; r < m; ++r) ss += AT(W, ldw, r, c) * AT(W, ldw, r, c);
+        const double nrm = sqrt(ss);
+        if (fabs(nrm) < DBL_EPSILON) return -1;              /* reference throws runtime_error */
+        const double inv = 1.0 / nrm;
+        for (i64 r = 0; r < m; ++r) AT(W, ldw, r, c) *= inv;
+        sf[c] = nrm;
+    }
+    for (i64 j = 0; j < n; ++j) { AT(H, ldh, 0, j) *= sf[0]; AT(H, ldh, 1, j) *= sf[1]; }
+    /* keep HHt and AHt consistent with the rescaled H (:424-437) */
+    const double e00 = s->HHt[0], e01 = s->HHt[2], e11 = s->HHt[3];
+    s->HHt[0] = e00 * sf[0] * sf[0]; s->HHt[2] = e01 * sf[0] * sf[1]; s->HHt[1] = e01 * sf[0] * sf[1]; s->HHt[3] = e11 * sf[1] * sf[1];
+    for (int c = 0; c < 2; ++c)
+        for (i64 r = 0; r < m; ++r) AT(s->AHt, m, r, c) *= sf[c];
+    orc_gemm(0, 0, m, 2, 2, 1.0, W, ldw, s->HHt, 2, 0.0, gradW, m);
+    mat_axpy(-1.0, m, 2, s->AHt, m, gradW, m);
+    orc_gemm(1, 0, 2, 2, m, 1.0, W, ldw, W, ldw, 0.0, s->WtW, 2);
+    orc_gemm(1, 0, 2, n, m, 1.0, W, ldw, s->A, s->lda, 0.0, s->WtA, 2);
+    orc_gemm(0, 0, 2, n, 2, 1.0, s->WtW, 2, H, ldh, 0.0, gradH, 2);
+    mat_axpy(-1.0, 2, n, s->WtA, 2, gradH, 2);
+    return 1;
+}
+
 /* ======================================================================== */
 /* IsValid: common/src/nmf_options.cpp:23-112                                 */
 /* ======================================================================== */
@@ -785,13 +886,12 @@ int orc_is_valid(const orc_options* o)
 /* progress_estimator_generic.hpp:30-69 (DeltaW), :74-109 (PgRatio).          */
 /* W (m x k) and H (k x n) are in/out.  `metrics` (optional, length max_iter) */
 /* receives the progress metric of every iteration that computed one (NaN     */
-/* elsewhere).  RANK2 is outside this oracle's scope (BAD_PARAM).             */
+/* elsewhere).             */
 /* ======================================================================== */
 int orc_nmf(const orc_options* o, const double* A, i64 lda, double* W, i64 ldw,
             double* H, i64 ldh, orc_stats* stats, double* metrics)
 {
     if (!orc_is_valid(o)) return ORC_BAD_PARAM;
-    if (o->algorithm == ORC_RANK2) return ORC_BAD_PARAM;
     const i64 m = o->height, n = o->width; const int k = o->k;
     if ((uint64_t)m * (uint64_t)k > 0x7FFFFFFFull) return ORC_SIZE_TOO_LARGE;   /* nmf.cpp:194-210 */
     if ((uint64_t)n * (uint64_t)k > 0x7FFFFFFFull) return ORC_SIZE_TOO_LARGE;
@@ -805,7 +905,7 @@ int orc_nmf(const orc_options* o, const double* A, i64 lda, double* W, i64 ldw,
     s.m = m; s.n = n; s.k = k; s.A = A; s.lda = lda;
     s.WtW = dalloc((size_t)k * k); s.HHt = dalloc((size_t)k * k);
     s.WtA = dalloc((size_t)k * n); s.AHt = dalloc((size_t)m * k);
-    s.T1 = dalloc((size_t)k * n);  s.T2 = dalloc((size_t)m * k);
+    s.T1 = dalloc((size_t)k * (n > m ? n : m));  s.T2 = dalloc((size_t)m * k);
     if (o->algorithm == ORC_BPP) {
         s.At = dalloc((size_t)m * n); s.Wt = dalloc((size_t)k * m);
         s.gradWt = dalloc((size_t)k * m); s.HAt = dalloc((size_t)k * m);
@@ -821,6 +921,7 @@ int orc_nmf(const orc_options* o, const double* A, i64 lda, double* W, i64 ldw,
     /* solver.Init, progress_est->Init */
     if (o->algorithm == ORC_MU) mu_init(&s, W, ldw);
     else if (o->algorithm == ORC_HALS) hals_init(&s, H, ldh);
+    else if (o->algorithm == ORC_RANK2) rank2_init(&s, W, ldw);
     else bpp_init(&s, W, ldw);
     if (o->prog_est_algorithm == ORC_DELTA_FNORM) {
         /* DeltaW::Init: Wprev = 0; Compute(W) -> Wprev = W (:38-45, :58-69) */
@@ -834,8 +935,9 @@ int orc_nmf(const orc_options* o, const double* A, i64 lda, double* W, i64 ldw,
         int ok;
         if (o->algorithm == ORC_MU) ok = mu_iter(&s, W, ldw, H, ldh, gradW, gradH);
         else if (o->algorithm == ORC_HALS) ok = hals_iter(&s, W, ldw, H, ldh, gradW, gradH);
+        else if (o->algorithm == ORC_RANK2) ok = rank2_iter(&s, W, ldw, H, ldh, gradW, gradH);
         else ok = bpp_iter(&s, W, ldw, H, ldh, gradW, gradH);
-        if (!ok) {
+        if (ok <= 0) {
             fprintf(stderr, "\tNMF solver failure on iteration %d\n", iter + 1);
             result = ORC_FAILURE;
             goto finish;

@@ -103,5 +103,9 @@ int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int*
 // delta-fnorm: out[0] = sum (W - Wprev)^2, out[1] = sum W^2 ; then Wprev = W
 int launch_delta_fnorm(const double* W, double* Wprev, i64 count, double* partials, double* out2, hipStream_t st);
 int launch_zero_f64(double* p, i64 n, hipStream_t st);
+// RANK2: closed-form 2x2 solve + optimal active set (side 0: H, side 1: W'), per-iteration rescale
+int launch_rank2_solve(double* X, i64 N, PartialView R, const double* G, int side, int* fail_flag, int iter_tag,
+                       hipStream_t st);
+int launch_rank2_rescale(double* Gh, const double* Gw, PartialView R, i64 N, hipStream_t st);
 
 }  // namespace smk

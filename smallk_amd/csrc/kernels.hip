@@ -615,6 +615,7 @@ static const BPVariant kVariants[] = {
     {64, 3, 1, 2},    // 11
     {64, 4, 1, 2},    // 12
     {32, 4, 1, 2},    // 13
+    {64, 2, 2, 2},    // 14: 256 columns, 8 waves
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -627,7 +628,7 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     pl.nsplit = storage == STORE_BF16 ? nsplit : (nsplit == 3 ? 3 : 1);
     // measured best on MI355X: bf16 -> 64-row stages, 2-deep ring, 2 workgroups per CU (C3: 5.98 TB/s)
     int v = (storage == STORE_BF16) ? 6 : 7;
-    if (pl.kt == 2) v = 11;
+    if (pl.kt == 2) v = (storage == STORE_BF16) ? 14 : 11;   // k in (32,64]: 8 waves; bf16: 256-column tiles
     const char* env = getenv("SMK_BP_VARIANT");
     if (env) v = atoi(env);
     if (v < 0 || v >= kNumVariants) v = 6;
@@ -722,6 +723,7 @@ static int launch_bigprod_v(const BigProdPlan& pl, const void* B, i64 ldb, const
         case 11: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 1, 2>(pl, B, ldb, Xp, P, st);
         case 12: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 4, 1, 2>(pl, B, ldb, Xp, P, st);
         case 13: return launch_bigprod_if<EBYTES, KT, NSPLIT, 32, 4, 1, 2>(pl, B, ldb, Xp, P, st);
+        case 14: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 2, 2, 2>(pl, B, ldb, Xp, P, st);
         default: break;
     }
     return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 1, 1>(pl, B, ldb, Xp, P, st);
@@ -1699,6 +1701,106 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 N, PartialView R, const dou
     const int gpb = 256 / KPv;
     const int grid = (int)((N + gpb - 1) / gpb);
     KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag)));
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ==========================================================================
+// RANK2 (nmf_solver_rank2.hpp): closed-form 2x2 solves by one fast Givens rotation
+// (SystemSolveH :25-135 / SystemSolveW :139-212) followed by the optimal active set
+// (:216-318).  One thread per column of X (KP = 8 layout, rows 0 and 1 live).
+// ==========================================================================
+__global__ __launch_bounds__(256) void rank2_solve_kernel(double* __restrict__ X, i64 N, PartialView R,
+                                                          const double* __restrict__ G, int side,
+                                                          int* __restrict__ fail_flag, int iter_tag)
+{
+    constexpr int KP = 8;
+    const double eps = DBL_EPSILON;
+    const double a00 = G[0], a10 = G[1], a01 = G[KP], a11 = G[KP + 1];
+    bool bad = (fabs(a00) < eps) && (fabs(a01) < eps);          // "singular matrix"
+    const bool cosine = fabs(a00) >= fabs(a01);
+    double t, a2, b2, d2;
+    if (side == 0) {
+        if (cosine) { t = -a10 / a00; a2 = a00 - t * a10; b2 = a01 - t * a11; d2 = a11 + t * a01; }
+        else        { t = -a00 / a10; a2 = -a10 + t * a00; b2 = -a11 + t * a01; d2 = a01 + t * a11; }
+    } else {
+        if (cosine) { t = a01 / a00; a2 = a00 + t * a01; b2 = a10 + t * a11; d2 = a11 - t * a10; }
+        else        { t = a00 / a01; a2 = -a01 - t * a00; b2 = -a11 - t * a10; d2 = a10 - t * a11; }
+    }
+    const double inv_a2 = 1.0 / a2, inv_d2 = 1.0 / d2;
+    if (fabs(d2 / a2) < eps) bad = true;
+    if (bad) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMin(fail_flag, iter_tag);
+        return;
+    }
+    const double inv0 = 1.0 / a00, inv1 = 1.0 / a11, sq0 = sqrt(a00), sq1 = sqrt(a11);
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const double b0 = rhs_elem(R, j, 0), b1 = rhs_elem(R, j, 1);
+    double e2, f2;
+    if (side == 0) {
+        if (cosine) { e2 = b0 - t * b1; f2 = b1 + t * b0; }
+        else        { e2 = -b1 + t * b0; f2 = b0 + t * b1; }
+    } else {
+        if (cosine) { e2 = b0 + t * b1; f2 = b1 - t * b0; }
+        else        { e2 = -b1 - t * b0; f2 = b0 - t * b1; }
+    }
+    double x1 = f2 * inv_d2;
+    double x0 = (e2 - b2 * x1) * inv_a2;
+    if (x0 <= 0.0 || x1 <= 0.0) {                   // OptimalActiveSet
+        double v1 = b0 * inv0, v2 = b1 * inv1;
+        if (v1 * sq0 >= v2 * sq1) v2 = 0.0; else v1 = 0.0;
+        x0 = v1;
+        x1 = v2;
+    }
+    f64x2_t v;
+    v[0] = x0;
+    v[1] = x1;
+    *(f64x2_t*)(X + j * KP) = v;
+}
+
+int launch_rank2_solve(double* X, i64 N, PartialView R, const double* G, int side, int* fail_flag, int iter_tag,
+                       hipStream_t st)
+{
+    const int grid = (int)((N + 255) / 256);
+    rank2_solve_kernel<<<grid, 256, 0, st>>>(X, N, R, G, side, fail_flag, iter_tag);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// after the per-iteration NormalizeAndScale (:418): HHt_ij *= nu_i nu_j, AHt(:,c) *= nu_c (:424-437),
+// nu_c = sqrt(Gw[c][c]) taken from the Gram matrix of the un-normalised W
+__global__ __launch_bounds__(256) void rank2_rescale_kernel(double* __restrict__ Gh, const double* __restrict__ Gw,
+                                                            void* __restrict__ P, int S, i64 slab, int kpp, int f64,
+                                                            i64 N)
+{
+    constexpr int KP = 8;
+    const double nu0 = sqrt(Gw[0]), nu1 = sqrt(Gw[KP + 1]);
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) {
+        Gh[0] *= nu0 * nu0;
+        Gh[1] *= nu0 * nu1;
+        Gh[KP] *= nu0 * nu1;
+        Gh[KP + 1] *= nu1 * nu1;
+    }
+    if (j >= N) return;
+    for (int s = 0; s < S; ++s) {
+        if (f64) {
+            double* p = (double*)P + s * slab + j * kpp;
+            p[0] *= nu0;
+            p[1] *= nu1;
+        } else {
+            float* p = (float*)P + s * slab + j * kpp;
+            p[0] = (float)((double)p[0] * nu0);
+            p[1] = (float)((double)p[1] * nu1);
+        }
+    }
+}
+
+int launch_rank2_rescale(double* Gh, const double* Gw, PartialView R, i64 N, hipStream_t st)
+{
+    const int grid = (int)((N + 255) / 256);
+    rank2_rescale_kernel<<<grid, 256, 0, st>>>(Gh, Gw, const_cast<void*>(R.p), R.S, R.slab, R.kpp, R.f64, N);
     SMK_HIP(hipGetLastError());
     return 0;
 }

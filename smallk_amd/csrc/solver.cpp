@@ -324,7 +324,6 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if (!opts || !a) return SMK_BAD_PARAM;
     if (!smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
     if (opts->height != a->m || opts->width != a->n_global) { set_error("options/matrix dimension mismatch"); return SMK_BAD_PARAM; }
-    if (opts->algorithm == SMK_ALG_RANK2) { set_error("RANK2 is not built on the device path yet"); return SMK_UNSUPPORTED; }
     if (opts->k > 64) { set_error("device path supports k <= 64"); return SMK_UNSUPPORTED; }
     // W and H element counts must fit the reference's 32-bit index (nmf.cpp:194-210)
     if ((uint64_t)a->m * (uint64_t)opts->k > 0x7FFFFFFFull) { fprintf(stderr, "W matrix size too large\n"); return SMK_SIZE_TOO_LARGE; }
@@ -498,7 +497,7 @@ static int solver_init(smk_solver* s)
     if (s->o.algorithm == SMK_ALG_HALS) {
         rc = gram_h(s);  if (rc) return rc;
         rc = prod2(s);   if (rc) return rc;
-    } else {   // MU, BPP: WtA and WtW from W0
+    } else {   // MU, BPP, RANK2: WtA and WtW from W0
         rc = prod1(s);   if (rc) return rc;
         rc = gram_w(s);  if (rc) return rc;
     }
@@ -537,6 +536,19 @@ static int solver_iteration(smk_solver* s)
             rc = prod2(s);    if (rc) return rc;
             rc = launch_nnls_bpp(s->Wt, nullptr, s->k, s->m, r2, s->Gh, s->fail_flag, s->iter, s->st); if (rc) return rc;
             rc = gram_w(s);   if (rc) return rc;
+            rc = prod1(s);    if (rc) return rc;
+            break;
+        case SMK_ALG_RANK2:  // nmf_solver_rank2.hpp:353-455
+            rc = launch_rank2_solve(s->H, s->n, r1, s->Gw, 0, s->fail_flag, s->iter, s->st); if (rc) return rc;
+            rc = gram_h(s);   if (rc) return rc;
+            rc = prod2(s);    if (rc) return rc;
+            rc = launch_rank2_solve(s->Wt, s->m, view2(s), s->Gh, 1, s->fail_flag, s->iter, s->st); if (rc) return rc;
+            // NormalizeAndScale(W, H, ScaleFactors) every iteration: norms from the Gram matrix of the new W
+            rc = gram_w(s);   if (rc) return rc;
+            rc = launch_scale_rows(s->H, s->k, s->n, s->Gw, 0, s->fail_flag, s->st);  if (rc) return rc;
+            rc = launch_scale_rows(s->Wt, s->k, s->m, s->Gw, 1, s->fail_flag, s->st); if (rc) return rc;
+            rc = launch_rank2_rescale(s->Gh, s->Gw, view2(s), s->m, s->st);          if (rc) return rc;
+            rc = gram_w(s);   if (rc) return rc;      // W'W of the normalised W
             rc = prod1(s);    if (rc) return rc;
             break;
         default:

@@ -148,6 +148,27 @@ def make_A(m, n, k, planted, quant):
     if quant == 1:
         A = bf16_round(A)
     return np.asfortranarray(A.astype(np.float64))
+def rank2(A, W, H, iters):
+    """nmf_solver_rank2.hpp:353-455 with the 2x2 systems solved by numpy (the reference uses one
+    fast Givens rotation) and the optimal-active-set rule (:216-318); per-iteration normalisation."""
+    def solve_side(G, B):
+        X = np.linalg.solve(G, B)
+        v1 = B[0] / G[0, 0]
+        v2 = B[1] / G[1, 1]
+        c = v1 * np.sqrt(G[0, 0]) >= v2 * np.sqrt(G[1, 1])
+        alt = np.vstack([np.where(c, v1, 0.0), np.where(c, 0.0, v2)])
+        bad = (X[0] <= 0) | (X[1] <= 0)
+        return np.where(bad, alt, X)
+    for _ in range(iters):
+        H = solve_side(W.T @ W, W.T @ A)
+        W = solve_side(H @ H.T, (A @ H.T).T).T
+        nrm = np.linalg.norm(W, axis=0)
+        W = W / nrm
+        H = H * nrm[:, None]
+    return W, H
+
+
+RANK2_CASES = [(300, 200), (512, 256), (64, 16)]
 ITERS = (1, 5, 20)
 ALGS = {"MU": mu, "HALS": hals, "BPP": bpp}
 
@@ -169,6 +190,20 @@ def main():
                     out[key + "_W"] = W
                     out[key + "_H"] = H
                     print(key, float(np.linalg.norm(A - W @ H) / np.linalg.norm(A)))
+    for (m, n) in RANK2_CASES:
+        for quant in (0, 1):
+            A = uniform(m, n, 42, quant)
+            W0 = uniform(m, 2, 43)
+            H0 = uniform(2, n, 44)
+            for it in ITERS:
+                if quant == 1 and it != 5:
+                    continue
+                W, H = rank2(A, W0.copy(), H0.copy(), it)
+                W, H = normalize_and_scale(W, H)
+                key = f"RANK2_{m}x{n}_k2_it{it}_q{quant}"
+                out[key + "_W"] = W
+                out[key + "_H"] = H
+                print(key, float(np.linalg.norm(A - W @ H) / np.linalg.norm(A)))
     np.savez_compressed(os.path.join(HERE, "nmf_golden.npz"), **out)
     print("wrote", len(out), "arrays")
 

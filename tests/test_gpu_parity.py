@@ -60,6 +60,45 @@ def test_nmf_matches_oracle_and_golden(gpu, golden, m, n, k, planted, quant, alg
     assert np.allclose(np.linalg.norm(got.W, axis=0), 1.0, atol=1e-9)
 
 
+R2CASES = [(m, n, q, it) for (m, n) in mg.RANK2_CASES for q in (0, 1) for it in ((1, 5, 20) if q == 0 else (5,))]
+
+
+@pytest.mark.parametrize("m,n,quant,iters", R2CASES)
+def test_rank2_matches_oracle_and_golden(gpu, golden, m, n, quant, iters):
+    A = mg.uniform(m, n, 42, quant)
+    W0 = oracle.fill_uniform(m, 2, 43)
+    H0 = oracle.fill_uniform(2, n, 44)
+    ref = oracle.nmf(A, W0, H0, "RANK2", min_iter=iters, max_iter=iters)
+    got = gpu.nmf(A, W0, H0, "RANK2", min_iter=iters, max_iter=iters, storage="bf16" if quant else "f32")
+    assert got.result == 0 and got.iteration_count == iters
+    assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL
+    key = f"RANK2_{m}x{n}_k2_it{iters}_q{quant}"
+    assert rel(got.W, golden[key + "_W"]) < TOL and rel(got.H, golden[key + "_H"]) < TOL
+
+
+def test_rank2_stopping_rule_and_facade(gpu, tmp_path):
+    """RANK2 through smallk::Nmf: k is forced to 2 (smallk.cpp:515-517), PG-ratio stopping rule"""
+    m, n = 2000, 900
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, 2, 43)
+    H0 = oracle.fill_uniform(2, n, 44)
+    ref = oracle.nmf(A, W0, H0, "RANK2", min_iter=3, max_iter=200, tol=0.01)
+    got = gpu.nmf(A, W0, H0, "RANK2", min_iter=3, max_iter=200, tol=0.01)
+    assert got.result == 0 and got.iteration_count == ref.iteration_count
+    assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL
+    l = gpu._lib.lib()
+    dp = C.POINTER(C.c_double)
+    fw, fh = str(tmp_path / "w0.csv"), str(tmp_path / "h0.csv")
+    l.smk_write_csv(W0.ctypes.data_as(dp), m, m, 2, fw.encode(), 17)
+    l.smk_write_csv(H0.ctypes.data_as(dp), 2, 2, n, fh.encode(), 17)
+    api = gpu.SmallkAPI()
+    api.load_matrix(matrix=A, column_major=True)
+    api.nmf(7, "RANK2", infile_W=fw, infile_H=fh, min_iter=3, max_iter=200, tol=0.01, outdir=str(tmp_path))
+    assert api.get_W().shape == (m, 2) and api.get_H().shape == (2, n)
+    assert api.get_iteration_count() == ref.iteration_count
+    assert rel(api.get_W(), ref.W) < TOL
+
+
 @pytest.mark.parametrize("alg", ["MU", "HALS", "BPP"])
 def test_unnormalized_and_leading_dimensions(gpu, alg):
     """normalize=false and ldim > height (views into larger buffers, nmf.cpp:224-226)."""

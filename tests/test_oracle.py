@@ -108,3 +108,31 @@ def test_hals_residual_decreases():
         r = oracle.nmf(A, W0, H0, "HALS", min_iter=it, max_iter=it)
         errs.append(np.linalg.norm(A - r.W @ r.H))
     assert errs[0] > errs[1] > errs[2]
+
+
+R2CASES = [(m, n, q, it) for (m, n) in mg.RANK2_CASES for q in (0, 1) for it in ((1, 5, 20) if q == 0 else (5,))]
+
+
+@pytest.mark.parametrize("m,n,quant,iters", R2CASES)
+def test_rank2_oracle_matches_independent_restatement(golden, m, n, quant, iters):
+    """Solver_Generic_Rank2 (nmf_solver_rank2.hpp:323-461): fast-Givens oracle == numpy 2x2 solves"""
+    A = mg.uniform(m, n, 42, quant)
+    W0 = oracle.fill_uniform(m, 2, 43)
+    H0 = oracle.fill_uniform(2, n, 44)
+    r = oracle.nmf(A, W0, H0, "RANK2", min_iter=iters, max_iter=iters)
+    key = f"RANK2_{m}x{n}_k2_it{iters}_q{quant}"
+    assert r.result == oracle.OK and r.iteration_count == iters
+    assert rel(r.W, golden[key + "_W"]) < 1e-10 and rel(r.H, golden[key + "_H"]) < 1e-10
+
+
+def test_rank2_requires_k2_and_solves_2x2_exactly():
+    A = oracle.fill_uniform(50, 40, 42)
+    assert oracle.nmf(A, np.ones((50, 3)), np.ones((3, 40)), "RANK2").result == oracle.BAD_PARAM
+    # residual of the 2x2 solves (reference tests/src/test_rank2_system_solve.cpp: ||AX-B|| < 1e-10):
+    # one iteration from a W0 whose unconstrained solution is positive gives H = (W'W)^-1 W'A
+    rng = np.random.default_rng(3)
+    W0 = rng.random((50, 2)) + 0.5
+    Hs = rng.random((2, 40)) + 0.5
+    A2 = W0 @ Hs
+    r = oracle.nmf(A2, W0, np.ones((2, 40)), "RANK2", min_iter=1, max_iter=1, normalize=False)
+    assert np.linalg.norm(A2 - r.W @ r.H) / np.linalg.norm(A2) < 1e-10
