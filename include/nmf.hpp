@@ -68,8 +68,7 @@ Result Nmf(const NmfOptions& options,
            double* buf_H, int ldim_H,
            NmfStats& stats);
 
-// Sparse input (CSC).  Not on the device path yet: returns BAD_PARAM-free `FAILURE`
-// after printing a message (next tier).
+// Sparse input (CSC, 32-bit indices): same algorithms, the products with A become gathers.
 Result NmfSparse(const NmfOptions& options,
                  const unsigned int height,
                  const unsigned int width,

@@ -4,8 +4,8 @@
 // (same names, argument meaning, defaults and exception behaviour) so that a program written
 // against libsmallk -- e.g. examples/smallk_example.cpp or pysmallk's cdef extern block
 // (pysmallk/interface/smallk_lib.pyx:42-88) -- links against libsmallk_amd.so instead.
-// Dense NMF (MU / HALS / BPP) runs on the GPU; entry points of the next tier (sparse input,
-// RANK2, HierNmf2) are declared and throw std::runtime_error until they are built.
+// NMF (MU / HALS / BPP / RANK2, dense or sparse A) runs on the GPU; the clustering entry points
+// (HierNmf2, dictionaries) are declared and throw std::runtime_error until they are built.
 #pragma once
 
 #include <string>
@@ -57,12 +57,12 @@ namespace smallk
     void SeedRNG(const int seed);
 
     // -- input matrix ------------------------------------------------------------------------
-    void LoadMatrix(const std::string& filepath);            // .csv dense (.mtx: next tier)
+    void LoadMatrix(const std::string& filepath);            // .csv dense, .mtx MatrixMarket sparse
     void LoadMatrix(const double* buffer,                    // dense, column-major
                     const unsigned int ldim,
                     const unsigned int height,
                     const unsigned int width);
-    void LoadMatrix(const unsigned int height,               // sparse CSC (next tier)
+    void LoadMatrix(const unsigned int height,               // sparse CSC
                     const unsigned int width,
                     const unsigned int nz,
                     const std::vector<double>& data,

@@ -91,6 +91,12 @@ int smk_set_stream(void* hip_stream);
 int smk_nmf_dense(const smk_options* opts, const double* A, int64_t ldA, double* W, int64_t ldW,
                   double* H, int64_t ldH, smk_stats* stats, int storage);
 
+/* ---- one shot, sparse: Result NmfSparse(const NmfOptions&, height, width, nz, col_offsets, row_indices,
+ *      data, W, ldW, H, ldH, NmfStats&), common/include/nmf.hpp:83-92 / src/nmf.cpp:232-300 */
+int smk_nmf_sparse(const smk_options* opts, unsigned height, unsigned width, unsigned nz,
+                   const unsigned* col_offsets, const unsigned* row_indices, const double* data,
+                   double* W, int64_t ldW, double* H, int64_t ldH, smk_stats* stats);
+
 /* ---- device-resident A (replaces the DenseMatrix view of buf_a, nmf.cpp:224) ---------------
  * A matrix object holds the column shard [col0, col0 + ncols_local) of a height x width_global
  * matrix, plus its transpose (the reference's BPP solver keeps At too, nmf_solver_bpp.hpp:319). */
@@ -104,6 +110,12 @@ int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed);
 /* read the shard back as fp64 (tests) */
 int smk_matrix_download_f64(const smk_matrix* a, double* host, int64_t ld);
 void smk_matrix_destroy(smk_matrix* a);
+/* sparse A in CSC (replaces SparseMatrix<double>, common/include/sparse_matrix_decl.hpp:21-132): the local
+ * columns [col0, col0+ncols_local); 32-bit indices as in the reference, duplicates allowed (they add up).
+ * The transpose is built here too (the reference does it in Solver_Generic_BPP::Init, nmf_solver_bpp.hpp:319). */
+int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0,
+                             int64_t ncols_local, int64_t nnz_local, const unsigned* col_offsets,
+                             const unsigned* row_indices, const double* data);
 /* same generator on the host, for W0/H0 (RandomMatrix stand-in, smallk.cpp:533,554) */
 void smk_uniform_fill_host(double* buf, int64_t ld, int64_t rows, int64_t cols, int64_t r0, int64_t c0,
                            int64_t global_height, uint64_t seed, int quant /* 0: 24 bit, 1: bf16 */);
@@ -145,6 +157,12 @@ int smk_solver_set_comm(smk_solver* s, int rank, int world, smk_allreduce_fn fn,
 int smk_write_csv(const double* buf, unsigned ldim, unsigned height, unsigned width, const char* filename,
                   unsigned precision);
 int smk_load_csv(const char* filename, double* out, unsigned long capacity, unsigned* height, unsigned* width);
+/* MatrixMarket coordinate files -> CSC (LoadMatrixMarketFile, common/include/sparse_matrix_io.hpp:118-262:
+ * real/integer/pattern x general/symmetric/skew-symmetric).  Two calls: sizes first (arrays NULL), then data.
+ * Returns 1 on success, 0 on failure. */
+int smk_load_matrix_market(const char* filename, unsigned* height, unsigned* width, unsigned* nnz,
+                           unsigned* col_offsets /* width+1 or NULL */, unsigned* row_indices /* nnz or NULL */,
+                           double* data /* nnz or NULL */);
 
 /* ---- flat handles onto the public C++ API `namespace smallk` (include/smallk.hpp), one per entry of
  * pysmallk's extern block (pysmallk/interface/smallk_lib.pyx:42-88), for bindings that cannot call C++

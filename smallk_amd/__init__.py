@@ -5,9 +5,9 @@ The numeric path is hand-written HIP for gfx950 in ``smallk_amd/csrc`` behind th
 surface (pysmallk ``SmallkAPI``) plus thin object wrappers.  No CPU fallback exists.
 """
 from . import _lib
-from .solver import (DenseMatrix, NmfSolver, NmfResult, nmf, initialize, finalize, is_initialized,
-                     make_options, uniform_host, set_stream)
+from .solver import (DenseMatrix, SparseMatrix, NmfSolver, NmfResult, nmf, nmf_sparse, load_matrix_market,
+                     initialize, finalize, is_initialized, make_options, uniform_host, set_stream)
 from .api import SmallkAPI
 
-__all__ = ["DenseMatrix", "NmfSolver", "NmfResult", "nmf", "initialize", "finalize", "is_initialized",
+__all__ = ["DenseMatrix", "SparseMatrix", "nmf_sparse", "load_matrix_market", "NmfSolver", "NmfResult", "nmf", "initialize", "finalize", "is_initialized",
            "make_options", "uniform_host", "set_stream", "SmallkAPI", "_lib"]

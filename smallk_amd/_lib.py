@@ -56,6 +56,12 @@ SYMBOLS = {
     "smk_matrix_fill_uniform": (C.c_int, [_vp, C.c_uint64]),
     "smk_matrix_download_f64": (C.c_int, [_vp, _dp, _i64]),
     "smk_matrix_destroy": (None, [_vp]),
+    "smk_matrix_create_sparse": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _i64, _i64, C.POINTER(C.c_uint),
+                                           C.POINTER(C.c_uint), _dp]),
+    "smk_nmf_sparse": (C.c_int, [C.POINTER(Options), C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint),
+                                 C.POINTER(C.c_uint), _dp, _dp, _i64, _dp, _i64, C.POINTER(Stats)]),
+    "smk_load_matrix_market": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint),
+                                         C.POINTER(C.c_uint), C.POINTER(C.c_uint), _dp]),
     "smk_uniform_fill_host": (None, [_dp, _i64, _i64, _i64, _i64, _i64, _i64, C.c_uint64, C.c_int]),
     "smk_solver_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Options), _vp]),
     "smk_solver_destroy": (None, [_vp]),

@@ -83,7 +83,102 @@ bool LoadCsv(std::vector<double>& buffer, unsigned int& height, unsigned int& wi
     return true;
 }
 
+// MatrixMarket coordinate -> CSC (LoadMatrixMarketFile, sparse_matrix_io.hpp:118-262):
+// banner "%%MatrixMarket matrix coordinate {real|integer|pattern} {general|symmetric|skew-symmetric}",
+// comment lines, "rows cols nnz", then 1-based "row col [value]" lines; symmetric / skew files mirror
+// off-diagonal entries; entries are bucketed by column in file order (duplicates kept, as Compress() does).
+bool LoadMatrixMarket(const std::string& filename, unsigned int& height, unsigned int& width,
+                      std::vector<unsigned int>& col_offsets, std::vector<unsigned int>& row_indices,
+                      std::vector<double>& data)
+{
+    std::ifstream in(filename);
+    if (!in) return false;
+    std::string line;
+    if (!std::getline(in, line)) return false;
+    std::string lower = line;
+    std::transform(lower.begin(), lower.end(), lower.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+    if (lower.compare(0, 14, "%%matrixmarket") != 0) return false;
+    std::istringstream banner(lower);
+    std::string tag, obj, fmt, field, symm;
+    banner >> tag >> obj >> fmt >> field >> symm;
+    if (obj != "matrix") return false;
+    if (fmt != "coordinate") { std::cerr << "Only sparse MatrixMarket files are supported." << std::endl; return false; }
+    const bool is_pattern = field == "pattern";
+    if (field != "real" && field != "integer" && !is_pattern) {
+        std::cerr << "Only real, integer, and pattern MatrixMarket formats are supported." << std::endl;
+        return false;
+    }
+    const bool is_symmetric = symm == "symmetric", is_skew = symm == "skew-symmetric";
+    if (symm != "general" && !is_symmetric && !is_skew) {
+        std::cerr << "Only general, symmetric, and skew-symmetric MatrixMarket formats are supported." << std::endl;
+        return false;
+    }
+    // skip comments
+    unsigned int nnz_file = 0;
+    for (;;) {
+        if (!std::getline(in, line)) return false;
+        if (line.empty() || line[0] == '%') continue;
+        std::istringstream sz(line);
+        if (!(sz >> height >> width >> nnz_file)) { std::cerr << "could not read matrix coordinate information" << std::endl; return false; }
+        break;
+    }
+    std::vector<unsigned int> r, c;
+    std::vector<double> v;
+    r.reserve(nnz_file); c.reserve(nnz_file); v.reserve(nnz_file);
+    unsigned int line_count = 0;
+    while (std::getline(in, line)) {
+        if (line.empty()) continue;
+        ++line_count;
+        std::istringstream d(line);
+        long long row = 0, col = 0;
+        double val = 1.0;
+        d >> row >> col;
+        if (!is_pattern) d >> val;
+        if (row <= 0 || col <= 0 || row > (long long)height || col > (long long)width) {
+            std::cerr << "\nError reading file " << filename << "\nLine " << line << " contains an invalid index." << std::endl;
+            return false;
+        }
+        r.push_back((unsigned)(row - 1)); c.push_back((unsigned)(col - 1)); v.push_back(val);
+        if (row != col && (is_symmetric || is_skew)) {
+            r.push_back((unsigned)(col - 1)); c.push_back((unsigned)(row - 1)); v.push_back(is_skew ? -val : val);
+        }
+    }
+    if (line_count != nnz_file) {
+        std::cerr << "\nError reading file " << filename << "\nFound " << line_count << " nonzero entries, expected "
+                  << nnz_file << std::endl;
+        return false;
+    }
+    if (v.empty()) return false;
+    // stable counting sort by column
+    col_offsets.assign((size_t)width + 1, 0u);
+    for (unsigned cc : c) col_offsets[(size_t)cc + 1] += 1;
+    for (unsigned j = 0; j < width; ++j) col_offsets[(size_t)j + 1] += col_offsets[j];
+    row_indices.resize(v.size());
+    data.resize(v.size());
+    std::vector<unsigned> fill(col_offsets.begin(), col_offsets.end() - 1);
+    for (size_t i = 0; i < v.size(); ++i) {
+        const unsigned q = fill[c[i]]++;
+        row_indices[q] = r[i];
+        data[q] = v[i];
+    }
+    return true;
+}
+
 }  // namespace smallk_amd_io
+
+extern "C" int smk_load_matrix_market(const char* filename, unsigned* height, unsigned* width, unsigned* nnz,
+                                      unsigned* col_offsets, unsigned* row_indices, double* data)
+{
+    std::vector<unsigned> co, ri;
+    std::vector<double> d;
+    unsigned h = 0, w = 0;
+    if (!smallk_amd_io::LoadMatrixMarket(filename ? filename : "", h, w, co, ri, d)) return 0;
+    *height = h; *width = w; *nnz = (unsigned)d.size();
+    if (col_offsets) std::memcpy(col_offsets, co.data(), co.size() * sizeof(unsigned));
+    if (row_indices) std::memcpy(row_indices, ri.data(), ri.size() * sizeof(unsigned));
+    if (data) std::memcpy(data, d.data(), d.size() * sizeof(double));
+    return 1;
+}
 
 extern "C" int smk_write_csv(const double* buf, unsigned ldim, unsigned height, unsigned width,
                              const char* filename, unsigned precision)
@@ -175,10 +270,23 @@ Result Nmf(const NmfOptions& options, double* buf_a, int ldim_a, double* buf_w, 
     return to_result(rc);
 }
 
-Result NmfSparse(const NmfOptions&, const unsigned int, const unsigned int, const unsigned int, const unsigned int*,
-                 const unsigned int*, const double*, double*, int, double*, int, NmfStats&)
+Result NmfSparse(const NmfOptions& options, const unsigned int height, const unsigned int width, const unsigned int nz,
+                 const unsigned int* col_offsets, const unsigned int* row_indices, const double* data, double* buf_w,
+                 int ldim_w, double* buf_h, int ldim_h, NmfStats& stats)
 {
-    throw std::runtime_error("smallk_amd: NmfSparse is not built on the MI355X path yet (dense input only)");
+    if (smk_is_initialized() != SMK_INITIALIZED) {
+        std::cerr << "nmflib error: nmf_initialize() must be called prior to any factorization routine\n" << std::endl;
+        return Result::NOTINITIALIZED;
+    }
+    if (!IsValid(options)) return Result::BAD_PARAM;
+    if (ldim_w < options.height) throw std::logic_error("nmflib error: leading dimension of W return buffer too small");
+    if (ldim_h < options.k) throw std::logic_error("nmflib error: leading dimension of H return buffer too small");
+    smk_options c = to_c(options);
+    smk_stats st{0, 0};
+    int rc = smk_nmf_sparse(&c, height, width, nz, col_offsets, row_indices, data, buf_w, ldim_w, buf_h, ldim_h, &st);
+    stats.elapsed_us = st.elapsed_us;
+    stats.iteration_count = st.iteration_count;
+    return to_result(rc);
 }
 
 // =============================================================================================
@@ -186,8 +294,10 @@ Result NmfSparse(const NmfOptions&, const unsigned int, const unsigned int, cons
 // =============================================================================================
 namespace smallk {
 
-static bool matrix_loaded = false;
+static bool matrix_loaded = false, is_sparse = false;
 static std::vector<double> buf_a, buf_w, buf_h;
+static std::vector<double> sp_data;
+static std::vector<unsigned int> sp_rows, sp_cols;   // CSC: row indices, column offsets (width+1)
 static unsigned int m = 0u, n = 0u, k = 0u;
 static unsigned int ldim_a = 0u, ldim_w = 0u, ldim_h = 0u;
 static double nmf_tolerance = 0.005;
@@ -222,8 +332,10 @@ void Reset()
     clustfile_format = OutputFormat::JSON;
     outdir = std::string("");
     matrix_loaded = false;
+    is_sparse = false;
     matrix_filepath.clear();
     buf_a.clear(); buf_w.clear(); buf_h.clear();
+    sp_data.clear(); sp_rows.clear(); sp_cols.clear();
     m = n = k = ldim_a = ldim_w = ldim_h = 0u;
 }
 
@@ -273,14 +385,23 @@ void LoadMatrix(const std::string& filepath)
     if (filepath.empty()) throw std::runtime_error("smallk error (LoadMatrix): matrix filename is invalid.");
     std::cout << "Loading matrix..." << std::endl;
     matrix_loaded = false;
-    if (has_ext(filepath, "MTX"))
-        throw std::runtime_error("smallk error (LoadMatrix): MatrixMarket/sparse input is not built on the MI355X path yet: " + filepath);
+    if (has_ext(filepath, "MTX")) {       // IsSparse(filepath): MatrixMarket -> sparse (smallk.cpp:172-186)
+        if (!smallk_amd_io::LoadMatrixMarket(filepath, m, n, sp_cols, sp_rows, sp_data)) {
+            matrix_filepath.clear();
+            throw std::runtime_error("smallk error (LoadMatrix): load failed for file " + filepath);
+        }
+        is_sparse = true;
+        matrix_loaded = true;
+        matrix_filepath = filepath;
+        return;
+    }
     bool ok = smallk_amd_io::LoadCsv(buf_a, m, n, filepath);
     if (!ok || buf_a.size() < (size_t)m * n) {
         matrix_filepath.clear();
         throw std::runtime_error("smallk error (LoadMatrix): load failed for file " + filepath);
     }
     ldim_a = m;
+    is_sparse = false;
     matrix_loaded = true;
     matrix_filepath = filepath;
 }
@@ -302,14 +423,34 @@ void LoadMatrix(const double* buffer, const unsigned int ldim, const unsigned in
         for (unsigned int r = 0; r != height; ++r) buf_a[(size_t)c * height + r] = buffer[(size_t)c * ldim + r];
     m = height;
     n = width;
+    is_sparse = false;
     matrix_loaded = true;
     matrix_filepath = "NA";
 }
 
-void LoadMatrix(const unsigned int, const unsigned int, const unsigned int, const std::vector<double>&,
-                const std::vector<unsigned int>&, const std::vector<unsigned int>&)
+// sparse CSC from memory (smallk.cpp:268-340)
+void LoadMatrix(const unsigned int height, const unsigned int width, const unsigned int nz,
+                const std::vector<double>& data, const std::vector<unsigned int>& row_indices,
+                const std::vector<unsigned int>& col_offsets)
 {
-    throw std::runtime_error("smallk error (LoadMatrix): sparse input is not built on the MI355X path yet.");
+    std::cout << "Loading sparse matrix..." << std::endl;
+    matrix_loaded = false;
+    if (row_indices.size() != data.size())
+        throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): invalid input vectors.");
+    if (0 == height) throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): invalid height input.");
+    if (0 == width) throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): invalid width input.");
+    if ((uint64_t)data.size() > (uint64_t)height * width)
+        throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): more nonzeros than matrix elements.");
+    if (col_offsets.size() < (size_t)width + 1 || data.size() < nz)
+        throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): invalid input vectors.");
+    sp_data.assign(data.begin(), data.begin() + nz);
+    sp_rows.assign(row_indices.begin(), row_indices.begin() + nz);
+    sp_cols.assign(col_offsets.begin(), col_offsets.begin() + width + 1);
+    m = height;
+    n = width;
+    is_sparse = true;
+    matrix_loaded = true;
+    matrix_filepath = "NA";
 }
 
 bool IsMatrixLoaded() { return matrix_loaded; }
@@ -490,7 +631,11 @@ void Nmf(const unsigned int kval, const Algorithm algorithm, const std::string& 
     NmfSetDeviceStorage((int)device_storage);
     Result result;
     try {
-        result = ::Nmf(opts, &buf_a[0], ldim_a, &buf_w[0], ldim_w, &buf_h[0], ldim_h, stats);
+        if (is_sparse)
+            result = ::NmfSparse(opts, m, n, (unsigned int)sp_data.size(), &sp_cols[0], &sp_rows[0], &sp_data[0],
+                                 &buf_w[0], ldim_w, &buf_h[0], ldim_h, stats);
+        else
+            result = ::Nmf(opts, &buf_a[0], ldim_a, &buf_w[0], ldim_w, &buf_h[0], ldim_h, stats);
     } catch (...) {
         NmfSetDeviceStorage(saved);
         throw;

@@ -1706,6 +1706,49 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 N, PartialView R, const dou
 }
 
 // ==========================================================================
+// Sparse A (CSC, fp64 values): the two big products become gathers
+//   out[:, j] = sum_{p in column j of B} val[p] * X[:, row[p]]
+// with B = A (X = W', out = W'A) or B = A' (X = H, out = (AH')'), i.e. the reference's
+// sparse Gemm variants (sparse_gemm_ab_impl.hpp / sparse_gemm_ba_impl.hpp) in gather form.
+// KP/4 lanes per output column, 4 fp64 values (32 B) of X per lane per nonzero.
+// ==========================================================================
+template <int KP>
+__global__ __launch_bounds__(256) void spmm_gather_kernel(const i64* __restrict__ colptr,
+                                                          const unsigned* __restrict__ rowidx,
+                                                          const double* __restrict__ val, i64 ncols,
+                                                          const double* __restrict__ X, double* __restrict__ P, int kpp)
+{
+    constexpr int LPC = KP / 4;
+    const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 j = gtid / LPC;
+    const int s = (int)(gtid % LPC);
+    if (j >= ncols) return;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const i64 p0 = colptr[j], p1 = colptr[j + 1];
+    for (i64 p = p0; p < p1; ++p) {
+        const double v = val[p];
+        double x[4];
+        load4(X + (i64)rowidx[p] * KP + 4 * s, x);
+        acc[0] += v * x[0];
+        acc[1] += v * x[1];
+        acc[2] += v * x[2];
+        acc[3] += v * x[3];
+    }
+    if (4 * s < kpp) store4(P + j * kpp + 4 * s, acc);
+}
+
+int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X,
+                       int k, double* P, int kpp, hipStream_t st)
+{
+    const int KPv = kp_of(k);
+    const int grid = (int)((ncols * (KPv / 4) + 255) / 256);
+    if (grid == 0) return 0;
+    KP_DISPATCH(KPv, (spmm_gather_kernel<KP><<<grid, 256, 0, st>>>(colptr, rowidx, val, ncols, X, P, kpp)));
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ==========================================================================
 // RANK2 (nmf_solver_rank2.hpp): closed-form 2x2 solves by one fast Givens rotation
 // (SystemSolveH :25-135 / SystemSolveW :139-212) followed by the optimal active set
 // (:216-318).  One thread per column of X (KP = 8 layout, rows 0 and 1 live).

@@ -58,6 +58,12 @@ struct smk_matrix {
     int storage = SMK_STORE_F32;
     void* A = nullptr;  i64 ldA = 0, colsA = 0;      // m_pad x n_pad
     void* At = nullptr; i64 ldAt = 0, colsAt = 0;    // n_pad x m_pad
+    // sparse A: CSC of the local columns and CSC of its transpose (fp64 values, 64-bit offsets)
+    bool sparse = false;
+    i64 nnz = 0;
+    i64 *colptr = nullptr, *colptr_t = nullptr;
+    unsigned *rowidx = nullptr, *rowidx_t = nullptr;
+    double *val = nullptr, *val_t = nullptr;
 };
 
 struct smk_solver {
@@ -222,7 +228,7 @@ static int matrix_make_transpose(smk_matrix* a)
 
 int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
 {
-    if (!a || !host || ld < a->m) return SMK_BAD_PARAM;
+    if (!a || !host || ld < a->m || a->sparse) return SMK_BAD_PARAM;
     const size_t budget = (size_t)64 << 20;   // staging bytes
     i64 chunk = (i64)(budget / ((size_t)a->m * sizeof(double)));
     if (chunk < 1) chunk = 1;
@@ -249,7 +255,7 @@ int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
 
 int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed)
 {
-    if (!a) return SMK_BAD_PARAM;
+    if (!a || a->sparse) return SMK_BAD_PARAM;
     int rc = launch_fill_uniform(a->A, a->storage, a->ldA, a->m, a->n, a->ldA, a->colsA, 0, a->c0, a->m, seed,
                                  a->storage == SMK_STORE_BF16 ? 1 : 0, g_stream);
     if (rc) return rc;
@@ -261,7 +267,7 @@ int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed)
 
 int smk_matrix_download_f64(const smk_matrix* a, double* host, int64_t ld)
 {
-    if (!a || !host || ld < a->m) return SMK_BAD_PARAM;
+    if (!a || !host || ld < a->m || a->sparse) return SMK_BAD_PARAM;
     const size_t es = (size_t)elem_size(a->storage);
     std::vector<unsigned char> col((size_t)a->m * es);
     SMK_HIP(hipStreamSynchronize(g_stream));
@@ -287,9 +293,71 @@ int smk_matrix_download_f64(const smk_matrix* a, double* host, int64_t ld)
 void smk_matrix_destroy(smk_matrix* a)
 {
     if (!a) return;
-    if (a->A) (void)hipFree(a->A);
-    if (a->At) (void)hipFree(a->At);
+    void* ptrs[] = {a->A, a->At, a->colptr, a->colptr_t, a->rowidx, a->rowidx_t, a->val, a->val_t};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
     delete a;
+}
+
+// CSC shard (columns [col0, col0+ncols_local) of a height x width_global matrix) -> HBM, plus the
+// CSC of its transpose built on the host by a counting sort (SparseMatrix::Transpose,
+// sparse_matrix_ops.hpp:37-127).  Duplicate entries are kept (they add up in every product, as in
+// the reference's Compress(), sparse_matrix_impl.hpp:184-260).
+int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0,
+                             int64_t ncols_local, int64_t nnz, const unsigned* col_offsets,
+                             const unsigned* row_indices, const double* data)
+{
+    if (!out) return SMK_BAD_PARAM;
+    *out = nullptr;
+    if (!g_init) { set_error("smk_initialize() has not been called"); return SMK_NOTINITIALIZED; }
+    if (height <= 0 || width_global <= 0 || ncols_local <= 0 || col0 < 0 || col0 + ncols_local > width_global ||
+        nnz < 0 || !col_offsets || (nnz > 0 && (!row_indices || !data)))
+        return SMK_BAD_PARAM;
+    if ((int64_t)col_offsets[ncols_local] - (int64_t)col_offsets[0] != nnz) { set_error("col_offsets do not span nnz"); return SMK_BAD_PARAM; }
+    const unsigned base = col_offsets[0];
+    std::vector<i64> cp((size_t)ncols_local + 1), cpt((size_t)height + 1, 0);
+    for (int64_t c = 0; c <= ncols_local; ++c) {
+        if (c > 0 && col_offsets[c] < col_offsets[c - 1]) { set_error("col_offsets not monotone"); return SMK_BAD_PARAM; }
+        cp[(size_t)c] = (i64)col_offsets[c] - base;
+    }
+    for (int64_t p = 0; p < nnz; ++p) {
+        if ((int64_t)row_indices[base + p] >= height) { set_error("row index out of range"); return SMK_BAD_PARAM; }
+        cpt[(size_t)row_indices[base + p] + 1] += 1;
+    }
+    for (int64_t r = 0; r < height; ++r) cpt[(size_t)r + 1] += cpt[(size_t)r];
+    std::vector<unsigned> rit((size_t)(nnz > 0 ? nnz : 1));
+    std::vector<double> vt((size_t)(nnz > 0 ? nnz : 1));
+    {
+        std::vector<i64> fill(cpt.begin(), cpt.end() - 1);
+        for (int64_t c = 0; c < ncols_local; ++c)
+            for (i64 p = cp[(size_t)c]; p < cp[(size_t)c + 1]; ++p) {
+                const unsigned r = row_indices[base + p];
+                const i64 q = fill[r]++;
+                rit[(size_t)q] = (unsigned)c;
+                vt[(size_t)q] = data[base + p];
+            }
+    }
+    smk_matrix* a = new smk_matrix;
+    a->m = height; a->n_global = width_global; a->c0 = col0; a->n = ncols_local; a->storage = SMK_STORE_F32;
+    a->sparse = true; a->nnz = nnz;
+    int rc = 0;
+    rc |= dev_alloc(&a->colptr, (size_t)ncols_local + 1);
+    rc |= dev_alloc(&a->colptr_t, (size_t)height + 1);
+    rc |= dev_alloc(&a->rowidx, (size_t)nnz);
+    rc |= dev_alloc(&a->rowidx_t, (size_t)nnz);
+    rc |= dev_alloc(&a->val, (size_t)nnz);
+    rc |= dev_alloc(&a->val_t, (size_t)nnz);
+    if (rc) { smk_matrix_destroy(a); return SMK_DEVICE_ERROR; }
+    SMK_HIP(hipMemcpy(a->colptr, cp.data(), cp.size() * sizeof(i64), hipMemcpyHostToDevice));
+    SMK_HIP(hipMemcpy(a->colptr_t, cpt.data(), cpt.size() * sizeof(i64), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        SMK_HIP(hipMemcpy(a->rowidx, row_indices + base, (size_t)nnz * sizeof(unsigned), hipMemcpyHostToDevice));
+        SMK_HIP(hipMemcpy(a->val, data + base, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+        SMK_HIP(hipMemcpy(a->rowidx_t, rit.data(), (size_t)nnz * sizeof(unsigned), hipMemcpyHostToDevice));
+        SMK_HIP(hipMemcpy(a->val_t, vt.data(), (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    }
+    *out = a;
+    return SMK_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -343,6 +411,10 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if (s->nsplit < 1 || s->nsplit > 3) s->nsplit = 3;
     s->pl1 = plan_bigprod(a->storage, s->k, s->m, s->n, s->nsplit, g_cus);
     s->pl2 = plan_bigprod(a->storage, s->k, s->n, s->m, s->nsplit, g_cus);
+    if (a->sparse) {   // gather products write one slab
+        s->pl1.S = 1; s->pl1.p_elems = (size_t)s->pl1.ncols_pad * s->kpp;
+        s->pl2.S = 1; s->pl2.p_elems = (size_t)s->pl2.ncols_pad * s->kpp;
+    }
 
     int rc = 0;
     const size_t kk = (size_t)s->KP * s->KP;
@@ -356,8 +428,10 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     rc |= dev_alloc(&s->pg_partials, 2 * s->pg_half);
     rc |= dev_alloc(&s->scal_own, (size_t)8);
     rc |= dev_alloc(&s->fail_flag, (size_t)1);
-    rc |= dev_alloc((unsigned char**)&s->packW, packed_bytes(a->storage, s->k, s->m, s->nsplit));
-    rc |= dev_alloc((unsigned char**)&s->packH, packed_bytes(a->storage, s->k, s->n, s->nsplit));
+    if (!a->sparse) {
+        rc |= dev_alloc((unsigned char**)&s->packW, packed_bytes(a->storage, s->k, s->m, s->nsplit));
+        rc |= dev_alloc((unsigned char**)&s->packH, packed_bytes(a->storage, s->k, s->n, s->nsplit));
+    }
     rc |= dev_alloc(&s->P1, s->pl1.p_elems);
     rc |= dev_alloc(&s->P2, s->pl2.p_elems);
     if (opts->algorithm == SMK_ALG_HALS) rc |= dev_alloc(&s->hals_scratch, hals_w_scratch_elems(s->k, s->m));
@@ -456,8 +530,27 @@ static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl, const 
 }
 
 // R1 = W'A  (k x n, local columns)
+static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols,
+                      const double* X, double* P)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s->timing) {
+        SMK_HIP(hipEventCreate(&e0));
+        SMK_HIP(hipEventCreate(&e1));
+        SMK_HIP(hipEventRecord(e0, s->st));
+    }
+    int rc = launch_spmm_gather(colptr, rowidx, val, ncols, X, s->k, P, s->kpp, s->st);
+    if (rc) return rc;
+    if (s->timing) {
+        SMK_HIP(hipEventRecord(e1, s->st));
+        s->ev[which].push_back({e0, e1});
+    }
+    return 0;
+}
+
 static int prod1(smk_solver* s)
 {
+    if (s->a->sparse) return timed_spmm(s, 0, s->a->colptr, s->a->rowidx, s->a->val, s->n, s->Wt, s->P1);
     int rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st);
     if (rc) return rc;
     return timed_bigprod(s, 0, s->pl1, s->a->A, s->a->ldA, s->packW, s->P1);
@@ -466,9 +559,14 @@ static int prod1(smk_solver* s)
 // R2 = H At = (A H')'  (k x m), summed over ranks when sharded
 static int prod2(smk_solver* s)
 {
-    int rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st);
-    if (rc) return rc;
-    rc = timed_bigprod(s, 1, s->pl2, s->a->At, s->a->ldAt, s->packH, s->P2);
+    int rc = 0;
+    if (s->a->sparse) {
+        rc = timed_spmm(s, 1, s->a->colptr_t, s->a->rowidx_t, s->a->val_t, s->m, s->H, s->P2);
+    } else {
+        rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st);
+        if (rc) return rc;
+        rc = timed_bigprod(s, 1, s->pl2, s->a->At, s->a->ldAt, s->packH, s->P2);
+    }
     if (rc) return rc;
     if (s->ar) {
         PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
@@ -764,6 +862,11 @@ int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* laun
 int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double* flops)
 {
     if (!s || which < 0 || which > 1) return SMK_BAD_PARAM;
+    if (s->a->sparse) {   // per nonzero: 12 bytes of A (value + row index) + one KP-row of X gathered
+        if (bytes) *bytes = (double)s->a->nnz * (12.0 + 8.0 * s->KP);
+        if (flops) *flops = 2.0 * (double)s->a->nnz * s->k;
+        return SMK_OK;
+    }
     const double mn = (double)s->m * (double)s->n;
     if (bytes) *bytes = mn * elem_size(s->a->storage);
     if (flops) *flops = 2.0 * mn * s->k;
@@ -794,6 +897,33 @@ int smk_nmf_dense(const smk_options* opts, const double* A, int64_t ldA, double*
         // like the reference, W/H hold the last iterate even when the solver reports failure
         if (run_rc == SMK_OK || run_rc == SMK_FAILURE) (void)smk_solver_get_factors(s, 0, W, ldW, H, ldH);
         rc = run_rc;
+    }
+    smk_solver_destroy(s);
+    smk_matrix_destroy(a);
+    return rc;
+}
+
+// Result NmfSparse(...), common/src/nmf.cpp:232-300 (CSC input, 32-bit indices as in the reference)
+int smk_nmf_sparse(const smk_options* opts, unsigned height, unsigned width, unsigned nz, const unsigned* col_offsets,
+                   const unsigned* row_indices, const double* data, double* W, int64_t ldW, double* H, int64_t ldH,
+                   smk_stats* stats)
+{
+    if (!g_init) {
+        fprintf(stderr, "nmflib error: nmf_initialize() must be called prior to any factorization routine\n\n");
+        return SMK_NOTINITIALIZED;
+    }
+    if (!opts || !smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
+    if (!col_offsets || !row_indices || !data || !W || !H) return SMK_BAD_PARAM;
+    if ((int64_t)height != opts->height || (int64_t)width != opts->width) return SMK_BAD_PARAM;
+    if (ldW < opts->height || ldH < opts->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
+    smk_matrix* a = nullptr;
+    smk_solver* s = nullptr;
+    int rc = smk_matrix_create_sparse(&a, height, width, 0, width, nz, col_offsets, row_indices, data);
+    if (rc == SMK_OK) rc = smk_solver_create(&s, opts, a);
+    if (rc == SMK_OK) rc = smk_solver_set_factors(s, W, ldW, H, ldH);
+    if (rc == SMK_OK) {
+        rc = smk_solver_run(s, stats);
+        if (rc == SMK_OK || rc == SMK_FAILURE) (void)smk_solver_get_factors(s, 0, W, ldW, H, ldH);
     }
     smk_solver_destroy(s);
     smk_matrix_destroy(a);

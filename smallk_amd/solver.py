@@ -103,6 +103,65 @@ class DenseMatrix:
             pass
 
 
+class SparseMatrix(DenseMatrix):
+    """Sparse A in CSC (scipy.sparse.csc_matrix or (data, indices, indptr, shape)), resident in HBM with
+    its transpose.  Shares the NmfSolver interface with DenseMatrix."""
+
+    def __init__(self, data, indices, indptr, shape, *, col0=0, width_global=None):
+        self.height = int(shape[0])
+        self.ncols = int(shape[1])
+        self.width_global = int(width_global if width_global is not None else shape[1])
+        self.col0 = int(col0)
+        self.storage = L.STORE_F32
+        d = np.ascontiguousarray(data, dtype=np.float64)
+        ri = np.ascontiguousarray(indices, dtype=np.uint32)
+        co = np.ascontiguousarray(indptr, dtype=np.uint32)
+        self.nnz = int(co[-1] - co[0])
+        self._h = C.c_void_p()
+        L.check(L.lib().smk_matrix_create_sparse(C.byref(self._h), self.height, self.width_global, self.col0,
+                                                 self.ncols, self.nnz, co.ctypes.data_as(C.POINTER(C.c_uint)),
+                                                 ri.ctypes.data_as(C.POINTER(C.c_uint)), _p(d)),
+                "smk_matrix_create_sparse")
+
+    @classmethod
+    def from_scipy(cls, A):
+        A = A.tocsc()
+        return cls(A.data, A.indices, A.indptr, A.shape)
+
+
+def load_matrix_market(path):
+    """MatrixMarket coordinate file -> (data, indices, indptr, (height, width)) in CSC."""
+    h, w, nz = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+    p = str(path).encode()
+    if L.lib().smk_load_matrix_market(p, C.byref(h), C.byref(w), C.byref(nz), None, None, None) != 1:
+        raise RuntimeError(f"could not load MatrixMarket file {path}")
+    indptr = np.zeros(w.value + 1, dtype=np.uint32)
+    indices = np.zeros(nz.value, dtype=np.uint32)
+    data = np.zeros(nz.value, dtype=np.float64)
+    L.lib().smk_load_matrix_market(p, C.byref(h), C.byref(w), C.byref(nz), indptr.ctypes.data_as(C.POINTER(C.c_uint)),
+                                   indices.ctypes.data_as(C.POINTER(C.c_uint)), _p(data))
+    return data, indices, indptr, (h.value, w.value)
+
+
+def nmf_sparse(A, W0, H0, algorithm, **kw):
+    """One-shot sparse NMF = ``NmfSparse(...)`` (common/src/nmf.cpp:232-300); A is a scipy sparse matrix."""
+    A = A.tocsc()
+    W = _f(W0).copy(order="F")
+    H = _f(H0).copy(order="F")
+    m, n = A.shape
+    k = W.shape[1]
+    o = make_options(m, n, k, algorithm, **kw)
+    st = L.Stats()
+    d = np.ascontiguousarray(A.data, dtype=np.float64)
+    ri = np.ascontiguousarray(A.indices, dtype=np.uint32)
+    co = np.ascontiguousarray(A.indptr, dtype=np.uint32)
+    rc = L.lib().smk_nmf_sparse(C.byref(o), m, n, d.size, co.ctypes.data_as(C.POINTER(C.c_uint)),
+                                ri.ctypes.data_as(C.POINTER(C.c_uint)), _p(d), _p(W), m, _p(H), k, C.byref(st))
+    if rc not in (L.OK, L.FAILURE, L.BAD_PARAM, L.NOTINITIALIZED, L.SIZE_TOO_LARGE):
+        L.check(rc, "smk_nmf_sparse")
+    return NmfResult(rc, W, H, st.iteration_count, st.elapsed_us)
+
+
 @dataclass
 class NmfResult:
     result: int

@@ -1,0 +1,129 @@
+"""Sparse input: MatrixMarket loader (CPU) and NmfSparse on the GPU against the dense oracle on
+MakeDense(A) -- the reference's own sparse-vs-dense test shape (tests/src/test_dense_nmf.cpp:205-378,
+threshold 1e-8 on ||dW||_F, ||dH||_F)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def random_sparse(m, n, density, seed):
+    rng = np.random.default_rng(seed)
+    A = sp.random(m, n, density=density, random_state=rng, data_rvs=lambda s: rng.random(s) + 0.05, format="csc")
+    # no empty rows / columns (they make W'W or HH' singular for BPP)
+    A = A.tolil()
+    for j in range(n):
+        if A[:, j].nnz == 0:
+            A[rng.integers(m), j] = 0.5
+    for i in range(m):
+        if A[i, :].nnz == 0:
+            A[i, rng.integers(n)] = 0.5
+    return A.tocsc()
+
+
+def test_matrix_market_loader(tmp_path):
+    import smallk_amd
+    f = tmp_path / "g.mtx"
+    f.write_text("%%MatrixMarket matrix coordinate real general\n% comment\n3 4 5\n1 1 1.5\n3 1 2.0\n2 3 -1.0\n1 4 4.0\n3 4 0.25\n")
+    d, ri, co, shape = smallk_amd.load_matrix_market(f)
+    A = sp.csc_matrix((d, ri, co), shape=shape).toarray()
+    assert np.array_equal(A, np.array([[1.5, 0, 0, 4.0], [0, 0, -1.0, 0], [2.0, 0, 0, 0.25]]))
+    g = tmp_path / "s.mtx"
+    g.write_text("%%MatrixMarket matrix coordinate real symmetric\n3 3 3\n1 1 2.0\n2 1 3.0\n3 2 4.0\n")
+    d, ri, co, shape = smallk_amd.load_matrix_market(g)
+    assert np.array_equal(sp.csc_matrix((d, ri, co), shape=shape).toarray(),
+                          np.array([[2.0, 3.0, 0], [3.0, 0, 4.0], [0, 4.0, 0]]))
+    h = tmp_path / "p.mtx"
+    h.write_text("%%MatrixMarket matrix coordinate pattern general\n2 2 2\n1 2\n2 1\n")
+    d, ri, co, shape = smallk_amd.load_matrix_market(h)
+    assert np.array_equal(sp.csc_matrix((d, ri, co), shape=shape).toarray(), np.array([[0, 1.0], [1.0, 0]]))
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 1.0\n")
+    with pytest.raises(RuntimeError):
+        smallk_amd.load_matrix_market(bad)          # fewer entries than announced
+    arr = tmp_path / "arr.mtx"
+    arr.write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(RuntimeError):
+        smallk_amd.load_matrix_market(arr)          # dense MatrixMarket is not a sparse input
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg,m,n,k,density,iters", [
+    ("MU", 300, 200, 8, 0.2, 20), ("BPP", 300, 200, 8, 0.2, 10), ("HALS", 300, 200, 8, 0.3, 10),
+    ("RANK2", 300, 200, 2, 0.2, 20), ("BPP", 512, 400, 33, 0.1, 5), ("MU", 1000, 700, 64, 0.02, 10),
+    ("BPP", 2000, 1500, 16, 0.05, 5),
+    # HALS is exercised only on the denser small case: on very sparse data rows of H die and the
+    # reference update is discontinuous there (see tests/golden/make_golden.py; the reference's own
+    # sparse-vs-dense test skips HALS, test_dense_nmf.cpp:263-266)
+])
+def test_sparse_matches_dense_oracle(gpu, alg, m, n, k, density, iters):
+    A = random_sparse(m, n, density, seed=m + n + k)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    ref = oracle.nmf(A.toarray(), W0, H0, alg, min_iter=iters, max_iter=iters)
+    got = gpu.nmf_sparse(A, W0, H0, alg, min_iter=iters, max_iter=iters)
+    assert ref.result == 0 and got.result == 0 and got.iteration_count == iters
+    eW, eH = np.linalg.norm(got.W - ref.W), np.linalg.norm(got.H - ref.H)
+    assert eW < 1e-8 and eH < 1e-8, (eW, eH)
+
+
+@pytest.mark.gpu
+def test_sparse_solver_object_and_duplicates(gpu):
+    """duplicate coordinates add up (SparseMatrix::Compress keeps them); solver object on a SparseMatrix"""
+    m, n, k = 120, 90, 5
+    A = random_sparse(m, n, 0.3, seed=7)
+    # split every value into two entries at the same coordinate
+    data = np.concatenate([A.data * 0.25, A.data * 0.75])
+    indices = np.concatenate([A.indices, A.indices])
+    counts = np.diff(A.indptr)
+    cols = np.repeat(np.arange(n), counts)
+    order = np.argsort(np.concatenate([cols, cols]), kind="stable")
+    indptr = np.concatenate([[0], np.cumsum(2 * counts)])
+    S = gpu.SparseMatrix(data[order], indices[order], indptr, (m, n))
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    s = gpu.NmfSolver(S, gpu.make_options(m, n, k, "BPP", min_iter=6, max_iter=6))
+    s.set_factors(W0, H0)
+    rc, it, _ = s.run()
+    W, H = s.factors()
+    ref = oracle.nmf(A.toarray(), W0, H0, "BPP", min_iter=6, max_iter=6)
+    assert rc == 0 and it == 6
+    assert rel(W, ref.W) < 1e-9 and rel(H, ref.H) < 1e-9
+
+
+@pytest.mark.gpu
+def test_smallkapi_sparse_inputs(gpu, tmp_path):
+    """pysmallk flow with a MatrixMarket file and with CSC buffers (pysmallk/tests/smallkapi_inmem.py:57-94)"""
+    m, n, k = 200, 150, 6
+    A = random_sparse(m, n, 0.15, seed=11)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    ref = oracle.nmf(A.toarray(), W0, H0, "BPP", min_iter=1, max_iter=200, tol=0.01)
+    l = gpu._lib.lib()
+    dp = C.POINTER(C.c_double)
+    fw, fh = str(tmp_path / "w0.csv"), str(tmp_path / "h0.csv")
+    l.smk_write_csv(W0.ctypes.data_as(dp), m, m, k, fw.encode(), 17)
+    l.smk_write_csv(H0.ctypes.data_as(dp), k, k, n, fh.encode(), 17)
+    mtx = tmp_path / "a.mtx"
+    coo = A.tocoo()
+    with open(mtx, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{m} {n} {coo.nnz}\n")
+        for r, c, v in zip(coo.row, coo.col, coo.data):
+            f.write(f"{r + 1} {c + 1} {float(v)!r}\n")
+    api = gpu.SmallkAPI()
+    api.load_matrix(filepath=str(mtx))
+    api.nmf(k, "BPP", infile_W=fw, infile_H=fh, min_iter=1, max_iter=200, tol=0.01, outdir=str(tmp_path))
+    assert api.get_iteration_count() == ref.iteration_count
+    assert rel(api.get_W(), ref.W) < 1e-8 and rel(api.get_H(), ref.H) < 1e-8
+    api.load_matrix(height=m, width=n, nz=A.nnz, buffer=list(A.data), row_indices=list(A.indices),
+                    col_offsets=list(A.indptr))
+    api.nmf(k, "BPP", infile_W=fw, infile_H=fh, min_iter=1, max_iter=200, tol=0.01, outdir=str(tmp_path))
+    assert rel(api.get_W(), ref.W) < 1e-8 and rel(api.get_H(), ref.H) < 1e-8
