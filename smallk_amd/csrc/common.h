@@ -96,8 +96,8 @@ int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* 
                          int* fail_flag, hipStream_t st);
 size_t hals_w_scratch_elems(int k, i64 M);
 // BPP / NNLS block principal pivoting over all columns
-int launch_nnls_bpp(double* X, double* Y, int k, i64 N, PartialView R, const double* G, int* fail_flag,
-                    int iter_tag, hipStream_t st);
+int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
+                    int* fail_flag, int iter_tag, hipStream_t st);
 // normalisation: scale Wt rows by 1/nu_c, H rows by nu_c where nu_c^2 = G[c][c]
 int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int* fail_flag, hipStream_t st);
 // delta-fnorm: out[0] = sum (W - Wprev)^2, out[1] = sum W^2 ; then Wprev = W

@@ -1582,7 +1582,7 @@ __device__ __forceinline__ unsigned long long group_ballot(bool pred, int lane)
 template <int KP>
 __global__ __launch_bounds__(256) void nnls_bpp_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N,
                                                        PartialView R, const double* __restrict__ G,
-                                                       int* __restrict__ fail_flag, int iter_tag)
+                                                       int* __restrict__ fail_flag, int iter_tag, i64 col_begin)
 {
     constexpr int GS = KP;
     constexpr int GPB = 256 / GS;                   // column groups per block
@@ -1592,7 +1592,7 @@ __global__ __launch_bounds__(256) void nnls_bpp_kernel(double* __restrict__ X, d
 
     const int lane = threadIdx.x & 63;
     const int i = threadIdx.x % GS;                 // component owned by this lane
-    const i64 col = (i64)blockIdx.x * GPB + threadIdx.x / GS;
+    const i64 col = col_begin + (i64)blockIdx.x * GPB + threadIdx.x / GS;
     const bool col_ok = col < N;
     const bool comp_ok = i < k;
     const i64 cc = col_ok ? col : (N - 1);
@@ -1694,13 +1694,17 @@ __global__ __launch_bounds__(256) void nnls_bpp_kernel(double* __restrict__ X, d
     if (failed && col_ok) atomicMin(fail_flag, iter_tag);
 }
 
-int launch_nnls_bpp(double* X, double* Y, int k, i64 N, PartialView R, const double* G, int* fail_flag,
-                    int iter_tag, hipStream_t st)
+// solves columns [col_begin, col_end) of X (col_end <= N); other columns are untouched
+int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
+                    int* fail_flag, int iter_tag, hipStream_t st)
 {
     const int KPv = kp_of(k);
     const int gpb = 256 / KPv;
-    const int grid = (int)((N + gpb - 1) / gpb);
-    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag)));
+    const i64 ncols = col_end - col_begin;
+    if (ncols <= 0) return 0;
+    const int grid = (int)((ncols + gpb - 1) / gpb);
+    const i64 N = col_end;
+    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin)));
     SMK_HIP(hipGetLastError());
     return 0;
 }

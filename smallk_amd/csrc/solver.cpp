@@ -74,7 +74,7 @@ struct smk_solver {
     hipStream_t st = nullptr;
     double *H = nullptr, *Wt = nullptr, *Gw = nullptr, *Gh = nullptr, *gram_scratch = nullptr;
     double *Wprev = nullptr, *hals_scratch = nullptr, *pg_partials = nullptr, *scal = nullptr, *tmpW = nullptr;
-    double *Gh_own = nullptr, *scal_own = nullptr;
+    double *Gh_own = nullptr, *scal_own = nullptr, *Wt_own = nullptr;
     void *packW = nullptr, *packH = nullptr;
     double *P1 = nullptr, *P2 = nullptr;
     float* R2red = nullptr;
@@ -381,6 +381,8 @@ static size_t comm_bytes(const smk_solver* s)
     b += (size_t)s->KP * s->KP * sizeof(double);
     b = (b + 255) / 256 * 256;
     b += 8 * sizeof(double);
+    b = (b + 255) / 256 * 256;
+    b += (size_t)s->KP * s->m * sizeof(double);     // Wt: row-sharded W-side NNLS gathers through an all-reduce
     return b;
 }
 
@@ -419,7 +421,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     int rc = 0;
     const size_t kk = (size_t)s->KP * s->KP;
     rc |= dev_alloc(&s->H, (size_t)s->KP * s->n);
-    rc |= dev_alloc(&s->Wt, (size_t)s->KP * s->m);
+    rc |= dev_alloc(&s->Wt_own, (size_t)s->KP * s->m);
     rc |= dev_alloc(&s->Gw, kk);
     rc |= dev_alloc(&s->Gh_own, kk);
     rc |= dev_alloc(&s->gram_scratch, gram_scratch_elems(s->k, GRAM_BLOCKS));
@@ -439,6 +441,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if (rc) { smk_solver_destroy(s); return SMK_DEVICE_ERROR; }
     s->Gh = s->Gh_own;
     s->scal = s->scal_own;
+    s->Wt = s->Wt_own;
     *out = s;
     return SMK_OK;
 }
@@ -446,7 +449,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
 void smk_solver_destroy(smk_solver* s)
 {
     if (!s) return;
-    void* ptrs[] = {s->H, s->Wt, s->Gw, s->Gh_own, s->gram_scratch, s->tmpW, s->pg_partials, s->scal_own,
+    void* ptrs[] = {s->H, s->Wt_own, s->Gw, s->Gh_own, s->gram_scratch, s->tmpW, s->pg_partials, s->scal_own,
                     s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -478,9 +481,13 @@ int smk_solver_set_comm(smk_solver* s, int rank, int world, smk_allreduce_fn fn,
         b += (size_t)s->KP * s->KP * sizeof(double);
         b = (b + 255) / 256 * 256;
         s->scal = (double*)(p + b);
+        b += 8 * sizeof(double);
+        b = (b + 255) / 256 * 256;
+        s->Wt = (double*)(p + b);
     } else {
         s->Gh = s->Gh_own;
         s->scal = s->scal_own;
+        s->Wt = s->Wt_own;
     }
     return SMK_OK;
 }
@@ -629,10 +636,22 @@ static int solver_iteration(smk_solver* s)
             rc = prod2(s);    if (rc) return rc;
             break;
         case SMK_ALG_BPP:  // nmf_solver_bpp.hpp:342-377
-            rc = launch_nnls_bpp(s->H, nullptr, s->k, s->n, r1, s->Gw, s->fail_flag, s->iter, s->st); if (rc) return rc;
+            rc = launch_nnls_bpp(s->H, nullptr, s->k, 0, s->n, r1, s->Gw, s->fail_flag, s->iter, s->st); if (rc) return rc;
             rc = gram_h(s);   if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
-            rc = launch_nnls_bpp(s->Wt, nullptr, s->k, s->m, r2, s->Gh, s->fail_flag, s->iter, s->st); if (rc) return rc;
+            if (s->ar && s->world > 1) {
+                // W is replicated but its rows are independent NNLS problems: every rank solves the rows
+                // [i0, i1) only, zeroes the rest and the slices are gathered by a sum-all-reduce of Wt.
+                const i64 base = s->m / s->world, extra = s->m % s->world;
+                const i64 i0 = s->rank * base + (s->rank < extra ? s->rank : extra);
+                const i64 i1 = i0 + base + (s->rank < extra ? 1 : 0);
+                rc = launch_nnls_bpp(s->Wt, nullptr, s->k, i0, i1, view2(s), s->Gh, s->fail_flag, s->iter, s->st); if (rc) return rc;
+                if (i0 > 0) SMK_HIP(hipMemsetAsync(s->Wt, 0, (size_t)i0 * s->KP * sizeof(double), s->st));
+                if (i1 < s->m) SMK_HIP(hipMemsetAsync(s->Wt + i1 * s->KP, 0, (size_t)(s->m - i1) * s->KP * sizeof(double), s->st));
+                if (s->ar(s->ar_user, s->Wt, (int64_t)s->KP * s->m, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
+            } else {
+                rc = launch_nnls_bpp(s->Wt, nullptr, s->k, 0, s->m, view2(s), s->Gh, s->fail_flag, s->iter, s->st); if (rc) return rc;
+            }
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
             break;
