@@ -30,6 +30,9 @@ typedef __attribute__((ext_vector_type(8))) float f32x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((ext_vector_type(2))) double f64x2_t;
 
+#ifndef NT_AUX
+#define NT_AUX 2
+#endif
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -309,7 +312,11 @@ __global__ __launch_bounds__(256 * WK, 1) void bigprod_kernel(const unsigned cha
             const int t = wave + C::NW * i;
             const unsigned char* g = is_b[i] ? (B + src_off[i] + stage * (C::MB * EBYTES))
                                              : (Xp + stage * C::X_BYTES + src_off[i]);
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
+            // B is streamed once: non-temporal policy (aux = 2) keeps it from displacing the X slice in L2
+            if (is_b[i])
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
+            else
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
         }
     };
 
