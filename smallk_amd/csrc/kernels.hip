@@ -1522,19 +1522,25 @@ int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* 
         mode = (env && env[0] == 'm') ? 0 : 1;
     }
     // fused path: at most one workgroup per CU so that all of them are resident by construction.
-    // Threads per workgroup are chosen so a whole W row (KP doubles) fits the register budget.
-    const int nt = (KPv == 64) ? 256 : (KPv == 32) ? 512 : 1024;
-    const i64 nblk_f = (M + nt - 1) / nt;
-    if (mode == 1 && nblk_f <= (i64)num_cus && nblk_f <= 1024) {
+    // Smallest workgroup (256 threads: cheapest in-block sync, measured best) that still covers M
+    // rows with <= num_cus workgroups; the register budget caps it at 512 for KP = 32 and 256 for 64.
+    int nt = 0;
+    const int nt_max = (KPv == 64) ? 256 : (KPv == 32) ? 512 : 1024;
+    for (int cand = 256; cand <= nt_max; cand *= 2)
+        if ((M + cand - 1) / cand <= (i64)num_cus) { nt = cand; break; }
+    if (mode == 1 && nt != 0) {
+        const i64 nblk_f = (M + nt - 1) / nt;
         unsigned long long* slots = (unsigned long long*)scratch;
         SMK_HIP(hipMemsetAsync(slots, 0xFF, (size_t)k * nblk_f * sizeof(unsigned long long), st));
         const int nb = (int)nblk_f;
+#define SMK_FUSED(KPX, NTX) hals_w_fused_kernel<KPX, NTX><<<nb, NTX, 0, st>>>(Wt, k, M, R, G, slots, nb, fail_flag)
         switch (KPv) {
-            case 8: hals_w_fused_kernel<8, 1024><<<nb, 1024, 0, st>>>(Wt, k, M, R, G, slots, nb, fail_flag); break;
-            case 16: hals_w_fused_kernel<16, 1024><<<nb, 1024, 0, st>>>(Wt, k, M, R, G, slots, nb, fail_flag); break;
-            case 32: hals_w_fused_kernel<32, 512><<<nb, 512, 0, st>>>(Wt, k, M, R, G, slots, nb, fail_flag); break;
-            default: hals_w_fused_kernel<64, 256><<<nb, 256, 0, st>>>(Wt, k, M, R, G, slots, nb, fail_flag); break;
+            case 8: if (nt == 256) SMK_FUSED(8, 256); else if (nt == 512) SMK_FUSED(8, 512); else SMK_FUSED(8, 1024); break;
+            case 16: if (nt == 256) SMK_FUSED(16, 256); else if (nt == 512) SMK_FUSED(16, 512); else SMK_FUSED(16, 1024); break;
+            case 32: if (nt == 256) SMK_FUSED(32, 256); else SMK_FUSED(32, 512); break;
+            default: SMK_FUSED(64, 256); break;
         }
+#undef SMK_FUSED
         SMK_HIP(hipGetLastError());
         return 0;
     }
