@@ -76,7 +76,6 @@ struct BigProdPlan {
 };
 BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus);
 int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st);
-const void* bigprod_kernel_ptr(const BigProdPlan& pl);
 
 int launch_reduce_partials(PartialView pv, int k, i64 N, float* out /* [N][kpp] */, hipStream_t st);
 

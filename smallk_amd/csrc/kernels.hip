@@ -982,17 +982,23 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
 #pragma unroll
         for (int b = 0; b < T; ++b) acc[a][b] = f64x4_t{0.0, 0.0, 0.0, 0.0};
     const int kc = lane >> 4, r16 = lane & 15;
-    for (i64 c0 = c_begin; c0 < c_end; c0 += 4) {
-        const i64 col = c0 + kc;
-        const bool ok = col < c_end;
-        double f[T];
+    // 16 columns (4 MFMA k-steps) per trip: all loads of the trip are issued before its MFMAs
+    for (i64 c0 = c_begin; c0 < c_end; c0 += 16) {
+        double f[4][T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) f[t] = ok ? X[col * KP + 16 * t + r16] : 0.0;
+        for (int u = 0; u < 4; ++u) {
+            const i64 col = c0 + 4 * u + kc;
+            const bool ok = col < c_end;
 #pragma unroll
-        for (int a = 0; a < T; ++a)
+            for (int t = 0; t < T; ++t) f[u][t] = ok ? X[col * KP + 16 * t + r16] : 0.0;
+        }
 #pragma unroll
-            for (int b = 0; b < T; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], acc[a][b], 0, 0, 0);
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int b = 0; b < T; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[u][a], f[u][b], acc[a][b], 0, 0, 0);
     }
     // deterministic in-block sum of the 4 waves
     for (int w = 0; w < 4; ++w) {
@@ -1052,7 +1058,7 @@ int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int m
         if (nblk > max_blocks) nblk = max_blocks;
         if (nblk < 1) nblk = 1;
         i64 cpw = (N + (i64)nblk * 4 - 1) / ((i64)nblk * 4);
-        cpw = (cpw + 3) / 4 * 4;
+        cpw = (cpw + 15) / 16 * 16;
         switch (KP) {
             case 16: gram_mfma_kernel<16><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
             case 32: gram_mfma_kernel<32><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
