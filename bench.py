@@ -54,7 +54,7 @@ def cpu_baseline(m, n, k, alg, quant, budget_s=20.0):
         t0 = time.perf_counter()
         r = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters)
         t = time.perf_counter() - t0
-        if t > budget_s / 3 or iters >= 64:
+        if t > budget_s / 2 or iters >= 128:
             break
         iters *= 2
     it_s_sample = r.iteration_count / t

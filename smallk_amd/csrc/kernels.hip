@@ -199,13 +199,19 @@ int launch_zero_f64(double* p, i64 n, hipStream_t st)
 //   2q+h) -- identical on both operands, so the result is the plain dot product.
 //   HBM-bound: algorithmic bytes = len*ncols*sizeof(B elt) per launch.
 // ==========================================================================
-template <int EBYTES, int KT, int NSPLIT, int MB_, int NSTAGE_, int CW_, int WK_>
+template <int EBYTES, int KT, int NSPLIT, int MB_, int NSTAGE_, int CW_, int WK_, int NWL_>
 struct BPCfg {
     static constexpr int MB = MB_;          // rows per stage
     static constexpr int CW = CW_;          // 32-column MFMA tiles per wave
     static constexpr int WK = WK_;          // wave groups along k: waves = 4*WK, each owns KT/WK k-tiles
     static constexpr int KTW = KT / WK_;
-    static constexpr int NW = 4 * WK_;      // waves per workgroup
+    static constexpr int NWC = 4 * WK_;     // compute waves per workgroup
+    // NWL > 0: wave specialisation -- NWL extra waves only issue the LDS-DMA loads (a vector-memory
+    // instruction occupies its wave ~100 cycles; keeping it off the MFMA waves is worth more than the
+    // registers the loader waves waste).  NWL = 0: every wave loads and computes.
+    static constexpr int NWL = NWL_;
+    static constexpr int NLD = NWL_ > 0 ? NWL_ : NWC;   // waves that issue loads
+    static constexpr int NW = NWC + NWL_;   // waves per workgroup
     static constexpr int E = 16 / EBYTES;
     static constexpr int CPC = MB / E;      // 16-B chunks per column per stage
     // XOR swizzle of the chunk index so that 16 lanes reading 16 different columns hit 16 distinct
@@ -224,12 +230,19 @@ struct BPCfg {
     static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PD = NSTAGE_ - 1;          // stages in flight ahead of the consumer
     static constexpr int TI = STAGE_BYTES / 1024;   // wave-level 1-KiB loads per stage
-    static constexpr int LPS = TI / NW;             // per wave
-    static_assert(TI % NW == 0, "loads per stage must split evenly over the waves");
+    static constexpr int LPS = TI / NLD;            // per loading wave
+    static_assert(TI % NLD == 0, "loads per stage must split evenly over the loading waves");
     static_assert(KT % WK_ == 0, "k tiles must split evenly over the wave groups");
     static_assert(LPS * PD <= 63, "vmcnt is a 6-bit counter");
     static_assert(STAGE_BYTES * NSTAGE <= 160 * 1024, "LDS ring exceeds 160 KiB");
 };
+
+#ifdef SMK_BP_PROFILE
+__device__ unsigned long long* g_bp_prof = nullptr;   // [wg][wave][4] cycles: wait, barrier, issue, compute
+#define BP_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#else
+#define BP_T(x)
+#endif
 
 template <int N> __device__ __forceinline__ void wait_vmcnt()
 {
@@ -246,13 +259,13 @@ template <int LPS, int PD> __device__ __forceinline__ void wait_stage(int ahead)
     wait_vmcnt<0>();
 }
 
-template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK>
-__global__ __launch_bounds__(256 * WK, 1) void bigprod_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK, int NWL>
+__global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                          const unsigned char* __restrict__ Xp,
                                                          double* __restrict__ P, i64 stages, i64 nst,
                                                          i64 tiles, i64 ncols_pad, int S, int logS)
 {
-    using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK>;
+    using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
     constexpr int KTW = C::KTW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -276,6 +289,9 @@ __global__ __launch_bounds__(256 * WK, 1) void bigprod_kernel(const unsigned cha
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = (NWL == 0) || (wave >= C::NWC);          // wave-uniform
+    const bool is_compute = wave < C::NWC;
+    const int lw = (NWL == 0) ? wave : (wave - C::NWC);             // index among the loading waves
 
     i64 st0 = (i64)split * nst;
     i64 st1 = st0 + nst;
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(256 * WK, 1) void bigprod_kernel(const unsigned cha
     int is_b[C::LPS];
 #pragma unroll
     for (int i = 0; i < C::LPS; ++i) {
-        const int t = wave + C::NW * i;            // wave-level load index within the stage
+        const int t = lw + C::NLD * i;             // wave-level load index within the stage
         if (t * 1024 < C::B_BYTES) {
             const int p = t * 64 + lane;           // chunk position inside the LDS B tile
             const int j = p / C::CPC;
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(256 * WK, 1) void bigprod_kernel(const unsigned cha
         unsigned char* lbase = smem + buf * C::STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < C::LPS; ++i) {
-            const int t = wave + C::NW * i;
+            const int t = lw + C::NLD * i;
             const unsigned char* g = is_b[i] ? (B + src_off[i] + stage * (C::MB * EBYTES))
                                              : (Xp + stage * C::X_BYTES + src_off[i]);
             // B is streamed once: non-temporal policy (aux = 2) keeps it from displacing the X slice in L2
@@ -363,14 +379,22 @@ __global__ __launch_bounds__(256 * WK, 1) void bigprod_kernel(const unsigned cha
             }
     };
 
+#ifdef SMK_BP_PROFILE
+    unsigned long long prof_[4] = {0, 0, 0, 0};
+#endif
     // one stage: wait for its data, refill the ring slot freed by the previous stage, MFMAs into
     // `cur`; the previous stage's fp32 sums (`prev`) are folded into fp64 after the first step.
     auto stage_body = [&](int t, f32x16_t (&cur)[NT], f32x16_t (&prev)[NT], bool flush_prev) {
         int ahead = my_nst - 1 - t;
         if (ahead > C::PD - 1) ahead = C::PD - 1;
-        wait_stage<C::LPS, C::PD>(ahead);
+        BP_T(t0_);
+        if (is_loader) wait_stage<C::LPS, C::PD>(ahead);
+        BP_T(t1_);
         __builtin_amdgcn_s_barrier();
-        if (t + C::PD < my_nst) issue(t + C::PD);
+        BP_T(t2_);
+        if (is_loader && t + C::PD < my_nst) issue(t + C::PD);
+        BP_T(t3_);
+        if (!is_compute) return;
 
         const unsigned char* sb = smem + (t % C::NSTAGE) * C::STAGE_BYTES;
         const unsigned char* sx = sb + C::B_BYTES;
@@ -471,11 +495,20 @@ __global__ __launch_bounds__(256 * WK, 1) void bigprod_kernel(const unsigned cha
             }
             if (q == 0 && flush_prev) flush(prev);
         }
+#ifdef SMK_BP_PROFILE
+        {
+            asm volatile("s_nop 0" ::: "memory");
+            const unsigned long long t4_ = __builtin_readcyclecounter();
+            prof_[0] += t1_ - t0_; prof_[1] += t2_ - t1_; prof_[2] += t3_ - t2_; prof_[3] += t4_ - t3_;
+        }
+#endif
     };
 
+    if (is_loader) {
 #pragma unroll
-    for (int i = 0; i < C::PD; ++i)
-        if (i < my_nst) issue(i);
+        for (int i = 0; i < C::PD; ++i)
+            if (i < my_nst) issue(i);
+    }
 
     int t = 0;
     for (; t + 1 < my_nst; t += 2) {
@@ -489,6 +522,13 @@ __global__ __launch_bounds__(256 * WK, 1) void bigprod_kernel(const unsigned cha
         flush(accB);
     }
 
+#ifdef SMK_BP_PROFILE
+    if (g_bp_prof && lane == 0) {
+        unsigned long long* o = g_bp_prof + ((size_t)blockIdx.x * C::NW + wave) * 4;
+        o[0] = prof_[0]; o[1] = prof_[1]; o[2] = prof_[2]; o[3] = prof_[3];
+    }
+#endif
+    if (!is_compute) return;
     // epilogue: fp64 totals (+ the small split terms), stored k-contiguous as doubles.
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #pragma unroll
@@ -604,25 +644,35 @@ int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* ou
     return 0;
 }
 
-constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw, int wk);
+constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw, int wk, int nwl);
 // ---- kernel variants (tile shape / pipeline depth); chosen per plan, SMK_BP_VARIANT overrides ----
-struct BPVariant { int mb, nstage, cw, wk; };
+struct BPVariant { int mb, nstage, cw, wk, nwl; };
 static const BPVariant kVariants[] = {
-    {64, 3, 1, 1},    // 0: 128 cols x 64 rows, 3-deep ring
-    {64, 4, 1, 1},    // 1
-    {64, 5, 1, 1},    // 2
-    {128, 2, 1, 1},   // 3
-    {128, 3, 1, 1},   // 4
-    {64, 3, 2, 1},    // 5: 256 cols per workgroup
-    {64, 2, 1, 1},    // 6: two workgroups per CU (bf16, k <= 32 default)
-    {32, 2, 1, 1},    // 7: 32-row stages (fp32: one 128-B line per column per stage)
-    {32, 3, 1, 1},    // 8
-    {32, 4, 1, 1},    // 9
-    {64, 2, 1, 2},    // 10: k in (32,64]: 8 waves, the two k tiles on different waves
-    {64, 3, 1, 2},    // 11
-    {64, 4, 1, 2},    // 12
-    {32, 4, 1, 2},    // 13
-    {64, 2, 2, 2},    // 14: 256 columns, 8 waves
+    {64, 3, 1, 1, 0},    // 0: 128 cols x 64 rows, 3-deep ring
+    {64, 4, 1, 1, 0},    // 1
+    {64, 5, 1, 1, 0},    // 2
+    {128, 2, 1, 1, 0},   // 3
+    {128, 3, 1, 1, 0},   // 4
+    {64, 3, 2, 1, 0},    // 5: 256 cols per workgroup
+    {64, 2, 1, 1, 0},    // 6: two workgroups per CU
+    {32, 2, 1, 1, 0},    // 7: 32-row stages (fp32: one 128-B line per column per stage)
+    {32, 3, 1, 1, 0},    // 8
+    {32, 4, 1, 1, 0},    // 9
+    {64, 2, 1, 2, 0},    // 10: k in (32,64]: 8 waves, the two k tiles on different waves
+    {64, 3, 1, 2, 0},    // 11
+    {64, 4, 1, 2, 0},    // 12
+    {32, 4, 1, 2, 0},    // 13
+    {64, 2, 2, 2, 0},    // 14: 256 columns, 8 waves
+    // wave-specialised: +4 (or +2) loader waves that only issue the LDS-DMA loads
+    {64, 3, 1, 1, 4},    // 15
+    {64, 4, 1, 1, 4},    // 16
+    {64, 5, 1, 1, 4},    // 17
+    {64, 3, 1, 2, 4},    // 18: k in (32,64]
+    {64, 4, 1, 2, 4},    // 19
+    {32, 4, 1, 1, 2},    // 20: fp32 emulation, k <= 32
+    {32, 4, 1, 2, 4},    // 21: fp32 emulation, k in (32,64]
+    {32, 5, 1, 2, 4},    // 22
+    {64, 2, 1, 1, 4},    // 23
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -635,16 +685,18 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     pl.nsplit = storage == STORE_BF16 ? nsplit : (nsplit == 3 ? 3 : 1);
     // measured best on MI355X: bf16 -> 64-row stages, 2-deep ring, 2 workgroups per CU (C3: 5.98 TB/s)
     int v = (storage == STORE_BF16) ? 6 : 7;
-    if (pl.kt == 2) v = (storage == STORE_BF16) ? 14 : 11;   // k in (32,64]: 8 waves; bf16: 256-column tiles
+    // k in (32,64]: 8 compute waves (one k tile each) + 4 loader waves
+    if (pl.kt == 2) v = (storage == STORE_BF16) ? 18 : 21;
     const char* env = getenv("SMK_BP_VARIANT");
     if (env) v = atoi(env);
     if (v < 0 || v >= kNumVariants) v = 6;
     // variants that do not fit the 160 KiB LDS for this dtype / k fall back to variant 0
     auto fits = [&](int vv) {
         return bp_fits(storage == STORE_BF16 ? 2 : 4, pl.kt, pl.nsplit, kVariants[vv].mb, kVariants[vv].nstage,
-                       kVariants[vv].cw, kVariants[vv].wk);
+                       kVariants[vv].cw, kVariants[vv].wk, kVariants[vv].nwl);
     };
     if (!fits(v)) v = (pl.kt == 2) ? 11 : 0;
+    if (!fits(v) && pl.kt == 2) v = 13;
     if (!fits(v)) v = 0;
     if (!fits(v)) v = 7;
     pl.variant = v;
@@ -664,13 +716,13 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     return pl;
 }
 
-template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK>
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK, int NWL>
 static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
-    using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK>;
+    using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
     constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
     static bool attr_set = false;
-    auto kern = bigprod_kernel<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK>;
+    auto kern = bigprod_kernel<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
     if (!attr_set) {
         SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -684,13 +736,13 @@ static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const
     } else {
         grid = pl.tiles * pl.S;
     }
-    kern<<<(unsigned)grid, 256 * WK, lds, st>>>((const unsigned char*)B, ldb * EBYTES, (const unsigned char*)Xp, P,
+    kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * EBYTES, (const unsigned char*)Xp, P,
                                            pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS);
     SMK_HIP(hipGetLastError());
     return 0;
 }
 
-constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw, int wk)
+constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw, int wk, int nwl)
 {
     if (kt % wk != 0) return false;
     const int cpc = mb / (16 / ebytes);
@@ -698,15 +750,15 @@ constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int c
     if (qs < 1) return false;
     const int stage = 128 * cw * mb * ebytes + qs * nsplit * kt * 1024;
     const int ti = stage / 1024;
-    const int nw = 4 * wk;
+    const int nw = nwl > 0 ? nwl : 4 * wk;
     return (ti % nw == 0) && (ti / nw * (nstage - 1) <= 63) && (stage * nstage <= 160 * 1024);
 }
 
-template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK>
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK, int NWL = 0>
 static int launch_bigprod_if(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
-    if constexpr (bp_fits(EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK))
-        return launch_bigprod_t<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK>(pl, B, ldb, Xp, P, st);
+    if constexpr (bp_fits(EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL))
+        return launch_bigprod_t<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>(pl, B, ldb, Xp, P, st);
     else {
         set_error("bigprod variant does not fit LDS");
         return -100;
@@ -731,6 +783,15 @@ static int launch_bigprod_v(const BigProdPlan& pl, const void* B, i64 ldb, const
         case 12: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 4, 1, 2>(pl, B, ldb, Xp, P, st);
         case 13: return launch_bigprod_if<EBYTES, KT, NSPLIT, 32, 4, 1, 2>(pl, B, ldb, Xp, P, st);
         case 14: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 2, 2, 2>(pl, B, ldb, Xp, P, st);
+        case 15: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 1, 1, 4>(pl, B, ldb, Xp, P, st);
+        case 16: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 4, 1, 1, 4>(pl, B, ldb, Xp, P, st);
+        case 17: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 5, 1, 1, 4>(pl, B, ldb, Xp, P, st);
+        case 18: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 1, 2, 4>(pl, B, ldb, Xp, P, st);
+        case 19: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 4, 1, 2, 4>(pl, B, ldb, Xp, P, st);
+        case 20: return launch_bigprod_if<EBYTES, KT, NSPLIT, 32, 4, 1, 1, 2>(pl, B, ldb, Xp, P, st);
+        case 21: return launch_bigprod_if<EBYTES, KT, NSPLIT, 32, 4, 1, 2, 4>(pl, B, ldb, Xp, P, st);
+        case 22: return launch_bigprod_if<EBYTES, KT, NSPLIT, 32, 5, 1, 2, 4>(pl, B, ldb, Xp, P, st);
+        case 23: return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 2, 1, 1, 4>(pl, B, ldb, Xp, P, st);
         default: break;
     }
     return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 1, 1>(pl, B, ldb, Xp, P, st);
