@@ -226,3 +226,26 @@ def test_smallkapi_mirror(gpu, tmp_path):
         ref = oracle.nmf(A, W0, H0, alg, min_iter=2, max_iter=40, tol=0.01)
         assert api.get_iteration_count() == ref.iteration_count
         assert rel(api.get_W(), ref.W) < TOL and rel(api.get_H(), ref.H) < TOL
+
+
+EDGE = [(1, 1, 1), (1, 5, 1), (5, 1, 1), (3, 2, 2), (2, 3, 2), (129, 1, 1), (1, 300, 1), (257, 130, 17),
+        (1000, 9, 9), (9, 1000, 9), (130, 258, 64), (64, 64, 64), (65, 63, 33)]
+
+
+@pytest.mark.parametrize("m,n,k", EDGE)
+def test_edge_shapes(gpu, m, n, k):
+    """tiny / degenerate dimensions (m == 1, n == 1, k == n, k == m, one tile, ragged tiles): same Result
+    code and factors as the oracle.  HALS is skipped where k is close to min(m, n) (dead rows of H make
+    the reference update discontinuous, see tests/golden/make_golden.py)."""
+    A = oracle.fill_uniform(m, n, 42) + 0.01
+    W0 = oracle.fill_uniform(m, k, 43) + 0.01
+    H0 = oracle.fill_uniform(k, n, 44) + 0.01
+    algs = ["MU", "BPP"] + (["HALS"] if 4 * k <= min(m, n) or k == 1 else []) + (["RANK2"] if k == 2 else [])
+    for alg in algs:
+        for st, q in (("f32", 0), ("bf16", 1)):
+            Aq = oracle.quantize(A, q)
+            ref = oracle.nmf(Aq, W0, H0, alg, min_iter=4, max_iter=4)
+            got = gpu.nmf(Aq, W0, H0, alg, min_iter=4, max_iter=4, storage=st)
+            assert got.result == ref.result, (alg, st, got.result, ref.result)
+            if ref.result == 0:
+                assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL, (alg, st)
