@@ -152,6 +152,60 @@ int smk_solver_comm_workspace_bytes(const smk_solver* s, size_t* bytes);
 int smk_solver_set_comm(smk_solver* s, int rank, int world, smk_allreduce_fn fn, void* user,
                         void* workspace, size_t workspace_bytes);
 
+/* ---- HierNMF2: rank-2 hierarchical clustering --------------------------------------
+ * Clust / ClustSparse (hierclust/include/clust.hpp:45-58, hierclust/src/clust.cpp:97-203) with
+ * ClustOptions (clust.hpp:27-37), ClustStats (:20-25) and the result Tree<T> (hierclust/include/tree.hpp).
+ * Every node factorisation is the RANK2 solver above on a column subset of the resident A
+ * (SubMatrixColsCompact). */
+typedef struct smk_clust_options {
+    smk_options nmf;       /* height/width = A's; k, algorithm are forced to 2 / RANK2 */
+    int maxterms;
+    double unbalanced;     /* [0, 1) */
+    int trial_allowance;
+    int num_clusters;      /* >= 2 */
+    int verbose;
+    int flat;              /* ClustFlat (next tier): SMK_UNSUPPORTED when set */
+} smk_clust_options;
+typedef struct smk_clust_stats { int nmf_count; int max_count; } smk_clust_stats;
+typedef struct smk_tree smk_tree;
+typedef struct smk_tree_node {
+    double priority;
+    unsigned parent, left_child, right_child;   /* SMK_TREE_NONE when absent */
+    int is_valid, is_left_child, is_leaf;
+    int64_t doc_count;
+} smk_tree_node;
+#define SMK_TREE_NONE 0xFFFFFFFFu
+
+int smk_clust_is_valid(const smk_clust_options* opts, int validate_matrix);   /* clust_options.cpp:16-110 */
+/* column subset of a resident matrix (dense: all rows kept; sparse: unused rows dropped, the kept
+ * rows are listed in new_to_old_rows[0 .. *new_height), capacity = height). */
+int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t ncols, smk_matrix** out,
+                           unsigned* new_to_old_rows, int64_t* new_height);
+/* Random initialisers: matrix i of the run is the counter-based uniform block with seed
+ * `seed + 0x9E37 * (++*draws)` (W then H per attempt); `initdir` non-empty: Winit_<i>.csv / Hinit_<i>.csv
+ * (full size, i = 1, 2, ...; clust_hier_util.hpp:206-241) are used instead.  `draws` may be NULL. */
+int smk_clust_dense(const smk_clust_options* opts, const double* A, int64_t ldA, int storage, uint64_t seed,
+                    uint64_t* draws, const char* initdir, smk_tree** tree, smk_clust_stats* stats);
+int smk_clust_sparse(const smk_clust_options* opts, int64_t nnz, const unsigned* col_offsets,
+                     const unsigned* row_indices, const double* data, uint64_t seed, uint64_t* draws,
+                     const char* initdir, smk_tree** tree, smk_clust_stats* stats);
+void smk_tree_destroy(smk_tree* t);
+int smk_tree_node_count(const smk_tree* t);
+int64_t smk_tree_term_count(const smk_tree* t);
+int64_t smk_tree_doc_count(const smk_tree* t);
+int smk_tree_get_node(const smk_tree* t, int q, smk_tree_node* out);
+int smk_tree_node_docs(const smk_tree* t, int q, unsigned* out /* doc_count */);
+int smk_tree_node_topic(const smk_tree* t, int q, double* out /* term_count */);
+int smk_tree_node_terms(const smk_tree* t, int q, int* out /* maxterms */);   /* returns entries written */
+int64_t smk_tree_assignments(const smk_tree* t, unsigned* out /* doc_count; SMK_TREE_NONE = outlier */);
+int64_t smk_tree_outliers(const smk_tree* t, unsigned* out /* NULL: count only */);
+int smk_tree_write_assignments(const smk_tree* t, const char* path);            /* tree.hpp:388-423 */
+/* format 0 = XML, 1 = JSON (hierclust_xml_writer.cpp / hierclust_json_writer.cpp, byte compatible) */
+int smk_tree_write(const smk_tree* t, const char* path, int format, const char* const* dictionary,
+                   int64_t dictionary_size);
+/* the priority score of a split: compute_priority(), clust_hier_util.hpp:105-173 */
+double smk_clust_priority(const double* w_parent, const double* w_child /* n x 2, ld n */, int64_t n);
+
 /* ---- CSV files: WriteDelimitedFile / LoadDelimitedFile, common/include/delimited_file.hpp:49-135 ----
  * (row-major text, scientific notation; used for w.csv / h.csv and init files) */
 int smk_write_csv(const double* buf, unsigned ldim, unsigned height, unsigned width, const char* filename,
@@ -208,8 +262,10 @@ unsigned smk_api_get_iteration_count(void);
 int smk_api_nmf(unsigned k, int algorithm, const char* initfile_w, const char* initfile_h);
 const double* smk_api_locked_buffer_w(unsigned* ldim, unsigned* height, unsigned* width);   /* :653-661 */
 const double* smk_api_locked_buffer_h(unsigned* ldim, unsigned* height, unsigned* width);   /* :664-672 */
-int smk_api_hiernmf2(unsigned num_clusters);            /* next tier: reports "not built" */
-int smk_api_load_dictionary_file(const char* path);     /* next tier */
+int smk_api_hiernmf2(unsigned num_clusters);            /* smallk::HierNmf2, smallk.cpp:859-862 */
+int smk_api_hiernmf2_with_flat(unsigned num_clusters);  /* flat clustering is the next tier: reports "not built" */
+int smk_api_load_dictionary_file(const char* path);     /* LoadDictionary(string), smallk.cpp:675-691 */
+int smk_api_load_dictionary(const char* const* terms, unsigned count);          /* smallk.cpp:694-707 */
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,8 @@ from . import _lib
 from .solver import (DenseMatrix, SparseMatrix, NmfSolver, NmfResult, nmf, nmf_sparse, load_matrix_market,
                      initialize, finalize, is_initialized, make_options, uniform_host, set_stream)
 from .api import SmallkAPI
+from . import hierclust
+from .hierclust import hier_nmf2, TreeResults
 
 __all__ = ["DenseMatrix", "SparseMatrix", "nmf_sparse", "load_matrix_market", "NmfSolver", "NmfResult", "nmf", "initialize", "finalize", "is_initialized",
-           "make_options", "uniform_host", "set_stream", "SmallkAPI", "_lib"]
+           "make_options", "uniform_host", "set_stream", "SmallkAPI", "hierclust", "hier_nmf2", "TreeResults", "_lib"]

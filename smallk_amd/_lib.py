@@ -36,6 +36,23 @@ class Stats(C.Structure):
     _fields_ = [("elapsed_us", C.c_ulonglong), ("iteration_count", C.c_int)]
 
 
+class ClustOptions(C.Structure):
+    """struct smk_clust_options == ClustOptions (hierclust/include/clust.hpp:27-37)."""
+    _fields_ = [("nmf", Options), ("maxterms", C.c_int), ("unbalanced", C.c_double), ("trial_allowance", C.c_int),
+                ("num_clusters", C.c_int), ("verbose", C.c_int), ("flat", C.c_int)]
+
+
+class ClustStats(C.Structure):
+    """struct smk_clust_stats == ClustStats (hierclust/include/clust.hpp:20-25)."""
+    _fields_ = [("nmf_count", C.c_int), ("max_count", C.c_int)]
+
+
+class TreeNodeInfo(C.Structure):
+    """struct smk_tree_node: the scalar fields of TreeNode<T> (hierclust/include/tree.hpp:31-50)."""
+    _fields_ = [("priority", C.c_double), ("parent", C.c_uint), ("left_child", C.c_uint), ("right_child", C.c_uint),
+                ("is_valid", C.c_int), ("is_left_child", C.c_int), ("is_leaf", C.c_int), ("doc_count", C.c_int64)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
 
 # every symbol include/smallk_amd.h declares: name -> (restype, argtypes)
@@ -119,7 +136,31 @@ SYMBOLS = {
     "smk_api_locked_buffer_w": (_dp, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "smk_api_locked_buffer_h": (_dp, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "smk_api_hiernmf2": (C.c_int, [C.c_uint]),
+    "smk_api_hiernmf2_with_flat": (C.c_int, [C.c_uint]),
     "smk_api_load_dictionary_file": (C.c_int, [C.c_char_p]),
+    "smk_api_load_dictionary": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint]),
+    # HierNMF2 (hierclust.cpp; reference hierclust/include/clust.hpp, tree.hpp)
+    "smk_clust_is_valid": (C.c_int, [C.POINTER(ClustOptions), C.c_int]),
+    "smk_matrix_gather_cols": (C.c_int, [_vp, C.POINTER(C.c_uint), _i64, C.POINTER(_vp), C.POINTER(C.c_uint),
+                                         C.POINTER(_i64)]),
+    "smk_clust_dense": (C.c_int, [C.POINTER(ClustOptions), _dp, _i64, C.c_int, C.c_uint64, C.POINTER(C.c_uint64),
+                                  C.c_char_p, C.POINTER(_vp), C.POINTER(ClustStats)]),
+    "smk_clust_sparse": (C.c_int, [C.POINTER(ClustOptions), _i64, C.POINTER(C.c_uint), C.POINTER(C.c_uint), _dp,
+                                   C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.POINTER(_vp),
+                                   C.POINTER(ClustStats)]),
+    "smk_tree_destroy": (None, [_vp]),
+    "smk_tree_node_count": (C.c_int, [_vp]),
+    "smk_tree_term_count": (_i64, [_vp]),
+    "smk_tree_doc_count": (_i64, [_vp]),
+    "smk_tree_get_node": (C.c_int, [_vp, C.c_int, C.POINTER(TreeNodeInfo)]),
+    "smk_tree_node_docs": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint)]),
+    "smk_tree_node_topic": (C.c_int, [_vp, C.c_int, _dp]),
+    "smk_tree_node_terms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    "smk_tree_assignments": (_i64, [_vp, C.POINTER(C.c_uint)]),
+    "smk_tree_outliers": (_i64, [_vp, C.POINTER(C.c_uint)]),
+    "smk_tree_write_assignments": (C.c_int, [_vp, C.c_char_p]),
+    "smk_tree_write": (C.c_int, [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), _i64]),
+    "smk_clust_priority": (C.c_double, [_dp, _dp, _i64]),
 }
 
 _lib = None

@@ -149,7 +149,9 @@ class SmallkAPI:
             _raise_if(L.lib().smk_api_load_dictionary_file(_b(filepath)), "LoadDictionary")
             self._dictionary_loaded = True
         elif len(dictionary) > 0:
-            raise RuntimeError("LoadDictionary: not built on the MI355X path yet.")
+            terms = (C.c_char_p * len(dictionary))(*[_b(str(t)) for t in dictionary])
+            _raise_if(L.lib().smk_api_load_dictionary(terms, len(dictionary)), "LoadDictionary")
+            self._dictionary_loaded = True
         else:
             print("Error: Invalid dictionary arguments.")
 

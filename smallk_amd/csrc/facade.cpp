@@ -309,6 +309,9 @@ static uint64_t rng_seed = 0;
 static uint64_t rng_draws = 0;            // so that successive RandomMatrix calls differ
 static DeviceStorage device_storage = DEVICE_F32;
 static NmfStats last_stats;
+static bool dict_loaded = false;
+static std::string dict_filepath;
+static std::vector<std::string> dictionary;
 
 static const std::string DEFAULT_FILENAME_W("w.csv");
 static const std::string DEFAULT_FILENAME_H("h.csv");
@@ -332,8 +335,10 @@ void Reset()
     clustfile_format = OutputFormat::JSON;
     outdir = std::string("");
     matrix_loaded = false;
+    dict_loaded = false;
     is_sparse = false;
     matrix_filepath.clear();
+    dict_filepath.clear();
     buf_a.clear(); buf_w.clear(); buf_h.clear();
     sp_data.clear(); sp_rows.clear(); sp_cols.clear();
     m = n = k = ldim_a = ldim_w = ldim_h = 0u;
@@ -667,15 +672,120 @@ const double* LockedBufferH(unsigned int& ldim, unsigned int& height, unsigned i
     return buf_h.empty() ? nullptr : &buf_h[0];
 }
 
-// ---- next tier ----------------------------------------------------------------------------
-static void not_built(const char* what)
+// ---- clustering ---------------------------------------------------------------------------
+
+// smallk.cpp:675-691; LoadStringsFromFile (common/src/utils.cpp:220-239): one term per complete
+// line, an unterminated last line is dropped
+void LoadDictionary(const std::string& filepath)
 {
-    throw std::runtime_error(std::string("smallk error (") + what + "): not built on the MI355X path yet.");
+    std::cout << "Loading dictionary..." << std::endl;
+    dictionary.clear();
+    dict_loaded = false;
+    std::ifstream in(filepath);
+    if (!in) throw std::runtime_error("smallk error (LoadDictionary): load failed for file " + filepath);
+    std::string line;
+    while (in) {
+        std::getline(in, line, '\n');
+        if (in.eof()) break;
+        dictionary.push_back(line);
+    }
+    dict_filepath = filepath;
+    dict_loaded = true;
 }
-void LoadDictionary(const std::string&) { not_built("LoadDictionary"); }
-void LoadDictionary(const std::vector<std::string>&) { not_built("LoadDictionary"); }
-void HierNmf2(const unsigned int) { not_built("HierNmf2"); }
-void HierNmf2WithFlat(const unsigned int) { not_built("HierNmf2WithFlat"); }
+
+// smallk.cpp:694-707
+void LoadDictionary(const std::vector<std::string>& terms)
+{
+    std::cout << "Loading dictionary..." << std::endl;
+    dictionary.assign(terms.begin(), terms.end());
+    dict_filepath.clear();
+    dict_loaded = true;
+}
+
+// smallk.cpp:738-856 (HierNmf2Internal): RANK2 + PG_RATIO, unbalanced 0.1, trial_allowance 3;
+// writes assignments_<N>.csv and tree_<N>.{xml,json} into the output directory.
+static void hier_nmf2_internal(const bool generate_flat, const unsigned int num_clusters)
+{
+    if (!matrix_loaded) throw std::logic_error("smallk error (HierNmf2): no matrix has been loaded.");
+    if (!dict_loaded) throw std::logic_error("smallk error (HierNmf2): no dictionary has been loaded.");
+    if (0 == num_clusters) throw std::logic_error("smallk error (HierNmf2): num_clusters must be greater than 0.");
+    if (2ull * m > (uint64_t)std::numeric_limits<int>::max())
+        throw std::logic_error("smallk error (HierNmf2): matrix height too large.");
+    if (2ull * n > (uint64_t)std::numeric_limits<int>::max())
+        throw std::logic_error("smallk error (HierNmf2): matrix width too large.");
+    if (generate_flat)
+        throw std::runtime_error("smallk error (HierNmf2WithFlat): flat clustering is not built on the MI355X path yet.");
+    if (dictionary.size() < m)
+        throw std::logic_error("smallk error (HierNmf2): dictionary has fewer terms than the matrix has rows.");
+
+    smk_clust_options co;
+    co.nmf.tol = hier_nmf2_tolerance;
+    co.nmf.algorithm = SMK_ALG_RANK2;
+    co.nmf.prog_est_algorithm = SMK_PROG_PG_RATIO;
+    co.nmf.height = (int)m;
+    co.nmf.width = (int)n;
+    co.nmf.k = 2;
+    co.nmf.min_iter = (int)min_iter;
+    co.nmf.max_iter = (int)max_iter;
+    co.nmf.tolcount = 1;
+    co.nmf.max_threads = (int)max_threads;
+    co.nmf.verbose = 0;
+    co.nmf.normalize = 1;
+    co.maxterms = (int)maxterms;
+    co.unbalanced = 0.1;
+    co.trial_allowance = 3;
+    co.num_clusters = (int)num_clusters;
+    co.verbose = 1;
+    co.flat = 0;
+
+    const std::string output_dir = ensure_trailing_sep(outdir);
+    const bool xml = (OutputFormat::XML == clustfile_format);
+    std::ostringstream assign_name, tree_name;
+    assign_name << output_dir << "assignments_" << num_clusters << ".csv";
+    tree_name << output_dir << "tree_" << num_clusters << (xml ? ".xml" : ".json");
+
+    using std::cout; using std::endl;
+    cout << "\n\t        parameters: \n" << endl;
+    cout << "\t            height: " << co.nmf.height << endl;
+    cout << "\t             width: " << co.nmf.width << endl;
+    cout << "\t        matrixfile: " << matrix_filepath << endl;
+    cout << "\t          dictfile: " << dict_filepath << endl;
+    cout << "\t               tol: " << co.nmf.tol << endl;
+    cout << "\t           miniter: " << co.nmf.min_iter << endl;
+    cout << "\t           maxiter: " << co.nmf.max_iter << endl;
+    cout << "\t          maxterms: " << co.maxterms << endl;
+    cout << "\t        maxthreads: " << co.nmf.max_threads << endl;
+
+    smk_tree* tree = nullptr;
+    smk_clust_stats stats = {0, 0};
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    int rc;
+    if (is_sparse)
+        rc = smk_clust_sparse(&co, (int64_t)sp_data.size(), &sp_cols[0], &sp_rows[0], &sp_data[0], rng_seed,
+                              &rng_draws, nullptr, &tree, &stats);
+    else
+        rc = smk_clust_dense(&co, &buf_a[0], ldim_a, (int)device_storage, rng_seed, &rng_draws, nullptr, &tree, &stats);
+    const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
+                            std::chrono::high_resolution_clock::now() - t0).count();
+    cout << "\nElapsed wall clock time: " << elapsed_string(us) << endl;
+    if (rc != SMK_OK) {
+        const std::string why = smk_last_error();
+        throw std::runtime_error(why.empty() ? std::string("smallk error (HierNMF2): HierNMF2 fatal error.")
+                                             : "smallk error (HierNMF2): " + why);
+    }
+    cout << (stats.nmf_count - stats.max_count) << "/" << stats.nmf_count << " factorizations converged." << endl << endl;
+    cout << "Writing output files..." << endl;
+    if (smk_tree_write_assignments(tree, assign_name.str().c_str()) != SMK_OK)
+        std::cerr << "\terror writing assignments file" << endl;
+    std::vector<const char*> terms(dictionary.size());
+    for (size_t i = 0; i < dictionary.size(); ++i) terms[i] = dictionary[i].c_str();
+    if (smk_tree_write(tree, tree_name.str().c_str(), xml ? 0 : 1, terms.data(), (int64_t)terms.size()) != SMK_OK)
+        std::cerr << "\terror writing hierarchical results file" << endl;
+    smk_tree_destroy(tree);
+}
+
+void HierNmf2(const unsigned int num_clusters) { hier_nmf2_internal(false, num_clusters); }
+void HierNmf2WithFlat(const unsigned int num_clusters) { hier_nmf2_internal(true, num_clusters); }
 
 }  // namespace smallk
 
@@ -784,6 +894,15 @@ const double* smk_api_locked_buffer_h(unsigned* ldim, unsigned* height, unsigned
     return smallk::LockedBufferH(*ldim, *height, *width);
 }
 int smk_api_hiernmf2(unsigned num_clusters) { return api_guard([&] { smallk::HierNmf2(num_clusters); }); }
+int smk_api_hiernmf2_with_flat(unsigned num_clusters) { return api_guard([&] { smallk::HierNmf2WithFlat(num_clusters); }); }
 int smk_api_load_dictionary_file(const char* path) { return api_guard([&] { smallk::LoadDictionary(std::string(path ? path : "")); }); }
+int smk_api_load_dictionary(const char* const* terms, unsigned count)
+{
+    return api_guard([&] {
+        std::vector<std::string> v;
+        for (unsigned i = 0; i < count; ++i) v.push_back(terms && terms[i] ? terms[i] : "");
+        smallk::LoadDictionary(v);
+    });
+}
 
 }  // extern "C"

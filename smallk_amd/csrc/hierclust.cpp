@@ -1,0 +1,655 @@
+// smallk_amd/csrc/hierclust.cpp -- HierNMF2 (rank-2 hierarchical clustering) on top of the
+// resident-matrix / solver C ABI.
+//
+// What the reference does (hierclust/include/clust_hier_generic.hpp:67-196): factor A with k = 2,
+// split the documents by the larger H row, then repeatedly split the leaf with the highest
+// priority score; each candidate split is a rank-2 NMF of the node's column subset, with an
+// outlier-dropping retry loop (TrialSplit :203-327) and a modified-NDCG priority
+// (compute_priority, clust_hier_util.hpp:105-173).
+//
+// Here A is uploaded once and stays in HBM; a node's submatrix is gathered HBM -> HBM for dense A
+// (smk_matrix_gather_cols) or cut from the host CSC and uploaded for sparse A, and every
+// factorisation is the RANK2 schedule of solver.cpp.  The tree search itself is a few sorts over m
+// values per node and stays on the host, like the reference's.
+#include "common.h"
+#include "../../include/smallk_amd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <functional>
+#include <limits>
+#include <numeric>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using smk::i64;
+using smk::set_error;
+
+namespace {
+
+const unsigned NONE = SMK_TREE_NONE;
+
+struct Node {
+    double priority = 0.0;
+    unsigned parent = NONE, left = NONE, right = NONE;
+    bool valid = false, is_left = false;
+    std::vector<double> topic;
+    std::vector<int> terms;
+    std::vector<unsigned> docs;
+};
+
+}  // namespace
+
+struct smk_tree {
+    std::vector<Node> nodes;
+    std::vector<char> is_leaf;
+    unsigned active = 0, index0 = 0, index1 = 0;
+    i64 term_count = 0, doc_count = 0, leaf_doc_count = 0;
+    int maxterms = 0;
+    std::vector<unsigned> assignments, outliers;
+};
+
+namespace {
+
+// ---- Tree<T>, hierclust/include/tree.hpp ----------------------------------------------------------
+void tree_init(smk_tree& t, unsigned node_count, i64 m, i64 n)      // Init :120-144
+{
+    t.doc_count = n;
+    t.term_count = m;
+    t.nodes.assign(node_count, Node());
+    for (Node& nd : t.nodes) nd.topic.assign((size_t)m, 0.0);
+    t.is_leaf.assign(node_count, 0);
+    t.active = 0;
+}
+
+void tree_min_max(const smk_tree& t, double& mn, double& mx, unsigned& mx_index)   // :147-170
+{
+    mn = std::numeric_limits<double>::max();
+    mx = std::numeric_limits<double>::lowest();
+    for (unsigned q = 0; q < t.is_leaf.size(); ++q) {
+        if (!t.is_leaf[q]) continue;
+        const double p = t.nodes[q].priority;
+        if (p > 0.0 && p < mn) mn = p;
+        if (p > mx) { mx = p; mx_index = q; }
+    }
+}
+
+void tree_open_children(smk_tree& t, unsigned parent)
+{
+    const unsigned idx[2] = {t.index0, t.index1};
+    for (int s = 0; s < 2; ++s) {
+        Node& nd = t.nodes[idx[s]];
+        nd.parent = parent; nd.left = NONE; nd.right = NONE; nd.valid = true; nd.is_left = (s == 0);
+        t.is_leaf[idx[s]] = 1;
+    }
+}
+
+// documents go left when H(0,c) > H(1,c); topic vectors are the two columns of W  (:173-211, :214-266)
+void tree_partition(smk_tree& t, const std::vector<unsigned>* source, const double* W, i64 m, const double* H, i64 w)
+{
+    for (i64 c = 0; c < w; ++c) {
+        const unsigned doc = source ? (*source)[(size_t)c] : (unsigned)c;
+        t.nodes[H[2 * c] > H[2 * c + 1] ? t.index0 : t.index1].docs.push_back(doc);
+    }
+    std::copy(W, W + m, t.nodes[t.index0].topic.begin());
+    std::copy(W + m, W + 2 * m, t.nodes[t.index1].topic.begin());
+}
+
+void tree_split_root(smk_tree& t, const double* W, i64 m, const double* H, i64 w)
+{
+    t.index0 = 0; t.index1 = 1;
+    tree_open_children(t, NONE);
+    t.active += 2;
+    tree_partition(t, nullptr, W, m, H, w);
+}
+
+void tree_split(smk_tree& t, unsigned node, const double* W, i64 m, const double* H, i64 w)
+{
+    t.index0 = t.active; t.index1 = t.active + 1;
+    t.active += 2;
+    t.nodes[node].left = t.index0; t.nodes[node].right = t.index1;
+    t.is_leaf[node] = 0;
+    tree_open_children(t, node);
+    const std::vector<unsigned> src = t.nodes[node].docs;
+    tree_partition(t, &src, W, m, H, w);
+}
+
+void tree_top_terms(smk_tree& t, int maxterms)     // ComputeTopTerms :282-299 + TopTerms, terms.hpp:25-58
+{
+    t.maxterms = maxterms;
+    std::vector<int> order((size_t)t.term_count);
+    for (Node& nd : t.nodes) {
+        if (!nd.valid) continue;
+        std::iota(order.begin(), order.end(), 0);
+        const double* d = nd.topic.data();
+        std::stable_sort(order.begin(), order.end(), [d](int a, int b) { return d[a] > d[b]; });
+        nd.terms.assign((size_t)maxterms, 0);
+        const size_t cnt = std::min<size_t>((size_t)maxterms, order.size());
+        std::copy(order.begin(), order.begin() + cnt, nd.terms.begin());
+    }
+}
+
+void tree_assignments(smk_tree& t)                 // ComputeAssignments :302-338
+{
+    t.outliers.clear();
+    t.assignments.assign((size_t)t.doc_count, NONE);
+    t.leaf_doc_count = 0;
+    for (unsigned q = 0; q < t.nodes.size(); ++q) {
+        if (!t.is_leaf[q]) continue;
+        t.leaf_doc_count += (i64)t.nodes[q].docs.size();
+        for (unsigned d : t.nodes[q].docs) t.assignments[d] = q;
+    }
+    for (unsigned q = 0; q < t.assignments.size(); ++q)
+        if (t.assignments[q] == NONE) t.outliers.push_back(q);
+}
+
+// ---- priority score, clust_hier_util.hpp:25-173 -----------------------------------------------------
+template <typename V>
+std::vector<int> ordered(const V* v, size_t n, bool descending)
+{
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    if (descending)
+        std::sort(idx.begin(), idx.end(), [v](int a, int b) { return v[a] > v[b] || (v[a] == v[b] && a < b); });
+    else
+        std::sort(idx.begin(), idx.end(), [v](int a, int b) { return v[a] < v[b] || (v[a] == v[b] && a < b); });
+    return idx;
+}
+
+double ndcg_part(const std::vector<int>& ground, const std::vector<int>& test, const std::vector<double>& weight,
+                 const std::vector<double>& weight_part)
+{
+    const std::vector<int> seq = ordered(ground.data(), ground.size(), false);
+    const size_t n = test.size();
+    double cum = 0.0, ideal_cum = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        double s = weight_part[(size_t)seq[(size_t)test[i]]];
+        if (i > 0) s /= std::log2((double)(i + 1));
+        cum += s;
+    }
+    std::vector<double> ideal(weight);
+    std::sort(ideal.begin(), ideal.end(), std::greater<double>());
+    for (size_t i = 0; i < n; ++i) ideal_cum += (i > 0) ? ideal[i] / std::log2((double)(i + 1)) : ideal[i];
+    return cum / ideal_cum;
+}
+
+double priority_score(const double* wp, const double* wc, i64 n)
+{
+    i64 n_part = 0;
+    for (i64 i = 0; i < n; ++i) n_part += (wp[i] != 0.0);
+    if (n_part <= 1) return -3.0;
+    const std::vector<int> idx_parent = ordered(wp, (size_t)n, true);
+    const std::vector<int> idx_c1 = ordered(wc, (size_t)n, true), idx_c2 = ordered(wc + n, (size_t)n, true);
+    std::vector<double> weight((size_t)n), weight_part((size_t)n, 0.0);
+    for (i64 j = 0; j < n; ++j) weight[(size_t)j] = std::log((double)(n - j));
+    for (i64 i = 0; i < n; ++i)
+        if (wp[idx_parent[(size_t)i]] == 0.0) {
+            for (i64 j = i; j < n; ++j) weight[(size_t)j] = 1.0;
+            break;
+        }
+    for (i64 j = 0; j < n_part; ++j) weight_part[(size_t)j] = std::log((double)(n_part - j));
+    const std::vector<int> pos1 = ordered(idx_c1.data(), (size_t)n, false), pos2 = ordered(idx_c2.data(), (size_t)n, false);
+    for (i64 i = 0; i < n; ++i) {
+        const int t = idx_parent[(size_t)i];
+        const int max_pos = std::max(pos1[(size_t)t], pos2[(size_t)t]);
+        double discount = std::log((double)(n - max_pos));
+        if (discount == 0.0) discount = std::log(2.0);
+        weight[(size_t)i] /= discount;
+        weight_part[(size_t)i] /= discount;
+    }
+    return ndcg_part(idx_parent, idx_c1, weight, weight_part) * ndcg_part(idx_parent, idx_c2, weight, weight_part);
+}
+
+std::vector<unsigned> set_diff(const std::vector<unsigned>& a, const std::vector<unsigned>& b)   // setdiff.hpp:23-46
+{
+    std::vector<unsigned> out;
+    size_t i = 0;
+    for (unsigned x : b) {
+        while (a[i] < x) out.push_back(a[i++]);
+        ++i;
+    }
+    out.insert(out.end(), a.begin() + (std::ptrdiff_t)i, a.end());
+    return out;
+}
+
+// ---- the search -------------------------------------------------------------------------------------
+struct Run {
+    const smk_clust_options* o = nullptr;
+    smk_matrix* full = nullptr;
+    i64 m = 0, n = 0;
+    uint64_t seed = 0, draws = 0;
+    std::string initdir;
+    int init_counter = 1;
+    smk_clust_stats stats = {0, 0};
+    std::vector<unsigned> new_to_old;
+    std::vector<double> Winit, Hinit;       // full-size initialisers from files
+};
+
+int load_init_file(const std::string& path, std::vector<double>& buf, unsigned h, unsigned w)
+{
+    buf.resize((size_t)h * w);
+    unsigned fh = 0, fw = 0;
+    if (!smk_load_csv(path.c_str(), buf.data(), (unsigned long)buf.size(), &fh, &fw) || fh != h || fw != w) {
+        set_error("Load failed for file " + path);
+        return SMK_FAILURE;
+    }
+    return SMK_OK;
+}
+
+// one node factorisation with up to three sets of initialisers (clust_hier_generic.hpp:97-121, :421-453)
+int factor_node(Run& r, const smk_matrix* a, i64 h, i64 w, const unsigned* rows, const unsigned* cols,
+                std::vector<double>& W, std::vector<double>& H, const char* what)
+{
+    W.assign((size_t)h * 2, 0.0);
+    H.assign((size_t)w * 2, 0.0);
+    smk_options so = r.o->nmf;
+    so.height = (int)h; so.width = (int)w; so.k = 2;
+    so.algorithm = SMK_ALG_RANK2;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (!r.initdir.empty()) {
+            std::ostringstream fw, fh;
+            fw << r.initdir << "Winit_" << r.init_counter << ".csv";
+            fh << r.initdir << "Hinit_" << r.init_counter << ".csv";
+            int rc = load_init_file(fw.str(), r.Winit, (unsigned)r.m, 2);
+            if (rc == SMK_OK) rc = load_init_file(fh.str(), r.Hinit, 2, (unsigned)r.n);
+            if (rc != SMK_OK) return rc;
+            ++r.init_counter;
+            for (i64 i = 0; i < h; ++i) {
+                const i64 src = rows ? rows[i] : i;
+                W[(size_t)i] = r.Winit[(size_t)src];
+                W[(size_t)(h + i)] = r.Winit[(size_t)(r.m + src)];
+            }
+            for (i64 c = 0; c < w; ++c) {
+                const i64 src = cols ? cols[c] : c;
+                H[(size_t)(2 * c)] = r.Hinit[(size_t)(2 * src)];
+                H[(size_t)(2 * c + 1)] = r.Hinit[(size_t)(2 * src + 1)];
+            }
+        } else {
+            smk_uniform_fill_host(W.data(), h, h, 2, 0, 0, h, r.seed + 0x9E37u * (++r.draws), 0);
+            smk_uniform_fill_host(H.data(), 2, 2, w, 0, 0, 2, r.seed + 0x9E37u * (++r.draws), 0);
+        }
+        smk_solver* s = nullptr;
+        smk_stats st = {0, 0};
+        int rc = smk_solver_create(&s, &so, a);
+        if (rc == SMK_OK) rc = smk_solver_set_factors(s, W.data(), h, H.data(), 2);
+        if (rc == SMK_OK) {
+            rc = smk_solver_run(s, &st);
+            if (rc == SMK_OK) rc = smk_solver_get_factors(s, 0, W.data(), h, H.data(), 2);
+        }
+        smk_solver_destroy(s);
+        if (rc == SMK_OK) {
+            r.stats.nmf_count += 1;
+            if (st.iteration_count == so.max_iter) r.stats.max_count += 1;
+            return SMK_OK;
+        }
+        if (rc != SMK_FAILURE) return rc;
+        printf("\n%s factorization failed, retrying with new initializers...\n", what);
+    }
+    set_error(std::string("HierNMF2: ") + (rows || cols ? "node" : "root node") +
+              " factorization failed after three attempts");
+    return SMK_FAILURE;
+}
+
+// ActualSplit, clust_hier_generic.hpp:383-499.  W is m x 2 (rows of the compacted problem scattered
+// back), H is 2 x |subset|.
+int actual_split(Run& r, const std::vector<unsigned>& subset, const double* w_parent, std::vector<double>& W,
+                 std::vector<double>& H, std::vector<unsigned>& labels, double* priority)
+{
+    const i64 m = r.m;
+    W.assign((size_t)m * 2, 0.0);
+    H.assign(subset.size() * 2, 0.0);
+    if (subset.size() <= 3) {
+        labels.assign(subset.size(), 1u);
+        *priority = -1.0;
+        return SMK_OK;
+    }
+    smk_matrix* sub = nullptr;
+    int64_t nh = 0;
+    r.new_to_old.resize((size_t)m);
+    int rc = smk_matrix_gather_cols(r.full, subset.data(), (int64_t)subset.size(), &sub, r.new_to_old.data(), &nh);
+    if (rc != SMK_OK) return rc;
+    std::vector<double> Ws, Hs;
+    rc = factor_node(r, sub, nh, (i64)subset.size(), r.new_to_old.data(), subset.data(), Ws, Hs, "Node");
+    smk_matrix_destroy(sub);
+    if (rc != SMK_OK) return rc;
+    bool has0 = false, has1 = false;
+    labels.clear();
+    for (size_t c = 0; c < subset.size(); ++c) {
+        if (Hs[2 * c] > Hs[2 * c + 1]) { labels.push_back(0u); has0 = true; }
+        else { labels.push_back(1u); has1 = true; }
+    }
+    for (i64 i = 0; i < nh; ++i) {
+        W[(size_t)r.new_to_old[(size_t)i]] = Ws[(size_t)i];
+        W[(size_t)(m + r.new_to_old[(size_t)i])] = Ws[(size_t)(nh + i)];
+    }
+    H = Hs;
+    *priority = (has0 && has1) ? priority_score(w_parent, W.data(), m) : -1.0;
+    return SMK_OK;
+}
+
+// TrialSplit, clust_hier_generic.hpp:203-327.  `subset` is the node's document list and is edited
+// in place when outliers are dropped.
+int trial_split(Run& r, std::vector<unsigned>& subset, double min_priority, const std::vector<double>& w_parent,
+                std::vector<double>& W, std::vector<double>& H, double* priority_out)
+{
+    const smk_clust_options& o = *r.o;
+    const std::vector<unsigned> backup(subset);
+    std::vector<unsigned> small, labels, labels_small;
+    std::vector<double> Wtmp, Htmp;
+    int trial = 0;
+    double pr = -2.0;
+    while (trial < o.trial_allowance) {
+        int rc = actual_split(r, subset, w_parent.data(), W, H, labels, &pr);
+        if (rc != SMK_OK) return rc;
+        if (pr < 0.0) break;
+        int counts[2] = {0, 0};
+        for (unsigned l : labels) counts[l] += 1;
+        const int smallest = std::min(counts[0], counts[1]);
+        if (!((double)smallest < o.unbalanced * (double)labels.size())) break;
+        const unsigned lab = (smallest == counts[0]) ? 0u : 1u;
+        small.clear();
+        for (size_t q = 0; q < labels.size(); ++q)
+            if (labels[q] == lab) small.push_back(subset[q]);
+        double pr_small = 0.0;
+        rc = actual_split(r, small, W.data() + (size_t)lab * r.m, Wtmp, Htmp, labels_small, &pr_small);
+        if (rc != SMK_OK) return rc;
+        if (!(pr_small < min_priority)) break;
+        trial += 1;
+        if (trial < o.trial_allowance) {
+            printf("dropping %zu items ...\n", small.size());
+            subset = set_diff(subset, small);
+        }
+    }
+    if (trial == o.trial_allowance) {
+        if (o.verbose) printf("recycling %zu items ...\n", small.size());
+        subset = backup;
+        W.assign((size_t)r.m * 2, 0.0);
+        H.assign(subset.size() * 2, 0.0);
+        pr = -2.0;
+    }
+    *priority_out = pr;
+    return SMK_OK;
+}
+
+// ClustHier, clust_hier_generic.hpp:67-196
+int clust_hier(Run& r, smk_tree& tree)
+{
+    const smk_clust_options& o = *r.o;
+    const i64 m = r.m, n = r.n;
+    const unsigned num_clusters = (unsigned)o.num_clusters;
+    const unsigned node_count = 2 * (num_clusters - 1);
+    tree_init(tree, node_count, m, n);
+
+    std::vector<double> W0, H0;
+    int rc = factor_node(r, r.full, m, n, nullptr, nullptr, W0, H0, "Root node");
+    if (rc != SMK_OK) return rc;
+
+    std::vector<std::vector<double>> Wbuf(node_count), Hbuf(node_count);
+    double min_priority = 0.0, max_priority = 0.0;
+    unsigned split_index = 0;
+    for (unsigned i = 0; i + 1 < num_clusters; ++i) {
+        if (i == 0) {
+            min_priority = INFINITY;
+            tree_split_root(tree, W0.data(), m, H0.data(), n);
+        } else {
+            tree_min_max(tree, min_priority, max_priority, split_index);
+            if (max_priority < 0.0) {
+                printf("\nHierNMF2: no further factorization possible.\n\n");
+                break;
+            }
+            tree_split(tree, split_index, Wbuf[split_index].data(), m, Hbuf[split_index].data(),
+                       (i64)(Hbuf[split_index].size() / 2));
+            std::vector<double>().swap(Wbuf[split_index]);
+            std::vector<double>().swap(Hbuf[split_index]);
+        }
+        const unsigned idx[2] = {tree.index0, tree.index1};
+        for (int s = 0; s < 2; ++s) {
+            double pr = 0.0;
+            // the parent's topic vector may not alias a buffer that trial_split resizes
+            const std::vector<double> w_parent(tree.nodes[idx[s]].topic);
+            rc = trial_split(r, tree.nodes[idx[s]].docs, min_priority, w_parent, Wbuf[idx[s]], Hbuf[idx[s]], &pr);
+            if (rc != SMK_OK) return rc;
+            tree.nodes[idx[s]].priority = pr;
+        }
+        if (o.verbose) { printf("[%u] ", i + 1); fflush(stdout); }
+    }
+    tree_top_terms(tree, o.maxterms);
+    tree_assignments(tree);
+    printf("\n");
+    return SMK_OK;
+}
+
+int check_sizes(const smk_clust_options* o)        // clust.cpp:116-131
+{
+    const uint64_t lim = (uint64_t)std::numeric_limits<int>::max();
+    if (2ull * (uint64_t)o->nmf.height > lim) { set_error("W matrix size too large"); return SMK_SIZE_TOO_LARGE; }
+    if (2ull * (uint64_t)o->nmf.width > lim) { set_error("H matrix size too large"); return SMK_SIZE_TOO_LARGE; }
+    return SMK_OK;
+}
+
+int run_clust(const smk_clust_options* opts, smk_matrix* full, uint64_t seed, uint64_t* draws, const char* initdir,
+              smk_tree** tree_out, smk_clust_stats* stats)
+{
+    Run r;
+    r.o = opts; r.full = full; r.m = opts->nmf.height; r.n = opts->nmf.width;
+    r.seed = seed; r.draws = draws ? *draws : 0;
+    if (initdir) r.initdir = initdir;
+    smk_tree* t = new smk_tree;
+    const int rc = clust_hier(r, *t);
+    if (draws) *draws = r.draws;
+    if (stats) *stats = r.stats;
+    if (rc != SMK_OK) { delete t; return rc; }
+    *tree_out = t;
+    return SMK_OK;
+}
+
+int precheck(const smk_clust_options* opts, smk_tree** tree)
+{
+    if (!tree) return SMK_BAD_PARAM;
+    *tree = nullptr;
+    if (smk_is_initialized() != SMK_INITIALIZED) {
+        set_error("clustlib error: smk_initialize() must be called prior to any clustering routine");
+        return SMK_NOTINITIALIZED;
+    }
+    if (!opts || !smk_clust_is_valid(opts, 1)) return SMK_BAD_PARAM;
+    if (opts->flat) { set_error("flat clustering (ClustFlat) is not built in this tier"); return SMK_UNSUPPORTED; }
+    return check_sizes(opts);
+}
+
+}  // namespace
+
+extern "C" {
+
+// IsValid(ClustOptions), hierclust/src/clust_options.cpp:16-110
+int smk_clust_is_valid(const smk_clust_options* o, int validate_matrix)
+{
+    if (!o) return 0;
+    const char* msg = nullptr;
+    if (validate_matrix) {
+        if (o->nmf.height <= 0) msg = "error: matrix height must be a positive integer";
+        else if (o->nmf.width <= 0) msg = "error: matrix width must be a positive integer";
+        else if (o->nmf.k <= 0) msg = "error: cluster count must be a positive integer";
+        else if (o->nmf.k > o->nmf.width) msg = "error: k value cannot exceed the matrix width";
+    }
+    if (!msg) {
+        if (o->num_clusters <= 1) msg = "error: number of clusters must be >= 2";
+        else if (o->nmf.tol <= 0.0 || o->nmf.tol >= 1.0) msg = "error: tolerance must be in the interval (0.0, 1.0)";
+        else if (o->nmf.min_iter <= 0) msg = "error: miniter must be a positive integer";
+        else if (o->nmf.max_iter <= 0) msg = "error: maxiter must be a positive integer";
+        else if (o->maxterms <= 0) msg = "error: maxterms must be a positive integer";
+        else if (o->trial_allowance < 0) msg = "error: trial_allowance for hierarchical clustering is negative";
+        else if (o->unbalanced < 0.0 || o->unbalanced >= 1.0) msg = "error: the unbalanced value should be in the interval [0, 1)";
+        else if (o->nmf.prog_est_algorithm != SMK_PROG_PG_RATIO && o->nmf.prog_est_algorithm != SMK_PROG_DELTA_FNORM)
+            msg = "error: unknown stopping criterion ";
+    }
+    if (msg) { fprintf(stderr, "%s\n", msg); set_error(msg); return 0; }
+    return 1;
+}
+
+int smk_clust_dense(const smk_clust_options* opts, const double* A, int64_t ldA, int storage, uint64_t seed,
+                    uint64_t* draws, const char* initdir, smk_tree** tree, smk_clust_stats* stats)
+{
+    int rc = precheck(opts, tree);
+    if (rc != SMK_OK) return rc;
+    if (!A || ldA < opts->nmf.height) { set_error("invalid leading dimension for input matrix"); return SMK_BAD_PARAM; }
+    smk_matrix* a = nullptr;
+    rc = smk_matrix_create(&a, opts->nmf.height, opts->nmf.width, 0, opts->nmf.width, storage);
+    if (rc == SMK_OK) rc = smk_matrix_upload_f64(a, A, ldA);
+    if (rc == SMK_OK) rc = run_clust(opts, a, seed, draws, initdir, tree, stats);
+    smk_matrix_destroy(a);
+    return rc;
+}
+
+int smk_clust_sparse(const smk_clust_options* opts, int64_t nnz, const unsigned* col_offsets,
+                     const unsigned* row_indices, const double* data, uint64_t seed, uint64_t* draws,
+                     const char* initdir, smk_tree** tree, smk_clust_stats* stats)
+{
+    int rc = precheck(opts, tree);
+    if (rc != SMK_OK) return rc;
+    smk_matrix* a = nullptr;
+    rc = smk_matrix_create_sparse(&a, opts->nmf.height, opts->nmf.width, 0, opts->nmf.width, nnz, col_offsets,
+                                  row_indices, data);
+    if (rc == SMK_OK) rc = run_clust(opts, a, seed, draws, initdir, tree, stats);
+    smk_matrix_destroy(a);
+    return rc;
+}
+
+void smk_tree_destroy(smk_tree* t) { delete t; }
+int smk_tree_node_count(const smk_tree* t) { return t ? (int)t->nodes.size() : 0; }
+int64_t smk_tree_term_count(const smk_tree* t) { return t ? t->term_count : 0; }
+int64_t smk_tree_doc_count(const smk_tree* t) { return t ? t->doc_count : 0; }
+
+int smk_tree_get_node(const smk_tree* t, int q, smk_tree_node* out)
+{
+    if (!t || !out || q < 0 || q >= (int)t->nodes.size()) return SMK_BAD_PARAM;
+    const Node& nd = t->nodes[(size_t)q];
+    out->priority = nd.priority;
+    out->parent = nd.parent; out->left_child = nd.left; out->right_child = nd.right;
+    out->is_valid = nd.valid; out->is_left_child = nd.is_left; out->is_leaf = t->is_leaf[(size_t)q];
+    out->doc_count = (int64_t)nd.docs.size();
+    return SMK_OK;
+}
+
+int smk_tree_node_docs(const smk_tree* t, int q, unsigned* out)
+{
+    if (!t || !out || q < 0 || q >= (int)t->nodes.size()) return SMK_BAD_PARAM;
+    std::copy(t->nodes[(size_t)q].docs.begin(), t->nodes[(size_t)q].docs.end(), out);
+    return SMK_OK;
+}
+
+int smk_tree_node_topic(const smk_tree* t, int q, double* out)
+{
+    if (!t || !out || q < 0 || q >= (int)t->nodes.size()) return SMK_BAD_PARAM;
+    std::copy(t->nodes[(size_t)q].topic.begin(), t->nodes[(size_t)q].topic.end(), out);
+    return SMK_OK;
+}
+
+int smk_tree_node_terms(const smk_tree* t, int q, int* out)
+{
+    if (!t || !out || q < 0 || q >= (int)t->nodes.size()) return 0;
+    std::copy(t->nodes[(size_t)q].terms.begin(), t->nodes[(size_t)q].terms.end(), out);
+    return (int)t->nodes[(size_t)q].terms.size();
+}
+
+int64_t smk_tree_assignments(const smk_tree* t, unsigned* out)
+{
+    if (!t) return 0;
+    if (out) std::copy(t->assignments.begin(), t->assignments.end(), out);
+    return (int64_t)t->assignments.size();
+}
+
+int64_t smk_tree_outliers(const smk_tree* t, unsigned* out)
+{
+    if (!t) return 0;
+    if (out) std::copy(t->outliers.begin(), t->outliers.end(), out);
+    return (int64_t)t->outliers.size();
+}
+
+// Tree::WriteAssignments, tree.hpp:388-423: labels on one line ("-1" for outliers), a blank line,
+// then the outlier document indices.
+int smk_tree_write_assignments(const smk_tree* t, const char* path)
+{
+    if (!t || !path || t->assignments.empty()) return SMK_BAD_PARAM;
+    std::ofstream f(path);
+    if (!f) {
+        fprintf(stderr, "Tree::WriteAssignments: could not open output file %s\n", path);
+        return SMK_FAILURE;
+    }
+    f << t->assignments[0];
+    for (size_t q = 1; q < t->assignments.size(); ++q) {
+        f << ",";
+        if (t->assignments[q] == NONE) f << -1; else f << t->assignments[q];
+    }
+    f << "\n\n";
+    if (!t->outliers.empty()) {
+        f << t->outliers[0];
+        for (size_t q = 1; q < t->outliers.size(); ++q) f << ',' << t->outliers[q];
+        f << "\n";
+    }
+    return f.good() ? SMK_OK : SMK_FAILURE;
+}
+
+// Tree::WriteTree (tree.hpp:426-465) through the XML / JSON node writers
+// (hierclust/src/hierclust_xml_writer.cpp, hierclust_json_writer.cpp).  Ids print as signed ints,
+// so an absent parent/child is -1.
+int smk_tree_write(const smk_tree* t, const char* path, int format, const char* const* dict, int64_t dict_size)
+{
+    if (!t || !path || (format != 0 && format != 1)) return SMK_BAD_PARAM;
+    for (const Node& nd : t->nodes)
+        for (int idx : nd.terms)
+            if (idx < 0 || idx >= dict_size || !dict) { set_error("Tree::Write: dictionary too small"); return SMK_BAD_PARAM; }
+    std::ofstream f(path);
+    if (!f) {
+        fprintf(stderr, "Tree::Write: could not open output file %s\n", path);
+        return SMK_FAILURE;
+    }
+    const std::string S4("    "), S8 = S4 + S4, S12 = S8 + S4, S16 = S12 + S4;
+    const bool json = (format == 1);
+    if (json) f << "{\n" << S4 << "\"doc_count\": " << t->leaf_doc_count << ",\n" << S4 << "\"nodes\": [\n";
+    else f << "<?xml version=\"1.0\"?>\n<DataSet id=\"" << t->leaf_doc_count << "\">\n";
+    for (size_t q = 0; q < t->nodes.size(); ++q) {
+        const Node& nd = t->nodes[q];
+        const int parent = (int)nd.parent, left = (int)nd.left, right = (int)nd.right;
+        if (json) {
+            if (q) f << ",\n";
+            f << S8 << "{\n" << S12 << "\"id\": " << q << ",\n";
+            f << S12 << "\"parent_id\": " << parent << ",\n";
+            f << S12 << "\"left_child\": " << (nd.is_left ? "true" : "false") << ",\n";
+            f << S12 << "\"left_child_id\": " << left << ",\n";
+            f << S12 << "\"right_child_id\": " << right << ",\n";
+            f << S12 << "\"doc_count\": " << nd.docs.size() << ",\n";
+            if (!nd.terms.empty()) {
+                f << S12 << "\"top_terms\": [\n";
+                for (size_t i = 0; i < nd.terms.size(); ++i)
+                    f << S16 << "\"" << dict[nd.terms[i]] << "\"" << (i + 1 < nd.terms.size() ? ",\n" : "\n");
+                f << S12 << "]\n";
+            }
+            f << S8 << "}";
+        } else {
+            f << S4 << "<node id=\"" << q << "\">\n";
+            f << S8 << "<parent_id>" << parent << "</parent_id>\n";
+            f << S8 << "<left_child>" << (nd.is_left ? "true" : "false") << "</left_child>\n";
+            f << S8 << "<left_child_id>" << left << "</left_child_id>\n";
+            f << S8 << "<right_child_id>" << right << "</right_child_id>\n";
+            f << S8 << "<doc_count>" << nd.docs.size() << "</doc_count>\n";
+            f << S8 << "<top_terms>\n";
+            for (int idx : nd.terms) f << S12 << "<term name=\"" << dict[idx] << "\"/>\n";
+            f << S8 << "</top_terms>\n";
+            f << S4 << "</node>\n";
+        }
+    }
+    if (json) f << "\n" << S4 << "]\n}\n";
+    else f << "</DataSet>\n";
+    return f.good() ? SMK_OK : SMK_FAILURE;
+}
+
+double smk_clust_priority(const double* w_parent, const double* w_child, int64_t n)
+{
+    if (!w_parent || !w_child || n <= 0) return -3.0;
+    return priority_score(w_parent, w_child, n);
+}
+
+}  // extern "C"

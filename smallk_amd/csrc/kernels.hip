@@ -169,6 +169,36 @@ int launch_transpose_f64(const double* src, i64 ld_src, double* dst, i64 ld_dst,
     return 0;
 }
 
+// dst[:, j] = src[:, cols[j]] for whole padded columns (col_bytes is a multiple of 16):
+// the HierNMF2 node submatrix (SubMatrixColsCompact, dense_matrix_impl.hpp:224-281) without
+// leaving HBM.  One uint4 per thread, fully coalesced on both sides.
+__global__ __launch_bounds__(256) void gather_cols_kernel(const uint4* __restrict__ src, i64 ld_src16,
+                                                          const unsigned* __restrict__ cols, uint4* __restrict__ dst,
+                                                          i64 ld_dst16, i64 col16)
+{
+    const i64 j = blockIdx.y;
+    const uint4* s = src + (i64)cols[j] * ld_src16;
+    uint4* d = dst + j * ld_dst16;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < col16; i += (i64)gridDim.x * 256)
+        d[i] = s[i];
+}
+int launch_gather_cols(const void* src, i64 ld_src_bytes, const unsigned* cols_dev, i64 ncols, void* dst,
+                       i64 ld_dst_bytes, i64 col_bytes, hipStream_t st)
+{
+    if (ncols <= 0) return 0;
+    const i64 col16 = col_bytes / 16;
+    unsigned gx = (unsigned)((col16 + 255) / 256);
+    if (gx > 64) gx = 64;
+    for (i64 j0 = 0; j0 < ncols; j0 += 65535) {      // gridDim.y limit
+        const i64 nj = ncols - j0 < 65535 ? ncols - j0 : 65535;
+        gather_cols_kernel<<<dim3(gx, (unsigned)nj), 256, 0, st>>>((const uint4*)src, ld_src_bytes / 16, cols_dev + j0,
+                                                                   (uint4*)((char*)dst + j0 * ld_dst_bytes),
+                                                                   ld_dst_bytes / 16, col16);
+    }
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ void zero_f64_kernel(double* p, i64 n)
 {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) p[i] = 0.0;

@@ -64,6 +64,9 @@ struct smk_matrix {
     i64 *colptr = nullptr, *colptr_t = nullptr;
     unsigned *rowidx = nullptr, *rowidx_t = nullptr;
     double *val = nullptr, *val_t = nullptr;
+    // host copy of the CSC (column subsets for HierNMF2 nodes are cut on the host)
+    std::vector<unsigned> h_colptr, h_rowidx;
+    std::vector<double> h_val;
 };
 
 struct smk_solver {
@@ -340,6 +343,10 @@ int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_glo
     smk_matrix* a = new smk_matrix;
     a->m = height; a->n_global = width_global; a->c0 = col0; a->n = ncols_local; a->storage = SMK_STORE_F32;
     a->sparse = true; a->nnz = nnz;
+    a->h_colptr.resize((size_t)ncols_local + 1);
+    for (int64_t c = 0; c <= ncols_local; ++c) a->h_colptr[(size_t)c] = col_offsets[c] - base;
+    a->h_rowidx.assign(row_indices + base, row_indices + base + nnz);
+    a->h_val.assign(data + base, data + base + nnz);
     int rc = 0;
     rc |= dev_alloc(&a->colptr, (size_t)ncols_local + 1);
     rc |= dev_alloc(&a->colptr_t, (size_t)height + 1);
@@ -358,6 +365,68 @@ int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_glo
     }
     *out = a;
     return SMK_OK;
+}
+
+// Column subset of a resident matrix as a new matrix (HierNMF2 node, SubMatrixColsCompact).
+// Dense (dense_matrix_impl.hpp:224-281): all rows kept, columns gathered HBM -> HBM, transpose rebuilt
+// on the device.  Sparse (sparse_matrix_impl.hpp:479-590): rows without a stored entry in the selected
+// columns are dropped; the cut is made on the host copy of the CSC and uploaded.
+int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t ncols, smk_matrix** out,
+                           unsigned* new_to_old_rows, int64_t* new_height)
+{
+    if (!out) return SMK_BAD_PARAM;
+    *out = nullptr;
+    if (!src || !cols || ncols <= 0) { set_error("SubMatrixColsCompact: empty column set"); return SMK_BAD_PARAM; }
+    for (int64_t j = 0; j < ncols; ++j)
+        if ((i64)cols[j] >= src->n) { set_error("SubMatrixColsCompact: column index out of range"); return SMK_BAD_PARAM; }
+    if (!src->sparse) {
+        smk_matrix* a = nullptr;
+        int rc = smk_matrix_create(&a, src->m, ncols, 0, ncols, src->storage);
+        if (rc) return rc;
+        unsigned* dcols = nullptr;
+        rc = dev_alloc(&dcols, (size_t)ncols);
+        if (rc) { smk_matrix_destroy(a); return rc; }
+        const i64 es = elem_size(src->storage);
+        hipError_t e = hipMemcpyAsync(dcols, cols, (size_t)ncols * sizeof(unsigned), hipMemcpyHostToDevice, g_stream);
+        if (e == hipSuccess) {
+            rc = launch_gather_cols(src->A, src->ldA * es, dcols, ncols, a->A, a->ldA * es, src->ldA * es, g_stream);
+            if (!rc) rc = matrix_make_transpose(a);
+            if (!rc) e = hipStreamSynchronize(g_stream);
+        }
+        (void)hipFree(dcols);
+        if (e != hipSuccess) { set_error(std::string("gather_cols: ") + hipGetErrorString(e)); rc = SMK_DEVICE_ERROR; }
+        if (rc) { smk_matrix_destroy(a); return rc; }
+        if (new_to_old_rows) for (i64 r = 0; r < src->m; ++r) new_to_old_rows[r] = (unsigned)r;
+        if (new_height) *new_height = src->m;
+        *out = a;
+        return SMK_OK;
+    }
+    const unsigned UNUSED = 0xFFFFFFFFu;
+    std::vector<unsigned> old_to_new((size_t)src->m, UNUSED), cp((size_t)ncols + 1), ri;
+    std::vector<double> va;
+    size_t total = 0;
+    for (int64_t j = 0; j < ncols; ++j) total += src->h_colptr[cols[j] + 1] - src->h_colptr[cols[j]];
+    if (total == 0) { set_error("SparseMatrix::SubMatrixColsCompact: submatrix is the zero matrix"); return SMK_BAD_PARAM; }
+    ri.reserve(total); va.reserve(total);
+    for (int64_t j = 0; j < ncols; ++j) {
+        cp[(size_t)j] = (unsigned)ri.size();
+        for (unsigned p = src->h_colptr[cols[j]]; p < src->h_colptr[cols[j] + 1]; ++p) {
+            old_to_new[src->h_rowidx[p]] = 0;
+            ri.push_back(src->h_rowidx[p]);
+            va.push_back(src->h_val[p]);
+        }
+    }
+    cp[(size_t)ncols] = (unsigned)ri.size();
+    i64 nh = 0;
+    for (i64 r = 0; r < src->m; ++r)
+        if (old_to_new[(size_t)r] != UNUSED) {
+            old_to_new[(size_t)r] = (unsigned)nh;
+            if (new_to_old_rows) new_to_old_rows[nh] = (unsigned)r;
+            ++nh;
+        }
+    for (unsigned& r : ri) r = old_to_new[r];
+    if (new_height) *new_height = nh;
+    return smk_matrix_create_sparse(out, nh, ncols, 0, ncols, (int64_t)ri.size(), cp.data(), ri.data(), va.data());
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,173 @@
+"""GPU parity for HierNMF2: the product's tree (smk_clust_dense / smk_clust_sparse through the C ABI)
+against the oracle restatement on the same inputs and the same initialiser stream.  The search is
+discrete (H(0,c) > H(1,c), priority ordering), so on these well-separated inputs the trees must be
+IDENTICAL: structure, per-node documents, top terms, assignments, outliers, factorisation counts.
+Topic vectors: these node problems converge slowly (100-1000 RANK2 iterations at tol 1e-4, i.e. a
+contraction factor close to 1), which amplifies the f32/bf16-storage accumulation-order difference
+(~1e-7) to ~1e-5 and moves the stopping iteration by a few counts (tools/hier_dbg.py): dense
+tolerance 2e-4 relative to the largest entry, sparse (fp64 end to end) 1e-6.  The priority score is a function of the RANKS of the topic
+vector entries (clust_hier_util.hpp:105-173); with A rounded to f32/bf16 the device accumulates in a
+different order than the oracle, noise-level entries that differ by ~1e-7 can swap ranks, and the
+score moves by ~1e-4: dense tolerance 2e-3, sparse (fp64 end to end) 1e-9."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from hier_cases import planted, tree_arrays
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_hier.so")
+
+
+def compare(res, otree, ostats, m, prio_rel=2e-3, topic_rel=2e-4):
+    from oracle import hierclust as oh
+    a, b = tree_arrays(res.nodes), tree_arrays(otree.nodes)
+    assert len(a) == len(b)
+    for q, (x, y) in enumerate(zip(a, b)):
+        assert x["valid"] == y["valid"], q
+        if not y["valid"]:
+            continue
+        for key in ("parent", "left", "right", "is_left", "docs", "terms"):
+            assert x[key] == y[key], (q, key)
+        assert x["priority"] == pytest.approx(y["priority"], rel=prio_rel, abs=1e-12), q
+    for q, nd in enumerate(res.nodes):
+        if nd.is_valid:
+            ref = otree.nodes[q].topic_vector
+            assert np.max(np.abs(nd.topic_vector - ref)) <= topic_rel * max(np.max(np.abs(ref)), 1e-30), q
+    assert list(res.get_assignments()) == list(otree.assignments)
+    assert list(res.get_outliers()) == list(otree.outliers)
+    assert (res.nmf_count, res.max_count) == (ostats.nmf_count, ostats.max_count)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(200, 300, 5, 1, 0, 5), (120, 240, 3, 3, 4, 4), (96, 150, 4, 9, 0, 7)])
+def test_dense_tree_matches_oracle(gpu, storage, case):
+    import oracle
+    from oracle import hierclust as oh
+    m, n, topics, seed, tiny, clusters = case
+    A, _ = planted(m, n, topics, seed, tiny=tiny)
+    Aq = oracle.quantize(A, 1 if storage == "bf16" else 0)     # what the device holds
+    res = gpu.hier_nmf2(A, clusters, seed=seed + 100, storage=storage)
+    otree, ostats = oh.hier_nmf2(Aq, clusters, seed=seed + 100)
+    compare(res, otree, ostats, m)
+    assert res.draws == 2 * ostats.nmf_count                   # W and H per successful attempt
+
+
+@pytest.mark.parametrize("case", [(300, 400, 6, 2, 0, 6), (150, 260, 3, 4, 5, 5)])
+def test_sparse_tree_matches_oracle(gpu, case):
+    from oracle import hierclust as oh
+    m, n, topics, seed, tiny, clusters = case
+    A, _ = planted(m, n, topics, seed, sparse=True, tiny=tiny)
+    res = gpu.hier_nmf2(A, clusters, seed=seed)
+    otree, ostats = oh.hier_nmf2(A, clusters, seed=seed)
+    compare(res, otree, ostats, m, prio_rel=1e-9, topic_rel=1e-6)
+
+
+def test_initdir_files(gpu, tmp_path):
+    """--initdir path: Winit_<i>.csv / Hinit_<i>.csv consumed in order (clust_hier_util.hpp:206-241)."""
+    from oracle import hierclust as oh
+    from smallk_amd import _lib as L
+    m, n = 120, 240
+    A, _ = planted(m, n, 3, 3, tiny=4)
+    rng = np.random.default_rng(5)
+    inits = [(np.asfortranarray(rng.random((m, 2))), np.asfortranarray(rng.random((2, n)))) for _ in range(24)]
+    d = str(tmp_path) + "/"
+    for i, (W, H) in enumerate(inits, start=1):
+        for name, M in (("Winit", W), ("Hinit", H)):
+            assert L.lib().smk_write_csv(M.ctypes.data_as(C.POINTER(C.c_double)), M.shape[0], M.shape[0], M.shape[1],
+                                         f"{d}{name}_{i}.csv".encode(), 17) == 1
+    res = gpu.hier_nmf2(A, 4, initdir=d)
+    otree, ostats = oh.hier_nmf2(oracle_quant(A), 4, initializers=inits)
+    compare(res, otree, ostats, m)
+    # a missing file is a load failure, not a silent random start
+    with pytest.raises(L.SmallkError):
+        gpu.hier_nmf2(A, 4, initdir=str(tmp_path / "nope") + "/")
+
+
+def oracle_quant(A):
+    import oracle
+    return oracle.quantize(A, 0)
+
+
+@pytest.mark.parametrize("fmt", ["JSON", "XML"])
+def test_tree_files(gpu, tmp_path, fmt):
+    """smk_tree_write / smk_tree_write_assignments: same bytes as the oracle's text and, where
+    oracle/_ref is present, as the reference's own writer objects."""
+    from oracle import hierclust as oh
+    A, _ = planted(96, 150, 4, 9)
+    res = gpu.hier_nmf2(A, 7, seed=3, maxterms=4)
+    otree, _ = oh.hier_nmf2(oracle_quant(A), 7, seed=3, maxterms=4)
+    dictionary = [f"w{i}" for i in range(96)]
+    p = str(tmp_path / f"tree.{fmt.lower()}")
+    assert res.write(p, dictionary, fmt)
+    text = open(p).read()
+    assert text == oh.tree_text(otree, dictionary, fmt)
+    pa = str(tmp_path / "assign.csv")
+    assert res.write_assignments(pa)
+    assert open(pa).read() == otree.assignments_text()
+    if os.path.exists(REF_SO):
+        from test_hierclust import _ref_write
+        assert text == _ref_write(otree, dictionary, fmt, str(tmp_path / "ref.out"))
+    # a dictionary shorter than the term count is refused
+    assert not res.write(p, dictionary[:3], fmt)
+
+
+def test_facade_hiernmf2(gpu, tmp_path):
+    """smallk::LoadDictionary + HierNmf2 (smallk.cpp:675-862) through the flat handles / SmallkAPI."""
+    from oracle import hierclust as oh
+    from smallk_amd import SmallkAPI
+    A, _ = planted(96, 150, 4, 9)
+    dictionary = [f"w{i}" for i in range(96)]
+    api = SmallkAPI()
+    api.load_matrix(matrix=A)
+    api.seed_rng(42)
+    # HierNmf2 before a dictionary is loaded: the pysmallk wrapper only prints (smallk_lib.pyx:825-832)
+    api.hiernmf2(5)
+    api.load_dictionary(dictionary=dictionary)
+    from smallk_amd import _lib as L
+    assert L.lib().smk_api_set_output_dir(str(tmp_path).encode()) == 0
+    api.hiernmf2(5, format="JSON", maxterms=3, tol=1e-4)
+    otree, _ = oh.hier_nmf2(oracle_quant(A), 5, seed=42, maxterms=3)
+    assert open(tmp_path / "tree_5.json").read() == oh.tree_text(otree, dictionary, "JSON")
+    assert open(tmp_path / "assignments_5.csv").read() == otree.assignments_text()
+    # dictionary from a file; XML output; unterminated last line is dropped (utils.cpp:220-239)
+    dpath = tmp_path / "dict.txt"
+    dpath.write_text("\n".join(dictionary) + "\nextra-without-newline")
+    api.load_dictionary(filepath=str(dpath))
+    api.seed_rng(42)
+    api.hiernmf2(5, format="XML", maxterms=3)
+    assert open(tmp_path / "tree_5.xml").read() == oh.tree_text(otree, dictionary, "XML")
+    # flat clustering is the next tier: reported, not faked
+    assert L.lib().smk_api_hiernmf2_with_flat(5) == 2
+    assert b"not built" in L.lib().smk_api_last_exception()
+
+
+def test_gather_cols_dense_and_sparse(gpu):
+    """smk_matrix_gather_cols == SubMatrixColsCompact (dense keeps all rows; sparse drops unused rows)."""
+    import scipy.sparse as sp
+    from smallk_amd import _lib as L
+    l = L.lib()
+    rng = np.random.default_rng(0)
+    m, n = 300, 517
+    A = np.asfortranarray(rng.random((m, n)))
+    cols = np.sort(rng.choice(n, size=140, replace=False)).astype(np.uint32)
+    for storage in (L.STORE_F32, L.STORE_BF16):
+        src = gpu.DenseMatrix.from_host(A, storage="bf16" if storage == L.STORE_BF16 else "f32")
+        sub = C.c_void_p()
+        nh = C.c_int64()
+        rows = np.zeros(m, dtype=np.uint32)
+        L.check(l.smk_matrix_gather_cols(src._h, cols.ctypes.data_as(C.POINTER(C.c_uint)), len(cols), C.byref(sub),
+                                         rows.ctypes.data_as(C.POINTER(C.c_uint)), C.byref(nh)), "gather")
+        assert nh.value == m and list(rows) == list(range(m))
+        out = np.zeros((m, len(cols)), order="F")
+        L.check(l.smk_matrix_download_f64(sub, out.ctypes.data_as(C.POINTER(C.c_double)), m), "download")
+        assert np.array_equal(out, src.download()[:, cols])
+        l.smk_matrix_destroy(sub)
+    # out-of-range column: BAD_PARAM (logic_error in the reference)
+    bad = np.array([n], dtype=np.uint32)
+    sub = C.c_void_p()
+    assert l.smk_matrix_gather_cols(src._h, bad.ctypes.data_as(C.POINTER(C.c_uint)), 1, C.byref(sub), None,
+                                    None) == L.BAD_PARAM
