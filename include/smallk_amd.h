@@ -164,7 +164,7 @@ typedef struct smk_clust_options {
     int trial_allowance;
     int num_clusters;      /* >= 2 */
     int verbose;
-    int flat;              /* ClustFlat (next tier): SMK_UNSUPPORTED when set */
+    int flat;              /* also run ClustFlat (clust_flat_generic.hpp:33-74) on the leaves */
 } smk_clust_options;
 typedef struct smk_clust_stats { int nmf_count; int max_count; } smk_clust_stats;
 typedef struct smk_tree smk_tree;
@@ -203,8 +203,36 @@ int smk_tree_write_assignments(const smk_tree* t, const char* path);            
 /* format 0 = XML, 1 = JSON (hierclust_xml_writer.cpp / hierclust_json_writer.cpp, byte compatible) */
 int smk_tree_write(const smk_tree* t, const char* path, int format, const char* const* dictionary,
                    int64_t dictionary_size);
+/* opts.flat: the flat factors (W m x num_clusters, H num_clusters x n) computed after the tree search */
+int smk_tree_flat_factors(const smk_tree* t, double* W, int64_t ldW, double* H, int64_t ldH);
 /* the priority score of a split: compute_priority(), clust_hier_util.hpp:105-173 */
 double smk_clust_priority(const double* w_parent, const double* w_child /* n x 2, ld n */, int64_t n);
+
+/* ---- flat clustering ------------------------------------------------------------------
+ * FlatClust / FlatClustSparse (flatclust/include/flat_clust.hpp, flatclust/src/flat_clust.cpp:118-264):
+ * NmfSolve<> restricted to HALS / RANK2 / BPP; same argument meaning as smk_nmf_dense / smk_nmf_sparse. */
+int smk_flatclust_dense(const smk_options* opts, const double* A, int64_t ldA, double* W, int64_t ldW, double* H,
+                        int64_t ldH, smk_stats* stats, int storage);
+int smk_flatclust_sparse(const smk_options* opts, unsigned height, unsigned width, unsigned nz,
+                         const unsigned* col_offsets, const unsigned* row_indices, const double* data, double* W,
+                         int64_t ldW, double* H, int64_t ldH, smk_stats* stats);
+/* NnlsHals (common/include/nnls.hpp:249-316): H-only HALS sweeps with W fixed, until
+ * PG(H) < tol * PG(H after sweep 1); normalises W, H on success.  SMK_FAILURE at the iteration limit. */
+int smk_solver_nnls_hals(smk_solver* s, double tol, int verbose, int max_iter, int* iterations);
+/* assignments.hpp:32-113, terms.hpp:62-108 (host post-processing of the returned factors) */
+int smk_compute_assignments(const double* H, unsigned ldH, unsigned k, unsigned n, unsigned* labels /* n */);
+int smk_compute_fuzzy_assignments(const double* H, unsigned ldH, unsigned k, unsigned n, float* probabilities);
+int smk_top_terms(int maxterms, const double* W, unsigned ldim, unsigned height, unsigned width,
+                  int* term_indices /* maxterms * width */);
+/* common/src/assignments.cpp:23-70; return 1 on success like the reference's bool */
+int smk_write_assignments_file(const unsigned* labels, unsigned n, const char* path);
+int smk_write_fuzzy_assignments_file(const float* probabilities, unsigned k, unsigned n, const char* path);
+/* FlatClustWriteResults, common/src/flat_clust_output.cpp:56-141; format 0 = XML, 1 = JSON */
+int smk_flatclust_write_results(const char* assignfile, const char* fuzzyfile, const char* resultfile,
+                                const unsigned* assignments, unsigned num_assignments, const float* probabilities,
+                                const char* const* dictionary, int64_t dictionary_size, const int* term_indices,
+                                int64_t num_term_indices, int format, unsigned maxterms, unsigned num_docs,
+                                unsigned num_clusters);
 
 /* ---- CSV files: WriteDelimitedFile / LoadDelimitedFile, common/include/delimited_file.hpp:49-135 ----
  * (row-major text, scientific notation; used for w.csv / h.csv and init files) */
@@ -263,7 +291,7 @@ int smk_api_nmf(unsigned k, int algorithm, const char* initfile_w, const char* i
 const double* smk_api_locked_buffer_w(unsigned* ldim, unsigned* height, unsigned* width);   /* :653-661 */
 const double* smk_api_locked_buffer_h(unsigned* ldim, unsigned* height, unsigned* width);   /* :664-672 */
 int smk_api_hiernmf2(unsigned num_clusters);            /* smallk::HierNmf2, smallk.cpp:859-862 */
-int smk_api_hiernmf2_with_flat(unsigned num_clusters);  /* flat clustering is the next tier: reports "not built" */
+int smk_api_hiernmf2_with_flat(unsigned num_clusters);  /* smallk::HierNmf2WithFlat, smallk.cpp:865-868 */
 int smk_api_load_dictionary_file(const char* path);     /* LoadDictionary(string), smallk.cpp:675-691 */
 int smk_api_load_dictionary(const char* const* terms, unsigned count);          /* smallk.cpp:694-707 */
 

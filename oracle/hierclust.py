@@ -238,17 +238,20 @@ class _Init:
         self.counter += 1
         return np.asfortranarray(W, dtype=np.float64), np.asfortranarray(H, dtype=np.float64)
 
+    def draw(self, rows, cols):
+        self.draws += 1
+        return fill_uniform(rows, cols, (self.seed + SEED_STRIDE * self.draws) & 0xFFFFFFFFFFFFFFFF)
+
     def random(self, h, w):
-        self.draws += 1
-        W = fill_uniform(h, 2, (self.seed + SEED_STRIDE * self.draws) & 0xFFFFFFFFFFFFFFFF)
-        self.draws += 1
-        H = fill_uniform(2, w, (self.seed + SEED_STRIDE * self.draws) & 0xFFFFFFFFFFFFFFFF)
+        W = self.draw(h, 2)
+        H = self.draw(2, w)
         return W, H
 
 
 def hier_nmf2(A, num_clusters, *, tol=1e-4, min_iter=5, max_iter=5000, maxterms=5, unbalanced=0.1,
-              trial_allowance=3, seed=0, draws=0, initializers=None):
-    """Returns (tree, stats).  ``initializers``: sequence of full-size (W m x 2, H 2 x n) pairs,
+              trial_allowance=3, seed=0, draws=0, initializers=None, flat=False):
+    """Returns (tree, stats).  ``flat``: also run ClustFlat (clust_flat_generic.hpp:33-74) on the leaf topic
+    vectors; the factors land in ``tree.flat_W`` (m x k) / ``tree.flat_H`` (k x n).  ``initializers``: sequence of full-size (W m x 2, H 2 x n) pairs,
     consumed like the reference's Winit_<i>.csv / Hinit_<i>.csv files (clust_hier_util.hpp:206-241)."""
     if num_clusters <= 1:
         raise ValueError("HierNMF2: number of clusters must be >= 2")
@@ -344,6 +347,21 @@ def hier_nmf2(A, num_clusters, *, tol=1e-4, min_iter=5, max_iter=5000, maxterms=
             tree.nodes[idx].priority = pr
     tree.compute_top_terms(maxterms)
     tree.compute_assignments()
+    tree.flat_W = tree.flat_H = None
+    if flat:
+        from .flatclust import nnls_hals
+        leaves = [q for q in range(node_count) if tree.is_leaf[q]]
+        if len(leaves) != num_clusters:              # Tree::FlatclustInitW, tree.hpp:341-385
+            raise RuntimeError("Insufficient number of leaf nodes for flat clustering.")
+        Wl = np.stack([tree.nodes[q].topic_vector for q in leaves], axis=1)
+        for _ in range(3):
+            ok, Wf, Hf, _its = nnls_hals(src.full(), Wl, init.draw(num_clusters, n), tol, max_iter)
+            if ok:
+                tree.flat_W, tree.flat_H = Wf, Hf
+                break
+        else:
+            raise RuntimeError("Flatclust NNLS solver failed after 3 attempts.")
+    tree.draws = init.draws
     return tree, stats
 
 

@@ -161,6 +161,20 @@ SYMBOLS = {
     "smk_tree_write_assignments": (C.c_int, [_vp, C.c_char_p]),
     "smk_tree_write": (C.c_int, [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), _i64]),
     "smk_clust_priority": (C.c_double, [_dp, _dp, _i64]),
+    "smk_tree_flat_factors": (C.c_int, [_vp, _dp, _i64, _dp, _i64]),
+    # flat clustering (flatclust.cpp; reference flatclust/src/flat_clust.cpp, common/include/assignments.hpp)
+    "smk_flatclust_dense": (C.c_int, [C.POINTER(Options), _dp, _i64, _dp, _i64, _dp, _i64, C.POINTER(Stats), C.c_int]),
+    "smk_flatclust_sparse": (C.c_int, [C.POINTER(Options), C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint),
+                                       C.POINTER(C.c_uint), _dp, _dp, _i64, _dp, _i64, C.POINTER(Stats)]),
+    "smk_solver_nnls_hals": (C.c_int, [_vp, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "smk_compute_assignments": (C.c_int, [_dp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint)]),
+    "smk_compute_fuzzy_assignments": (C.c_int, [_dp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_float)]),
+    "smk_top_terms": (C.c_int, [C.c_int, _dp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_int)]),
+    "smk_write_assignments_file": (C.c_int, [C.POINTER(C.c_uint), C.c_uint, C.c_char_p]),
+    "smk_write_fuzzy_assignments_file": (C.c_int, [C.POINTER(C.c_float), C.c_uint, C.c_uint, C.c_char_p]),
+    "smk_flatclust_write_results": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint), C.c_uint,
+                                              C.POINTER(C.c_float), C.POINTER(C.c_char_p), _i64, C.POINTER(C.c_int),
+                                              _i64, C.c_int, C.c_uint, C.c_uint, C.c_uint]),
 }
 
 _lib = None

@@ -713,8 +713,6 @@ static void hier_nmf2_internal(const bool generate_flat, const unsigned int num_
         throw std::logic_error("smallk error (HierNmf2): matrix height too large.");
     if (2ull * n > (uint64_t)std::numeric_limits<int>::max())
         throw std::logic_error("smallk error (HierNmf2): matrix width too large.");
-    if (generate_flat)
-        throw std::runtime_error("smallk error (HierNmf2WithFlat): flat clustering is not built on the MI355X path yet.");
     if (dictionary.size() < m)
         throw std::logic_error("smallk error (HierNmf2): dictionary has fewer terms than the matrix has rows.");
 
@@ -736,7 +734,7 @@ static void hier_nmf2_internal(const bool generate_flat, const unsigned int num_
     co.trial_allowance = 3;
     co.num_clusters = (int)num_clusters;
     co.verbose = 1;
-    co.flat = 0;
+    co.flat = generate_flat ? 1 : 0;
 
     const std::string output_dir = ensure_trailing_sep(outdir);
     const bool xml = (OutputFormat::XML == clustfile_format);
@@ -781,6 +779,34 @@ static void hier_nmf2_internal(const bool generate_flat, const unsigned int num_
     for (size_t i = 0; i < dictionary.size(); ++i) terms[i] = dictionary[i].c_str();
     if (smk_tree_write(tree, tree_name.str().c_str(), xml ? 0 : 1, terms.data(), (int64_t)terms.size()) != SMK_OK)
         std::cerr << "\terror writing hierarchical results file" << endl;
+    if (generate_flat) {
+        // RunHierNmf2 (run_hier_nmf2.hpp:57-66) + FlatClustWriteResults(outdir, ...) (flat_clust_output.cpp:144-173)
+        const unsigned int kc = num_clusters;
+        k = kc; ldim_w = m; ldim_h = kc;
+        buf_w.assign((size_t)m * kc, 0.0);
+        buf_h.assign((size_t)kc * n, 0.0);
+        std::vector<float> probabilities((size_t)kc * n);
+        std::vector<unsigned int> assignments_flat(n);
+        std::vector<int> term_indices((size_t)maxterms * kc, 0);
+        int frc = smk_tree_flat_factors(tree, &buf_w[0], m, &buf_h[0], kc);
+        if (frc == SMK_OK) frc = smk_compute_fuzzy_assignments(&buf_h[0], kc, kc, n, probabilities.data());
+        if (frc == SMK_OK) frc = smk_compute_assignments(&buf_h[0], kc, kc, n, assignments_flat.data());
+        if (frc == SMK_OK) frc = smk_top_terms((int)maxterms, &buf_w[0], m, m, kc, term_indices.data());
+        if (frc == SMK_OK) {
+            std::ostringstream fa, ff, fr;
+            fa << output_dir << "assignments_flat_" << kc << ".csv";
+            ff << output_dir << "assignments_fuzzy_" << kc << ".csv";
+            fr << output_dir << "clusters_" << kc << (xml ? ".xml" : ".json");
+            frc = smk_flatclust_write_results(fa.str().c_str(), ff.str().c_str(), fr.str().c_str(), assignments_flat.data(),
+                                              n, probabilities.data(), terms.data(), (int64_t)terms.size(),
+                                              term_indices.data(), (int64_t)term_indices.size(), xml ? 0 : 1, maxterms,
+                                              n, kc);
+        }
+        if (frc != SMK_OK) {
+            smk_tree_destroy(tree);
+            throw std::runtime_error(std::string("smallk error (HierNMF2): ") + smk_last_error());
+        }
+    }
     smk_tree_destroy(tree);
 }
 

@@ -50,6 +50,8 @@ struct smk_tree {
     i64 term_count = 0, doc_count = 0, leaf_doc_count = 0;
     int maxterms = 0;
     std::vector<unsigned> assignments, outliers;
+    int flat_k = 0;                         // ClustFlat result (opts.flat): W m x k, H k x n
+    std::vector<double> flatW, flatH;
 };
 
 namespace {
@@ -422,6 +424,53 @@ int clust_hier(Run& r, smk_tree& tree)
     return SMK_OK;
 }
 
+// ClustFlat, hierclust/include/clust_flat_generic.hpp:33-74: W = the leaf topic vectors
+// (Tree::FlatclustInitW, tree.hpp:341-385), H random, then NnlsHals with W fixed.
+int clust_flat(Run& r, smk_tree& t)
+{
+    const smk_clust_options& o = *r.o;
+    const i64 m = r.m, n = r.n;
+    const int k = o.num_clusters;
+    int leaves = 0;
+    for (char l : t.is_leaf) leaves += (l != 0);
+    if (leaves != k) {
+        fprintf(stderr, "Insufficient number of leaf nodes for flat clustering.\n");
+        set_error("Insufficient number of leaf nodes for flat clustering.");
+        return SMK_FLATCLUST_FAILURE;
+    }
+    if (k > 64) { set_error("flat clustering: more than 64 clusters is not built on the device path"); return SMK_UNSUPPORTED; }
+    std::vector<double> W((size_t)m * k), H((size_t)k * n);
+    int c = 0;
+    for (size_t q = 0; q < t.nodes.size(); ++q)
+        if (t.is_leaf[q]) std::copy(t.nodes[q].topic.begin(), t.nodes[q].topic.end(), W.begin() + (size_t)(c++) * m);
+    smk_options so = o.nmf;
+    so.height = (int)m; so.width = (int)n; so.k = k;
+    so.algorithm = SMK_ALG_HALS;
+    so.prog_est_algorithm = SMK_PROG_PG_RATIO;
+    int rc = SMK_FAILURE;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        smk_uniform_fill_host(H.data(), k, k, n, 0, 0, k, r.seed + 0x9E37u * (++r.draws), 0);
+        smk_solver* s = nullptr;
+        int its = 0;
+        rc = smk_solver_create(&s, &so, r.full);
+        if (rc == SMK_OK) rc = smk_solver_set_factors(s, W.data(), m, H.data(), k);
+        if (rc == SMK_OK) rc = smk_solver_nnls_hals(s, o.nmf.tol, o.verbose, o.nmf.max_iter, &its);
+        if (rc == SMK_OK) rc = smk_solver_get_factors(s, 0, W.data(), m, H.data(), k);
+        smk_solver_destroy(s);
+        if (rc != SMK_FAILURE) break;
+    }
+    if (rc == SMK_FAILURE) {
+        printf("Flatclust NNLS solver failed after 3 attempts.\n");
+        fprintf(stderr, "Flat clustering failed.\n");
+        return SMK_FLATCLUST_FAILURE;
+    }
+    if (rc != SMK_OK) return rc;
+    t.flat_k = k;
+    t.flatW.swap(W);
+    t.flatH.swap(H);
+    return SMK_OK;
+}
+
 int check_sizes(const smk_clust_options* o)        // clust.cpp:116-131
 {
     const uint64_t lim = (uint64_t)std::numeric_limits<int>::max();
@@ -438,7 +487,8 @@ int run_clust(const smk_clust_options* opts, smk_matrix* full, uint64_t seed, ui
     r.seed = seed; r.draws = draws ? *draws : 0;
     if (initdir) r.initdir = initdir;
     smk_tree* t = new smk_tree;
-    const int rc = clust_hier(r, *t);
+    int rc = clust_hier(r, *t);
+    if (rc == SMK_OK && opts->flat) rc = clust_flat(r, *t);
     if (draws) *draws = r.draws;
     if (stats) *stats = r.stats;
     if (rc != SMK_OK) { delete t; return rc; }
@@ -455,7 +505,6 @@ int precheck(const smk_clust_options* opts, smk_tree** tree)
         return SMK_NOTINITIALIZED;
     }
     if (!opts || !smk_clust_is_valid(opts, 1)) return SMK_BAD_PARAM;
-    if (opts->flat) { set_error("flat clustering (ClustFlat) is not built in this tier"); return SMK_UNSUPPORTED; }
     return check_sizes(opts);
 }
 
@@ -644,6 +693,18 @@ int smk_tree_write(const smk_tree* t, const char* path, int format, const char* 
     if (json) f << "\n" << S4 << "]\n}\n";
     else f << "</DataSet>\n";
     return f.good() ? SMK_OK : SMK_FAILURE;
+}
+
+// factors of the flat clustering that followed the tree search (opts.flat): W m x k, H k x n
+int smk_tree_flat_factors(const smk_tree* t, double* W, int64_t ldW, double* H, int64_t ldH)
+{
+    if (!t || !W || !H) return SMK_BAD_PARAM;
+    if (t->flat_k == 0) { set_error("no flat clustering result in this tree"); return SMK_BAD_PARAM; }
+    const i64 m = t->term_count, n = t->doc_count, k = t->flat_k;
+    if (ldW < m || ldH < k) return SMK_BAD_PARAM;
+    for (i64 c = 0; c < k; ++c) std::copy(t->flatW.begin() + c * m, t->flatW.begin() + (c + 1) * m, W + c * ldW);
+    for (i64 c = 0; c < n; ++c) std::copy(t->flatH.begin() + c * k, t->flatH.begin() + (c + 1) * k, H + c * ldH);
+    return SMK_OK;
 }
 
 double smk_clust_priority(const double* w_parent, const double* w_child, int64_t n)

@@ -915,6 +915,54 @@ done:
     return result;
 }
 
+// NnlsHals (common/include/nnls.hpp:249-316): W stays fixed, H is swept with the HALS row update until
+// the projected-gradient norm of H drops below tol * (its value after the first sweep).  W'A is
+// formed once by the streaming product, every iteration is two column-tile kernels over H.
+// Returns SMK_OK on convergence (W, H then normalised like the reference does) or SMK_FAILURE when
+// the iteration limit is reached.
+int smk_solver_nnls_hals(smk_solver* s, double tol, int verbose, int max_iter, int* iterations)
+{
+    if (!s || max_iter < 0) return SMK_BAD_PARAM;
+    if (!s->have_factors) { set_error("set_factors() first"); return SMK_BAD_PARAM; }
+    if (s->ar) { set_error("NnlsHals: not available on a sharded solver"); return SMK_UNSUPPORTED; }
+    if (verbose) printf("\nRunning NNLS solver...\n");
+    int rc = prod1(s);
+    if (!rc) rc = gram_w(s);
+    if (rc) return rc;
+    bool success = false;
+    double pg0 = 0.0;
+    int i = 0;
+    for (i = 0; i < max_iter; ++i) {
+        rc = launch_hals_sweep(s->H, s->k, s->n, view1(s), s->Gw, s->st);
+        if (!rc) rc = launch_grad_pg(s->H, s->k, s->n, view1(s), s->Gw, nullptr, s->pg_partials + s->pg_half, s->scal, 1, s->st);
+        if (rc) return rc;
+        double sum = 0.0;
+        SMK_HIP(hipMemcpyAsync(&sum, s->scal + 1, sizeof(double), hipMemcpyDeviceToHost, s->st));
+        SMK_HIP(hipStreamSynchronize(s->st));
+        const double pg = std::sqrt(sum);
+        if (std::isnan(pg)) { set_error("ProjectedGradientNorm: NaN"); return SMK_FAILURE; }
+        if (i == 0) {
+            pg0 = pg;
+            if (verbose) printf("1:\tprogress metric:\t%g\n", 1.0);
+            continue;
+        }
+        if (verbose && ((i + 1 < 10) || ((i + 1) % 10 == 0))) printf("%d:\tprogress metric:\t%g\n", i + 1, pg / pg0);
+        if (pg < tol * pg0) {
+            success = true;
+            s->normalized = false;
+            rc = normalize_device(s);
+            if (rc) return rc;
+            break;
+        }
+    }
+    if (iterations) *iterations = success ? i + 1 : i;
+    s->inited = false;       // Gw/R1 no longer describe a solver schedule
+    rc = sync_and_check(s, nullptr);
+    if (rc) return rc;
+    if (!success) fprintf(stderr, "NNLS solver reached iteration limit.\n");
+    return success ? SMK_OK : SMK_FAILURE;
+}
+
 int smk_solver_get_factors(smk_solver* s, int normalize, double* W, int64_t ldW, double* H, int64_t ldH)
 {
     if (!s || !W || !H) return SMK_BAD_PARAM;

@@ -77,6 +77,17 @@ class TreeResults:
         L.lib().smk_tree_outliers(self._h, out.ctypes.data_as(C.POINTER(C.c_uint)))
         return out[:cnt]
 
+    def flat_factors(self):
+        """(W m x k, H k x n) of the flat clustering run with ``flat=True`` (ClustFlat)."""
+        l = L.lib()
+        m, n = l.smk_tree_term_count(self._h), l.smk_tree_doc_count(self._h)
+        k = sum(1 for q in range(self.node_count) if self.node(q).is_leaf)
+        W = np.zeros((m, k), order="F")
+        H = np.zeros((k, n), order="F")
+        L.check(l.smk_tree_flat_factors(self._h, W.ctypes.data_as(C.POINTER(C.c_double)), m,
+                                        H.ctypes.data_as(C.POINTER(C.c_double)), k), "smk_tree_flat_factors")
+        return W, H
+
     def write_assignments(self, filepath):
         return L.lib().smk_tree_write_assignments(self._h, str(filepath).encode()) == L.OK
 

@@ -140,9 +140,9 @@ def test_facade_hiernmf2(gpu, tmp_path):
     api.seed_rng(42)
     api.hiernmf2(5, format="XML", maxterms=3)
     assert open(tmp_path / "tree_5.xml").read() == oh.tree_text(otree, dictionary, "XML")
-    # flat clustering is the next tier: reported, not faked
+    # this input stops after 3 splits (4 leaves): the flat step refuses like RunClust does (clust.cpp:53-61)
     assert L.lib().smk_api_hiernmf2_with_flat(5) == 2
-    assert b"not built" in L.lib().smk_api_last_exception()
+    assert b"Insufficient number of leaf nodes" in L.lib().smk_api_last_exception()
 
 
 def test_gather_cols_dense_and_sparse(gpu):
