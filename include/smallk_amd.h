@@ -181,7 +181,9 @@ int smk_clust_is_valid(const smk_clust_options* opts, int validate_matrix);   /*
  * rows are listed in new_to_old_rows[0 .. *new_height), capacity = height). */
 int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t ncols, smk_matrix** out,
                            unsigned* new_to_old_rows, int64_t* new_height);
-/* Random initialisers: matrix i of the run is the counter-based uniform block with seed
+/* Returns SMK_OK, or SMK_FLATCLUST_FAILURE with *tree still valid (opts.flat and the flat step failed:
+ * fewer leaves than clusters, or NnlsHals did not converge), or an error with *tree == NULL.
+ * Random initialisers: matrix i of the run is the counter-based uniform block with seed
  * `seed + 0x9E37 * (++*draws)` (W then H per attempt); `initdir` non-empty: Winit_<i>.csv / Hinit_<i>.csv
  * (full size, i = 1, 2, ...; clust_hier_util.hpp:206-241) are used instead.  `draws` may be NULL. */
 int smk_clust_dense(const smk_clust_options* opts, const double* A, int64_t ldA, int storage, uint64_t seed,

@@ -767,6 +767,7 @@ static void hier_nmf2_internal(const bool generate_flat, const unsigned int num_
                             std::chrono::high_resolution_clock::now() - t0).count();
     cout << "\nElapsed wall clock time: " << elapsed_string(us) << endl;
     if (rc != SMK_OK) {
+        smk_tree_destroy(tree);
         const std::string why = smk_last_error();
         throw std::runtime_error(why.empty() ? std::string("smallk error (HierNMF2): HierNMF2 fatal error.")
                                              : "smallk error (HierNMF2): " + why);

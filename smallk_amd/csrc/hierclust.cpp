@@ -491,9 +491,10 @@ int run_clust(const smk_clust_options* opts, smk_matrix* full, uint64_t seed, ui
     if (rc == SMK_OK && opts->flat) rc = clust_flat(r, *t);
     if (draws) *draws = r.draws;
     if (stats) *stats = r.stats;
-    if (rc != SMK_OK) { delete t; return rc; }
+    // a failed flat step still returns the tree (RunClust, clust.cpp:53-61: the caller writes it)
+    if (rc != SMK_OK && rc != SMK_FLATCLUST_FAILURE) { delete t; return rc; }
     *tree_out = t;
-    return SMK_OK;
+    return rc;
 }
 
 int precheck(const smk_clust_options* opts, smk_tree** tree)

@@ -130,6 +130,8 @@ def hier_nmf2(A, num_clusters, *, seed=0, draws=0, initdir="", storage="f32", **
         st = L.STORE_BF16 if str(storage).lower() == "bf16" else L.STORE_F32
         rc = l.smk_clust_dense(C.byref(o), a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[0], st, seed,
                                C.byref(dr), idir, C.byref(tree), C.byref(stats))
+    if rc != L.OK and tree:            # FLATCLUST_FAILURE hands the tree back; this wrapper raises instead
+        l.smk_tree_destroy(tree)
     L.check(rc, "smk_clust")
     res = TreeResults(tree, stats)
     res.draws = dr.value

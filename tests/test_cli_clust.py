@@ -1,0 +1,126 @@
+"""The `hierclust` and `flatclust` command line tools (reference: hierclust/src/main.cpp,
+flatclust/src/main.cpp; regression shape of tests/scripts/test_hierclust.sh:36 and test_flatclust.sh:
+fixed initialisers + --miniter 1, then compare the output files)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from hier_cases import planted
+from test_cli import write_csv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIER = os.path.join(ROOT, "smallk_amd", "bin", "hierclust")
+FLAT = os.path.join(ROOT, "smallk_amd", "bin", "flatclust")
+
+
+def run(*args):
+    return subprocess.run([str(a) for a in args], capture_output=True, text=True, timeout=300)
+
+
+def test_usage_and_argument_errors(tmp_path):
+    for tool in (HIER, FLAT):
+        assert os.path.exists(tool), "build the CLIs with make -C smallk_amd/csrc"
+        r = run(tool)
+        assert r.returncode == 0 and "--dictfile" in r.stdout                    # no args -> help
+        r = run(tool, "--help")
+        assert r.returncode == 0 and "--clusters" in r.stdout
+        r = run(tool, "--dictfile", "d.txt", "--clusters", "3")
+        assert r.returncode != 0 and "required command line argument --matrixfile" in r.stderr
+        r = run(tool, "--matrixfile", "a.csv", "--clusters", "3")
+        assert r.returncode != 0 and "required command line argument --dictfile" in r.stderr
+        r = run(tool, "--matrixfile", "a.csv", "--dictfile", "d.txt")
+        assert r.returncode != 0 and "required command line argument --clusters" in r.stderr
+        r = run(tool, "--matrixfile", "a.csv", "--dictfile", "d.txt", "--clusters", "3", "--format", "YAML")
+        assert r.returncode != 0 and "Invalid value" in r.stderr
+        r = run(tool, "--matrixfile", "a.csv", "--dictfile", "d.txt", "--clusters", "3", "--outdir", tmp_path / "missing")
+        assert r.returncode != 0 and "does not exist" in r.stderr
+        r = run(tool, "--matrixfile", "a.csv", "--dictfile", "d.txt", "--clusters", "3", "--tol", "1.5")
+        assert r.returncode != 0 and "tolerance must be in the interval" in r.stderr
+    r = run(HIER, "--matrixfile", "a.csv", "--dictfile", "d.txt", "--clusters", "1")
+    assert r.returncode != 0 and "number of clusters must be >= 2" in r.stderr
+    r = run(HIER, "--matrixfile", "a.csv", "--dictfile", "d.txt", "--clusters", "3", "--unbalanced", "1.0")
+    assert r.returncode != 0 and "unbalanced" in r.stderr
+    r = run(FLAT, "--matrixfile", "a.csv", "--dictfile", "d.txt", "--clusters", "3", "--algorithm", "MU")
+    assert r.returncode != 0 and "Invalid value" in r.stderr
+
+
+def _write_mtx(path, A):
+    A = A.tocoo()
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{A.shape[0]} {A.shape[1]} {A.nnz}\n")
+        for r, c, v in zip(A.row, A.col, A.data):
+            f.write(f"{r + 1} {c + 1} {float(v)!r}\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sparse", [False, True])
+def test_hierclust_cli_with_initdir(tmp_path, sparse):
+    import oracle
+    from oracle import hierclust as oh, flatclust as of
+    m, n, clusters = 120, 200, 4
+    A, _ = planted(m, n, 4, 21, sparse=sparse)
+    mpath = tmp_path / ("a.mtx" if sparse else "a.csv")
+    _write_mtx(mpath, A) if sparse else write_csv(mpath, A)
+    dictionary = [f"w{i}" for i in range(m)]
+    (tmp_path / "dict.txt").write_text("\n".join(dictionary) + "\n")
+    init = tmp_path / "init"
+    init.mkdir()
+    rng = np.random.default_rng(8)
+    inits = [(np.asfortranarray(rng.random((m, 2))), np.asfortranarray(rng.random((2, n)))) for _ in range(20)]
+    for i, (W, H) in enumerate(inits, start=1):
+        write_csv(init / f"Winit_{i}.csv", W)
+        write_csv(init / f"Hinit_{i}.csv", H)
+    out = tmp_path / "out"
+    out.mkdir()
+    r = run(HIER, "--matrixfile", mpath, "--dictfile", tmp_path / "dict.txt", "--clusters", clusters, "--initdir", init,
+            "--miniter", "1", "--outdir", out, "--format", "JSON", "--maxterms", "3", "--flat", "1", "--seed", "77")
+    assert r.returncode == 0, r.stderr
+    assert "factorizations converged" in r.stdout
+    Ad = A if sparse else oracle.quantize(A, 0)
+    otree, _ = oh.hier_nmf2(Ad, clusters, min_iter=1, maxterms=3, initializers=inits, flat=True, seed=77)
+    assert (out / "tree_4.json").read_text() == oh.tree_text(otree, dictionary, "JSON")
+    assert (out / "assignments_4.csv").read_text() == otree.assignments_text()
+    labels = of.compute_assignments(otree.flat_H)
+    assert (out / "assignments_flat_4.csv").read_text() == of.assignments_text(labels)
+    assert (out / "clusters_4.json").read_text() == of.results_text(labels, of.top_terms(otree.flat_W, 3), dictionary,
+                                                                    "JSON", 3, n, clusters)
+    assert (out / "assignments_fuzzy_4.csv").exists()
+    # explicit file names, XML default
+    r = run(HIER, "--matrixfile", mpath, "--dictfile", tmp_path / "dict.txt", "--clusters", clusters, "--initdir", init,
+            "--miniter", "1", "--outdir", out, "--treefile", "t.xml", "--assignfile", "a.txt", "--verbose", "0")
+    assert r.returncode == 0, r.stderr
+    otree2, _ = oh.hier_nmf2(Ad, clusters, min_iter=1, initializers=inits)
+    assert (out / "t.xml").read_text() == oh.tree_text(otree2, dictionary, "XML")
+    assert (out / "a.txt").read_text() == otree2.assignments_text()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["BPP", "HALS", "RANK2"])
+def test_flatclust_cli(tmp_path, alg):
+    import oracle
+    from oracle import flatclust as of
+    k = 2 if alg == "RANK2" else 4
+    m, n = 150, 220
+    A, _ = planted(m, n, k, 13)
+    W0, H0 = oracle.fill_uniform(m, k, 1), oracle.fill_uniform(k, n, 2)
+    write_csv(tmp_path / "a.csv", A)
+    write_csv(tmp_path / "w0.csv", W0)
+    write_csv(tmp_path / "h0.csv", H0)
+    dictionary = [f"t{i}" for i in range(m)]
+    (tmp_path / "dict.txt").write_text("\n".join(dictionary) + "\n")
+    r = run(FLAT, "--matrixfile", tmp_path / "a.csv", "--dictfile", tmp_path / "dict.txt", "--clusters", "4",
+            "--algorithm", alg, "--infile_W", tmp_path / "w0.csv", "--infile_H", tmp_path / "h0.csv", "--miniter", "1",
+            "--maxiter", "60", "--tol", "1e-9", "--outdir", tmp_path, "--maxterms", "4", "--verbose", "0")
+    assert r.returncode == 0, r.stderr
+    ref = of.flatclust(oracle.quantize(A, 0), W0, H0, alg, min_iter=1, max_iter=60, tol=1e-9)
+    labels = of.compute_assignments(ref.H)
+    # RANK2 forces clusters = 2 AFTER the default file names were formed from the requested 4
+    # (flatclust/src/command_line.cpp:391-431): the names keep the 4
+    assert (tmp_path / "assignments_4.csv").read_text() == of.assignments_text(labels)
+    assert (tmp_path / "clusters_4.xml").read_text() == of.results_text(labels, of.top_terms(ref.W, 4), dictionary, "XML",
+                                                                          4, n, k)
+    got = np.loadtxt(tmp_path / "assignments_fuzzy_4.csv", delimiter=",")
+    assert np.allclose(got, of.compute_fuzzy_assignments(ref.H).T, atol=2e-3)
