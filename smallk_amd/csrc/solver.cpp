@@ -495,7 +495,9 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     rc |= dev_alloc(&s->Gh_own, kk);
     rc |= dev_alloc(&s->gram_scratch, gram_scratch_elems(s->k, GRAM_BLOCKS));
     rc |= dev_alloc(&s->tmpW, (size_t)s->KP * s->m);
-    s->pg_half = (size_t)((std::max(s->m, s->n) + 255) / 256) + 1024;
+    // one partial per workgroup of the column-tile kernels (grid = N*(KP/4)/256 blocks) and at most
+    // 2 x 512 for delta_fnorm
+    s->pg_half = (size_t)((std::max(s->m, s->n) * (s->KP / 4) + 255) / 256) + 1024;
     rc |= dev_alloc(&s->pg_partials, 2 * s->pg_half);
     rc |= dev_alloc(&s->scal_own, (size_t)8);
     rc |= dev_alloc(&s->fail_flag, (size_t)1);

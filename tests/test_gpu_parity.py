@@ -249,3 +249,22 @@ def test_edge_shapes(gpu, m, n, k):
             assert got.result == ref.result, (alg, st, got.result, ref.result)
             if ref.result == 0:
                 assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL, (alg, st)
+
+
+@pytest.mark.parametrize("alg,k", [("RANK2", 2), ("BPP", 8), ("HALS", 33)])
+def test_tall_matrix_progress_scratch(gpu, alg, k):
+    """m large enough that the projected-gradient kernels launch more workgroups than m/256 + 1024
+    (one partial sum per workgroup): regression for an undersized scratch buffer that corrupted the
+    neighbouring allocations and made RANK2 fail sporadically at m >= 262144."""
+    import oracle
+    m, n = 300000, 40
+    rng = np.random.default_rng(5)
+    Wt = rng.random((m, 12)) * (rng.random((m, 12)) > 0.5)
+    A = np.asfortranarray(Wt @ rng.random((12, n)) + 0.01 * rng.random((m, n)))
+    W0, H0 = oracle.fill_uniform(m, k, 3), oracle.fill_uniform(k, n, 4)
+    for _ in range(3):                                   # the failure was intermittent
+        r = gpu.nmf(A, W0, H0, alg, min_iter=1, max_iter=4, tol=1e-12)
+        ref = oracle.nmf(oracle.quantize(A, 0), W0, H0, alg, min_iter=1, max_iter=4, tol=1e-12)
+        assert r.result == ref.result == 0 and r.iteration_count == ref.iteration_count == 4
+        assert np.linalg.norm(r.W - ref.W) / np.linalg.norm(ref.W) < 1e-4
+        assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
