@@ -113,4 +113,9 @@ int launch_rank2_rescale(double* Gh, const double* Gw, PartialView R, i64 N, hip
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X,
                        int k, double* P, int kpp, hipStream_t st);
 
+// sort.hip: stable descending radix sort of host vectors on the device (argsort when idx_host[v] != nullptr,
+// keys-only into sorted_host[v] otherwise)
+int device_sort_desc(const double* const* keys_host, int* const* idx_host, double* const* sorted_host, int count, i64 n,
+                     hipStream_t st);
+
 }  // namespace smk

@@ -112,7 +112,8 @@ int smk_top_terms(int maxterms, const double* W, unsigned ldim, unsigned height,
     for (unsigned c = 0; c < width; ++c) {
         const double* d = W + (size_t)c * height;
         std::iota(order.begin(), order.end(), 0u);
-        std::stable_sort(order.begin(), order.end(), [d](unsigned a, unsigned b) { return d[a] > d[b]; });
+        std::partial_sort(order.begin(), order.begin() + cnt, order.end(),
+                          [d](unsigned a, unsigned b) { return d[a] > d[b] || (d[a] == d[b] && a < b); });
         for (unsigned q = 0; q < cnt; ++q) term_indices[(size_t)c * maxterms + q] = (int)order[q];
     }
     return SMK_OK;

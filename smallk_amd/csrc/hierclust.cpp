@@ -15,7 +15,9 @@
 #include "../../include/smallk_amd.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <fstream>
 #include <functional>
@@ -23,6 +25,8 @@
 #include <numeric>
 #include <sstream>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 using smk::i64;
@@ -31,6 +35,7 @@ using smk::set_error;
 namespace {
 
 const unsigned NONE = SMK_TREE_NONE;
+const i64 DEVICE_SORT_MIN = 131072;      // below this the PCIe round trip outweighs the host sort
 
 struct Node {
     double priority = 0.0;
@@ -127,9 +132,11 @@ void tree_top_terms(smk_tree& t, int maxterms)     // ComputeTopTerms :282-299 +
         if (!nd.valid) continue;
         std::iota(order.begin(), order.end(), 0);
         const double* d = nd.topic.data();
-        std::stable_sort(order.begin(), order.end(), [d](int a, int b) { return d[a] > d[b]; });
         nd.terms.assign((size_t)maxterms, 0);
         const size_t cnt = std::min<size_t>((size_t)maxterms, order.size());
+        // only the first `cnt` positions of the (value desc, index asc) order are needed
+        std::partial_sort(order.begin(), order.begin() + (std::ptrdiff_t)cnt, order.end(),
+                          [d](int a, int b) { return d[a] > d[b] || (d[a] == d[b] && a < b); });
         std::copy(order.begin(), order.begin() + cnt, nd.terms.begin());
     }
 }
@@ -149,33 +156,40 @@ void tree_assignments(smk_tree& t)                 // ComputeAssignments :302-33
 }
 
 // ---- priority score, clust_hier_util.hpp:25-173 -----------------------------------------------------
-template <typename V>
-std::vector<int> ordered(const V* v, size_t n, bool descending)
+// desc_ordered(): indices by decreasing value, ties by increasing index.  Sorting (value, index)
+// pairs gives the same permutation as the reference's indirect comparator without the random
+// access per comparison.
+std::vector<int> desc_ordered(const double* v, size_t n)
 {
+    std::vector<std::pair<double, int>> p(n);
+    for (size_t i = 0; i < n; ++i) p[i] = std::make_pair(v[i], (int)i);
+    std::sort(p.begin(), p.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
+        return a.first > b.first || (a.first == b.first && a.second < b.second);
+    });
     std::vector<int> idx(n);
-    std::iota(idx.begin(), idx.end(), 0);
-    if (descending)
-        std::sort(idx.begin(), idx.end(), [v](int a, int b) { return v[a] > v[b] || (v[a] == v[b] && a < b); });
-    else
-        std::sort(idx.begin(), idx.end(), [v](int a, int b) { return v[a] < v[b] || (v[a] == v[b] && a < b); });
+    for (size_t i = 0; i < n; ++i) idx[i] = p[i].second;
     return idx;
 }
 
-double ndcg_part(const std::vector<int>& ground, const std::vector<int>& test, const std::vector<double>& weight,
-                 const std::vector<double>& weight_part)
+// ordered() of a permutation (no ties) is its inverse
+std::vector<int> inverse_permutation(const std::vector<int>& perm)
 {
-    const std::vector<int> seq = ordered(ground.data(), ground.size(), false);
-    const size_t n = test.size();
-    double cum = 0.0, ideal_cum = 0.0;
-    for (size_t i = 0; i < n; ++i) {
+    std::vector<int> inv(perm.size());
+    for (size_t i = 0; i < perm.size(); ++i) inv[(size_t)perm[i]] = (int)i;
+    return inv;
+}
+
+// numerator of NDCG_part (clust_hier_util.hpp:50-99); the denominator (ideal score) is the same for
+// both children and computed once by the caller
+double ndcg_cum(const std::vector<int>& seq, const std::vector<int>& test, const std::vector<double>& weight_part)
+{
+    double cum = 0.0;
+    for (size_t i = 0; i < test.size(); ++i) {
         double s = weight_part[(size_t)seq[(size_t)test[i]]];
         if (i > 0) s /= std::log2((double)(i + 1));
         cum += s;
     }
-    std::vector<double> ideal(weight);
-    std::sort(ideal.begin(), ideal.end(), std::greater<double>());
-    for (size_t i = 0; i < n; ++i) ideal_cum += (i > 0) ? ideal[i] / std::log2((double)(i + 1)) : ideal[i];
-    return cum / ideal_cum;
+    return cum;
 }
 
 double priority_score(const double* wp, const double* wc, i64 n)
@@ -183,8 +197,31 @@ double priority_score(const double* wp, const double* wc, i64 n)
     i64 n_part = 0;
     for (i64 i = 0; i < n; ++i) n_part += (wp[i] != 0.0);
     if (n_part <= 1) return -3.0;
-    const std::vector<int> idx_parent = ordered(wp, (size_t)n, true);
-    const std::vector<int> idx_c1 = ordered(wc, (size_t)n, true), idx_c2 = ordered(wc + n, (size_t)n, true);
+    // Large vocabularies: the three argsorts (and the weight sort below) run as stable radix sorts on
+    // the otherwise idle GPU (sort.hip); same permutation as the host comparator.  Without an
+    // initialised device (host-only callers of smk_clust_priority) or for small n: host sorts, the
+    // three independent ones side by side.
+    const bool on_device = n >= DEVICE_SORT_MIN && smk_is_initialized() == SMK_INITIALIZED;
+    std::vector<int> idx_parent, idx_c1, idx_c2;
+    bool sorted = false;
+    if (on_device) {
+        idx_parent.resize((size_t)n); idx_c1.resize((size_t)n); idx_c2.resize((size_t)n);
+        const double* keys[3] = {wp, wc, wc + n};
+        int* idx[3] = {idx_parent.data(), idx_c1.data(), idx_c2.data()};
+        double* none[3] = {nullptr, nullptr, nullptr};
+        sorted = smk::device_sort_desc(keys, idx, none, 3, n, nullptr) == 0;
+    }
+    if (!sorted && n >= 65536) {
+        std::thread t1([&] { idx_c1 = desc_ordered(wc, (size_t)n); });
+        std::thread t2([&] { idx_c2 = desc_ordered(wc + n, (size_t)n); });
+        idx_parent = desc_ordered(wp, (size_t)n);
+        t1.join();
+        t2.join();
+    } else if (!sorted) {
+        idx_parent = desc_ordered(wp, (size_t)n);
+        idx_c1 = desc_ordered(wc, (size_t)n);
+        idx_c2 = desc_ordered(wc + n, (size_t)n);
+    }
     std::vector<double> weight((size_t)n), weight_part((size_t)n, 0.0);
     for (i64 j = 0; j < n; ++j) weight[(size_t)j] = std::log((double)(n - j));
     for (i64 i = 0; i < n; ++i)
@@ -193,7 +230,7 @@ double priority_score(const double* wp, const double* wc, i64 n)
             break;
         }
     for (i64 j = 0; j < n_part; ++j) weight_part[(size_t)j] = std::log((double)(n_part - j));
-    const std::vector<int> pos1 = ordered(idx_c1.data(), (size_t)n, false), pos2 = ordered(idx_c2.data(), (size_t)n, false);
+    const std::vector<int> pos1 = inverse_permutation(idx_c1), pos2 = inverse_permutation(idx_c2);
     for (i64 i = 0; i < n; ++i) {
         const int t = idx_parent[(size_t)i];
         const int max_pos = std::max(pos1[(size_t)t], pos2[(size_t)t]);
@@ -202,7 +239,19 @@ double priority_score(const double* wp, const double* wc, i64 n)
         weight[(size_t)i] /= discount;
         weight_part[(size_t)i] /= discount;
     }
-    return ndcg_part(idx_parent, idx_c1, weight, weight_part) * ndcg_part(idx_parent, idx_c2, weight, weight_part);
+    const std::vector<int> seq = inverse_permutation(idx_parent);
+    const double c1 = ndcg_cum(seq, idx_c1, weight_part), c2 = ndcg_cum(seq, idx_c2, weight_part);
+    bool weight_sorted = false;
+    if (on_device) {
+        const double* keys[1] = {weight.data()};
+        int* idx[1] = {nullptr};
+        double* out[1] = {weight.data()};
+        weight_sorted = smk::device_sort_desc(keys, idx, out, 1, n, nullptr) == 0;
+    }
+    if (!weight_sorted) std::sort(weight.begin(), weight.end(), std::greater<double>());
+    double ideal_cum = 0.0;
+    for (i64 i = 0; i < n; ++i) ideal_cum += (i > 0) ? weight[(size_t)i] / std::log2((double)(i + 1)) : weight[(size_t)i];
+    return (c1 / ideal_cum) * (c2 / ideal_cum);
 }
 
 std::vector<unsigned> set_diff(const std::vector<unsigned>& a, const std::vector<unsigned>& b)   // setdiff.hpp:23-46
@@ -218,7 +267,16 @@ std::vector<unsigned> set_diff(const std::vector<unsigned>& a, const std::vector
 }
 
 // ---- the search -------------------------------------------------------------------------------------
+struct Stopwatch {       // SMK_CLUST_TIMING=1: where the wall time of a run goes
+    double* acc;
+    std::chrono::high_resolution_clock::time_point t0;
+    explicit Stopwatch(double* a) : acc(a), t0(std::chrono::high_resolution_clock::now()) {}
+    ~Stopwatch() { *acc += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count(); }
+};
+
 struct Run {
+    double t_subset = 0, t_factor = 0, t_priority = 0, t_init = 0;
+    long iterations = 0;
     const smk_clust_options* o = nullptr;
     smk_matrix* full = nullptr;
     i64 m = 0, n = 0;
@@ -270,9 +328,11 @@ int factor_node(Run& r, const smk_matrix* a, i64 h, i64 w, const unsigned* rows,
                 H[(size_t)(2 * c + 1)] = r.Hinit[(size_t)(2 * src + 1)];
             }
         } else {
+            Stopwatch sw(&r.t_init);
             smk_uniform_fill_host(W.data(), h, h, 2, 0, 0, h, r.seed + 0x9E37u * (++r.draws), 0);
             smk_uniform_fill_host(H.data(), 2, 2, w, 0, 0, 2, r.seed + 0x9E37u * (++r.draws), 0);
         }
+        Stopwatch sw(&r.t_factor);
         smk_solver* s = nullptr;
         smk_stats st = {0, 0};
         int rc = smk_solver_create(&s, &so, a);
@@ -282,6 +342,7 @@ int factor_node(Run& r, const smk_matrix* a, i64 h, i64 w, const unsigned* rows,
             if (rc == SMK_OK) rc = smk_solver_get_factors(s, 0, W.data(), h, H.data(), 2);
         }
         smk_solver_destroy(s);
+        r.iterations += st.iteration_count;
         if (rc == SMK_OK) {
             r.stats.nmf_count += 1;
             if (st.iteration_count == so.max_iter) r.stats.max_count += 1;
@@ -311,7 +372,11 @@ int actual_split(Run& r, const std::vector<unsigned>& subset, const double* w_pa
     smk_matrix* sub = nullptr;
     int64_t nh = 0;
     r.new_to_old.resize((size_t)m);
-    int rc = smk_matrix_gather_cols(r.full, subset.data(), (int64_t)subset.size(), &sub, r.new_to_old.data(), &nh);
+    int rc;
+    {
+        Stopwatch sw(&r.t_subset);
+        rc = smk_matrix_gather_cols(r.full, subset.data(), (int64_t)subset.size(), &sub, r.new_to_old.data(), &nh);
+    }
     if (rc != SMK_OK) return rc;
     std::vector<double> Ws, Hs;
     rc = factor_node(r, sub, nh, (i64)subset.size(), r.new_to_old.data(), subset.data(), Ws, Hs, "Node");
@@ -328,6 +393,7 @@ int actual_split(Run& r, const std::vector<unsigned>& subset, const double* w_pa
         W[(size_t)(m + r.new_to_old[(size_t)i])] = Ws[(size_t)(nh + i)];
     }
     H = Hs;
+    Stopwatch sw(&r.t_priority);
     *priority = (has0 && has1) ? priority_score(w_parent, W.data(), m) : -1.0;
     return SMK_OK;
 }
@@ -491,6 +557,10 @@ int run_clust(const smk_clust_options* opts, smk_matrix* full, uint64_t seed, ui
     if (rc == SMK_OK && opts->flat) rc = clust_flat(r, *t);
     if (draws) *draws = r.draws;
     if (stats) *stats = r.stats;
+    if (const char* e = getenv("SMK_CLUST_TIMING"))
+        if (atoi(e))
+            fprintf(stderr, "[smk_clust] subset %.3fs  factor %.3fs (%ld RANK2 iterations)  priority %.3fs  init %.3fs\n",
+                    r.t_subset, r.t_factor, r.iterations, r.t_priority, r.t_init);
     // a failed flat step still returns the tree (RunClust, clust.cpp:53-61: the caller writes it)
     if (rc != SMK_OK && rc != SMK_FLATCLUST_FAILURE) { delete t; return rc; }
     *tree_out = t;

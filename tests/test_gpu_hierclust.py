@@ -171,3 +171,18 @@ def test_gather_cols_dense_and_sparse(gpu):
     sub = C.c_void_p()
     assert l.smk_matrix_gather_cols(src._h, bad.ctypes.data_as(C.POINTER(C.c_uint)), 1, C.byref(sub), None,
                                     None) == L.BAD_PARAM
+
+
+def test_priority_device_sort_matches_host(gpu):
+    """Above 131072 terms the priority score sorts on the GPU (sort.hip, stable radix sort); the
+    permutation -- and therefore the score -- must be the one the host comparator gives, ties, zeros
+    and negative zeros included."""
+    from oracle import hierclust as oh
+    rng = np.random.default_rng(2)
+    n = 300_000
+    wp = rng.random(n) * (rng.random(n) > 0.3)
+    wc = rng.random((n, 2)) * (rng.random((n, 2)) > 0.3)
+    wc[:, 0] = np.round(wc[:, 0], 3)                    # many ties
+    wc[::7, 1] = -0.0                                   # -0.0 == 0.0 for the reference's comparator
+    got = gpu.hierclust.priority(wp, wc)
+    assert got == pytest.approx(oh.compute_priority(wp, wc), rel=1e-12)
