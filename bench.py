@@ -47,7 +47,7 @@ def cpu_baseline(m, n, k, alg, quant, budget_s=20.0):
     ms, ns = min(m, 8192), min(n, 4096)
     A = oracle.fill_uniform(ms, ns, 42, quant=quant)
     W0 = oracle.fill_uniform(ms, k, 43)
-    H0 = oracle.fill_uniform(k, ns, 44)
+    H0 = oracle.fill_uniform(k, ns, 44) * (2.0 / k)          # same start as the GPU leg: E[W0 H0] = E[A]
     oracle.nmf(A, W0, H0, alg, min_iter=1, max_iter=1)        # warm up threads/pages
     iters, t = 2, 0.0
     while True:
@@ -102,7 +102,9 @@ def main():
     A = smallk_amd.DenseMatrix(m, n, col0=col0, ncols=ncols, storage=storage)
     A.fill_uniform(42)
     W0 = smallk_amd.uniform_host(m, k, 43)
-    H0 = smallk_amd.uniform_host(k, ncols, 44, c0=col0, gheight=k)
+    # E[A] = 1/2: scale H0 so that W0 H0 has the same mean.  (An unscaled uniform start makes the first HALS
+    # W update clamp every entry to zero and the run would iterate on the all-eps guard columns.)
+    H0 = smallk_amd.uniform_host(k, ncols, 44, c0=col0, gheight=k) * (2.0 / k)
     opts = smallk_amd.make_options(m, n, k, alg, min_iter=total_iters, max_iter=total_iters)
     solver = smallk_amd.NmfSolver(A, opts)
     if world > 1:

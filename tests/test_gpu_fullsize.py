@@ -1,0 +1,109 @@
+"""Full-size checks at BASELINE.json's configurations (C2 directly against the oracle; C3 and one
+GPU's shard of C4 through size-independent properties).
+
+The update of column j of H depends only on A[:, j], W and W'W, and the update of row i of W only on
+A[i, :], H and HH' (plus, for HALS, one global norm per column).  So a full-size device run can be
+checked exactly on SAMPLED columns and rows: A is generated on the device by the counter-based
+generator, the host regenerates just the sampled columns / rows (same seed, same rounding) and the
+oracle solves the small sub-problems.  Every sampled entry exercises the complete contraction over
+the other dimension, i.e. the streaming kernel at its full length and split count."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def sampled_cols(oracle, m, seed, quant, cols):
+    return np.asfortranarray(np.concatenate([oracle.fill_uniform(m, 1, seed, quant=quant, c0=int(c), gheight=m)
+                                             for c in cols], axis=1))
+
+
+def sampled_rows(oracle, m, n, seed, quant, rows):
+    return np.asfortranarray(np.concatenate([oracle.fill_uniform(1, n, seed, quant=quant, r0=int(r), gheight=m)
+                                             for r in rows], axis=0))
+
+
+def test_c2_bpp_f32_full_size_against_oracle(gpu):
+    """configs[1]: dense 8192 x 4096, k = 16, BPP, A in fp32 -- small enough for the oracle itself."""
+    import oracle
+    m, n, k = 8192, 4096, 16
+    A = oracle.fill_uniform(m, n, 11)
+    W0, H0 = oracle.fill_uniform(m, k, 12), oracle.fill_uniform(k, n, 13)
+    r = gpu.nmf(A, W0, H0, "BPP", min_iter=1, max_iter=4, tol=1e-12)
+    ref = oracle.nmf(A, W0, H0, "BPP", min_iter=1, max_iter=4, tol=1e-12)
+    assert r.result == ref.result == 0 and r.iteration_count == ref.iteration_count == 4
+    assert np.linalg.norm(r.W - ref.W) / np.linalg.norm(ref.W) < 1e-4     # north_star: 1e-4 relative Frobenius
+    assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
+
+
+def _one_iteration(gpu, m, n, k, alg, storage, seeds):
+    from smallk_amd import DenseMatrix, NmfSolver, make_options, uniform_host
+    A = DenseMatrix(m, n, storage=storage)
+    A.fill_uniform(seeds[0])
+    # E[A] = 1/2: scale H0 so that W0 H0 has the same mean (an unscaled uniform start makes the first HALS
+    # W update clamp every entry to zero, which would test nothing)
+    W0, H0 = uniform_host(m, k, seeds[1]), uniform_host(k, n, seeds[2]) * (2.0 / k)
+    s = NmfSolver(A, make_options(m, n, k, alg, normalize=False))
+    s.set_factors(W0, H0)
+    s.iterate(1)
+    assert s.sync() == 0
+    W1, H1 = s.factors(normalize=False)
+    s.close()
+    A.close()
+    return W0, H0, W1, H1
+
+
+def test_c3_hals_bf16_full_size_sampled(gpu):
+    """configs[2]: dense 65536 x 16384, k = 32, HALS, A in bf16 (the bench workload)."""
+    import oracle
+    from oracle import flatclust as of
+    m, n, k, seed = 65536, 16384, 32, 101
+    W0, H0, W1, H1 = _one_iteration(gpu, m, n, k, "HALS", "bf16", (seed, 102, 103))
+    rng = np.random.default_rng(0)
+    assert np.all(W1 >= 0) and np.all(H1 >= 0) and np.isfinite(W1).all() and np.isfinite(H1).all()
+    # W update (nmf_solver_hals.hpp:66-117): every column is normalised inside the sweep
+    assert np.allclose(np.sqrt((W1 * W1).sum(axis=0)), 1.0, rtol=1e-10)
+    # sampled rows: t_c[i] = w[i,c] + (R[i,c] - W_cur[i,:] G[:,c]) / G[c,c] must equal nu_c * W1[i,c] with
+    # ONE nu_c per column (the column norm the device computed over all 65536 rows)
+    rows = np.sort(rng.choice(m, size=40, replace=False))
+    Ar = sampled_rows(oracle, m, n, seed, 1, rows)
+    G = H0 @ H0.T
+    R = Ar @ H0.T
+    Wc = W0[rows, :].copy()
+    for c in range(k):
+        t = Wc[:, c] + (R[:, c] - Wc @ G[:, c]) / G[c, c]
+        t[t < 0] = 0.0
+        pos = (t > 0) & (W1[rows, c] > 0)
+        assert pos.sum() >= 10
+        nu = np.median(t[pos] / W1[rows, c][pos])
+        assert np.max(np.abs(t - nu * W1[rows, c])) <= 1e-4 * np.max(t), c
+        Wc[:, c] = W1[rows, c]                       # Gauss-Seidel: later columns see the normalised value
+    # H update with the new W (nmf_solver_hals.hpp:26-62): exact on sampled columns
+    cols = np.sort(rng.choice(n, size=48, replace=False))
+    Ac = sampled_cols(oracle, m, seed, 1, cols)
+    _, _, Hs, _ = of.nnls_hals(Ac, W1, H0[:, cols], 1e-30, 1)     # one sweep, W fixed, no normalisation
+    assert relerr(H1[:, cols], Hs) < 1e-4
+
+
+@pytest.mark.parametrize("alg", ["BPP", "MU"])
+def test_c4_shard_f32_sampled(gpu, alg):
+    """configs[3] as ONE GPU of the eight sees it: 262144 x 8192 column shard, k = 64, A in fp32.
+    MU and BPP update H first, so the oracle on the sub-problem A[:, J] reproduces H1[:, J] exactly;
+    the W side is the same statement for the transposed sub-problem A[I, :]' with H1 as the fixed factor."""
+    import oracle
+    m, n, k, seed = 262144, 8192, 64, 201
+    W0, H0, W1, H1 = _one_iteration(gpu, m, n, k, alg, "f32", (seed, 202, 203))
+    rng = np.random.default_rng(1)
+    cols = np.sort(rng.choice(n, size=k + 8, replace=False))
+    Ac = sampled_cols(oracle, m, seed, 0, cols)
+    ref = oracle.nmf(Ac, W0, H0[:, cols], alg, min_iter=1, max_iter=1, normalize=False)
+    assert ref.result == 0 and relerr(H1[:, cols], ref.H) < 1e-4
+    rows = np.sort(rng.choice(m, size=k + 8, replace=False))
+    Ar = sampled_rows(oracle, m, n, seed, 0, rows)
+    ref = oracle.nmf(np.asfortranarray(Ar.T), np.asfortranarray(H1.T), np.asfortranarray(W0[rows, :].T), alg,
+                     min_iter=1, max_iter=1, normalize=False)
+    assert ref.result == 0 and relerr(W1[rows, :], ref.H.T) < 1e-4
