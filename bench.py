@@ -85,12 +85,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Test hooks for a 1-GPU box (the multi-rank path otherwise only runs on the driver's 8-GPU node):
+    # SMK_BENCH_SHARE_GPU=1 puts every rank on device 0, SMK_BENCH_BACKEND=gloo replaces RCCL (which refuses
+    # two ranks on one device) by gloo on device tensors.  Numbers from such a run mean nothing.
+    share = os.environ.get("SMK_BENCH_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("SMK_BENCH_BACKEND", "nccl")
+    device_index = 0 if share else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-    smallk_amd.initialize(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    smallk_amd.initialize(device_index)
     if world > 1:
         # the solver launches on torch's current stream so that RCCL all-reduces order against it
         smallk_amd.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -135,6 +144,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    dump = os.environ.get("SMK_BENCH_DUMP_W")        # test hook: W (replicated) after the timed steps, rank 0
+    if dump:
+        Wd, _ = solver.factors(normalize=False)
+        if rank == 0:
+            np.save(dump, Wd)
 
     ms0, c0 = solver.kernel_time(0)
     ms1, c1 = solver.kernel_time(1)

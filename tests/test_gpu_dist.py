@@ -112,3 +112,31 @@ def test_torch_nccl_world_of_one(gpu):
         assert rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_processes_match_one(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process
+    per rank), squeezed onto this box's single GPU: both ranks on device 0 and gloo on the device
+    tensors instead of RCCL (which refuses two ranks on one device).  Everything else is the real
+    path: rendezvous, column shards, workspace registration, the all-reduce callback from C, max-over-
+    ranks timing, the JSON line.  W after the same number of HALS iterations must match the 1-GPU run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMK_BENCH_SHARE_GPU="1", SMK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    common = ["--steps", "3", "--warmup", "1", "--workload", "c2", "--no-cpu-baseline"]
+    r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=root, capture_output=True, text=True,
+                        timeout=600, env=dict(env, SMK_BENCH_DUMP_W=str(tmp_path / "w1.npy")))
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2"] + common,
+                        cwd=root, capture_output=True, text=True, timeout=600,
+                        env=dict(env, SMK_BENCH_DUMP_W=str(tmp_path / "w2.npy")))
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    line = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1                                  # rank 0 prints ONE JSON line
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["config"]["parallelism"] == "column-shard x2"
+    W1, W2 = np.load(tmp_path / "w1.npy"), np.load(tmp_path / "w2.npy")
+    assert np.linalg.norm(W1 - W2) / np.linalg.norm(W1) < 1e-5
