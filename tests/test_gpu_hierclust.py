@@ -186,3 +186,20 @@ def test_priority_device_sort_matches_host(gpu):
     wc[::7, 1] = -0.0                                   # -0.0 == 0.0 for the reference's comparator
     got = gpu.hierclust.priority(wp, wc)
     assert got == pytest.approx(oh.compute_priority(wp, wc), rel=1e-12)
+
+
+@pytest.mark.parametrize("m,n,clusters,sparse", [(10, 8, 2, False), (12, 5, 2, False), (30, 9, 3, True), (40, 64, 2, True),
+                                                  (7, 40, 6, False)])
+def test_small_and_degenerate_inputs(gpu, m, n, clusters, sparse):
+    """Tiny matrices: subsets of <= 3 documents are never factored (ActualSplit :399-410), the search
+    stops when every leaf priority is negative, two clusters means a single root split."""
+    import oracle
+    from oracle import hierclust as oh
+    A, _ = planted(m, n, 2, 31, sparse=sparse)
+    if sparse:
+        A = A + 0.01 * __import__("scipy.sparse", fromlist=["eye"]).eye(m, n, format="csc")   # no empty column
+    Ad = A if sparse else oracle.quantize(A, 0)
+    res = gpu.hier_nmf2(A, clusters, seed=9)
+    otree, ostats = oh.hier_nmf2(Ad, clusters, seed=9)
+    compare(res, otree, ostats, m, prio_rel=(1e-9 if sparse else 2e-3), topic_rel=(1e-6 if sparse else 2e-4))
+    assert len(res.nodes) == 2 * (clusters - 1)
