@@ -268,3 +268,23 @@ def test_tall_matrix_progress_scratch(gpu, alg, k):
         assert r.result == ref.result == 0 and r.iteration_count == ref.iteration_count == 4
         assert np.linalg.norm(r.W - ref.W) / np.linalg.norm(ref.W) < 1e-4
         assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
+
+
+@pytest.mark.parametrize("storage,quant", [("f32", 0), ("bf16", 1)])
+@pytest.mark.parametrize("m,n,k", [(300, 200, 5), (1024, 768, 32), (2048, 512, 64), (777, 1300, 17)])
+def test_hals_mean_matched_start(gpu, m, n, k, storage, quant):
+    """HALS from a start with E[W0 H0] = E[A]: the first W sweep is a regular update.  (From an unscaled
+    uniform start it clamps every entry of W to zero and takes the all-zero-column guard,
+    nmf_solver_hals.hpp:105-111 -- that path is what most other HALS cases exercise first.)"""
+    import oracle
+    A = oracle.fill_uniform(m, n, 42, quant=quant)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    ref1 = oracle.nmf(A, W0, H0, "HALS", min_iter=1, max_iter=1, normalize=False)
+    assert (ref1.W > 0).mean() > 0.5                     # not the guard path
+    for iters in (1, 6):
+        r = gpu.nmf(A, W0, H0, "HALS", min_iter=iters, max_iter=iters, storage=storage)
+        ref = oracle.nmf(A, W0, H0, "HALS", min_iter=iters, max_iter=iters)
+        assert r.result == ref.result == 0
+        assert np.linalg.norm(r.W - ref.W) / np.linalg.norm(ref.W) < 1e-4
+        assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
