@@ -108,7 +108,8 @@ int launch_zero_f64(double* p, i64 n, hipStream_t st);
 // RANK2: closed-form 2x2 solve + optimal active set (side 0: H, side 1: W'), per-iteration rescale
 int launch_rank2_solve(double* X, i64 N, PartialView R, const double* G, int side, int* fail_flag, int iter_tag,
                        hipStream_t st);
-int launch_rank2_rescale(double* Gh, const double* Gw, PartialView R, i64 N, hipStream_t st);
+// (also leaves Gw = W'W of the normalised W: Gw_ij / (nu_i nu_j))
+int launch_rank2_rescale(double* Gh, double* Gw, PartialView R, i64 N, hipStream_t st);
 // sparse A (CSC): out[:, j] = sum_p val[p] * X[:, row[p]] over the nonzeros of column j
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X,
                        int k, double* P, int kpp, hipStream_t st);

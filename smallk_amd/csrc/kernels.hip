@@ -1133,6 +1133,46 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
     }
 }
 
+// KP = 8 (k <= 8: rank-2 hierarchical clustering lives here): one column (64 bytes) per thread per
+// step, the 36 products of the upper triangle in registers, wave sums by DPP, four waves through LDS.
+// Streams X once at HBM rate; the LDS-chunked kernel above spends its time in barriers at this width.
+__global__ __launch_bounds__(256) void gram_stream8_kernel(const double* __restrict__ X, i64 N, double* __restrict__ Gp)
+{
+    constexpr int KP = 8;
+    __shared__ double sh[4][36];
+    double acc[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) acc[q] = 0.0;
+    for (i64 c = (i64)blockIdx.x * 256 + threadIdx.x; c < N; c += (i64)gridDim.x * 256) {
+        double x[KP];
+        const f64x2_t* p = (const f64x2_t*)(X + c * KP);
+#pragma unroll
+        for (int j = 0; j < KP / 2; ++j) {
+            const f64x2_t v = p[j];
+            x[2 * j] = v[0];
+            x[2 * j + 1] = v[1];
+        }
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < KP; ++a)
+#pragma unroll
+            for (int b = a; b < KP; ++b) acc[q++] += x[a] * x[b];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 36; ++q) {
+        const double t = wave_sum(acc[q]);
+        if (lane == 0) sh[wave][q] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int a = threadIdx.x / KP, b = threadIdx.x % KP;
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        const int q = lo * KP - lo * (lo - 1) / 2 + (hi - lo);       // index of (lo, hi) in the packed triangle
+        Gp[(i64)blockIdx.x * KP * KP + threadIdx.x] = (sh[0][q] + sh[1][q]) + (sh[2][q] + sh[3][q]);
+    }
+}
+
 size_t gram_scratch_elems(int k, int max_blocks)
 {
     int KP = kp_of(k);
@@ -1156,14 +1196,10 @@ int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int m
             default: gram_mfma_kernel<64><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
         }
     } else {
-        nblk = (int)((N + 127) / 128);
+        nblk = (int)((N + 255) / 256);
         if (nblk > max_blocks) nblk = max_blocks;
         if (nblk < 1) nblk = 1;
-        i64 cpb = (N + nblk - 1) / nblk;
-        cpb = (cpb + 31) / 32 * 32;
-        nblk = (int)((N + cpb - 1) / cpb);
-        if (nblk < 1) nblk = 1;
-        gram_partial_kernel<8><<<nblk, 256, 0, st>>>(X, N, cpb, scratch);
+        gram_stream8_kernel<<<nblk, 256, 0, st>>>(X, N, scratch);
     }
     SMK_HIP(hipGetLastError());
     gram_reduce_kernel<<<(elems + 15) / 16, 256, 0, st>>>(scratch, nblk, elems, G);
@@ -1954,10 +1990,25 @@ __global__ __launch_bounds__(256) void rank2_rescale_kernel(double* __restrict__
     }
 }
 
-int launch_rank2_rescale(double* Gh, const double* Gw, PartialView R, i64 N, hipStream_t st)
+// W'W of the NORMALISED W without another pass over W: (D^-1 W'W D^-1)_ij = Gw_ij / (nu_i nu_j).
+// Runs after every consumer of the un-normalised Gram matrix (scale_rows, rank2_rescale) on the stream.
+__global__ void rank2_gw_normalize_kernel(double* __restrict__ Gw)
+{
+    constexpr int KP = 8;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double nu0 = sqrt(Gw[0]), nu1 = sqrt(Gw[KP + 1]);
+    Gw[0] = Gw[0] / (nu0 * nu0);
+    Gw[1] = Gw[1] / (nu0 * nu1);
+    Gw[KP] = Gw[KP] / (nu0 * nu1);
+    Gw[KP + 1] = Gw[KP + 1] / (nu1 * nu1);
+}
+
+int launch_rank2_rescale(double* Gh, double* Gw, PartialView R, i64 N, hipStream_t st)
 {
     const int grid = (int)((N + 255) / 256);
     rank2_rescale_kernel<<<grid, 256, 0, st>>>(Gh, Gw, const_cast<void*>(R.p), R.S, R.slab, R.kpp, R.f64, N);
+    SMK_HIP(hipGetLastError());
+    rank2_gw_normalize_kernel<<<1, 64, 0, st>>>(Gw);
     SMK_HIP(hipGetLastError());
     return 0;
 }

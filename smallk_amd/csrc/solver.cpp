@@ -735,8 +735,9 @@ static int solver_iteration(smk_solver* s)
             rc = gram_w(s);   if (rc) return rc;
             rc = launch_scale_rows(s->H, s->k, s->n, s->Gw, 0, s->fail_flag, s->st);  if (rc) return rc;
             rc = launch_scale_rows(s->Wt, s->k, s->m, s->Gw, 1, s->fail_flag, s->st); if (rc) return rc;
+            // rescales HH' and AH' for the new scaling and leaves Gw = W'W of the normalised W
+            // (D^-1 Gw D^-1: no second pass over W)
             rc = launch_rank2_rescale(s->Gh, s->Gw, view2(s), s->m, s->st);          if (rc) return rc;
-            rc = gram_w(s);   if (rc) return rc;      // W'W of the normalised W
             rc = prod1(s);    if (rc) return rc;
             break;
         default:
