@@ -114,6 +114,18 @@ int launch_rank2_rescale(double* Gh, double* Gw, PartialView R, i64 N, hipStream
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X,
                        int k, double* P, int kpp, hipStream_t st);
 
+// sparse_subset.hip: CSC(A[:, cols]) and CSC(A[:, cols]') with unused rows dropped, assembled on the device
+// from the resident CSC(A) / CSC(A').  `cols` must be strictly increasing.  The six output arrays are
+// hipMalloc'ed for the caller; new_to_old_host (capacity src.m) receives the kept rows.
+struct SparseDev {
+    i64 m = 0, n = 0, nnz = 0;
+    i64 *colptr = nullptr, *colptr_t = nullptr;
+    unsigned *rowidx = nullptr, *rowidx_t = nullptr;
+    double *val = nullptr, *val_t = nullptr;
+};
+int device_sparse_subset(const SparseDev& src, const unsigned* cols_host, i64 ncols, SparseDev* out,
+                         unsigned* new_to_old_host, hipStream_t st);
+
 // sort.hip: stable descending radix sort of host vectors on the device (argsort when idx_host[v] != nullptr,
 // keys-only into sorted_host[v] otherwise)
 int device_sort_desc(const double* const* keys_host, int* const* idx_host, double* const* sorted_host, int count, i64 n,

@@ -401,6 +401,31 @@ int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t 
         *out = a;
         return SMK_OK;
     }
+    // strictly increasing column lists (every HierNMF2 document list): cut on the device, nothing but
+    // the row map crosses PCIe (sparse_subset.hip).  SMK_SPARSE_SUBSET=host forces the host cut below.
+    bool increasing = true;
+    for (int64_t j = 1; j < ncols && increasing; ++j) increasing = cols[j] > cols[j - 1];
+    static const bool force_host = [] { const char* e = getenv("SMK_SPARSE_SUBSET"); return e && e[0] == 'h'; }();
+    if ((increasing && !force_host) || src->h_colptr.empty()) {
+        if (!increasing) { set_error("SubMatrixColsCompact: this matrix needs an increasing column list"); return SMK_UNSUPPORTED; }
+        SparseDev sd, od;
+        sd.m = src->m; sd.n = src->n; sd.nnz = src->nnz;
+        sd.colptr = src->colptr; sd.rowidx = src->rowidx; sd.val = src->val;
+        sd.colptr_t = src->colptr_t; sd.rowidx_t = src->rowidx_t; sd.val_t = src->val_t;
+        std::vector<unsigned> n2o_tmp;
+        unsigned* n2o = new_to_old_rows;
+        if (!n2o) { n2o_tmp.resize((size_t)src->m); n2o = n2o_tmp.data(); }
+        const int rc = device_sparse_subset(sd, cols, ncols, &od, n2o, g_stream);
+        if (rc) return rc == -3 ? SMK_BAD_PARAM : SMK_DEVICE_ERROR;
+        smk_matrix* a = new smk_matrix;
+        a->m = od.m; a->n_global = ncols; a->c0 = 0; a->n = ncols; a->storage = SMK_STORE_F32;
+        a->sparse = true; a->nnz = od.nnz;
+        a->colptr = od.colptr; a->rowidx = od.rowidx; a->val = od.val;
+        a->colptr_t = od.colptr_t; a->rowidx_t = od.rowidx_t; a->val_t = od.val_t;
+        if (new_height) *new_height = od.m;
+        *out = a;
+        return SMK_OK;
+    }
     const unsigned UNUSED = 0xFFFFFFFFu;
     std::vector<unsigned> old_to_new((size_t)src->m, UNUSED), cp((size_t)ncols + 1), ri;
     std::vector<double> va;
@@ -482,7 +507,8 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if (s->nsplit < 1 || s->nsplit > 3) s->nsplit = 3;
     s->pl1 = plan_bigprod(a->storage, s->k, s->m, s->n, s->nsplit, g_cus);
     s->pl2 = plan_bigprod(a->storage, s->k, s->n, s->m, s->nsplit, g_cus);
-    if (a->sparse) {   // gather products write one slab
+    if (a->sparse) {   // gather products write one slab, as dense as the factor layout (KP values per column)
+        s->kpp = s->KP;
         s->pl1.S = 1; s->pl1.p_elems = (size_t)s->pl1.ncols_pad * s->kpp;
         s->pl2.S = 1; s->pl2.p_elems = (size_t)s->pl2.ncols_pad * s->kpp;
     }

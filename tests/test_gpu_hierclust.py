@@ -203,3 +203,57 @@ def test_small_and_degenerate_inputs(gpu, m, n, clusters, sparse):
     otree, ostats = oh.hier_nmf2(Ad, clusters, seed=9)
     compare(res, otree, ostats, m, prio_rel=(1e-9 if sparse else 2e-3), topic_rel=(1e-6 if sparse else 2e-4))
     assert len(res.nodes) == 2 * (clusters - 1)
+
+
+@pytest.mark.parametrize("alg", ["MU", "RANK2"])
+def test_sparse_gather_cols_on_device(gpu, alg):
+    """Sparse SubMatrixColsCompact assembled on the device (sparse_subset.hip): the kept-row map is the
+    reference's, and a factorisation of the gathered matrix -- W'A reads its CSC, AH' the CSC of its
+    transpose -- matches the oracle on A[rows][:, cols]."""
+    import oracle
+    import scipy.sparse as sp
+    from smallk_amd import _lib as L, NmfSolver, make_options
+    l = L.lib()
+    rng = np.random.default_rng(3)
+    m, n = 500, 700
+    A = sp.random(m, n, density=0.01, random_state=5, format="csc", data_rvs=lambda s: rng.random(s) + 0.1)
+    src = gpu.SparseMatrix.from_scipy(A)
+    cols = np.sort(rng.choice(n, size=260, replace=False)).astype(np.uint32)
+    sub = C.c_void_p()
+    nh = C.c_int64()
+    rows = np.zeros(m, dtype=np.uint32)
+    L.check(l.smk_matrix_gather_cols(src._h, cols.ctypes.data_as(C.POINTER(C.c_uint)), len(cols), C.byref(sub),
+                                     rows.ctypes.data_as(C.POINTER(C.c_uint)), C.byref(nh)), "gather")
+    Asub = A[:, cols]
+    used = np.zeros(m, dtype=bool)
+    used[Asub.indices] = True
+    want_rows = np.nonzero(used)[0]
+    assert nh.value == len(want_rows) and np.array_equal(rows[:nh.value], want_rows)
+    D = Asub[want_rows, :].toarray(order="F")
+    k = 2 if alg == "RANK2" else 5
+
+    class Handle:            # what NmfSolver needs from a matrix object
+        _h, height, ncols = sub, int(nh.value), len(cols)
+    W0, H0 = oracle.fill_uniform(Handle.height, k, 1), oracle.fill_uniform(k, Handle.ncols, 2)
+    s = NmfSolver(Handle, make_options(Handle.height, Handle.ncols, k, alg, min_iter=4, max_iter=4, tol=1e-12))
+    s.set_factors(W0, H0)
+    rc, its, _ = s.run()
+    W, H = s.factors()
+    s.close()
+    ref = oracle.nmf(D, W0, H0, alg, min_iter=4, max_iter=4, tol=1e-12)
+    assert rc == ref.result == 0 and its == ref.iteration_count
+    assert np.max(np.abs(W - ref.W)) <= 1e-9 * np.max(np.abs(ref.W))
+    assert np.max(np.abs(H - ref.H)) <= 1e-9 * np.max(np.abs(ref.H))
+    l.smk_matrix_destroy(sub)
+    # a column list that is not increasing goes through the host cut and gives the same matrix up to
+    # the column permutation
+    perm = cols[::-1].copy()
+    L.check(l.smk_matrix_gather_cols(src._h, perm.ctypes.data_as(C.POINTER(C.c_uint)), len(perm), C.byref(sub),
+                                     rows.ctypes.data_as(C.POINTER(C.c_uint)), C.byref(nh)), "gather")
+    assert nh.value == len(want_rows) and np.array_equal(rows[:nh.value], want_rows)
+    l.smk_matrix_destroy(sub)
+    # all-empty selection: "submatrix is the zero matrix" (logic_error in the reference)
+    empty = np.nonzero(np.diff(A.indptr) == 0)[0][:3].astype(np.uint32)
+    if len(empty):
+        assert l.smk_matrix_gather_cols(src._h, empty.ctypes.data_as(C.POINTER(C.c_uint)), len(empty), C.byref(sub), None,
+                                        None) == L.BAD_PARAM
