@@ -11,6 +11,7 @@ from .api import SmallkAPI
 from . import hierclust
 from . import flatclust
 from .hierclust import hier_nmf2, TreeResults
+from .pyclust import Flatclust, Hierclust
 
 __all__ = ["DenseMatrix", "SparseMatrix", "nmf_sparse", "load_matrix_market", "NmfSolver", "NmfResult", "nmf", "initialize", "finalize", "is_initialized",
-           "make_options", "uniform_host", "set_stream", "SmallkAPI", "hierclust", "flatclust", "hier_nmf2", "TreeResults", "_lib"]
+           "make_options", "uniform_host", "set_stream", "SmallkAPI", "hierclust", "flatclust", "hier_nmf2", "TreeResults", "Flatclust", "Hierclust", "_lib"]

@@ -121,3 +121,58 @@ def test_facade_hiernmf2_with_flat(gpu, tmp_path):
     # W / H of the flat run are what LockedBufferW/H now expose
     Wf = api.get_W()
     assert Wf.shape == (120, 4) and relerr(Wf, otree.flat_W) < 2e-4
+
+
+def test_pysmallk_style_classes(gpu, tmp_path):
+    """pysmallk's Flatclust / Hierclust classes (smallk_lib.pyx:1080-1420) re-hosted on the C ABI: same
+    calls as pysmallk/tests/flatclust.py and hierclust.py, results against the oracle."""
+    import oracle
+    from oracle import hierclust as oh, flatclust as of
+    from smallk_amd import Flatclust, Hierclust
+    from test_cli import write_csv
+    m, n, k = 120, 200, 4
+    A, _ = planted(m, n, k, 21)
+    dictionary = [f"w{i}" for i in range(m)]
+    (tmp_path / "dict.txt").write_text("\n".join(dictionary) + "\n")
+    W0, H0 = oracle.fill_uniform(m, k, 1), oracle.fill_uniform(k, n, 2)
+    write_csv(tmp_path / "w0.csv", W0)
+    write_csv(tmp_path / "h0.csv", H0)
+    write_csv(tmp_path / "a.csv", A)
+
+    f = Flatclust()
+    f.load_matrix(filepath=str(tmp_path / "a.csv"))
+    f.load_dictionary(filepath=str(tmp_path / "dict.txt"))
+    f.cluster(k, infile_W=str(tmp_path / "w0.csv"), infile_H=str(tmp_path / "h0.csv"), algorithm="HALS", maxterms=3,
+              verbose=False, min_iter=1, max_iter=50, tol=1e-9)
+    ref = of.flatclust(oracle.quantize(A, 0), W0, H0, "HALS", min_iter=1, max_iter=50, tol=1e-9)
+    labels = of.compute_assignments(ref.H)
+    assert np.array_equal(f.get_assignments(), labels)
+    assert np.array_equal(f.get_top_indices(), of.top_terms(ref.W, 3))
+    assert f.get_top_terms() == [dictionary[i] for i in of.top_terms(ref.W, 3)]
+    out = str(tmp_path) + "/"
+    assert f.write_output("assignments", "assignments_fuzzy", "tree", outdir=out, format="JSON")
+    assert open(out + "assignments_4.csv").read() == of.assignments_text(labels)
+    assert open(out + "tree_4.json").read() == of.results_text(labels, of.top_terms(ref.W, 3), dictionary, "JSON", 3, n, k)
+
+    h = Hierclust()
+    h.load_matrix(matrix=A)
+    h.load_dictionary(dictionary=dictionary)
+    h.cluster(k, maxterms=3, verbose=False, seed=5)
+    otree, _ = oh.hier_nmf2(oracle.quantize(A, 0), k, maxterms=3, seed=5)
+    assert h.get_assignments() == [(-1 if a == oh.NONE else a) for a in otree.assignments]
+    assert h.get_top_indices() == []                                   # only with flat=1 (:1355-1360)
+    h.write_output("assign", "htree", "fuzzy", outdir=out, format="XML")
+    assert open(out + "htree_4.xml").read() == oh.tree_text(otree, dictionary, "XML")
+    assert open(out + "assign_4.csv").read() == otree.assignments_text()
+    h.cluster(k, maxterms=3, verbose=False, flat=1, seed=5)
+    otree, _ = oh.hier_nmf2(oracle.quantize(A, 0), k, maxterms=3, seed=5, flat=True)
+    assert np.array_equal(h.get_assignments(), of.compute_assignments(otree.flat_H))
+    assert np.array_equal(h.get_top_indices(), of.top_terms(otree.flat_W, 3))
+    # sparse input through the scipy object, as pysmallk/tests/hierclust_inmem.py does with its Sparse class
+    As, _ = planted(150, 260, 3, 4, sparse=True)
+    hs = Hierclust()
+    hs.load_matrix(sparse_matrix=As)
+    hs.load_dictionary(dictionary=[f"t{i}" for i in range(150)])
+    hs.cluster(5, verbose=False, seed=4)
+    ot, _ = oh.hier_nmf2(As, 5, seed=4)
+    assert hs.get_assignments() == [(-1 if a == oh.NONE else a) for a in ot.assignments]
