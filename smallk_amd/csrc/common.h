@@ -105,11 +105,15 @@ int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int*
 // delta-fnorm: out[0] = sum (W - Wprev)^2, out[1] = sum W^2 ; then Wprev = W
 int launch_delta_fnorm(const double* W, double* Wprev, i64 count, double* partials, double* out2, hipStream_t st);
 int launch_zero_f64(double* p, i64 n, hipStream_t st);
-// RANK2: closed-form 2x2 solve + optimal active set (side 0: H, side 1: W'), per-iteration rescale
+// RANK2: closed-form 2x2 solve + optimal active set (side 0: H, side 1: W'); with Gout the Gram matrix
+// X X' of the result comes out of the same pass (scratch: rank2_gram_scratch_elems(N) doubles)
 int launch_rank2_solve(double* X, i64 N, PartialView R, const double* G, int side, int* fail_flag, int iter_tag,
-                       hipStream_t st);
-// (also leaves Gw = W'W of the normalised W: Gw_ij / (nu_i nu_j))
-int launch_rank2_rescale(double* Gh, double* Gw, PartialView R, i64 N, hipStream_t st);
+                       double* Gout, double* scratch, hipStream_t st);
+size_t rank2_gram_scratch_elems(i64 N);
+// per-iteration NormalizeAndScale in one launch (H, W, the stored AH', HH'); leaves Gw = W'W of the
+// normalised W (Gw_ij / (nu_i nu_j))
+int launch_rank2_normalize(double* H, i64 n, double* Wt, i64 m, PartialView R, double* Gh, double* Gw, int* fail_flag,
+                           hipStream_t st);
 // sparse A (CSC): out[:, j] = sum_p val[p] * X[:, row[p]] over the nonzeros of column j
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X,
                        int k, double* P, int kpp, hipStream_t st);

@@ -1903,11 +1903,15 @@ int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* 
 // (SystemSolveH :25-135 / SystemSolveW :139-212) followed by the optimal active set
 // (:216-318).  One thread per column of X (KP = 8 layout, rows 0 and 1 live).
 // ==========================================================================
+// Gp != nullptr: the kernel also leaves per-workgroup partial sums of X X' (the Gram matrix every
+// RANK2 step needs right after the solve) in Gp[block][64], so the solved factor is not re-read.
 __global__ __launch_bounds__(256) void rank2_solve_kernel(double* __restrict__ X, i64 N, PartialView R,
                                                           const double* __restrict__ G, int side,
-                                                          int* __restrict__ fail_flag, int iter_tag)
+                                                          int* __restrict__ fail_flag, int iter_tag,
+                                                          double* __restrict__ Gp)
 {
     constexpr int KP = 8;
+    __shared__ double shg[4][3];
     const double eps = DBL_EPSILON;
     const double a00 = G[0], a10 = G[1], a01 = G[KP], a11 = G[KP + 1];
     bool bad = (fabs(a00) < eps) && (fabs(a01) < eps);          // "singular matrix"
@@ -1928,70 +1932,107 @@ __global__ __launch_bounds__(256) void rank2_solve_kernel(double* __restrict__ X
     }
     const double inv0 = 1.0 / a00, inv1 = 1.0 / a11, sq0 = sqrt(a00), sq1 = sqrt(a11);
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    const double b0 = rhs_elem(R, j, 0), b1 = rhs_elem(R, j, 1);
-    double e2, f2;
-    if (side == 0) {
-        if (cosine) { e2 = b0 - t * b1; f2 = b1 + t * b0; }
-        else        { e2 = -b1 + t * b0; f2 = b0 + t * b1; }
-    } else {
-        if (cosine) { e2 = b0 + t * b1; f2 = b1 - t * b0; }
-        else        { e2 = -b1 - t * b0; f2 = b0 - t * b1; }
+    const bool valid = j < N;
+    if (!valid && !Gp) return;
+    double x0 = 0.0, x1 = 0.0;
+    if (valid) {
+        const double b0 = rhs_elem(R, j, 0), b1 = rhs_elem(R, j, 1);
+        double e2, f2;
+        if (side == 0) {
+            if (cosine) { e2 = b0 - t * b1; f2 = b1 + t * b0; }
+            else        { e2 = -b1 + t * b0; f2 = b0 + t * b1; }
+        } else {
+            if (cosine) { e2 = b0 + t * b1; f2 = b1 - t * b0; }
+            else        { e2 = -b1 - t * b0; f2 = b0 - t * b1; }
+        }
+        x1 = f2 * inv_d2;
+        x0 = (e2 - b2 * x1) * inv_a2;
+        if (x0 <= 0.0 || x1 <= 0.0) {               // OptimalActiveSet
+            double v1 = b0 * inv0, v2 = b1 * inv1;
+            if (v1 * sq0 >= v2 * sq1) v2 = 0.0; else v1 = 0.0;
+            x0 = v1;
+            x1 = v2;
+        }
+        f64x2_t v;
+        v[0] = x0;
+        v[1] = x1;
+        *(f64x2_t*)(X + j * KP) = v;
     }
-    double x1 = f2 * inv_d2;
-    double x0 = (e2 - b2 * x1) * inv_a2;
-    if (x0 <= 0.0 || x1 <= 0.0) {                   // OptimalActiveSet
-        double v1 = b0 * inv0, v2 = b1 * inv1;
-        if (v1 * sq0 >= v2 * sq1) v2 = 0.0; else v1 = 0.0;
-        x0 = v1;
-        x1 = v2;
+    if (!Gp) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double s00 = wave_sum(x0 * x0), s01 = wave_sum(x0 * x1), s11 = wave_sum(x1 * x1);
+    if (lane == 0) { shg[wave][0] = s00; shg[wave][1] = s01; shg[wave][2] = s11; }
+    __syncthreads();
+    if (threadIdx.x < KP * KP) {
+        const int e = threadIdx.x;
+        const int q = (e == 0) ? 0 : (e == 1 || e == KP) ? 1 : (e == KP + 1) ? 2 : -1;
+        Gp[(i64)blockIdx.x * KP * KP + e] = (q < 0) ? 0.0 : (shg[0][q] + shg[1][q]) + (shg[2][q] + shg[3][q]);
     }
-    f64x2_t v;
-    v[0] = x0;
-    v[1] = x1;
-    *(f64x2_t*)(X + j * KP) = v;
 }
 
+// Gout != nullptr: also Gout = X X' (KP x KP), through `scratch` (rank2_gram_scratch_elems(N) doubles)
 int launch_rank2_solve(double* X, i64 N, PartialView R, const double* G, int side, int* fail_flag, int iter_tag,
-                       hipStream_t st)
+                       double* Gout, double* scratch, hipStream_t st)
 {
     const int grid = (int)((N + 255) / 256);
-    rank2_solve_kernel<<<grid, 256, 0, st>>>(X, N, R, G, side, fail_flag, iter_tag);
+    rank2_solve_kernel<<<grid, 256, 0, st>>>(X, N, R, G, side, fail_flag, iter_tag, Gout ? scratch : nullptr);
     SMK_HIP(hipGetLastError());
+    if (Gout) {
+        gram_reduce_kernel<<<4, 256, 0, st>>>(scratch, grid, 64, Gout);
+        SMK_HIP(hipGetLastError());
+    }
     return 0;
 }
+size_t rank2_gram_scratch_elems(i64 N) { return (size_t)((N + 255) / 256) * 64; }
 
-// after the per-iteration NormalizeAndScale (:418): HHt_ij *= nu_i nu_j, AHt(:,c) *= nu_c (:424-437),
-// nu_c = sqrt(Gw[c][c]) taken from the Gram matrix of the un-normalised W
-__global__ __launch_bounds__(256) void rank2_rescale_kernel(double* __restrict__ Gh, const double* __restrict__ Gw,
-                                                            void* __restrict__ P, int S, i64 slab, int kpp, int f64,
-                                                            i64 N)
+// Per-iteration NormalizeAndScale of RANK2 (nmf_solver_rank2.hpp:418-437) in one launch: H rows *= nu,
+// W columns /= nu, the stored AH' *= nu per column, HH'_ij *= nu_i nu_j; nu_c = sqrt(Gw[c][c]).
+// A zero norm reports -2 through fail_flag and leaves that component unscaled (the reference throws).
+__global__ __launch_bounds__(256) void rank2_normalize_kernel(double* __restrict__ H, i64 n, double* __restrict__ Wt, i64 m,
+                                                              void* __restrict__ P, int S, i64 slab, int kpp, int f64,
+                                                              double* __restrict__ Gh, const double* __restrict__ Gw,
+                                                              int* __restrict__ fail_flag)
 {
     constexpr int KP = 8;
     const double nu0 = sqrt(Gw[0]), nu1 = sqrt(Gw[KP + 1]);
+    const bool ok0 = !(fabs(nu0) < DBL_EPSILON), ok1 = !(fabs(nu1) < DBL_EPSILON);
+    const double h0 = ok0 ? nu0 : 1.0, h1 = ok1 ? nu1 : 1.0;
+    const double w0 = ok0 ? 1.0 / nu0 : 1.0, w1 = ok1 ? 1.0 / nu1 : 1.0;
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0) {
+        if (!ok0 || !ok1) atomicMin(fail_flag, -2);
         Gh[0] *= nu0 * nu0;
         Gh[1] *= nu0 * nu1;
         Gh[KP] *= nu0 * nu1;
         Gh[KP + 1] *= nu1 * nu1;
     }
-    if (j >= N) return;
-    for (int s = 0; s < S; ++s) {
-        if (f64) {
-            double* p = (double*)P + s * slab + j * kpp;
-            p[0] *= nu0;
-            p[1] *= nu1;
-        } else {
-            float* p = (float*)P + s * slab + j * kpp;
-            p[0] = (float)((double)p[0] * nu0);
-            p[1] = (float)((double)p[1] * nu1);
+    if (j < n) {
+        f64x2_t v = *(f64x2_t*)(H + j * KP);
+        v[0] *= h0;
+        v[1] *= h1;
+        *(f64x2_t*)(H + j * KP) = v;
+    }
+    if (j < m) {
+        f64x2_t v = *(f64x2_t*)(Wt + j * KP);
+        v[0] *= w0;
+        v[1] *= w1;
+        *(f64x2_t*)(Wt + j * KP) = v;
+        for (int s = 0; s < S; ++s) {
+            if (f64) {
+                double* p = (double*)P + s * slab + j * kpp;
+                p[0] *= nu0;
+                p[1] *= nu1;
+            } else {
+                float* p = (float*)P + s * slab + j * kpp;
+                p[0] = (float)((double)p[0] * nu0);
+                p[1] = (float)((double)p[1] * nu1);
+            }
         }
     }
 }
 
 // W'W of the NORMALISED W without another pass over W: (D^-1 W'W D^-1)_ij = Gw_ij / (nu_i nu_j).
-// Runs after every consumer of the un-normalised Gram matrix (scale_rows, rank2_rescale) on the stream.
+// Runs after the consumer of the un-normalised Gram matrix (rank2_normalize_kernel) on the stream.
 __global__ void rank2_gw_normalize_kernel(double* __restrict__ Gw)
 {
     constexpr int KP = 8;
@@ -2003,10 +2044,13 @@ __global__ void rank2_gw_normalize_kernel(double* __restrict__ Gw)
     Gw[KP + 1] = Gw[KP + 1] / (nu1 * nu1);
 }
 
-int launch_rank2_rescale(double* Gh, double* Gw, PartialView R, i64 N, hipStream_t st)
+int launch_rank2_normalize(double* H, i64 n, double* Wt, i64 m, PartialView R, double* Gh, double* Gw, int* fail_flag,
+                           hipStream_t st)
 {
-    const int grid = (int)((N + 255) / 256);
-    rank2_rescale_kernel<<<grid, 256, 0, st>>>(Gh, Gw, const_cast<void*>(R.p), R.S, R.slab, R.kpp, R.f64, N);
+    const i64 cnt = n > m ? n : m;
+    const int grid = (int)((cnt + 255) / 256);
+    rank2_normalize_kernel<<<grid, 256, 0, st>>>(H, n, Wt, m, const_cast<void*>(R.p), R.S, R.slab, R.kpp, R.f64, Gh, Gw,
+                                                 fail_flag);
     SMK_HIP(hipGetLastError());
     rank2_gw_normalize_kernel<<<1, 64, 0, st>>>(Gw);
     SMK_HIP(hipGetLastError());

@@ -519,7 +519,11 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     rc |= dev_alloc(&s->Wt_own, (size_t)s->KP * s->m);
     rc |= dev_alloc(&s->Gw, kk);
     rc |= dev_alloc(&s->Gh_own, kk);
-    rc |= dev_alloc(&s->gram_scratch, gram_scratch_elems(s->k, GRAM_BLOCKS));
+    {
+        size_t gs = gram_scratch_elems(s->k, GRAM_BLOCKS);
+        if (s->o.algorithm == SMK_ALG_RANK2) gs = std::max(gs, rank2_gram_scratch_elems(std::max(s->m, s->n)));
+        rc |= dev_alloc(&s->gram_scratch, gs);
+    }
     rc |= dev_alloc(&s->tmpW, (size_t)s->KP * s->m);
     // one partial per workgroup of the column-tile kernels (grid = N*(KP/4)/256 blocks) and at most
     // 2 x 512 for delta_fnorm
@@ -753,17 +757,15 @@ static int solver_iteration(smk_solver* s)
             rc = prod1(s);    if (rc) return rc;
             break;
         case SMK_ALG_RANK2:  // nmf_solver_rank2.hpp:353-455
-            rc = launch_rank2_solve(s->H, s->n, r1, s->Gw, 0, s->fail_flag, s->iter, s->st); if (rc) return rc;
-            rc = gram_h(s);   if (rc) return rc;
+            // each closed-form solve also emits the Gram matrix of its result (no second pass over H / W)
+            rc = launch_rank2_solve(s->H, s->n, r1, s->Gw, 0, s->fail_flag, s->iter, s->Gh, s->gram_scratch, s->st); if (rc) return rc;
+            if (s->ar)
+                if (s->ar(s->ar_user, s->Gh, (int64_t)s->KP * s->KP, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
             rc = prod2(s);    if (rc) return rc;
-            rc = launch_rank2_solve(s->Wt, s->m, view2(s), s->Gh, 1, s->fail_flag, s->iter, s->st); if (rc) return rc;
-            // NormalizeAndScale(W, H, ScaleFactors) every iteration: norms from the Gram matrix of the new W
-            rc = gram_w(s);   if (rc) return rc;
-            rc = launch_scale_rows(s->H, s->k, s->n, s->Gw, 0, s->fail_flag, s->st);  if (rc) return rc;
-            rc = launch_scale_rows(s->Wt, s->k, s->m, s->Gw, 1, s->fail_flag, s->st); if (rc) return rc;
-            // rescales HH' and AH' for the new scaling and leaves Gw = W'W of the normalised W
-            // (D^-1 Gw D^-1: no second pass over W)
-            rc = launch_rank2_rescale(s->Gh, s->Gw, view2(s), s->m, s->st);          if (rc) return rc;
+            rc = launch_rank2_solve(s->Wt, s->m, view2(s), s->Gh, 1, s->fail_flag, s->iter, s->Gw, s->gram_scratch, s->st); if (rc) return rc;
+            // NormalizeAndScale(W, H, ScaleFactors) every iteration, norms from the Gram matrix of the new W;
+            // also rescales HH' and AH' and leaves Gw = W'W of the normalised W (D^-1 Gw D^-1)
+            rc = launch_rank2_normalize(s->H, s->n, s->Wt, s->m, view2(s), s->Gh, s->Gw, s->fail_flag, s->st); if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
             break;
         default:
