@@ -20,7 +20,7 @@ enum NmfAlgorithm
 {
     MU,     // multiplicative updating (Lee & Seung)
     HALS,   // hierarchical alternating least squares (Cichocki & Pan)
-    RANK2,  // rank-2 specialisation (Kuang & Park) -- next tier, not on the device path yet
+    RANK2,  // rank-2 specialisation (Kuang & Park): closed-form 2x2 solves, k is forced to 2
     BPP     // block principal pivoting (Kim & Park)
 };
 

@@ -83,7 +83,8 @@ namespace smallk
     const double* LockedBufferW(unsigned int& ldim, unsigned int& height, unsigned int& width);
     const double* LockedBufferH(unsigned int& ldim, unsigned int& height, unsigned int& width);
 
-    // -- clustering (next tier) --------------------------------------------------------------
+    // -- clustering: HierNMF2 (+ optional flat clustering of the leaves); writes tree_N.{xml,json},
+    //    assignments_N.csv (and assignments_flat_N.csv, assignments_fuzzy_N.csv, clusters_N.*) --------
     void LoadDictionary(const std::string& filepath);
     void LoadDictionary(const std::vector<std::string>& terms);
     unsigned int GetMaxTerms();
