@@ -14,6 +14,8 @@ def pytest_configure(config):
     # a fresh checkout has no built artefacts: build them once (hipcc cross-compiles without a GPU)
     need = [os.path.join(ROOT, "smallk_amd", "lib", "libsmallk_amd.so"),
             os.path.join(ROOT, "smallk_amd", "bin", "nmf"),
+            os.path.join(ROOT, "smallk_amd", "bin", "hierclust"),
+            os.path.join(ROOT, "smallk_amd", "bin", "flatclust"),
             os.path.join(ROOT, "oracle", "_build", "liboracle.so")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__
