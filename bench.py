@@ -35,6 +35,7 @@ WORKLOADS = {
     "c4t": (65536, 262144, 64, "BPP", "f32", "EXPERIMENT transposed C4 shape 65536x262144 k=64 BPP fp32"),
     "c4s": (262144, 8192, 64, "BPP", "f32", "EXPERIMENT one 1/8 column shard of C4: 262144x8192 k=64 BPP fp32"),
     "c4b": (262144, 65536, 64, "BPP", "bf16", "EXPERIMENT C4 with A held as bf16"),
+    "b32": (32768, 8192, 32, "BPP", "f32", "EXPERIMENT 32768x8192 k=32 BPP fp32"),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
