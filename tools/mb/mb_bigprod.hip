@@ -11,13 +11,15 @@ int main(int argc, char** argv)
 {
     const int k = argc > 1 ? atoi(argv[1]) : 64;
     const i64 len = argc > 2 ? atoll(argv[2]) : 65536, ncols = argc > 3 ? atoll(argv[3]) : 32768;
-    const int storage = STORE_BF16, nsplit = argc > 4 ? atoi(argv[4]) : 3;
+    const int nsplit = argc > 4 ? atoi(argv[4]) : 3;
+    const int storage = (argc > 5 && atoi(argv[5]) == 0) ? STORE_F32 : STORE_BF16;
+    const int es = storage == STORE_BF16 ? 2 : 4;
     hipStream_t st; hipStreamCreate(&st);
     const i64 ld = round_up(len, ROW_PAD), cp = round_up(ncols, COL_PAD);
-    void* B; hipMalloc(&B, (size_t)ld * cp * 2);
-    launch_fill_uniform(B, storage, ld, len, ncols, ld, cp, 0, 0, len, 42, 1, st);
+    void* B; hipMalloc(&B, (size_t)ld * cp * es);
+    launch_fill_uniform(B, storage, ld, len, ncols, ld, cp, 0, 0, len, 42, storage == STORE_BF16 ? 1 : 0, st);
     double* X; hipMalloc(&X, (size_t)kp_of(k) * len * 8);
-    launch_fill_uniform(B, storage, ld, len, ncols, ld, cp, 0, 0, len, 42, 1, st);
+    launch_fill_uniform(B, storage, ld, len, ncols, ld, cp, 0, 0, len, 42, storage == STORE_BF16 ? 1 : 0, st);
     hipMemset(X, 0, (size_t)kp_of(k) * len * 8);
     void* Xp; hipMalloc(&Xp, packed_bytes(storage, k, len, nsplit));
     launch_pack(X, k, len, storage, nsplit, Xp, st);
@@ -44,7 +46,7 @@ int main(int argc, char** argv)
     }
     const double tot = s[0] + s[1] + s[2] + s[3];
     printf("k=%d len=%ld ncols=%ld nsplit=%d variant=%d S=%d: %.3f ms  %.0f GB/s | per-wave cycles (avg over %zu waves): wait %.0f (%.0f%%) barrier %.0f (%.0f%%) issue %.0f (%.0f%%) compute %.0f (%.0f%%) | per stage: %.0f cycles\n",
-           k, (long)len, (long)ncols, nsplit, pl.variant, pl.S, ms, (double)len * ncols * 2 / ms / 1e6, n, s[0] / n, 100 * s[0] / tot,
+           k, (long)len, (long)ncols, nsplit, pl.variant, pl.S, ms, (double)len * ncols * es / ms / 1e6, n, s[0] / n, 100 * s[0] / tot,
            s[1] / n, 100 * s[1] / tot, s[2] / n, 100 * s[2] / tot, s[3] / n, 100 * s[3] / tot, tot / n / (double)pl.nst);
     return 0;
 }
