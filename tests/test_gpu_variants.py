@@ -39,3 +39,13 @@ def test_hals_w_multi_launch_fallback():
 def test_two_term_operand_split():
     # 16-bit operand: looser but still inside the bar on these shapes
     run_quick_parity({"SMK_NSPLIT": "2"})
+
+
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py: 80 random (shape, rank, algorithm, storage, dense/sparse, stopping rule)
+    problems through the C ABI against the oracle.  Longer sweeps (1500 cases, other seeds) were run
+    clean while developing; this keeps a slice of it in the suite."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "80", "7"], capture_output=True,
+                       text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "all cases within tolerance" in r.stdout

@@ -1,0 +1,61 @@
+"""Randomised parity sweep: many small random problems (shape, rank, algorithm, storage, dense/sparse,
+stopping rule) through the C ABI against the oracle.  usage: python tools/fuzz_parity.py [cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, scipy.sparse as sp
+import oracle, smallk_amd
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+smallk_amd.initialize(0)
+oracle.set_num_threads(8)
+bad = []
+t0 = time.time()
+stats = {}
+for case in range(cases):
+    alg = rng.choice(["MU", "HALS", "BPP", "RANK2"])
+    sparse = rng.random() < 0.3
+    storage = "f32" if sparse else rng.choice(["f32", "bf16"])
+    kmax = 2 if alg == "RANK2" else int(rng.choice([3, 8, 9, 16, 17, 32, 33, 48, 64]))
+    m = int(rng.integers(max(kmax, 2) * (4 if alg in ("HALS", "BPP") else 1), 1500))
+    n = int(rng.integers(max(kmax, 2) * (4 if alg in ("HALS", "BPP") else 1), 1500))
+    k = 2 if alg == "RANK2" else int(rng.integers(1, kmax + 1))
+    # planted rank >= k plus noise keeps the Gram matrices well conditioned
+    r = max(k + 2, 4)
+    Wt = rng.random((m, r)) * (rng.random((m, r)) > 0.4)
+    Ht = rng.random((r, n)) * (rng.random((r, n)) > 0.4)
+    A = Wt @ Ht + 0.05 * rng.random((m, n))
+    if sparse:
+        A = A * (rng.random((m, n)) < 0.2)
+        A[:, A.sum(axis=0) == 0] += 1e-3            # no empty columns (BPP: HH' stays non-singular)
+        As = sp.csc_matrix(A)
+    iters = int(rng.integers(1, 7))
+    prog = int(rng.integers(0, 2))
+    W0 = oracle.fill_uniform(m, k, 100 + case)
+    H0 = oracle.fill_uniform(k, n, 200 + case) * (2.0 * A.mean() / (0.5 * k))
+    quant = 1 if storage == "bf16" else 0
+    Aq = A if sparse else oracle.quantize(A, quant)
+    ref = oracle.nmf(Aq, W0, H0, alg, min_iter=1, max_iter=iters, tol=1e-14, prog_est=prog)
+    if sparse:
+        got = smallk_amd.nmf_sparse(As, W0, H0, alg, min_iter=1, max_iter=iters, tol=1e-14, prog_est=prog)
+    else:
+        got = smallk_amd.nmf(A, W0, H0, alg, min_iter=1, max_iter=iters, tol=1e-14, prog_est=prog, storage=storage)
+    key = (alg, "sparse" if sparse else storage)
+    stats[key] = stats.get(key, 0) + 1
+    desc = f"case {case}: {alg} {m}x{n} k={k} {'sparse' if sparse else storage} iters={iters} prog={prog}"
+    if got.result != ref.result:
+        bad.append(desc + f" result {got.result} vs oracle {ref.result}")
+        continue
+    if ref.result != 0:
+        continue
+    eW = np.linalg.norm(got.W - ref.W) / max(np.linalg.norm(ref.W), 1e-300)
+    eH = np.linalg.norm(got.H - ref.H) / max(np.linalg.norm(ref.H), 1e-300)
+    tol = 1e-8 if sparse else 1e-4
+    if not (eW < tol and eH < tol) or got.iteration_count != ref.iteration_count:
+        bad.append(desc + f" relW {eW:.2e} relH {eH:.2e} iters {got.iteration_count}/{ref.iteration_count}")
+print(f"{cases} cases in {time.time()-t0:.1f}s; coverage {sorted(stats.items())}")
+print("FAILURES:" if bad else "all cases within tolerance")
+for b in bad:
+    print("  ", b)
+sys.exit(1 if bad else 0)
