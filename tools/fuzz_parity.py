@@ -1,5 +1,5 @@
 """Randomised parity sweep: many small random problems (shape, rank, algorithm, storage, dense/sparse,
-stopping rule) through the C ABI against the oracle.  usage: python tools/fuzz_parity.py [cases] [seed]"""
+stopping rule) through the C ABI against the oracle.  usage: python tools/fuzz_parity.py [cases] [seed] [max_dim]"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, scipy.sparse as sp
@@ -7,6 +7,7 @@ import oracle, smallk_amd
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+maxdim = int(sys.argv[3]) if len(sys.argv) > 3 else 1500
 rng = np.random.default_rng(seed)
 smallk_amd.initialize(0)
 oracle.set_num_threads(8)
@@ -18,8 +19,8 @@ for case in range(cases):
     sparse = rng.random() < 0.3
     storage = "f32" if sparse else rng.choice(["f32", "bf16"])
     kmax = 2 if alg == "RANK2" else int(rng.choice([3, 8, 9, 16, 17, 32, 33, 48, 64]))
-    m = int(rng.integers(max(kmax, 2) * (4 if alg in ("HALS", "BPP") else 1), 1500))
-    n = int(rng.integers(max(kmax, 2) * (4 if alg in ("HALS", "BPP") else 1), 1500))
+    m = int(rng.integers(max(kmax, 2) * (4 if alg in ("HALS", "BPP") else 1), maxdim))
+    n = int(rng.integers(max(kmax, 2) * (4 if alg in ("HALS", "BPP") else 1), maxdim))
     k = 2 if alg == "RANK2" else int(rng.integers(1, kmax + 1))
     # planted rank >= k plus noise keeps the Gram matrices well conditioned
     r = max(k + 2, 4)
