@@ -199,6 +199,29 @@ int launch_gather_cols(const void* src, i64 ld_src_bytes, const unsigned* cols_d
     return 0;
 }
 
+// three fp64 arrays in one launch (snapshot / restore of W, H and W'W around a speculative iteration)
+__global__ __launch_bounds__(256) void copy3_kernel(double* __restrict__ d0, const double* __restrict__ s0, i64 n0,
+                                                    double* __restrict__ d1, const double* __restrict__ s1, i64 n1,
+                                                    double* __restrict__ d2, const double* __restrict__ s2, i64 n2)
+{
+    const i64 total = n0 + n1 + n2;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
+        if (i < n0) d0[i] = s0[i];
+        else if (i < n0 + n1) d1[i - n0] = s1[i - n0];
+        else d2[i - n0 - n1] = s2[i - n0 - n1];
+    }
+}
+int launch_copy3(double* d0, const double* s0, i64 n0, double* d1, const double* s1, i64 n1, double* d2, const double* s2,
+                 i64 n2, hipStream_t st)
+{
+    const i64 total = n0 + n1 + n2;
+    if (total <= 0) return 0;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    copy3_kernel<<<grid, 256, 0, st>>>(d0, s0, n0, d1, s1, n1, d2, s2, n2);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ void zero_f64_kernel(double* p, i64 n)
 {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) p[i] = 0.0;

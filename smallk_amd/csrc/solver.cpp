@@ -91,6 +91,12 @@ struct smk_solver {
     int rank = 0, world = 1;
     smk_allreduce_fn ar = nullptr;
     void* ar_user = nullptr;
+    // stopping rule evaluated one iteration late (smk_solver_run): pinned result slots, events, and a
+    // snapshot of (W, H, W'W) per checked iteration so that a speculative iteration can be undone
+    struct ProgSlot { double h[4]; int flag; int pad; };
+    ProgSlot* pin = nullptr;
+    hipEvent_t pev[2] = {nullptr, nullptr};
+    double* snap[2] = {nullptr, nullptr};
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
@@ -556,6 +562,11 @@ void smk_solver_destroy(smk_solver* s)
         if (p) (void)hipFree(p);
     for (int w = 0; w < 2; ++w)
         for (auto& e : s->ev[w]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (int b = 0; b < 2; ++b) {
+        if (s->snap[b]) (void)hipFree(s->snap[b]);
+        if (s->pev[b]) (void)hipEventDestroy(s->pev[b]);
+    }
+    if (s->pin) (void)hipHostFree(s->pin);
     delete s;
 }
 
@@ -805,7 +816,8 @@ static int sync_and_check(smk_solver* s, int* fail_iter)
 }
 
 // progress_est->Update(iter, W, H, gradW, gradH): returns the metric (synchronises)
-static int update_progress(smk_solver* s, int iter_index, double* metric)
+// the kernels (and, sharded, the scalar all-reduce) of one progress evaluation; results land in s->scal
+static int enqueue_progress_kernels(smk_solver* s)
 {
     int rc = 0;
     if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM) {
@@ -820,11 +832,12 @@ static int update_progress(smk_solver* s, int iter_index, double* metric)
         if (s->ar)
             if (s->ar(s->ar_user, s->scal + 1, 1, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
     }
-    double h[4] = {0, 0, 0, 0};
-    SMK_HIP(hipMemcpyAsync(h, s->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s->st));
-    int fail_iter = INT_MAX;
-    rc = sync_and_check(s, &fail_iter);
-    if (rc) return rc;
+    return 0;
+}
+
+// metric from the four scalars (PG sums for W and H, delta-Fnorm numerator / denominator)
+static int evaluate_progress(smk_solver* s, const double* h, int iter_index, double* metric)
+{
     if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM) {
         *metric = std::sqrt(h[2]) / std::sqrt(h[3]);
     } else {
@@ -835,6 +848,64 @@ static int update_progress(smk_solver* s, int iter_index, double* metric)
     }
     s->last_metric = *metric;
     return SMK_OK;
+}
+
+// progress_est->Update(iter, W, H, gradW, gradH): returns the metric (synchronises)
+static int update_progress(smk_solver* s, int iter_index, double* metric)
+{
+    int rc = enqueue_progress_kernels(s);
+    if (rc) return rc;
+    double h[4] = {0, 0, 0, 0};
+    SMK_HIP(hipMemcpyAsync(h, s->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    int fail_iter = INT_MAX;
+    rc = sync_and_check(s, &fail_iter);
+    if (rc) return rc;
+    return evaluate_progress(s, h, iter_index, metric);
+}
+
+// ---- the same evaluation, one iteration late ------------------------------------------------
+// Enqueue the progress kernels of the iteration that has just been enqueued, copy their scalars and
+// the failure flag into pinned slot `b` and record an event; when `snapshot` is set also keep
+// (W, H, W'W) of this iteration so that the NEXT, speculatively enqueued iteration can be undone.
+static int progress_begin(smk_solver* s, int b, bool snapshot)
+{
+    if (!s->pin) {
+        SMK_HIP(hipHostMalloc((void**)&s->pin, 2 * sizeof(smk_solver::ProgSlot)));
+        for (int i = 0; i < 2; ++i) SMK_HIP(hipEventCreateWithFlags(&s->pev[i], hipEventDisableTiming));
+    }
+    int rc = enqueue_progress_kernels(s);
+    if (rc) return rc;
+    SMK_HIP(hipMemcpyAsync(s->pin[b].h, s->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    SMK_HIP(hipMemcpyAsync(&s->pin[b].flag, s->fail_flag, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    if (snapshot) {
+        const i64 nw = (i64)s->KP * s->m, nh = (i64)s->KP * s->n, ng = (i64)s->KP * s->KP;
+        if (!s->snap[b]) { rc = dev_alloc(&s->snap[b], (size_t)(nw + nh + ng)); if (rc) return rc; }
+        rc = launch_copy3(s->snap[b], s->Wt, nw, s->snap[b] + nw, s->H, nh, s->snap[b] + nw + nh, s->Gw, ng, s->st);
+        if (rc) return rc;
+    }
+    SMK_HIP(hipEventRecord(s->pev[b], s->st));
+    return 0;
+}
+
+// wait for slot b; SMK_FAILURE when the device flagged a solver failure up to that iteration
+static int progress_end(smk_solver* s, int b, int iter_index, double* metric)
+{
+    SMK_HIP(hipEventSynchronize(s->pev[b]));
+    if (s->pin[b].flag != INT_MAX) return SMK_FAILURE;
+    return evaluate_progress(s, s->pin[b].h, iter_index, metric);
+}
+
+static int progress_restore(smk_solver* s, int b)
+{
+    const i64 nw = (i64)s->KP * s->m, nh = (i64)s->KP * s->n, ng = (i64)s->KP * s->KP;
+    int rc = launch_copy3(s->Wt, s->snap[b], nw, s->H, s->snap[b] + nw, nh, s->Gw, s->snap[b] + nw + nh, ng, s->st);
+    if (rc) return rc;
+    // whatever the undone iteration did to the failure flag is void; products / HH' are stale
+    const int big = INT_MAX;
+    SMK_HIP(hipMemcpyAsync(s->fail_flag, &big, sizeof(int), hipMemcpyHostToDevice, s->st));
+    SMK_HIP(hipStreamSynchronize(s->st));
+    s->inited = false;
+    return 0;
 }
 
 static int normalize_device(smk_solver* s)
@@ -890,34 +961,62 @@ int smk_solver_run(smk_solver* s, smk_stats* stats)
 
     if (!s->inited) { rc = solver_init(s); if (rc) { result = rc; goto done; } }
 
-    for (iter = 0; iter < o.max_iter; ++iter) {
-        rc = solver_iteration(s);
-        if (rc) { result = rc; goto done; }
-
-        if (iter < o.min_iter) {
-            if (iter == 0) {
-                double metric;
-                rc = update_progress(s, 0, &metric);
-                if (rc) { result = rc; goto failed_check; }
-            }
-            if (o.verbose) printf("%d:\tprogress metric: \t(min_iter)\n", iter + 1);
-            continue;
-        }
-        {
+    // The stopping rule of iteration i (NmfSolve, nmf_solve_generic.hpp:81-121) is evaluated AFTER
+    // iteration i+1 has been enqueued: the host never leaves the GPU idle waiting for a scalar.  When
+    // the rule fires for i, the state of i is restored from its snapshot and i+1 is discarded, so
+    // results and iteration counts are those of the check-every-iteration loop (SMK_SYNC_PROGRESS=1
+    // runs that loop instead).
+    {
+        static const bool sync_mode = [] { const char* e = getenv("SMK_SYNC_PROGRESS"); return e && atoi(e) != 0; }();
+        int pending = -1;                              // iteration whose check is outstanding
+        auto resolve = [&](int p, bool speculated) -> int {      // 0: go on, 1: converged at p, < 0: error
             double metric = 1.0;
-            rc = update_progress(s, iter, &metric);
-            if (rc) { result = rc; goto failed_check; }
-            if (o.verbose && ((iter + 1 < 10) || ((iter + 1) % 10 == 0)))
-                printf("%d:\tprogress metric:\t%g\n", iter + 1, metric);     // nmf_progress_estimation.hpp:22-33
+            int prc = progress_end(s, p & 1, p, &metric);
+            if (prc) { result = prc; return -1; }
+            if (p < o.min_iter) return 0;              // iteration 0 only initialises the estimator
+            if (o.verbose && ((p + 1 < 10) || ((p + 1) % 10 == 0)))
+                printf("%d:\tprogress metric:\t%g\n", p + 1, metric);     // nmf_progress_estimation.hpp:22-33
             if (metric <= o.tol) {
                 if (++success_count >= o.tolcount) {
-                    success = true;
-                    if (o.verbose) printf("\nSolution converged after %d iterations.\n\n", iter + 1);
-                    break;
+                    if (o.verbose) printf("\nSolution converged after %d iterations.\n\n", p + 1);
+                    if (speculated) { prc = progress_restore(s, p & 1); if (prc) { result = prc; return -1; } s->iter = p + 1; }
+                    return 1;
                 }
             } else {
                 success_count = 0;
             }
+            return 0;
+        };
+        for (iter = 0; iter < o.max_iter; ++iter) {
+            rc = solver_iteration(s);
+            if (rc) { result = rc; goto done; }
+            const bool check = (iter == 0) || (iter >= o.min_iter);
+            if (sync_mode) {
+                if (!check) { if (o.verbose) printf("%d:\tprogress metric: \t(min_iter)\n", iter + 1); continue; }
+                rc = progress_begin(s, iter & 1, false);
+                if (rc) { result = rc; goto done; }
+                const int r = resolve(iter, false);
+                if (r < 0) goto failed_check;
+                if (iter < o.min_iter && o.verbose) printf("%d:\tprogress metric: \t(min_iter)\n", iter + 1);
+                if (r == 1) { success = true; break; }
+                continue;
+            }
+            if (check) {
+                rc = progress_begin(s, iter & 1, iter >= o.min_iter);
+                if (rc) { result = rc; goto done; }
+            }
+            if (pending >= 0) {
+                const int r = resolve(pending, true);
+                if (r < 0) goto failed_check;
+                if (r == 1) { success = true; iter = pending; pending = -1; break; }
+            }
+            if (iter < o.min_iter && o.verbose) printf("%d:\tprogress metric: \t(min_iter)\n", iter + 1);
+            pending = check ? iter : -1;
+        }
+        if (!success && pending >= 0) {                // the last iteration's check: nothing ran after it
+            const int r = resolve(pending, false);
+            if (r < 0) goto failed_check;
+            if (r == 1) { success = true; iter = pending; }
         }
     }
 

@@ -49,3 +49,13 @@ def test_randomised_parity_sweep():
                        text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "all cases within tolerance" in r.stdout
+
+
+def test_check_every_iteration_loop():
+    """SMK_SYNC_PROGRESS=1: the plain check-every-iteration driver loop instead of the one that evaluates
+    the stopping rule one iteration late (both must reproduce the oracle's iteration counts: the sweep
+    lets the rule fire in ~20 % of its cases)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "60", "5"], capture_output=True,
+                       text=True, cwd=ROOT, timeout=600, env=dict(os.environ, SMK_SYNC_PROGRESS="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "converged early" in r.stdout

@@ -32,19 +32,28 @@ for case in range(cases):
         A[:, A.sum(axis=0) == 0] += 1e-3            # no empty columns (BPP: HH' stays non-singular)
         As = sp.csc_matrix(A)
     iters = int(rng.integers(1, 7))
+    tol = 1e-14
+    min_iter = 1
+    if rng.random() < 0.4:                       # let the stopping rule fire somewhere in the run
+        tol = float(rng.choice([0.2, 0.05, 0.01, 0.003]))
+        iters = int(rng.integers(5, 40))
+        min_iter = int(rng.integers(1, 6))
+    tolcount = int(rng.integers(1, 3))
     prog = int(rng.integers(0, 2))
     W0 = oracle.fill_uniform(m, k, 100 + case)
     H0 = oracle.fill_uniform(k, n, 200 + case) * (2.0 * A.mean() / (0.5 * k))
     quant = 1 if storage == "bf16" else 0
     Aq = A if sparse else oracle.quantize(A, quant)
-    ref = oracle.nmf(Aq, W0, H0, alg, min_iter=1, max_iter=iters, tol=1e-14, prog_est=prog)
+    ref = oracle.nmf(Aq, W0, H0, alg, min_iter=min_iter, max_iter=iters, tol=tol, tolcount=tolcount, prog_est=prog)
     if sparse:
-        got = smallk_amd.nmf_sparse(As, W0, H0, alg, min_iter=1, max_iter=iters, tol=1e-14, prog_est=prog)
+        got = smallk_amd.nmf_sparse(As, W0, H0, alg, min_iter=min_iter, max_iter=iters, tol=tol, tolcount=tolcount, prog_est=prog)
     else:
-        got = smallk_amd.nmf(A, W0, H0, alg, min_iter=1, max_iter=iters, tol=1e-14, prog_est=prog, storage=storage)
+        got = smallk_amd.nmf(A, W0, H0, alg, min_iter=min_iter, max_iter=iters, tol=tol, tolcount=tolcount, prog_est=prog, storage=storage)
     key = (alg, "sparse" if sparse else storage)
     stats[key] = stats.get(key, 0) + 1
-    desc = f"case {case}: {alg} {m}x{n} k={k} {'sparse' if sparse else storage} iters={iters} prog={prog}"
+    desc = f"case {case}: {alg} {m}x{n} k={k} {'sparse' if sparse else storage} iters={iters} prog={prog} tol={tol} min_iter={min_iter} tolcount={tolcount}"
+    if ref.result == 0 and ref.iteration_count < iters:
+        stats["converged early"] = stats.get("converged early", 0) + 1
     if got.result != ref.result:
         bad.append(desc + f" result {got.result} vs oracle {ref.result}")
         continue
@@ -55,7 +64,7 @@ for case in range(cases):
     tol = 1e-8 if sparse else 1e-4
     if not (eW < tol and eH < tol) or got.iteration_count != ref.iteration_count:
         bad.append(desc + f" relW {eW:.2e} relH {eH:.2e} iters {got.iteration_count}/{ref.iteration_count}")
-print(f"{cases} cases in {time.time()-t0:.1f}s; coverage {sorted(stats.items())}")
+print(f"{cases} cases in {time.time()-t0:.1f}s; coverage {sorted(stats.items(), key=str)}")
 print("FAILURES:" if bad else "all cases within tolerance")
 for b in bad:
     print("  ", b)
