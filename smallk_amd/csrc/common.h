@@ -105,8 +105,9 @@ int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int*
 // delta-fnorm: out[0] = sum (W - Wprev)^2, out[1] = sum W^2 ; then Wprev = W
 int launch_delta_fnorm(const double* W, double* Wprev, i64 count, double* partials, double* out2, hipStream_t st);
 int launch_zero_f64(double* p, i64 n, hipStream_t st);
-int launch_copy3(double* d0, const double* s0, i64 n0, double* d1, const double* s1, i64 n1, double* d2, const double* s2,
-                 i64 n2, hipStream_t st);
+// live rows of W' and H + the Gram matrix <-> one compact buffer (pack != 0: factors -> buffer)
+size_t snapshot_elems(int k, i64 m, i64 n);
+int launch_snapshot(double* Wt, i64 m, double* H, i64 n, double* G, double* buf, int k, int pack, hipStream_t st);
 // RANK2: closed-form 2x2 solve + optimal active set (side 0: H, side 1: W'); with Gout the Gram matrix
 // X X' of the result comes out of the same pass (scratch: rank2_gram_scratch_elems(N) doubles)
 int launch_rank2_solve(double* X, i64 N, PartialView R, const double* G, int side, int* fail_flag, int iter_tag,

@@ -199,25 +199,36 @@ int launch_gather_cols(const void* src, i64 ld_src_bytes, const unsigned* cols_d
     return 0;
 }
 
-// three fp64 arrays in one launch (snapshot / restore of W, H and W'W around a speculative iteration)
-__global__ __launch_bounds__(256) void copy3_kernel(double* __restrict__ d0, const double* __restrict__ s0, i64 n0,
-                                                    double* __restrict__ d1, const double* __restrict__ s1, i64 n1,
-                                                    double* __restrict__ d2, const double* __restrict__ s2, i64 n2)
+// Snapshot / restore of the factors around a speculative iteration: the k2 = round_up(k, 2) live rows
+// of W' (KP x m) and H (KP x n) -- pad rows are zero and stay zero -- plus the KP x KP Gram matrix, in
+// one launch.  `pack` != 0: factors -> compact buffer, else the reverse.
+__global__ __launch_bounds__(256) void snapshot_kernel(double* __restrict__ Wt, i64 m, double* __restrict__ H, i64 n,
+                                                       double* __restrict__ G, double* __restrict__ buf, int KP, int k2,
+                                                       int pack)
 {
-    const i64 total = n0 + n1 + n2;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
-        if (i < n0) d0[i] = s0[i];
-        else if (i < n0 + n1) d1[i - n0] = s1[i - n0];
-        else d2[i - n0 - n1] = s2[i - n0 - n1];
+    const int h2 = k2 / 2;                                 // 16-byte pairs per column
+    const i64 nw = m * h2, nh = n * h2, ng = (i64)KP * KP / 2;
+    f64x2_t* b2 = (f64x2_t*)buf;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nw + nh + ng; i += (i64)gridDim.x * 256) {
+        f64x2_t* p;
+        if (i < nw) p = (f64x2_t*)(Wt + (i / h2) * KP) + (i % h2);
+        else if (i < nw + nh) p = (f64x2_t*)(H + ((i - nw) / h2) * KP) + ((i - nw) % h2);
+        else p = (f64x2_t*)G + (i - nw - nh);
+        if (pack) b2[i] = *p;
+        else *p = b2[i];
     }
 }
-int launch_copy3(double* d0, const double* s0, i64 n0, double* d1, const double* s1, i64 n1, double* d2, const double* s2,
-                 i64 n2, hipStream_t st)
+size_t snapshot_elems(int k, i64 m, i64 n)
 {
-    const i64 total = n0 + n1 + n2;
-    if (total <= 0) return 0;
+    const int KP = kp_of(k), k2 = (k + 1) / 2 * 2;
+    return (size_t)((m + n) * k2 + (i64)KP * KP);
+}
+int launch_snapshot(double* Wt, i64 m, double* H, i64 n, double* G, double* buf, int k, int pack, hipStream_t st)
+{
+    const int KP = kp_of(k), k2 = (k + 1) / 2 * 2;
+    const i64 total = (m + n) * (k2 / 2) + (i64)KP * KP / 2;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    copy3_kernel<<<grid, 256, 0, st>>>(d0, s0, n0, d1, s1, n1, d2, s2, n2);
+    snapshot_kernel<<<grid, 256, 0, st>>>(Wt, m, H, n, G, buf, KP, k2, pack);
     SMK_HIP(hipGetLastError());
     return 0;
 }

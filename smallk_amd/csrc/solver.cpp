@@ -878,9 +878,8 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
     SMK_HIP(hipMemcpyAsync(s->pin[b].h, s->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s->st));
     SMK_HIP(hipMemcpyAsync(&s->pin[b].flag, s->fail_flag, sizeof(int), hipMemcpyDeviceToHost, s->st));
     if (snapshot) {
-        const i64 nw = (i64)s->KP * s->m, nh = (i64)s->KP * s->n, ng = (i64)s->KP * s->KP;
-        if (!s->snap[b]) { rc = dev_alloc(&s->snap[b], (size_t)(nw + nh + ng)); if (rc) return rc; }
-        rc = launch_copy3(s->snap[b], s->Wt, nw, s->snap[b] + nw, s->H, nh, s->snap[b] + nw + nh, s->Gw, ng, s->st);
+        if (!s->snap[b]) { rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
+        rc = launch_snapshot(s->Wt, s->m, s->H, s->n, s->Gw, s->snap[b], s->k, 1, s->st);
         if (rc) return rc;
     }
     SMK_HIP(hipEventRecord(s->pev[b], s->st));
@@ -897,8 +896,7 @@ static int progress_end(smk_solver* s, int b, int iter_index, double* metric)
 
 static int progress_restore(smk_solver* s, int b)
 {
-    const i64 nw = (i64)s->KP * s->m, nh = (i64)s->KP * s->n, ng = (i64)s->KP * s->KP;
-    int rc = launch_copy3(s->Wt, s->snap[b], nw, s->H, s->snap[b] + nw, nh, s->Gw, s->snap[b] + nw + nh, ng, s->st);
+    int rc = launch_snapshot(s->Wt, s->m, s->H, s->n, s->Gw, s->snap[b], s->k, 0, s->st);
     if (rc) return rc;
     // whatever the undone iteration did to the failure flag is void; products / HH' are stale
     const int big = INT_MAX;
