@@ -90,6 +90,10 @@ int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, h
 // gradient G*X - R, optional store, projected-gradient partial sums -> pg_accum[slot] += sum
 int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
                    double* pg_partials, double* pg_accum, int slot, hipStream_t st);
+// both factors in two launches; also mirrors *flag into pg_accum[flag_slot] (as a double)
+int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,
+                    PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,
+                    int flag_slot, hipStream_t st);
 // projected-gradient sum from an existing gradient array
 int launch_pg_from_grad(const double* X, const double* Y, int k, i64 N, double* pg_partials, double* pg_accum,
                         int slot, hipStream_t st);

@@ -1029,6 +1029,19 @@ __global__ void sum_partials_kernel(const double* __restrict__ partials, int n, 
     if (threadIdx.x == 0) *out = t;
 }
 
+// two partial arrays in one launch (block b sums array b into out[b]); block 0 also mirrors the
+// solver's failure flag into out[flag_slot] so that one 64-byte read-back carries everything
+__global__ void sum_partials2_kernel(const double* __restrict__ p0, int n0, const double* __restrict__ p1, int n1,
+                                     double* __restrict__ out, const int* __restrict__ flag, int flag_slot)
+{
+    __shared__ double sh[16];
+    const double t = (blockIdx.x == 0) ? block_sum_array(p0, n0, sh) : block_sum_array(p1, n1, sh);
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = t;
+        if (blockIdx.x == 0 && flag) out[flag_slot] = (double)*flag;
+    }
+}
+
 // ==========================================================================
 // Gram matrix  G(KP x KP, ld KP) = X X'   (X: KP x N fp64), deterministic two stage
 // ==========================================================================
@@ -1313,13 +1326,20 @@ __global__ __launch_bounds__(256) void hals_sweep_kernel(double* __restrict__ X,
 
 // ---- gradient g = G x - R, projected-gradient partial sums ---------------------------
 //      (mu :156-161, hals :181-195, bpp :370-371; projected_gradient.hpp:125-171)
+// one workgroup of the gradient / projected-gradient pass over the column tile `bid` of X
 template <int KP>
-__global__ __launch_bounds__(256) void grad_pg_kernel(const double* __restrict__ X, int k, i64 N, PartialView R,
-                                                      const double* __restrict__ G, double* __restrict__ grad_out,
-                                                      double* __restrict__ partials)
+__device__ __forceinline__ void grad_pg_body(const double* __restrict__ X, int k, i64 N, const PartialView& R,
+                                             const double* __restrict__ G, double* __restrict__ grad_out,
+                                             double* __restrict__ partials, int bid, double* gs, double* sh)
 {
-    __shared__ double sh[16];
-    COLTILE_PROLOGUE(KP)
+    constexpr int LPC = KP / 4;
+    for (int i_ = threadIdx.x; i_ < KP * KP; i_ += blockDim.x) gs[i_] = G[i_];
+    __syncthreads();
+    const i64 gtid = (i64)bid * blockDim.x + threadIdx.x;
+    const i64 j = gtid / LPC;
+    const int s = (int)(gtid % LPC);
+    const bool valid = j < N;
+    const i64 jc = valid ? j : (N - 1);
     double x[4], b[4], g[4] = {0, 0, 0, 0};
     load4(X + jc * KP + 4 * s, x);
     load_rhs4(R, jc, 4 * s, b);
@@ -1338,7 +1358,30 @@ __global__ __launch_bounds__(256) void grad_pg_kernel(const double* __restrict__
         if (grad_out) store4(grad_out + j * KP + 4 * s, g);
     }
     const double t = block_sum(sum, sh);
-    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    if (threadIdx.x == 0) partials[bid] = t;
+}
+
+template <int KP>
+__global__ __launch_bounds__(256) void grad_pg_kernel(const double* __restrict__ X, int k, i64 N, PartialView R,
+                                                      const double* __restrict__ G, double* __restrict__ grad_out,
+                                                      double* __restrict__ partials)
+{
+    __shared__ double sh[16];
+    __shared__ __attribute__((aligned(16))) double gs[KP * KP];
+    grad_pg_body<KP>(X, k, N, R, G, grad_out, partials, blockIdx.x, gs, sh);
+}
+
+// both factors in one launch: workgroups [0, grid1) take side 1 (W'), the rest side 2 (H)
+template <int KP>
+__global__ __launch_bounds__(256) void grad_pg2_kernel(const double* __restrict__ X1, i64 N1, PartialView R1,
+                                                       const double* __restrict__ G1, double* __restrict__ part1,
+                                                       int grid1, const double* __restrict__ X2, i64 N2, PartialView R2,
+                                                       const double* __restrict__ G2, double* __restrict__ part2, int k)
+{
+    __shared__ double sh[16];
+    __shared__ __attribute__((aligned(16))) double gs[KP * KP];
+    if ((int)blockIdx.x < grid1) grad_pg_body<KP>(X1, k, N1, R1, G1, nullptr, part1, blockIdx.x, gs, sh);
+    else grad_pg_body<KP>(X2, k, N2, R2, G2, nullptr, part2, blockIdx.x - grid1, gs, sh);
 }
 
 __global__ __launch_bounds__(256) void pg_from_grad_kernel(const double* __restrict__ X, const double* __restrict__ Y,
@@ -1387,6 +1430,20 @@ int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G
     KP_DISPATCH(KPv, (grad_pg_kernel<KP><<<grid, 256, 0, st>>>(X, k, N, R, G, grad_out, pg_partials)));
     SMK_HIP(hipGetLastError());
     sum_partials_kernel<<<1, 256, 0, st>>>(pg_partials, grid, pg_accum + slot);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// projected-gradient sums of both factors: pg_accum[0] (side 1), pg_accum[1] (side 2), and the failure flag
+// as a double in pg_accum[flag_slot]; two launches instead of four
+int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,
+                    PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,
+                    int flag_slot, hipStream_t st)
+{
+    const int KPv = kp_of(k), g1 = coltile_grid(KPv, N1), g2 = coltile_grid(KPv, N2);
+    KP_DISPATCH(KPv, (grad_pg2_kernel<KP><<<g1 + g2, 256, 0, st>>>(X1, N1, R1, G1, part1, g1, X2, N2, R2, G2, part2, k)));
+    SMK_HIP(hipGetLastError());
+    sum_partials2_kernel<<<2, 256, 0, st>>>(part1, g1, part2, g2, pg_accum, flag, flag_slot);
     SMK_HIP(hipGetLastError());
     return 0;
 }

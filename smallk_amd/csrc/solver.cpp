@@ -93,7 +93,7 @@ struct smk_solver {
     void* ar_user = nullptr;
     // stopping rule evaluated one iteration late (smk_solver_run): pinned result slots, events, and a
     // snapshot of (W, H, W'W) per checked iteration so that a speculative iteration can be undone
-    struct ProgSlot { double h[4]; int flag; int pad; };
+    struct ProgSlot { double h[8]; int flag; int fused; };     // fused: the flag travels in h[5]
     ProgSlot* pin = nullptr;
     hipEvent_t pev[2] = {nullptr, nullptr};
     double* snap[2] = {nullptr, nullptr};
@@ -873,10 +873,21 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
         SMK_HIP(hipHostMalloc((void**)&s->pin, 2 * sizeof(smk_solver::ProgSlot)));
         for (int i = 0; i < 2; ++i) SMK_HIP(hipEventCreateWithFlags(&s->pev[i], hipEventDisableTiming));
     }
-    int rc = enqueue_progress_kernels(s);
-    if (rc) return rc;
-    SMK_HIP(hipMemcpyAsync(s->pin[b].h, s->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s->st));
-    SMK_HIP(hipMemcpyAsync(&s->pin[b].flag, s->fail_flag, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    int rc = 0;
+    if (s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !s->ar) {
+        // both gradients in one launch, both sums + the failure flag in a second, one 64-byte read-back
+        rc = launch_grad_pg2(s->Wt, s->m, view2(s), s->Gh, s->pg_partials, s->H, s->n, view1(s), s->Gw,
+                             s->pg_partials + s->pg_half, s->k, s->scal, s->fail_flag, 5, s->st);
+        if (rc) return rc;
+        s->pin[b].fused = 1;
+        SMK_HIP(hipMemcpyAsync(s->pin[b].h, s->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    } else {
+        rc = enqueue_progress_kernels(s);
+        if (rc) return rc;
+        s->pin[b].fused = 0;
+        SMK_HIP(hipMemcpyAsync(s->pin[b].h, s->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, s->st));
+        SMK_HIP(hipMemcpyAsync(&s->pin[b].flag, s->fail_flag, sizeof(int), hipMemcpyDeviceToHost, s->st));
+    }
     if (snapshot) {
         if (!s->snap[b]) { rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
         rc = launch_snapshot(s->Wt, s->m, s->H, s->n, s->Gw, s->snap[b], s->k, 1, s->st);
@@ -890,6 +901,7 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
 static int progress_end(smk_solver* s, int b, int iter_index, double* metric)
 {
     SMK_HIP(hipEventSynchronize(s->pev[b]));
+    if (s->pin[b].fused) s->pin[b].flag = (int)s->pin[b].h[5];
     if (s->pin[b].flag != INT_MAX) return SMK_FAILURE;
     return evaluate_progress(s, s->pin[b].h, iter_index, metric);
 }
