@@ -109,6 +109,8 @@ int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int*
 // delta-fnorm: out[0] = sum (W - Wprev)^2, out[1] = sum W^2 ; then Wprev = W
 int launch_delta_fnorm(const double* W, double* Wprev, i64 count, double* partials, double* out2, hipStream_t st);
 int launch_zero_f64(double* p, i64 n, hipStream_t st);
+// dst (k x N, ld k) = first k rows of src (KP x N, ld KP)
+int launch_compact_rows(const double* src, int KP, double* dst, int k, i64 N, hipStream_t st);
 // live rows of W' and H + the Gram matrix <-> one compact buffer (pack != 0: factors -> buffer)
 size_t snapshot_elems(int k, i64 m, i64 n);
 int launch_snapshot(double* Wt, i64 m, double* H, i64 n, double* G, double* buf, int k, int pack, hipStream_t st);

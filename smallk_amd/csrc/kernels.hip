@@ -233,6 +233,24 @@ int launch_snapshot(double* Wt, i64 m, double* H, i64 n, double* G, double* buf,
     return 0;
 }
 
+// dst (k x N, ld k) = first k rows of src (KP x N, ld KP): the host-facing layout of a factor
+__global__ __launch_bounds__(256) void compact_rows_kernel(const double* __restrict__ src, int KP, double* __restrict__ dst,
+                                                           int k, i64 N)
+{
+    const i64 total = N * k;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256)
+        dst[i] = src[(i / k) * KP + (i % k)];
+}
+int launch_compact_rows(const double* src, int KP, double* dst, int k, i64 N, hipStream_t st)
+{
+    const i64 total = N * k;
+    if (total <= 0) return 0;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    compact_rows_kernel<<<grid, 256, 0, st>>>(src, KP, dst, k, N);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ void zero_f64_kernel(double* p, i64 n)
 {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) p[i] = 0.0;

@@ -77,6 +77,7 @@ struct smk_solver {
     hipStream_t st = nullptr;
     double *H = nullptr, *Wt = nullptr, *Gw = nullptr, *Gh = nullptr, *gram_scratch = nullptr;
     double *Wprev = nullptr, *hals_scratch = nullptr, *pg_partials = nullptr, *scal = nullptr, *tmpW = nullptr;
+    double* tmpH = nullptr;               // k x n compact copy of H for the host (get_factors)
     double *Gh_own = nullptr, *scal_own = nullptr, *Wt_own = nullptr;
     void *packW = nullptr, *packH = nullptr;
     double *P1 = nullptr, *P2 = nullptr;
@@ -557,7 +558,7 @@ void smk_solver_destroy(smk_solver* s)
 {
     if (!s) return;
     void* ptrs[] = {s->H, s->Wt_own, s->Gw, s->Gh_own, s->gram_scratch, s->tmpW, s->pg_partials, s->scal_own,
-                    s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev};
+                    s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int w = 0; w < 2; ++w)
@@ -1111,10 +1112,31 @@ int smk_solver_get_factors(smk_solver* s, int normalize, double* W, int64_t ldW,
     if (normalize) { rc = normalize_device(s); if (rc) return rc; }
     rc = launch_transpose_f64(s->Wt, s->KP, s->tmpW, s->m, s->k, s->m, s->st);
     if (rc) return rc;
-    SMK_HIP(hipMemcpy2DAsync(W, (size_t)ldW * sizeof(double), s->tmpW, (size_t)s->m * sizeof(double),
-                             (size_t)s->m * sizeof(double), (size_t)s->k, hipMemcpyDeviceToHost, s->st));
-    SMK_HIP(hipMemcpy2DAsync(H, (size_t)ldH * sizeof(double), s->H, (size_t)s->KP * sizeof(double),
-                             (size_t)s->k * sizeof(double), (size_t)s->n, hipMemcpyDeviceToHost, s->st));
+    // Device-to-host copies are kept contiguous: a strided hipMemcpy2DAsync into pageable memory leaves
+    // ~190 KiB of runtime staging behind per call on this ROCm (1200 one-shot sparse runs: 230 MiB).
+    if (ldW == s->m) {
+        SMK_HIP(hipMemcpyAsync(W, s->tmpW, (size_t)s->m * s->k * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    } else {
+        for (int c = 0; c < s->k; ++c)
+            SMK_HIP(hipMemcpyAsync(W + (size_t)c * ldW, s->tmpW + (size_t)c * s->m, (size_t)s->m * sizeof(double),
+                                   hipMemcpyDeviceToHost, s->st));
+    }
+    if (s->k == s->KP && ldH == s->k) {
+        SMK_HIP(hipMemcpyAsync(H, s->H, (size_t)s->k * s->n * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    } else {
+        if (!s->tmpH) { rc = dev_alloc(&s->tmpH, (size_t)s->k * s->n); if (rc) return rc; }
+        rc = launch_compact_rows(s->H, s->KP, s->tmpH, s->k, s->n, s->st);
+        if (rc) return rc;
+        if (ldH == s->k) {
+            SMK_HIP(hipMemcpyAsync(H, s->tmpH, (size_t)s->k * s->n * sizeof(double), hipMemcpyDeviceToHost, s->st));
+        } else {      // caller's leading dimension exceeds k: compact on the device, scatter on the host
+            std::vector<double> tmp((size_t)s->k * s->n);
+            SMK_HIP(hipMemcpyAsync(tmp.data(), s->tmpH, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, s->st));
+            SMK_HIP(hipStreamSynchronize(s->st));
+            for (i64 c = 0; c < s->n; ++c)
+                std::copy(tmp.begin() + c * s->k, tmp.begin() + (c + 1) * s->k, H + c * ldH);
+        }
+    }
     return sync_and_check(s, nullptr);
 }
 
