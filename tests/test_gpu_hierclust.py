@@ -257,3 +257,43 @@ def test_sparse_gather_cols_on_device(gpu, alg):
     if len(empty):
         assert l.smk_matrix_gather_cols(src._h, empty.ctypes.data_as(C.POINTER(C.c_uint)), len(empty), C.byref(sub), None,
                                         None) == L.BAD_PARAM
+
+
+@pytest.mark.parametrize("name", ["dense5", "dense_outliers", "sparse6", "sparse_outliers"])
+def test_against_committed_fixtures(gpu, tmp_path, name):
+    """The product against tests/golden/hier_golden.npz (committed; generator: make_hier_golden.py):
+    tree structure, document counts, top terms, assignments, outliers, factorisation counts, the tree
+    files byte for byte, and the flat labels where the fixture has a flat step."""
+    import importlib.util
+    g = np.load(os.path.join(ROOT, "tests", "golden", "hier_golden.npz"))
+    spec = importlib.util.spec_from_file_location("make_hier_golden", os.path.join(ROOT, "tests", "golden", "make_hier_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    m, n, topics, dseed, tiny, sparse, clusters, seed, flat = mod.CASES[name]
+    A, _ = planted(m, n, topics, dseed, sparse=sparse, tiny=tiny)
+    res = gpu.hier_nmf2(A, clusters, seed=seed, maxterms=4, flat=flat)
+    nodes = res.nodes
+    assert np.array_equal(res.get_assignments(), g[f"{name}/assignments"])
+    assert np.array_equal(res.get_outliers(), g[f"{name}/outliers"])
+    assert [nd.parent for nd in nodes] == list(g[f"{name}/parent"])
+    assert [nd.left for nd in nodes] == list(g[f"{name}/left"]) and [nd.right for nd in nodes] == list(g[f"{name}/right"])
+    assert [len(nd.docs) for nd in nodes] == list(g[f"{name}/doc_count"])
+    assert (res.nmf_count, res.max_count) == tuple(g[f"{name}/counts"])
+    for q, nd in enumerate(nodes):
+        if nd.is_valid:
+            assert nd.term_indices == list(g[f"{name}/terms"][q]), q
+            assert nd.priority == pytest.approx(float(g[f"{name}/priority"][q]), rel=(1e-9 if sparse else 2e-3), abs=1e-12)
+    dictionary = [f"w{i}" for i in range(m)]
+    for fmt, key in (("JSON", "tree_json"), ("XML", "tree_xml")):
+        p = str(tmp_path / f"t.{fmt}")
+        assert res.write(p, dictionary, fmt)
+        assert open(p).read() == str(g[f"{name}/{key}"])
+    pa = str(tmp_path / "a.csv")
+    assert res.write_assignments(pa) and open(pa).read() == str(g[f"{name}/assign_text"])
+    if flat:
+        W, H = res.flat_factors()
+        assert np.array_equal(gpu.flatclust.compute_assignments(H), g[f"{name}/flat_labels"])
+        assert np.array_equal(gpu.flatclust.top_terms(W, 4), g[f"{name}/flat_terms"])
+        tol = 1e-7 if sparse else 2e-4
+        assert np.max(np.abs(W - g[f"{name}/flat_W"])) <= tol * np.max(np.abs(g[f"{name}/flat_W"]))
+        assert np.max(np.abs(H - g[f"{name}/flat_H"])) <= tol * np.max(np.abs(g[f"{name}/flat_H"]))

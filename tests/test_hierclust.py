@@ -142,3 +142,32 @@ def test_clust_options_validation():
         with pytest.raises(L.SmallkError) as e:
             smallk_amd.hier_nmf2(np.ones((8, 8)), 2)
         assert e.value.code == L.NOTINITIALIZED
+
+
+@pytest.fixture(scope="module")
+def hier_golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "hier_golden.npz"))
+
+
+def _hier_case(name):
+    sys_path = os.path.join(ROOT, "tests", "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_hier_golden", os.path.join(sys_path, "make_hier_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("name", ["dense5", "dense_outliers", "sparse6", "sparse_outliers"])
+def test_oracle_reproduces_committed_hier_fixtures(hier_golden, name):
+    """tests/golden/hier_golden.npz (made by tests/golden/make_hier_golden.py) pins the clustering
+    oracle: trees, assignments, file texts and the flat factors must come out bit for bit."""
+    got = _hier_case(name).run(name)
+    for key, val in got.items():
+        ref = hier_golden[f"{name}/{key}"]
+        if val.dtype.kind in "US":
+            assert str(val) == str(ref), key
+        elif val.dtype.kind == "f":
+            assert np.allclose(val, ref, rtol=1e-12, atol=0), key
+        else:
+            assert np.array_equal(val, ref), key
