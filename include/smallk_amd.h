@@ -191,6 +191,9 @@ int smk_clust_dense(const smk_clust_options* opts, const double* A, int64_t ldA,
 int smk_clust_sparse(const smk_clust_options* opts, int64_t nnz, const unsigned* col_offsets,
                      const unsigned* row_indices, const double* data, uint64_t seed, uint64_t* draws,
                      const char* initdir, smk_tree** tree, smk_clust_stats* stats);
+/* on a matrix that already lives in HBM (smk_matrix_create[_sparse]); options height/width must match it */
+int smk_clust_resident(const smk_clust_options* opts, const smk_matrix* a, uint64_t seed, uint64_t* draws,
+                       const char* initdir, smk_tree** tree, smk_clust_stats* stats);
 void smk_tree_destroy(smk_tree* t);
 int smk_tree_node_count(const smk_tree* t);
 int64_t smk_tree_term_count(const smk_tree* t);

@@ -148,6 +148,8 @@ SYMBOLS = {
     "smk_clust_sparse": (C.c_int, [C.POINTER(ClustOptions), _i64, C.POINTER(C.c_uint), C.POINTER(C.c_uint), _dp,
                                    C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.POINTER(_vp),
                                    C.POINTER(ClustStats)]),
+    "smk_clust_resident": (C.c_int, [C.POINTER(ClustOptions), _vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p,
+                                     C.POINTER(_vp), C.POINTER(ClustStats)]),
     "smk_tree_destroy": (None, [_vp]),
     "smk_tree_node_count": (C.c_int, [_vp]),
     "smk_tree_term_count": (_i64, [_vp]),

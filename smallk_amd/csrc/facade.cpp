@@ -309,6 +309,36 @@ static uint64_t rng_seed = 0;
 static uint64_t rng_draws = 0;            // so that successive RandomMatrix calls differ
 static DeviceStorage device_storage = DEVICE_F32;
 static NmfStats last_stats;
+// The loaded matrix is uploaded to HBM once and stays there across Nmf / HierNmf2 calls
+// (smallk_example.cpp factors the same matrix seven times); dropped by Reset / LoadMatrix / Finalize
+// and rebuilt when the device storage type changes.
+static smk_matrix* resident = nullptr;
+static int resident_storage = -1;
+static void drop_resident()
+{
+    if (resident) smk_matrix_destroy(resident);
+    resident = nullptr;
+    resident_storage = -1;
+}
+static smk_matrix* ensure_resident()
+{
+    const int want = is_sparse ? SMK_STORE_F32 : (int)device_storage;
+    if (resident && resident_storage == want) return resident;
+    drop_resident();
+    int rc;
+    if (is_sparse) {
+        rc = smk_matrix_create_sparse(&resident, m, n, 0, n, (int64_t)sp_data.size(), &sp_cols[0], &sp_rows[0], &sp_data[0]);
+    } else {
+        rc = smk_matrix_create(&resident, m, n, 0, n, want);
+        if (rc == SMK_OK) rc = smk_matrix_upload_f64(resident, &buf_a[0], ldim_a);
+    }
+    if (rc != SMK_OK) {
+        drop_resident();
+        throw std::runtime_error(std::string("smallk error: could not place the matrix on the device: ") + smk_last_error());
+    }
+    resident_storage = want;
+    return resident;
+}
 static bool dict_loaded = false;
 static std::string dict_filepath;
 static std::vector<std::string> dictionary;
@@ -335,6 +365,7 @@ void Reset()
     clustfile_format = OutputFormat::JSON;
     outdir = std::string("");
     matrix_loaded = false;
+    drop_resident();
     dict_loaded = false;
     is_sparse = false;
     matrix_filepath.clear();
@@ -354,7 +385,11 @@ void Initialize(int& /*argc*/, char**& /*argv*/)
 }
 
 bool IsInitialized() { return smk_is_initialized() == SMK_INITIALIZED; }
-void Finalize() { smk_finalize(); }
+void Finalize()
+{
+    drop_resident();
+    smk_finalize();
+}
 
 unsigned int GetMajorVersion() { return SMALLK_MAJOR_VERSION; }
 unsigned int GetMinorVersion() { return SMALLK_MINOR_VERSION; }
@@ -390,6 +425,7 @@ void LoadMatrix(const std::string& filepath)
     if (filepath.empty()) throw std::runtime_error("smallk error (LoadMatrix): matrix filename is invalid.");
     std::cout << "Loading matrix..." << std::endl;
     matrix_loaded = false;
+    drop_resident();
     if (has_ext(filepath, "MTX")) {       // IsSparse(filepath): MatrixMarket -> sparse (smallk.cpp:172-186)
         if (!smallk_amd_io::LoadMatrixMarket(filepath, m, n, sp_cols, sp_rows, sp_data)) {
             matrix_filepath.clear();
@@ -418,6 +454,7 @@ void LoadMatrix(const double* buffer, const unsigned int ldim, const unsigned in
 {
     std::cout << "Loading dense matrix..." << std::endl;
     matrix_loaded = false;
+    drop_resident();
     if (0 == height) throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): invalid height input.");
     if (0 == width) throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): invalid width input.");
     if (!buffer) throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): empty data pointer.");
@@ -440,6 +477,7 @@ void LoadMatrix(const unsigned int height, const unsigned int width, const unsig
 {
     std::cout << "Loading sparse matrix..." << std::endl;
     matrix_loaded = false;
+    drop_resident();
     if (row_indices.size() != data.size())
         throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): invalid input vectors.");
     if (0 == height) throw std::runtime_error("smallk error (LoadSparseMatrixFromBuffer): invalid height input.");
@@ -631,21 +669,32 @@ void Nmf(const unsigned int kval, const Algorithm algorithm, const std::string& 
     opts.normalize = true;
     print_opts(opts);
 
+    // the inner seam's checks (::Nmf, nmf.cpp:173-229) without its per-call upload: A is resident
     NmfStats stats;
-    const int saved = NmfGetDeviceStorage();
-    NmfSetDeviceStorage((int)device_storage);
-    Result result;
-    try {
-        if (is_sparse)
-            result = ::NmfSparse(opts, m, n, (unsigned int)sp_data.size(), &sp_cols[0], &sp_rows[0], &sp_data[0],
-                                 &buf_w[0], ldim_w, &buf_h[0], ldim_h, stats);
-        else
-            result = ::Nmf(opts, &buf_a[0], ldim_a, &buf_w[0], ldim_w, &buf_h[0], ldim_h, stats);
-    } catch (...) {
-        NmfSetDeviceStorage(saved);
-        throw;
+    Result result = Result::OK;
+    {
+        smk_options c = to_c(opts);
+        if (smk_is_initialized() != SMK_INITIALIZED) {
+            std::cerr << "nmflib error: nmf_initialize() must be called prior to any factorization routine\n" << std::endl;
+            result = Result::NOTINITIALIZED;
+        } else if (!smk_is_valid(&c, 1)) {
+            result = Result::BAD_PARAM;
+        } else {
+            smk_matrix* a = ensure_resident();
+            smk_solver* sv = nullptr;
+            smk_stats st{0, 0};
+            int rc = smk_solver_create(&sv, &c, a);
+            if (rc == SMK_OK) rc = smk_solver_set_factors(sv, &buf_w[0], ldim_w, &buf_h[0], ldim_h);
+            if (rc == SMK_OK) {
+                rc = smk_solver_run(sv, &st);
+                if (rc == SMK_OK || rc == SMK_FAILURE) (void)smk_solver_get_factors(sv, 0, &buf_w[0], ldim_w, &buf_h[0], ldim_h);
+            }
+            smk_solver_destroy(sv);
+            stats.elapsed_us = st.elapsed_us;
+            stats.iteration_count = st.iteration_count;
+            result = to_result(rc);
+        }
     }
-    NmfSetDeviceStorage(saved);
     last_stats = stats;
 
     std::cout << "Elapsed wall clock time: " << elapsed_string(stats.elapsed_us) << std::endl << std::endl;
@@ -758,11 +807,7 @@ static void hier_nmf2_internal(const bool generate_flat, const unsigned int num_
     smk_clust_stats stats = {0, 0};
     const auto t0 = std::chrono::high_resolution_clock::now();
     int rc;
-    if (is_sparse)
-        rc = smk_clust_sparse(&co, (int64_t)sp_data.size(), &sp_cols[0], &sp_rows[0], &sp_data[0], rng_seed,
-                              &rng_draws, nullptr, &tree, &stats);
-    else
-        rc = smk_clust_dense(&co, &buf_a[0], ldim_a, (int)device_storage, rng_seed, &rng_draws, nullptr, &tree, &stats);
+    rc = smk_clust_resident(&co, ensure_resident(), rng_seed, &rng_draws, nullptr, &tree, &stats);
     const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
                             std::chrono::high_resolution_clock::now() - t0).count();
     cout << "\nElapsed wall clock time: " << elapsed_string(us) << endl;

@@ -637,6 +637,16 @@ int smk_clust_sparse(const smk_clust_options* opts, int64_t nnz, const unsigned*
     return rc;
 }
 
+// the same on a matrix that already lives in HBM (dense or sparse; not modified, not owned)
+int smk_clust_resident(const smk_clust_options* opts, const smk_matrix* a, uint64_t seed, uint64_t* draws,
+                       const char* initdir, smk_tree** tree, smk_clust_stats* stats)
+{
+    int rc = precheck(opts, tree);
+    if (rc != SMK_OK) return rc;
+    if (!a) return SMK_BAD_PARAM;
+    return run_clust(opts, const_cast<smk_matrix*>(a), seed, draws, initdir, tree, stats);
+}
+
 void smk_tree_destroy(smk_tree* t) { delete t; }
 int smk_tree_node_count(const smk_tree* t) { return t ? (int)t->nodes.size() : 0; }
 int64_t smk_tree_term_count(const smk_tree* t) { return t ? t->term_count : 0; }

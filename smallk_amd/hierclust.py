@@ -108,15 +108,19 @@ def make_clust_options(m, n, num_clusters, *, tol=1e-4, min_iter=5, max_iter=500
 
 
 def hier_nmf2(A, num_clusters, *, seed=0, draws=0, initdir="", storage="f32", **kw) -> TreeResults:
-    """Clust (dense ndarray) / ClustSparse (scipy.sparse matrix) -> TreeResults."""
+    """Clust (dense ndarray) / ClustSparse (scipy.sparse matrix) -> TreeResults.  A may also be a
+    ``DenseMatrix`` / ``SparseMatrix`` that is already resident in HBM (no upload, ``storage`` ignored)."""
     l = L.lib()
-    m, n = A.shape
+    resident = hasattr(A, "_h") and hasattr(A, "height")       # a DenseMatrix / SparseMatrix already in HBM
+    m, n = (A.height, A.ncols) if resident else A.shape
     o = make_clust_options(m, n, num_clusters, **kw)
     tree = C.c_void_p()
     stats = L.ClustStats()
     dr = C.c_uint64(draws)
     idir = initdir.encode() if initdir else None
-    if hasattr(A, "tocsc"):
+    if resident:
+        rc = l.smk_clust_resident(C.byref(o), A._h, seed, C.byref(dr), idir, C.byref(tree), C.byref(stats))
+    elif hasattr(A, "tocsc"):
         a = A.tocsc()
         a.sort_indices()
         co = np.ascontiguousarray(a.indptr, dtype=np.uint32)

@@ -297,3 +297,29 @@ def test_against_committed_fixtures(gpu, tmp_path, name):
         tol = 1e-7 if sparse else 2e-4
         assert np.max(np.abs(W - g[f"{name}/flat_W"])) <= tol * np.max(np.abs(g[f"{name}/flat_W"]))
         assert np.max(np.abs(H - g[f"{name}/flat_H"])) <= tol * np.max(np.abs(g[f"{name}/flat_H"]))
+
+
+def test_resident_matrix_is_reused(gpu):
+    """smk_clust_resident: the tree search on a matrix that is already in HBM (what smallk::HierNmf2 now
+    does: the façade uploads the loaded matrix once and keeps it for every later Nmf / HierNmf2 call)."""
+    import oracle
+    from oracle import hierclust as oh
+    A, _ = planted(150, 260, 3, 4, sparse=True, tiny=5)
+    D, _ = planted(120, 200, 4, 21)
+    sm = gpu.SparseMatrix.from_scipy(A)
+    dm = gpu.DenseMatrix.from_host(D, storage="bf16")
+    for seed in (1, 2):                                  # twice on the same resident matrices
+        r = gpu.hier_nmf2(sm, 4, seed=seed)
+        ot, ost = oh.hier_nmf2(A, 4, seed=seed)
+        compare(r, ot, ost, 150, prio_rel=1e-9, topic_rel=1e-6)
+        r = gpu.hier_nmf2(dm, 4, seed=seed)
+        ot, ost = oh.hier_nmf2(oracle.quantize(D, 1), 4, seed=seed)
+        compare(r, ot, ost, 120)
+    # and a plain factorisation on the same resident dense matrix afterwards
+    W0, H0 = oracle.fill_uniform(120, 6, 1), oracle.fill_uniform(6, 200, 2) / 3
+    s = gpu.NmfSolver(dm, gpu.make_options(120, 200, 6, "BPP", min_iter=4, max_iter=4))
+    s.set_factors(W0, H0)
+    s.run()
+    W, H = s.factors()
+    ref = oracle.nmf(oracle.quantize(D, 1), W0, H0, "BPP", min_iter=4, max_iter=4)
+    assert np.linalg.norm(W - ref.W) / np.linalg.norm(ref.W) < 1e-4
