@@ -1999,10 +1999,52 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const i64* __restrict_
     if (4 * s < kpp) store4(P + j * kpp + 4 * s, acc);
 }
 
+// k <= 2 (the RANK2 / HierNMF2 hot loop): one lane per output column, 16 bytes of the X row per stored
+// entry instead of two lanes x 32 bytes, two independent accumulation chains per lane so that two
+// gathers are in flight.  `ldx` = row pitch of X in doubles (KP, or 2 for a compact copy).
+__global__ __launch_bounds__(256) void spmm_gather2_kernel(const i64* __restrict__ colptr,
+                                                           const unsigned* __restrict__ rowidx,
+                                                           const double* __restrict__ val, i64 ncols,
+                                                           const double* __restrict__ X, int ldx,
+                                                           double* __restrict__ P, int kpp)
+{
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    const i64 p0 = colptr[j], p1 = colptr[j + 1];
+    i64 p = p0;
+    for (; p + 1 < p1; p += 2) {
+        const double v0 = val[p], v1 = val[p + 1];
+        const f64x2_t x0 = *(const f64x2_t*)(X + (i64)rowidx[p] * ldx);
+        const f64x2_t x1 = *(const f64x2_t*)(X + (i64)rowidx[p + 1] * ldx);
+        a0 += v0 * x0[0]; a1 += v0 * x0[1];
+        b0 += v1 * x1[0]; b1 += v1 * x1[1];
+    }
+    if (p < p1) {
+        const double v0 = val[p];
+        const f64x2_t x0 = *(const f64x2_t*)(X + (i64)rowidx[p] * ldx);
+        a0 += v0 * x0[0]; a1 += v0 * x0[1];
+    }
+    double* out = P + j * kpp;
+    f64x2_t r;
+    r[0] = a0 + b0;
+    r[1] = a1 + b1;
+    *(f64x2_t*)out = r;
+    for (int e = 2; e < kpp && e < 8; e += 2) { f64x2_t z; z[0] = 0.0; z[1] = 0.0; *(f64x2_t*)(out + e) = z; }
+}
+
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X,
                        int k, double* P, int kpp, hipStream_t st)
 {
     const int KPv = kp_of(k);
+    static const bool rank2_path = [] { const char* e = getenv("SMK_SPMM2"); return !(e && e[0] == '0'); }();
+    if (k <= 2 && rank2_path) {
+        const int grid2 = (int)((ncols + 255) / 256);
+        if (grid2 == 0) return 0;
+        spmm_gather2_kernel<<<grid2, 256, 0, st>>>(colptr, rowidx, val, ncols, X, KPv, P, kpp);
+        SMK_HIP(hipGetLastError());
+        return 0;
+    }
     const int grid = (int)((ncols * (KPv / 4) + 255) / 256);
     if (grid == 0) return 0;
     KP_DISPATCH(KPv, (spmm_gather_kernel<KP><<<grid, 256, 0, st>>>(colptr, rowidx, val, ncols, X, P, kpp)));
