@@ -7,10 +7,11 @@
 // outlier-dropping retry loop (TrialSplit :203-327) and a modified-NDCG priority
 // (compute_priority, clust_hier_util.hpp:105-173).
 //
-// Here A is uploaded once and stays in HBM; a node's submatrix is gathered HBM -> HBM for dense A
-// (smk_matrix_gather_cols) or cut from the host CSC and uploaded for sparse A, and every
-// factorisation is the RANK2 schedule of solver.cpp.  The tree search itself is a few sorts over m
-// values per node and stays on the host, like the reference's.
+// Here A is uploaded once and stays in HBM; a node's submatrix is assembled on the device
+// (smk_matrix_gather_cols: HBM -> HBM column gather for dense A, CSC cut by prefix sums for sparse A,
+// sparse_subset.hip) and every factorisation is the RANK2 schedule of solver.cpp.  The tree search
+// itself stays on the host like the reference's; for large vocabularies its argsorts run on the GPU
+// (sort.hip).
 #include "common.h"
 #include "../../include/smallk_amd.h"
 
