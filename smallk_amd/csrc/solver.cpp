@@ -246,6 +246,7 @@ int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
     double* stage = nullptr;
     int rc = dev_alloc(&stage, (size_t)a->m * chunk);
     if (rc) return rc;
+    struct Free { void* p; ~Free() { if (p) (void)hipFree(p); } } stage_guard{stage};   // also on the error returns
     const size_t es = (size_t)elem_size(a->storage);
     for (i64 c = 0; c < a->n; c += chunk) {
         const i64 nc = (a->n - c < chunk) ? (a->n - c) : chunk;
@@ -256,7 +257,6 @@ int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
         if (rc) return rc;
         SMK_HIP(hipStreamSynchronize(g_stream));
     }
-    (void)hipFree(stage);
     rc = matrix_make_transpose(a);
     if (rc) return rc;
     SMK_HIP(hipStreamSynchronize(g_stream));

@@ -288,3 +288,14 @@ def test_hals_mean_matched_start(gpu, m, n, k, storage, quant):
         assert r.result == ref.result == 0
         assert np.linalg.norm(r.W - ref.W) / np.linalg.norm(ref.W) < 1e-4
         assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
+
+
+def test_rank_above_64_is_refused_loudly(gpu):
+    """k > 64 is valid for the reference and not built on the device path: SMK_UNSUPPORTED with a message,
+    never a silent fallback."""
+    import oracle
+    from smallk_amd import _lib as L
+    A = oracle.fill_uniform(200, 150, 1)
+    with pytest.raises(L.SmallkError) as e:
+        gpu.nmf(A, oracle.fill_uniform(200, 65, 2), oracle.fill_uniform(65, 150, 3), "HALS", min_iter=1, max_iter=2)
+    assert e.value.code == L.UNSUPPORTED and "k <= 64" in str(e.value)
