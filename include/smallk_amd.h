@@ -116,6 +116,22 @@ void smk_matrix_destroy(smk_matrix* a);
 int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0,
                              int64_t ncols_local, int64_t nnz_local, const unsigned* col_offsets,
                              const unsigned* row_indices, const double* data);
+/* Host-side CSC bookkeeping behind the sparse matrix objects (no device needed).
+ * smk_csc_transpose: Transpose(SparseMatrix), common/include/sparse_matrix_ops.hpp:36-127 (counting sort).
+ * smk_csc_subset_cols_compact: SparseMatrix::SubMatrixColsCompact, common/include/sparse_matrix_impl.hpp:478-592;
+ *   call with out_col_offsets == NULL for the sizes, then with arrays of *out_nnz / ncols+1 entries;
+ *   old_to_new (height entries, 0xFFFFFFFF = dropped row) and new_to_old (*new_height entries) may be NULL.
+ * smk_matrix_download_csc: the resident CSC (transposed != 0: the CSC of A') back on the host (tests). */
+int smk_csc_transpose(int64_t height, int64_t width, const unsigned* col_offsets, const unsigned* row_indices,
+                      const double* data, unsigned* out_col_offsets, unsigned* out_row_indices, double* out_data);
+int smk_csc_subset_cols_compact(int64_t height, int64_t width, const unsigned* col_offsets, const unsigned* row_indices,
+                                const double* data, const unsigned* cols, int64_t ncols, unsigned* out_col_offsets,
+                                unsigned* out_row_indices, double* out_data, unsigned* old_to_new, unsigned* new_to_old,
+                                int64_t* new_height, int64_t* out_nnz);
+int smk_matrix_download_csc(const smk_matrix* a, int transposed, unsigned* col_offsets, unsigned* row_indices,
+                            double* data);
+int64_t smk_matrix_nnz(const smk_matrix* a);
+int64_t smk_matrix_height(const smk_matrix* a);
 /* same generator on the host, for W0/H0 (RandomMatrix stand-in, smallk.cpp:533,554) */
 void smk_uniform_fill_host(double* buf, int64_t ld, int64_t rows, int64_t cols, int64_t r0, int64_t c0,
                            int64_t global_height, uint64_t seed, int quant /* 0: 24 bit, 1: bf16 */);

@@ -79,6 +79,14 @@ SYMBOLS = {
                                  C.POINTER(C.c_uint), _dp, _dp, _i64, _dp, _i64, C.POINTER(Stats)]),
     "smk_load_matrix_market": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint),
                                          C.POINTER(C.c_uint), C.POINTER(C.c_uint), _dp]),
+    "smk_csc_transpose": (C.c_int, [_i64, _i64, C.POINTER(C.c_uint), C.POINTER(C.c_uint), _dp, C.POINTER(C.c_uint),
+                                    C.POINTER(C.c_uint), _dp]),
+    "smk_csc_subset_cols_compact": (C.c_int, [_i64, _i64, C.POINTER(C.c_uint), C.POINTER(C.c_uint), _dp,
+                                              C.POINTER(C.c_uint), _i64, C.POINTER(C.c_uint), C.POINTER(C.c_uint), _dp,
+                                              C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(_i64), C.POINTER(_i64)]),
+    "smk_matrix_download_csc": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), _dp]),
+    "smk_matrix_nnz": (_i64, [_vp]),
+    "smk_matrix_height": (_i64, [_vp]),
     "smk_uniform_fill_host": (None, [_dp, _i64, _i64, _i64, _i64, _i64, _i64, C.c_uint64, C.c_int]),
     "smk_solver_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Options), _vp]),
     "smk_solver_destroy": (None, [_vp]),

@@ -31,6 +31,7 @@ static bool g_init = false;
 static int g_cus = 256;
 static hipStream_t g_stream = nullptr;
 static bool g_own_stream = false;
+static int g_live_solvers = 0;          // solver handles cache the stream: it cannot change under them
 
 void set_error(const std::string& msg) { g_err = msg; }
 
@@ -140,6 +141,8 @@ int smk_device_cu_count(void) { return g_cus; }
 
 int smk_set_stream(void* hip_stream)
 {
+    if (g_live_solvers > 0) { set_error("smk_set_stream: destroy every solver handle first"); return SMK_BAD_PARAM; }
+    if (g_stream) (void)hipStreamSynchronize(g_stream);     // resident-matrix work queued on the old stream
     if (g_own_stream && g_stream) (void)hipStreamDestroy(g_stream);
     g_stream = (hipStream_t)hip_stream;
     g_own_stream = false;
@@ -225,8 +228,13 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
         delete a;
         return SMK_DEVICE_ERROR;
     }
-    SMK_HIP(hipMemsetAsync(a->A, 0, (size_t)a->ldA * a->colsA * es, g_stream));
-    SMK_HIP(hipMemsetAsync(a->At, 0, (size_t)a->ldAt * a->colsAt * es, g_stream));
+    e1 = hipMemsetAsync(a->A, 0, (size_t)a->ldA * a->colsA * es, g_stream);
+    if (e1 == hipSuccess) e1 = hipMemsetAsync(a->At, 0, (size_t)a->ldAt * a->colsAt * es, g_stream);
+    if (e1 != hipSuccess) {
+        set_error(std::string("hipMemsetAsync(A): ") + hipGetErrorString(e1));
+        smk_matrix_destroy(a);
+        return SMK_DEVICE_ERROR;
+    }
     *out = a;
     return SMK_OK;
 }
@@ -309,6 +317,96 @@ void smk_matrix_destroy(smk_matrix* a)
     delete a;
 }
 
+// ---- host-side CSC bookkeeping (no device involved; pinned against the reference's own SparseMatrix code
+// compiled in place, oracle/_ref/libref_sparse.so, by tests/test_ref_sparse.py) -------------------------
+// Transpose(SparseMatrix), common/include/sparse_matrix_ops.hpp:36-127: counting sort by row; inside a
+// row of the result the entries keep the source's column order.
+int smk_csc_transpose(int64_t height, int64_t width, const unsigned* col_offsets, const unsigned* row_indices,
+                      const double* data, unsigned* out_col_offsets /* height+1 */, unsigned* out_row_indices,
+                      double* out_data)
+{
+    if (height < 0 || width < 0 || !col_offsets || !out_col_offsets) return SMK_BAD_PARAM;
+    const unsigned base = col_offsets[0];
+    const int64_t nnz = (int64_t)col_offsets[width] - base;
+    if (nnz > 0 && (!row_indices || !data || !out_row_indices || !out_data)) return SMK_BAD_PARAM;
+    std::vector<i64> cnt((size_t)height + 1, 0);
+    for (int64_t p = 0; p < nnz; ++p) {
+        if ((int64_t)row_indices[base + p] >= height) { set_error("row index out of range"); return SMK_BAD_PARAM; }
+        cnt[(size_t)row_indices[base + p] + 1] += 1;
+    }
+    for (int64_t r = 0; r < height; ++r) cnt[(size_t)r + 1] += cnt[(size_t)r];
+    for (int64_t r = 0; r <= height; ++r) out_col_offsets[r] = (unsigned)cnt[(size_t)r];
+    std::vector<i64> fill(cnt.begin(), cnt.end() - 1);
+    for (int64_t c = 0; c < width; ++c)
+        for (i64 p = (i64)col_offsets[c] - base; p < (i64)col_offsets[c + 1] - base; ++p) {
+            const i64 q = fill[row_indices[base + p]]++;
+            out_row_indices[q] = (unsigned)c;
+            out_data[q] = data[base + p];
+        }
+    return SMK_OK;
+}
+
+// SparseMatrix::SubMatrixColsCompact, common/include/sparse_matrix_impl.hpp:478-592: the listed columns in
+// the listed order, rows without a stored entry dropped and the rest renumbered in increasing order.
+// Call once with out_* NULL for the sizes (*out_nnz, *new_height), then with arrays of that capacity.
+// old_to_new (height entries, 0xFFFFFFFF = dropped) and new_to_old may be NULL.
+int smk_csc_subset_cols_compact(int64_t height, int64_t width, const unsigned* col_offsets, const unsigned* row_indices,
+                                const double* data, const unsigned* cols, int64_t ncols, unsigned* out_col_offsets,
+                                unsigned* out_row_indices, double* out_data, unsigned* old_to_new, unsigned* new_to_old,
+                                int64_t* new_height, int64_t* out_nnz)
+{
+    if (height <= 0 || width <= 0 || !col_offsets || !cols || ncols <= 0) { set_error("SubMatrixColsCompact: empty column set"); return SMK_BAD_PARAM; }
+    const unsigned UNUSED = 0xFFFFFFFFu;
+    std::vector<unsigned> o2n((size_t)height, UNUSED);
+    int64_t total = 0;
+    for (int64_t j = 0; j < ncols; ++j) {
+        if ((int64_t)cols[j] >= width) { set_error("SubMatrixColsCompact: column index out of range"); return SMK_BAD_PARAM; }
+        for (unsigned p = col_offsets[cols[j]]; p < col_offsets[cols[j] + 1]; ++p) o2n[row_indices[p]] = 0;
+        total += col_offsets[cols[j] + 1] - col_offsets[cols[j]];
+    }
+    if (total == 0) { set_error("SparseMatrix::SubMatrixColsCompact: submatrix is the zero matrix"); return SMK_BAD_PARAM; }
+    int64_t nh = 0;
+    for (int64_t r = 0; r < height; ++r)
+        if (o2n[(size_t)r] != UNUSED) {
+            o2n[(size_t)r] = (unsigned)nh;
+            if (new_to_old) new_to_old[nh] = (unsigned)r;
+            ++nh;
+        }
+    if (old_to_new) std::copy(o2n.begin(), o2n.end(), old_to_new);
+    if (new_height) *new_height = nh;
+    if (out_nnz) *out_nnz = total;
+    if (!out_col_offsets) return SMK_OK;
+    if (!out_row_indices || !out_data) return SMK_BAD_PARAM;
+    unsigned q = 0;
+    for (int64_t j = 0; j < ncols; ++j) {
+        out_col_offsets[j] = q;
+        for (unsigned p = col_offsets[cols[j]]; p < col_offsets[cols[j] + 1]; ++p, ++q) {
+            out_row_indices[q] = o2n[row_indices[p]];
+            out_data[q] = data[p];
+        }
+    }
+    out_col_offsets[ncols] = q;
+    return SMK_OK;
+}
+
+// read a resident sparse matrix (or the stored CSC of its transpose) back to the host (tests)
+int smk_matrix_download_csc(const smk_matrix* a, int transposed, unsigned* col_offsets, unsigned* row_indices, double* data)
+{
+    if (!a || !a->sparse || !col_offsets) return SMK_BAD_PARAM;
+    const i64 nc = transposed ? a->m : a->n;
+    std::vector<i64> cp((size_t)nc + 1);
+    SMK_HIP(hipStreamSynchronize(g_stream));
+    SMK_HIP(hipMemcpy(cp.data(), transposed ? a->colptr_t : a->colptr, cp.size() * sizeof(i64), hipMemcpyDeviceToHost));
+    for (i64 c = 0; c <= nc; ++c) col_offsets[c] = (unsigned)cp[(size_t)c];
+    if (a->nnz > 0 && row_indices && data) {
+        SMK_HIP(hipMemcpy(row_indices, transposed ? a->rowidx_t : a->rowidx, (size_t)a->nnz * sizeof(unsigned), hipMemcpyDeviceToHost));
+        SMK_HIP(hipMemcpy(data, transposed ? a->val_t : a->val, (size_t)a->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return SMK_OK;
+}
+int64_t smk_matrix_nnz(const smk_matrix* a) { return a ? a->nnz : 0; }
+int64_t smk_matrix_height(const smk_matrix* a) { return a ? a->m : 0; }
+
 // CSC shard (columns [col0, col0+ncols_local) of a height x width_global matrix) -> HBM, plus the
 // CSC of its transpose built on the host by a counting sort (SparseMatrix::Transpose,
 // sparse_matrix_ops.hpp:37-127).  Duplicate entries are kept (they add up in every product, as in
@@ -330,22 +428,13 @@ int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_glo
         if (c > 0 && col_offsets[c] < col_offsets[c - 1]) { set_error("col_offsets not monotone"); return SMK_BAD_PARAM; }
         cp[(size_t)c] = (i64)col_offsets[c] - base;
     }
-    for (int64_t p = 0; p < nnz; ++p) {
-        if ((int64_t)row_indices[base + p] >= height) { set_error("row index out of range"); return SMK_BAD_PARAM; }
-        cpt[(size_t)row_indices[base + p] + 1] += 1;
-    }
-    for (int64_t r = 0; r < height; ++r) cpt[(size_t)r + 1] += cpt[(size_t)r];
     std::vector<unsigned> rit((size_t)(nnz > 0 ? nnz : 1));
     std::vector<double> vt((size_t)(nnz > 0 ? nnz : 1));
     {
-        std::vector<i64> fill(cpt.begin(), cpt.end() - 1);
-        for (int64_t c = 0; c < ncols_local; ++c)
-            for (i64 p = cp[(size_t)c]; p < cp[(size_t)c + 1]; ++p) {
-                const unsigned r = row_indices[base + p];
-                const i64 q = fill[r]++;
-                rit[(size_t)q] = (unsigned)c;
-                vt[(size_t)q] = data[base + p];
-            }
+        std::vector<unsigned> cpt32((size_t)height + 1);
+        const int trc = smk_csc_transpose(height, ncols_local, col_offsets, row_indices, data, cpt32.data(), rit.data(), vt.data());
+        if (trc != SMK_OK) return trc;
+        for (int64_t r = 0; r <= height; ++r) cpt[(size_t)r] = cpt32[(size_t)r];
     }
     smk_matrix* a = new smk_matrix;
     a->m = height; a->n_global = width_global; a->c0 = col0; a->n = ncols_local; a->storage = SMK_STORE_F32;
@@ -362,13 +451,18 @@ int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_glo
     rc |= dev_alloc(&a->val, (size_t)nnz);
     rc |= dev_alloc(&a->val_t, (size_t)nnz);
     if (rc) { smk_matrix_destroy(a); return SMK_DEVICE_ERROR; }
-    SMK_HIP(hipMemcpy(a->colptr, cp.data(), cp.size() * sizeof(i64), hipMemcpyHostToDevice));
-    SMK_HIP(hipMemcpy(a->colptr_t, cpt.data(), cpt.size() * sizeof(i64), hipMemcpyHostToDevice));
-    if (nnz > 0) {
-        SMK_HIP(hipMemcpy(a->rowidx, row_indices + base, (size_t)nnz * sizeof(unsigned), hipMemcpyHostToDevice));
-        SMK_HIP(hipMemcpy(a->val, data + base, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-        SMK_HIP(hipMemcpy(a->rowidx_t, rit.data(), (size_t)nnz * sizeof(unsigned), hipMemcpyHostToDevice));
-        SMK_HIP(hipMemcpy(a->val_t, vt.data(), (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    {
+        hipError_t e = hipMemcpy(a->colptr, cp.data(), cp.size() * sizeof(i64), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(a->colptr_t, cpt.data(), cpt.size() * sizeof(i64), hipMemcpyHostToDevice);
+        if (e == hipSuccess && nnz > 0) e = hipMemcpy(a->rowidx, row_indices + base, (size_t)nnz * sizeof(unsigned), hipMemcpyHostToDevice);
+        if (e == hipSuccess && nnz > 0) e = hipMemcpy(a->val, data + base, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess && nnz > 0) e = hipMemcpy(a->rowidx_t, rit.data(), (size_t)nnz * sizeof(unsigned), hipMemcpyHostToDevice);
+        if (e == hipSuccess && nnz > 0) e = hipMemcpy(a->val_t, vt.data(), (size_t)nnz * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error(std::string("hipMemcpy(CSC): ") + hipGetErrorString(e));
+            smk_matrix_destroy(a);
+            return SMK_DEVICE_ERROR;
+        }
     }
     *out = a;
     return SMK_OK;
@@ -433,32 +527,17 @@ int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t 
         *out = a;
         return SMK_OK;
     }
-    const unsigned UNUSED = 0xFFFFFFFFu;
-    std::vector<unsigned> old_to_new((size_t)src->m, UNUSED), cp((size_t)ncols + 1), ri;
-    std::vector<double> va;
-    size_t total = 0;
-    for (int64_t j = 0; j < ncols; ++j) total += src->h_colptr[cols[j] + 1] - src->h_colptr[cols[j]];
-    if (total == 0) { set_error("SparseMatrix::SubMatrixColsCompact: submatrix is the zero matrix"); return SMK_BAD_PARAM; }
-    ri.reserve(total); va.reserve(total);
-    for (int64_t j = 0; j < ncols; ++j) {
-        cp[(size_t)j] = (unsigned)ri.size();
-        for (unsigned p = src->h_colptr[cols[j]]; p < src->h_colptr[cols[j] + 1]; ++p) {
-            old_to_new[src->h_rowidx[p]] = 0;
-            ri.push_back(src->h_rowidx[p]);
-            va.push_back(src->h_val[p]);
-        }
-    }
-    cp[(size_t)ncols] = (unsigned)ri.size();
-    i64 nh = 0;
-    for (i64 r = 0; r < src->m; ++r)
-        if (old_to_new[(size_t)r] != UNUSED) {
-            old_to_new[(size_t)r] = (unsigned)nh;
-            if (new_to_old_rows) new_to_old_rows[nh] = (unsigned)r;
-            ++nh;
-        }
-    for (unsigned& r : ri) r = old_to_new[r];
+    int64_t nh = 0, nz = 0;
+    int rc = smk_csc_subset_cols_compact(src->m, src->n, src->h_colptr.data(), src->h_rowidx.data(), src->h_val.data(), cols,
+                                         ncols, nullptr, nullptr, nullptr, nullptr, nullptr, &nh, &nz);
+    if (rc != SMK_OK) return rc;
+    std::vector<unsigned> cp((size_t)ncols + 1), ri((size_t)nz);
+    std::vector<double> va((size_t)nz);
+    rc = smk_csc_subset_cols_compact(src->m, src->n, src->h_colptr.data(), src->h_rowidx.data(), src->h_val.data(), cols,
+                                     ncols, cp.data(), ri.data(), va.data(), nullptr, new_to_old_rows, &nh, &nz);
+    if (rc != SMK_OK) return rc;
     if (new_height) *new_height = nh;
-    return smk_matrix_create_sparse(out, nh, ncols, 0, ncols, (int64_t)ri.size(), cp.data(), ri.data(), va.data());
+    return smk_matrix_create_sparse(out, nh, ncols, 0, ncols, nz, cp.data(), ri.data(), va.data());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -501,6 +580,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if ((uint64_t)a->n_global * (uint64_t)opts->k > 0x7FFFFFFFull) { fprintf(stderr, "H matrix size too large\n"); return SMK_SIZE_TOO_LARGE; }
 
     smk_solver* s = new smk_solver;
+    ++g_live_solvers;
     s->o = *opts;
     s->a = a;
     s->k = opts->k;
@@ -568,6 +648,7 @@ void smk_solver_destroy(smk_solver* s)
         if (s->pev[b]) (void)hipEventDestroy(s->pev[b]);
     }
     if (s->pin) (void)hipHostFree(s->pin);
+    --g_live_solvers;
     delete s;
 }
 
@@ -636,14 +717,14 @@ static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl, const 
                          double* P)
 {
     if (s->timing) {
-        hipEvent_t e0, e1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
         SMK_HIP(hipEventCreate(&e0));
-        SMK_HIP(hipEventCreate(&e1));
+        if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
+        s->ev[which].push_back({e0, e1});          // owned by the solver from here on (destroyed with it)
         SMK_HIP(hipEventRecord(e0, s->st));
         int rc = launch_bigprod(pl, B, ldb, Xp, P, s->st);
-        if (rc) return rc;
+        if (rc) { s->ev[which].pop_back(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         SMK_HIP(hipEventRecord(e1, s->st));
-        s->ev[which].push_back({e0, e1});
         return 0;
     }
     return launch_bigprod(pl, B, ldb, Xp, P, s->st);
@@ -656,16 +737,16 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing) {
         SMK_HIP(hipEventCreate(&e0));
-        SMK_HIP(hipEventCreate(&e1));
-        SMK_HIP(hipEventRecord(e0, s->st));
+        if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
+        (void)hipEventRecord(e0, s->st);
     }
     int rc = launch_spmm_gather(colptr, rowidx, val, ncols, X, s->k, P, s->kpp, s->st);
-    if (rc) return rc;
     if (s->timing) {
-        SMK_HIP(hipEventRecord(e1, s->st));
+        if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+        (void)hipEventRecord(e1, s->st);
         s->ev[which].push_back({e0, e1});
     }
-    return 0;
+    return rc;
 }
 
 static int prod1(smk_solver* s)
@@ -730,6 +811,7 @@ static int solver_init(smk_solver* s)
 static int solver_iteration(smk_solver* s)
 {
     int rc = 0;
+    s->normalized = false;          // the factors are about to change
     const PartialView r1 = view1(s), r2 = view2(s);
     switch (s->o.algorithm) {
         case SMK_ALG_MU:   // nmf_solver_mu.hpp:121-164
@@ -928,6 +1010,9 @@ static int normalize_device(smk_solver* s)
     rc = launch_scale_rows(s->Wt, s->k, s->m, s->Gw, 1, s->fail_flag, s->st);
     if (rc) return rc;
     s->normalized = true;
+    // Gw/Gh and the stored products describe the un-normalised factors: a later iterate()/run() on this
+    // handle starts from solver.Init on the scaled (W, H), exactly like a fresh solver given them
+    s->inited = false;
     return 0;
 }
 
