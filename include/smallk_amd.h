@@ -153,6 +153,13 @@ int smk_solver_progress(smk_solver* s, double* metric);
 int smk_solver_get_factors(smk_solver* s, int normalize, double* W, int64_t ldW, double* H, int64_t ldH);
 int smk_solver_iteration_count(const smk_solver* s);
 
+/* bool NnlsBlockpivot(LHS, RHS, X, Y), common/include/nnls.hpp:144-244, by itself (the reference's
+ * tests/src/test_bpp.cpp drives the solver this way): LHS k x k SPD, RHS k x ncols, X in/out (warm start:
+ * passive set = X > 0), Y = LHS X - RHS out (may be NULL).  SMK_FAILURE = the reference's `false`
+ * (pivot limit 5k reached, or a passive block that is not positive definite). */
+int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, const double* RHS, int64_t ldR,
+                        double* X, int64_t ldX, double* Y, int64_t ldY);
+
 /* measurement: HIP events around the streaming-product launches (stream of the solver) */
 int smk_solver_enable_timing(smk_solver* s, int on);
 /* which: 0 = W'A pass, 1 = H*At pass.  Returns total ms and launch count since enable. */

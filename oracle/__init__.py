@@ -65,6 +65,9 @@ def lib():
         i64 = C.c_int64
         _lib.orc_nmf.restype = C.c_int
         _lib.orc_nmf.argtypes = [C.POINTER(_Options), dp, i64, dp, i64, dp, i64, C.POINTER(_Stats), dp]
+        up = C.POINTER(C.c_uint)
+        _lib.orc_nmf_sparse.restype = C.c_int
+        _lib.orc_nmf_sparse.argtypes = [C.POINTER(_Options), up, up, dp, dp, i64, dp, i64, C.POINTER(_Stats), dp]
         _lib.orc_nnls_blockpivot.restype = C.c_int
         _lib.orc_nnls_blockpivot.argtypes = [C.c_int, i64, dp, C.c_int, dp, i64, dp, i64, dp, i64, C.POINTER(C.c_int)]
         _lib.orc_fill_uniform.restype = None
@@ -120,6 +123,32 @@ def nmf(A, W0, H0, algorithm, *, min_iter=5, max_iter=5000, tol=0.005, tolcount=
     metrics = np.full(max(max_iter, 1), np.nan)
     rc = lib().orc_nmf(C.byref(o), _p(A), A.shape[0], _p(W), W.shape[0], _p(H), H.shape[0],
                        C.byref(st), _p(metrics))
+    return NmfResult(rc, W, H, st.iteration_count, st.elapsed_us, metrics)
+
+
+def nmf_sparse(A, W0, H0, algorithm, *, min_iter=5, max_iter=5000, tol=0.005, tolcount=1,
+               prog_est=None, normalize=True, max_threads=0, verbose=False) -> NmfResult:
+    """Restatement of ``NmfSparse`` (common/src/nmf.cpp:232-300): A is a scipy CSC matrix; the driver and the
+    solvers are the dense ones, only the three products with A run over the stored entries."""
+    alg = ALGORITHMS[algorithm] if isinstance(algorithm, str) else int(algorithm)
+    if prog_est is None:
+        prog_est = DELTA_FNORM if alg == MU else PG_RATIO
+    A = A.tocsc()
+    cp = np.ascontiguousarray(A.indptr, dtype=np.uint32)
+    ri = np.ascontiguousarray(A.indices, dtype=np.uint32)
+    va = np.ascontiguousarray(A.data, dtype=np.float64)
+    if len(ri) == 0:
+        ri, va = np.zeros(1, np.uint32), np.zeros(1)
+    W = _f(W0).copy(order="F")
+    H = _f(H0).copy(order="F")
+    m, n = A.shape
+    k = W.shape[1]
+    o = _Options(tol, alg, prog_est, m, n, k, min_iter, max_iter, tolcount, max_threads, int(verbose), int(normalize))
+    st = _Stats()
+    metrics = np.full(max(max_iter, 1), np.nan)
+    up = C.POINTER(C.c_uint)
+    rc = lib().orc_nmf_sparse(C.byref(o), cp.ctypes.data_as(up), ri.ctypes.data_as(up), _p(va), _p(W), W.shape[0],
+                              _p(H), H.shape[0], C.byref(st), _p(metrics))
     return NmfResult(rc, W, H, st.iteration_count, st.elapsed_us, metrics)
 
 

@@ -27,7 +27,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from . import fill_uniform, nmf, PG_RATIO, OK
+from . import fill_uniform, nmf, nmf_sparse, PG_RATIO, OK
 
 NONE = 0xFFFFFFFF
 SEED_STRIDE = 0x9E37          # smallk_amd/csrc/facade.cpp RandomMatrix(): seed + stride * (++draws)
@@ -206,7 +206,11 @@ class _Source:
         self.A = A.tocsc() if self.sparse else np.asfortranarray(A, dtype=np.float64)
         self.m, self.n = self.A.shape
 
+    DENSE_LIMIT = 1 << 24
+
     def full(self):
+        if self.sparse and self.m * self.n > self.DENSE_LIMIT:
+            return self.A
         return self.A.toarray(order="F") if self.sparse else self.A
 
     def subset(self, cols):
@@ -218,7 +222,12 @@ class _Source:
         used = np.zeros(self.m, dtype=bool)
         used[sub.indices] = True            # structural entries, explicit zeros included
         rows = np.nonzero(used)[0]
-        return sub[rows, :].toarray(order="F"), rows
+        sub = sub[rows, :]
+        # small nodes as dense arrays (what the tests always did); large ones stay CSC and are factored by
+        # oracle.nmf_sparse -- same driver and solver, the products with A run over the stored entries
+        if sub.shape[0] * sub.shape[1] <= self.DENSE_LIMIT:
+            return sub.toarray(order="F"), rows
+        return sub.tocsc(), rows
 
 
 @dataclass
@@ -263,7 +272,8 @@ def hier_nmf2(A, num_clusters, *, tol=1e-4, min_iter=5, max_iter=5000, maxterms=
     tree = Tree(num_clusters, node_count, m, n)
 
     def solve(Asub, W0, H0):
-        r = nmf(Asub, W0, H0, "RANK2", min_iter=min_iter, max_iter=max_iter, tol=tol, tolcount=1,
+        run = nmf if isinstance(Asub, np.ndarray) else nmf_sparse
+        r = run(Asub, W0, H0, "RANK2", min_iter=min_iter, max_iter=max_iter, tol=tol, tolcount=1,
                 prog_est=PG_RATIO, normalize=True)
         return r.result == OK, r.W, r.H, r.iteration_count
 
@@ -286,7 +296,7 @@ def hier_nmf2(A, num_clusters, *, tol=1e-4, min_iter=5, max_iter=5000, maxterms=
         if len(subset) <= 3:
             return -1.0, np.zeros((m, 2), order="F"), np.zeros((2, len(subset)), order="F"), [1] * len(subset)
         Asub, rows = src.subset(subset)
-        Ws, Hs = factor(np.asfortranarray(Asub), rows, subset)
+        Ws, Hs = factor(np.asfortranarray(Asub) if isinstance(Asub, np.ndarray) else Asub, rows, subset)
         labels = [0 if Hs[0, c] > Hs[1, c] else 1 for c in range(Hs.shape[1])]
         W = np.zeros((m, 2), order="F")
         W[rows, :] = Ws
@@ -331,7 +341,8 @@ def hier_nmf2(A, num_clusters, *, tol=1e-4, min_iter=5, max_iter=5000, maxterms=
         return pr, W, H
 
     # root (clust_hier_generic.hpp:97-121)
-    W0, H0 = factor(np.asfortranarray(src.full()), np.arange(m), list(range(n)))
+    Afull = src.full()
+    W0, H0 = factor(np.asfortranarray(Afull) if isinstance(Afull, np.ndarray) else Afull, np.arange(m), list(range(n)))
     Wbuf, Hbuf = [None] * node_count, [None] * node_count
     for i in range(num_clusters - 1):
         if i == 0:

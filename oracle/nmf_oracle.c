@@ -617,6 +617,10 @@ int orc_normalize_and_scale(i64 m, i64 n, int k, double* W, i64 ldw, double* H, 
 typedef struct {
     i64 m, n; int k;
     const double* A; i64 lda;
+    /* sparse A (NmfSparse, common/src/nmf.cpp:232-300): CSC of A and, for BPP, of A' (SparseMatrix   */
+    /* Transpose, sparse_matrix_ops.hpp:36-127); A == NULL then                                        */
+    const unsigned *cp, *ri; const double* va;
+    unsigned *cpt, *rit; double* vat;
     double *WtW, *HHt;          /* k x k */
     double *WtA;                /* k x n */
     double *AHt;                /* m x k */
@@ -629,10 +633,77 @@ typedef struct {
 
 static double* dalloc(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
 
+/* ---- the three products that touch A.  Dense: Gemm -> BLAS.  Sparse: the reference's own loops,     */
+/* sparse_gemm_ba_impl.hpp (B'A and BA: one dot / axpy per stored entry, column by column of A) and    */
+/* sparse_gemm_ab_impl.hpp (AB': scatter of every stored entry into row i of the result).              */
+static void prod_WtA(const solver_ws* s, const double* W, i64 ldw, double* out)      /* k x n, ld k */
+{
+    const int k = s->k;
+    if (s->A) { orc_gemm(1, 0, k, s->n, s->m, 1.0, W, ldw, s->A, s->lda, 0.0, out, k); return; }
+#pragma omp parallel for schedule(dynamic, 64)
+    for (i64 j = 0; j < s->n; ++j) {
+        double* o = out + j * k;
+        for (int r = 0; r < k; ++r) o[r] = 0.0;
+        for (unsigned p = s->cp[j]; p < s->cp[j + 1]; ++p) {
+            const double v = s->va[p];
+            const i64 i = s->ri[p];
+            for (int r = 0; r < k; ++r) o[r] += v * W[r * ldw + i];
+        }
+    }
+}
+
+static void prod_AHt(const solver_ws* s, const double* H, i64 ldh, double* out)      /* m x k, ld m */
+{
+    const int k = s->k;
+    if (s->A) { orc_gemm(0, 1, s->m, k, s->n, 1.0, s->A, s->lda, H, ldh, 0.0, out, s->m); return; }
+    for (i64 e = 0; e < s->m * k; ++e) out[e] = 0.0;
+    for (i64 j = 0; j < s->n; ++j)
+        for (unsigned p = s->cp[j]; p < s->cp[j + 1]; ++p) {
+            const double v = s->va[p];
+            const i64 i = s->ri[p];
+            for (int r = 0; r < k; ++r) out[r * s->m + i] += v * H[j * ldh + r];
+        }
+}
+
+static void prod_HAt(const solver_ws* s, const double* H, i64 ldh, double* out)      /* k x m, ld k */
+{
+    const int k = s->k;
+    if (s->A) { orc_gemm(0, 0, k, s->m, s->n, 1.0, H, ldh, s->At, s->n, 0.0, out, k); return; }
+#pragma omp parallel for schedule(dynamic, 64)
+    for (i64 i = 0; i < s->m; ++i) {
+        double* o = out + i * k;
+        for (int r = 0; r < k; ++r) o[r] = 0.0;
+        for (unsigned p = s->cpt[i]; p < s->cpt[i + 1]; ++p) {
+            const double v = s->vat[p];
+            const i64 j = s->rit[p];
+            for (int r = 0; r < k; ++r) o[r] += v * H[j * ldh + r];
+        }
+    }
+}
+
+static void sparse_transpose(solver_ws* s)
+{
+    const unsigned nnz = s->cp[s->n];
+    s->cpt = (unsigned*)calloc((size_t)s->m + 1, sizeof(unsigned));
+    s->rit = (unsigned*)malloc((size_t)(nnz ? nnz : 1) * sizeof(unsigned));
+    s->vat = (double*)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
+    for (unsigned p = 0; p < nnz; ++p) s->cpt[s->ri[p] + 1] += 1;
+    for (i64 r = 0; r < s->m; ++r) s->cpt[r + 1] += s->cpt[r];
+    unsigned* fill = (unsigned*)malloc((size_t)(s->m ? s->m : 1) * sizeof(unsigned));
+    memcpy(fill, s->cpt, (size_t)s->m * sizeof(unsigned));
+    for (i64 j = 0; j < s->n; ++j)
+        for (unsigned p = s->cp[j]; p < s->cp[j + 1]; ++p) {
+            const unsigned q = fill[s->ri[p]]++;
+            s->rit[q] = (unsigned)j;
+            s->vat[q] = s->va[p];
+        }
+    free(fill);
+}
+
 /* ---- MU: nmf_solver_mu.hpp:98-114 (Init), :121-164 (iteration), :27-71 ---- */
 static void mu_init(solver_ws* s, const double* W, i64 ldw)
 {
-    orc_gemm(1, 0, s->k, s->n, s->m, 1.0, W, ldw, s->A, s->lda, 0.0, s->WtA, s->k);
+    prod_WtA(s, W, ldw, s->WtA);
     orc_gemm(1, 0, s->k, s->k, s->m, 1.0, W, ldw, W, ldw, 0.0, s->WtW, s->k);
 }
 
@@ -647,13 +718,13 @@ static int mu_iter(solver_ws* s, double* W, i64 ldw, double* H, i64 ldh,
         for (int r = 0; r < k; ++r)
             AT(H, ldh, r, c) *= (AT(s->WtA, k, r, c) / (AT(s->T1, k, r, c) + EPS));
     orc_gemm(0, 1, k, k, n, 1.0, H, ldh, H, ldh, 0.0, s->HHt, k);             /* HHt */
-    orc_gemm(0, 1, m, k, n, 1.0, s->A, s->lda, H, ldh, 0.0, s->AHt, m);       /* AHt */
+    prod_AHt(s, H, ldh, s->AHt);       /* AHt */
     orc_gemm(0, 0, m, k, k, 1.0, W, ldw, s->HHt, k, 0.0, s->T2, m);           /* WHHt */
 #pragma omp parallel for schedule(static)
     for (int c = 0; c < k; ++c)
         for (i64 r = 0; r < m; ++r)
             AT(W, ldw, r, c) *= (AT(s->AHt, m, r, c) / (AT(s->T2, m, r, c) + EPS));
-    orc_gemm(1, 0, k, n, m, 1.0, W, ldw, s->A, s->lda, 0.0, s->WtA, k);       /* WtA (new W) */
+    prod_WtA(s, W, ldw, s->WtA);       /* WtA (new W) */
     orc_gemm(1, 0, k, k, m, 1.0, W, ldw, W, ldw, 0.0, s->WtW, k);             /* WtW */
     orc_gemm(0, 0, m, k, k, 1.0, W, ldw, s->HHt, k, 0.0, gradW, m);           /* gradW = W*HHt - AHt */
     mat_axpy(-1.0, m, k, s->AHt, m, gradW, m);
@@ -666,7 +737,7 @@ static int mu_iter(solver_ws* s, double* W, i64 ldw, double* H, i64 ldh,
 static void hals_init(solver_ws* s, const double* H, i64 ldh)
 {
     orc_gemm(0, 1, s->k, s->k, s->n, 1.0, H, ldh, H, ldh, 0.0, s->HHt, s->k);
-    orc_gemm(0, 1, s->m, s->k, s->n, 1.0, s->A, s->lda, H, ldh, 0.0, s->AHt, s->m);
+    prod_AHt(s, H, ldh, s->AHt);
 }
 
 static void hals_update_w(solver_ws* s, double* W, i64 ldw)
@@ -726,12 +797,12 @@ static int hals_iter(solver_ws* s, double* W, i64 ldw, double* H, i64 ldh,
     const i64 m = s->m, n = s->n; const int k = s->k;
     hals_update_w(s, W, ldw);
     orc_gemm(1, 0, k, k, m, 1.0, W, ldw, W, ldw, 0.0, s->WtW, k);
-    orc_gemm(1, 0, k, n, m, 1.0, W, ldw, s->A, s->lda, 0.0, s->WtA, k);
+    prod_WtA(s, W, ldw, s->WtA);
     hals_update_h(s, H, ldh);
     orc_gemm(0, 0, k, n, k, 1.0, s->WtW, k, H, ldh, 0.0, gradH, k);
     mat_axpy(-1.0, k, n, s->WtA, k, gradH, k);
     orc_gemm(0, 1, k, k, n, 1.0, H, ldh, H, ldh, 0.0, s->HHt, k);
-    orc_gemm(0, 1, m, k, n, 1.0, s->A, s->lda, H, ldh, 0.0, s->AHt, m);
+    prod_AHt(s, H, ldh, s->AHt);
     orc_gemm(0, 0, m, k, k, 1.0, W, ldw, s->HHt, k, 0.0, gradW, m);
     mat_axpy(-1.0, m, k, s->AHt, m, gradW, m);
     return 1;
@@ -740,9 +811,10 @@ static int hals_iter(solver_ws* s, double* W, i64 ldw, double* H, i64 ldh,
 /* ---- BPP: nmf_solver_bpp.hpp:310-335 (Init), :342-377 (iteration) --------- */
 static void bpp_init(solver_ws* s, const double* W, i64 ldw)
 {
-    mat_transpose(s->m, s->n, s->A, s->lda, s->At, s->n);
+    if (s->A) mat_transpose(s->m, s->n, s->A, s->lda, s->At, s->n);
+    else sparse_transpose(s);
     orc_gemm(1, 0, s->k, s->k, s->m, 1.0, W, ldw, W, ldw, 0.0, s->WtW, s->k);
-    orc_gemm(1, 0, s->k, s->n, s->m, 1.0, W, ldw, s->A, s->lda, 0.0, s->WtA, s->k);
+    prod_WtA(s, W, ldw, s->WtA);
     mat_transpose(s->m, s->k, W, ldw, s->Wt, s->k);
 }
 
@@ -752,12 +824,12 @@ static int bpp_iter(solver_ws* s, double* W, i64 ldw, double* H, i64 ldh,
     const i64 m = s->m, n = s->n; const int k = s->k;
     if (!orc_nnls_blockpivot(k, n, s->WtW, k, s->WtA, k, H, ldh, gradH, k, NULL)) return 0;
     orc_gemm(0, 1, k, k, n, 1.0, H, ldh, H, ldh, 0.0, s->HHt, k);
-    orc_gemm(0, 0, k, m, n, 1.0, H, ldh, s->At, n, 0.0, s->HAt, k);
+    prod_HAt(s, H, ldh, s->HAt);
     if (!orc_nnls_blockpivot(k, m, s->HHt, k, s->HAt, k, s->Wt, k, s->gradWt, k, NULL)) return 0;
     mat_transpose(k, m, s->Wt, k, W, ldw);
     mat_transpose(k, m, s->gradWt, k, gradW, m);
     orc_gemm(1, 0, k, k, m, 1.0, W, ldw, W, ldw, 0.0, s->WtW, k);
-    orc_gemm(1, 0, k, n, m, 1.0, W, ldw, s->A, s->lda, 0.0, s->WtA, k);
+    prod_WtA(s, W, ldw, s->WtA);
     orc_gemm(0, 0, k, n, k, 1.0, s->WtW, k, H, ldh, 0.0, gradH, k);
     mat_axpy(-1.0, k, n, s->WtA, k, gradH, k);
     return 1;
@@ -820,7 +892,7 @@ static void rank2_optimal_active_set(i64 N, double* X, i64 ldx, const double* G,
 static void rank2_init(solver_ws* s, const double* W, i64 ldw)
 {
     orc_gemm(1, 0, 2, 2, s->m, 1.0, W, ldw, W, ldw, 0.0, s->WtW, 2);
-    orc_gemm(1, 0, 2, s->n, s->m, 1.0, W, ldw, s->A, s->lda, 0.0, s->WtA, 2);
+    prod_WtA(s, W, ldw, s->WtA);
 }
 
 static int rank2_iter(solver_ws* s, double* W, i64 ldw, double* H, i64 ldh, double* gradW, double* gradH)
@@ -829,7 +901,7 @@ static int rank2_iter(solver_ws* s, double* W, i64 ldw, double* H, i64 ldh, doub
     if (!rank2_system_solve(0, n, H, ldh, s->WtW, s->WtA, 2)) return 0;
     rank2_optimal_active_set(n, H, ldh, s->WtW, s->WtA, 2);
     orc_gemm(0, 1, 2, 2, n, 1.0, H, ldh, H, ldh, 0.0, s->HHt, 2);
-    orc_gemm(0, 1, m, 2, n, 1.0, s->A, s->lda, H, ldh, 0.0, s->AHt, m);
+    prod_AHt(s, H, ldh, s->AHt);
     /* W side works on rows of W; reuse the column routines on W' (2 x m) */
     double* Wt = s->T1;        /* 2 x m scratch (T1 has k*n >= ? doubles: allocated max(k*n, k*m) below) */
     double* Bt = s->T2;        /* 2 x m */
@@ -858,7 +930,7 @@ static int rank2_iter(solver_ws* s, double* W, i64 ldw, double* H, i64 ldh, doub
     orc_gemm(0, 0, m, 2, 2, 1.0, W, ldw, s->HHt, 2, 0.0, gradW, m);
     mat_axpy(-1.0, m, 2, s->AHt, m, gradW, m);
     orc_gemm(1, 0, 2, 2, m, 1.0, W, ldw, W, ldw, 0.0, s->WtW, 2);
-    orc_gemm(1, 0, 2, n, m, 1.0, W, ldw, s->A, s->lda, 0.0, s->WtA, 2);
+    prod_WtA(s, W, ldw, s->WtA);
     orc_gemm(0, 0, 2, n, 2, 1.0, s->WtW, 2, H, ldh, 0.0, gradH, 2);
     mat_axpy(-1.0, 2, n, s->WtA, 2, gradH, 2);
     return 1;
@@ -888,8 +960,27 @@ int orc_is_valid(const orc_options* o)
 /* receives the progress metric of every iteration that computed one (NaN     */
 /* elsewhere).             */
 /* ======================================================================== */
+static int nmf_driver(const orc_options* o, const double* A, i64 lda, const unsigned* cp, const unsigned* ri,
+                      const double* va, double* W, i64 ldw, double* H, i64 ldh, orc_stats* stats, double* metrics);
+
 int orc_nmf(const orc_options* o, const double* A, i64 lda, double* W, i64 ldw,
             double* H, i64 ldh, orc_stats* stats, double* metrics)
+{
+    if (!A) return ORC_BAD_PARAM;
+    return nmf_driver(o, A, lda, NULL, NULL, NULL, W, ldw, H, ldh, stats, metrics);
+}
+
+/* NmfSparse (common/src/nmf.cpp:232-300): the same driver on a CSC matrix (32-bit indices as in the    */
+/* reference); only the three products that touch A differ.                                             */
+int orc_nmf_sparse(const orc_options* o, const unsigned* col_offsets, const unsigned* row_indices, const double* data,
+                   double* W, i64 ldw, double* H, i64 ldh, orc_stats* stats, double* metrics)
+{
+    if (!col_offsets || !row_indices || !data) return ORC_BAD_PARAM;
+    return nmf_driver(o, NULL, o->height, col_offsets, row_indices, data, W, ldw, H, ldh, stats, metrics);
+}
+
+static int nmf_driver(const orc_options* o, const double* A, i64 lda, const unsigned* cp, const unsigned* ri,
+                      const double* va, double* W, i64 ldw, double* H, i64 ldh, orc_stats* stats, double* metrics)
 {
     if (!orc_is_valid(o)) return ORC_BAD_PARAM;
     const i64 m = o->height, n = o->width; const int k = o->k;
@@ -903,11 +994,12 @@ int orc_nmf(const orc_options* o, const double* A, i64 lda, double* W, i64 ldw,
     solver_ws s;
     memset(&s, 0, sizeof(s));
     s.m = m; s.n = n; s.k = k; s.A = A; s.lda = lda;
+    s.cp = cp; s.ri = ri; s.va = va;
     s.WtW = dalloc((size_t)k * k); s.HHt = dalloc((size_t)k * k);
     s.WtA = dalloc((size_t)k * n); s.AHt = dalloc((size_t)m * k);
     s.T1 = dalloc((size_t)k * (n > m ? n : m));  s.T2 = dalloc((size_t)m * k);
     if (o->algorithm == ORC_BPP) {
-        s.At = dalloc((size_t)m * n); s.Wt = dalloc((size_t)k * m);
+        s.At = A ? dalloc((size_t)m * n) : NULL; s.Wt = dalloc((size_t)k * m);
         s.gradWt = dalloc((size_t)k * m); s.HAt = dalloc((size_t)k * m);
     }
     double* gradH = dalloc((size_t)k * n);
@@ -991,6 +1083,7 @@ finish:
     }
     free(s.WtW); free(s.HHt); free(s.WtA); free(s.AHt); free(s.T1); free(s.T2);
     free(s.At); free(s.Wt); free(s.gradWt); free(s.HAt);
+    free(s.cpt); free(s.rit); free(s.vat);
     free(gradH); free(gradW); free(Wprev);
     return result;
 }

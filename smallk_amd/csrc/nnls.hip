@@ -1,0 +1,419 @@
+// smallk_amd/csrc/nnls.hip -- NnlsBlockpivot on the device (nnls.hpp:144-244, src/nnls.cpp:18-74,
+// nmf_solver_bpp.hpp:146-219, normal_eq.hpp:27-54): the per-column masked Gauss-Jordan kernel and the
+// inverse-based kernel for k in (32, 64].
+#include "devutil.h"
+
+namespace smk {
+
+// ==========================================================================
+// NNLS by block principal pivoting, one column per GS-lane group (GS = KP).
+// Lane i of a group owns component i of the column: x_i, y_i, rhs_i, its
+// passive bit, and row i of the masked Gram matrix in registers.  The passive
+// sub-system G[F,F] x_F = rhs_F is solved by Gauss-Jordan elimination on the
+// masked matrix (non-passive rows/columns replaced by identity) -- pivots are
+// the Cholesky pivots, so "pivot <= 0" is exactly the reference's non-SPD
+// failure (normal_eq.hpp:35-50).  Pivot-row values are broadcast with
+// v_readlane (GS = 64) or ds_bpermute (GS < 64).
+// Per-column state machine = NnlsBlockpivot (nnls.hpp:144-244) restricted to one
+// column: columns are independent in the reference except for the shared
+// iteration cap (5k), which here is per column.  The backup rule toggles the
+// TRUE largest index (the reference's MaxRowIndex is off by 32 for k >= 64,
+// bit_matrix.cpp:456-468; the NNLS optimum is unique so results agree).
+// ==========================================================================
+template <int GS>
+__device__ __forceinline__ double group_bcast(double v, int src /* compile-time after unroll */)
+{
+    if constexpr (GS == 64) {
+        int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+        int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __shfl(v, src, GS);
+    }
+}
+
+template <int GS>
+__device__ __forceinline__ unsigned long long group_ballot(bool pred, int lane)
+{
+    unsigned long long b = __ballot(pred);
+    if constexpr (GS == 64) return b;
+    else {
+        const int shift = (lane / GS) * GS;
+        return (b >> shift) & ((1ull << GS) - 1ull);
+    }
+}
+
+// KP = 64: left alone the compiler takes 256 VGPRs + 40 AGPRs (one wave per SIMD) and every
+// readlane -> FMA dependency is exposed; capping at 168 registers (3 waves per SIMD, 516 B of
+// scratch per lane) is 1.45x faster on a 262144 x 8192 k = 64 BPP iteration.  No gain at KP <= 32.
+template <int KP>
+__global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N,
+                                                       PartialView R, const double* __restrict__ G,
+                                                       int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
+                                                       const int* __restrict__ skip_if)
+{
+    constexpr int GS = KP;
+    constexpr int GPB = 256 / GS;                   // column groups per block
+    if (skip_if && *skip_if != 0) return;           // the inverse-based kernel below took this launch
+    __shared__ double gs[KP * KP];                  // gs[c*KP + i] = G[i][c] (symmetric)
+    for (int t = threadIdx.x; t < KP * KP; t += blockDim.x) gs[t] = G[t];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int i = threadIdx.x % GS;                 // component owned by this lane
+    const i64 col = col_begin + (i64)blockIdx.x * GPB + threadIdx.x / GS;
+    const bool col_ok = col < N;
+    const bool comp_ok = i < k;
+    const i64 cc = col_ok ? col : (N - 1);
+
+    double rhs = 0.0, x = 0.0, y = 0.0;
+    if (comp_ok) {
+        rhs = rhs_elem(R, cc, i);
+        x = X[cc * KP + i];
+    }
+    bool passive = comp_ok && (x > 0.0);            // passive_set = (X > 0), nnls.hpp:157
+    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+    int failed = 0;
+
+    auto solve = [&](unsigned long long F) {
+        // masked matrix row i
+        double a[KP];
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+            const bool pc = (F >> c) & 1ull;
+            a[c] = (passive && pc) ? gs[c * KP + i] : ((c == i) ? 1.0 : 0.0);
+        }
+        double b = passive ? rhs : 0.0;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            // wave-uniform skip when no group in this wave has j passive
+            const bool pj = (F >> j) & 1ull;
+            if (__ballot(pj) == 0ull) continue;
+            const double piv = group_bcast<GS>(a[j], j);
+            if (pj && !(piv > 0.0)) failed = 1;
+            const double f = (i == j || !pj) ? 0.0 : a[j] / piv;
+#pragma unroll
+            for (int c = j + 1; c < KP; ++c) a[c] -= f * group_bcast<GS>(a[c], j);
+            b -= f * group_bcast<GS>(b, j);
+        }
+        double d = 1.0;
+#pragma unroll
+        for (int c = 0; c < KP; ++c)
+            if (c == i) d = a[c];
+        x = passive ? (b / d) : 0.0;
+    };
+
+    auto residual = [&]() {          // y = G x - rhs
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < KP; ++c) acc += gs[c * KP + i] * group_bcast<GS>(x, c);
+        y = comp_ok ? (acc - rhs) : 0.0;
+    };
+
+    unsigned long long F = group_ballot<GS>(passive, lane) & kmask;
+    solve(F);
+    residual();
+
+    unsigned long long nonopt = group_ballot<GS>(comp_ok && !passive && (y < 0.0), lane);
+    unsigned long long infeas = group_ballot<GS>(comp_ok && passive && (x < 0.0), lane);
+    int ng = __popcll(nonopt) + __popcll(infeas);
+    int Pc = 3, Ninf = k + 1;                       // PBAR = 3, nnls.hpp:152,170
+    const int max_iter = 5 * k;
+    int iter = 0;
+    bool active = col_ok && ng > 0;
+
+    while (__ballot(active) != 0ull) {
+        if (active) {
+            if (iter >= max_iter) { failed = 1; active = false; }
+        }
+        if (active) {
+            // UpdatePassiveSet, src/nnls.cpp:18-74
+            if (ng < Ninf) { Pc = 3; Ninf = ng; F = (F | nonopt) & ~infeas; }
+            else if (Pc >= 1) { Pc -= 1; F = (F | nonopt) & ~infeas; }
+            else {
+                const int r1 = nonopt ? (63 - __clzll(nonopt)) : 0;
+                const int r2 = infeas ? (63 - __clzll(infeas)) : 0;
+                F ^= (1ull << (r1 > r2 ? r1 : r2));
+            }
+            F &= kmask;
+            passive = (F >> i) & 1ull;
+        }
+        // all lanes execute the cross-lane code; inactive groups keep their state
+        const double x_keep = x, y_keep = y;
+        solve(F);
+        if (fabs(x) < 1.0e-12) x = 0.0;             // ZeroizeSmallValues, nnls.hpp:213,224
+        residual();
+        if (fabs(y) < 1.0e-12) y = 0.0;             // :225
+        if (!active) { x = x_keep; y = y_keep; }
+        const unsigned long long no2 = group_ballot<GS>(comp_ok && !passive && (y < 0.0), lane);
+        const unsigned long long in2 = group_ballot<GS>(comp_ok && passive && (x < 0.0), lane);
+        if (active) {
+            nonopt = no2;
+            infeas = in2;
+            ng = __popcll(nonopt) + __popcll(infeas);
+            ++iter;
+            if (ng == 0) active = false;
+        }
+    }
+
+    if (col_ok && comp_ok) {
+        X[col * KP + i] = x;
+        if (Y) Y[col * KP + i] = y;
+    }
+    if (failed && col_ok) atomicMin(fail_flag, iter_tag);
+}
+
+// --------------------------------------------------------------------------
+// k in (32, 64]: block principal pivoting through the INVERSE of the Gram matrix.
+//
+// On noise-like data every column has its own passive set F (|F| ~ 45-58 of 64, 8192 distinct sets in
+// 8192 columns) and needs ~2 solves, so neither the reference's "all passive" shortcut nor its grouping
+// by identical sets (nmf_solver_bpp.hpp:29-142) ever fires; a factorisation per column and pivot of the
+// |F| x |F| system costs O(k^3).  With Ginv = G^-1 (one 64 x 64 inversion per launch) and v = Ginv r:
+//     Z = complement of F,  S = Ginv[Z,Z]:   y_Z = -S^-1 v_Z,   x = v + Ginv[:,Z] y_Z   (x_Z = 0, y_F = 0)
+// (block elimination on G x = r + y), i.e. one |Z| x |Z| solve plus |Z| rank-one terms -- and both x and
+// the dual y come out of it.  When |F| < |Z| the direct form G[F,F] x_F = r_F, y = G[:,F] x_F - r is
+// cheaper; both are the same "compact solve + accumulate" on (M, T, s) = (Ginv, Z, -v) or (G, F, r) with
+// t = min(|F|, |Z|) <= 32 rows in the first t lanes of the wave.  One wave per column; the set is
+// wave-uniform, so index lists, loop bounds and pivot broadcasts are scalar.
+// The inverse is taken only when every Gauss-Jordan pivot of G is positive and not tiny (gram_inverse_kernel
+// sets status = 1); otherwise nnls_bpp_kernel<64> above runs and reproduces the reference's non-SPD failure.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+// Ginv = G^-1 (k x k live, KP x KP storage, pads zero) by in-place Gauss-Jordan in LDS, one workgroup.
+// status = 1 when every pivot p_j satisfies p_j > 1e-9 * G[j][j] (SPD and usable), else 0.
+template <int KP>
+__global__ __launch_bounds__(256) void gram_inverse_kernel(const double* __restrict__ G, int k,
+                                                           double* __restrict__ Ginv, int* __restrict__ status)
+{
+    __shared__ double a[KP][KP + 1];
+    __shared__ double colj[KP], rowj[KP], diag0[KP];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    if (tid < KP) diag0[tid] = (tid < k) ? G[tid * KP + tid] : 1.0;
+    for (int e = tid; e < KP * KP; e += 256) {
+        const int r = e % KP, c = e / KP;
+        a[r][c] = (r < k && c < k) ? G[c * KP + r] : ((r == c) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        // row j and column j of the current matrix, staged so that the update below touches only a[r][c]
+        if (tid < KP) { colj[tid] = a[tid][j]; rowj[tid] = a[j][tid]; }
+        __syncthreads();
+        const double piv = rowj[j];
+        if (tid == 0 && !(piv > 1.0e-9 * diag0[j])) bad = 1;
+        const double ip = 1.0 / piv;
+        for (int e = tid; e < KP * KP; e += 256) {
+            const int r = e / KP, c = e % KP;           // consecutive threads walk a row: conflict-free
+            double val;
+            if (r == j) val = (c == j) ? ip : rowj[c] * ip;
+            else {
+                const double f = colj[r] * ip;
+                val = (c == j) ? -f : a[r][c] - f * rowj[c];
+            }
+            a[r][c] = val;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < KP * KP; e += 256) {
+        const int r = e % KP, c = e / KP;
+        Ginv[c * KP + r] = (r < k && c < k) ? 0.5 * (a[r][c] + a[c][r]) : 0.0;     // exactly symmetric
+    }
+    if (tid == 0) *status = bad ? 0 : 1;
+}
+
+template <int KP, int NT>
+__global__ __launch_bounds__(NT, 4) void nnls_bpp_inv_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N,
+                                                          PartialView R, const double* __restrict__ G,
+                                                          const double* __restrict__ Ginv,
+                                                          const int* __restrict__ status,
+                                                          int* __restrict__ fail_flag, int iter_tag, i64 col_begin)
+{
+    static_assert(KP == 64, "one wave per column");
+    constexpr int NW = NT / 64;
+    constexpr int TM = 32;                          // max compact dimension = min(|F|, |Z|) <= k/2
+    if (*status == 0) return;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* gs = lds;                               // gs[c*KP + i]  = G[i][c]
+    double* gis = lds + KP * KP;                    // gis[c*KP + i] = Ginv[i][c]
+    for (int t = threadIdx.x; t < KP * KP; t += NT) { gs[t] = G[t]; gis[t] = Ginv[t]; }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* sv = lds + 2 * KP * KP + wave * (2 * KP);          // wave-private: 64 doubles of values
+    int* sidx = (int*)(sv + KP);                               //               64 ints of indices
+    __syncthreads();
+
+    const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+    const bool comp_ok = lane < k;
+    const int max_iter = 5 * k;
+    int failed_any = 0;
+
+    for (i64 col = col_begin + (i64)blockIdx.x * NW + wave; col < N; col += (i64)gridDim.x * NW) {
+        double rhs = 0.0, x = 0.0, y = 0.0;
+        if (comp_ok) {
+            rhs = rhs_elem(R, col, lane);
+            x = X[col * KP + lane];
+        }
+        unsigned long long F = __ballot(comp_ok && x > 0.0) & kmask;       // passive_set = (X > 0), nnls.hpp:157
+
+        // v = Ginv r
+        sv[lane] = rhs;
+        double v = 0.0;
+        {
+            double v1 = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < KP; c += 2) {
+                const f64x2_t rr = *(const f64x2_t*)(sv + c);              // broadcast read
+                v = __builtin_fma(gis[c * KP + lane], rr[0], v);
+                v1 = __builtin_fma(gis[(c + 1) * KP + lane], rr[1], v1);
+            }
+            v += v1;
+        }
+
+        int failed = 0;
+        // one block-pivot solve for the passive set F: leaves x (zero outside F) and y (zero inside F)
+        auto solve = [&](unsigned long long Fs) {
+            const unsigned long long Zs = ~Fs & kmask;
+            const int p = __popcll(Fs), q = __popcll(Zs);
+            const bool inF = (Fs >> lane) & 1ull;
+            if (q == 0) { x = v; y = 0.0; return; }
+            if (p == 0) { x = 0.0; y = comp_ok ? -rhs : 0.0; return; }
+            const bool comp = q <= p;                                       // complement form on Ginv
+            const unsigned long long T = comp ? Zs : Fs;
+            const int t = comp ? q : p;
+            const double* M = comp ? gis : gs;
+            const bool inT = (T >> lane) & 1ull;
+            // compact index list: lane l < t gets the l-th member of T
+            const int rank = __popcll(T & ((1ull << lane) - 1ull));
+            if (inT) sidx[rank] = lane;
+            sv[lane] = comp ? -v : rhs;
+            const int tl = (lane < t) ? sidx[lane] : 0;
+            double sc = (lane < t) ? sv[tl] : 0.0;
+            // row l of M[T,T]
+            double a[TM];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                a[b] = 0.0;
+                if (b < t) {
+                    const int tb = __builtin_amdgcn_readlane(tl, b);
+                    a[b] = M[tb * KP + tl];
+                }
+            }
+            // Gauss-Jordan, pivots in order (= the Cholesky pivots of the SPD block)
+            double d = 1.0;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                if (j < t) {
+                    const double piv = readlane_f64(a[j], j);
+                    if (!(piv > 0.0)) failed = 1;
+                    const double ip = fast_rcp(piv);
+                    if (lane == j) d = a[j];
+                    const double f = (lane == j) ? 0.0 : a[j] * ip;
+#pragma unroll
+                    for (int c = j + 1; c < TM; ++c)
+                        if (c < t) a[c] = __builtin_fma(-f, readlane_f64(a[c], j), a[c]);
+                    sc = __builtin_fma(-f, readlane_f64(sc, j), sc);
+                }
+            }
+            const double u = (lane < t) ? sc * fast_rcp(d) : 0.0;
+            // out = base + M[:,T] u
+            double out = comp ? v : -rhs;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                if (b < t) {
+                    const int tb = __builtin_amdgcn_readlane(tl, b);
+                    out = __builtin_fma(M[tb * KP + lane], readlane_f64(u, b), out);
+                }
+            }
+            // u back to component positions
+            if (lane < t) sv[tl] = u;
+            const double ut = inT ? sv[lane] : 0.0;
+            if (comp) { x = inF ? out : 0.0; y = ut; }
+            else      { x = ut; y = (comp_ok && !inF) ? out : 0.0; }
+        };
+
+        solve(F);
+        bool passive = (F >> lane) & 1ull;
+        unsigned long long nonopt = __ballot(comp_ok && !passive && (y < 0.0));
+        unsigned long long infeas = __ballot(comp_ok && passive && (x < 0.0));
+        int ng = __popcll(nonopt) + __popcll(infeas);
+        int Pc = 3, Ninf = k + 1;                    // PBAR = 3, nnls.hpp:152,170
+        int iter = 0;
+        while (ng > 0) {                             // uniform
+            if (iter >= max_iter) { failed = 1; break; }
+            // UpdatePassiveSet, src/nnls.cpp:18-74
+            if (ng < Ninf) { Pc = 3; Ninf = ng; F = (F | nonopt) & ~infeas; }
+            else if (Pc >= 1) { Pc -= 1; F = (F | nonopt) & ~infeas; }
+            else {
+                const int r1 = nonopt ? (63 - __clzll(nonopt)) : 0;
+                const int r2 = infeas ? (63 - __clzll(infeas)) : 0;
+                F ^= (1ull << (r1 > r2 ? r1 : r2));
+            }
+            F &= kmask;
+            passive = (F >> lane) & 1ull;
+            solve(F);
+            if (fabs(x) < 1.0e-12) x = 0.0;          // ZeroizeSmallValues, nnls.hpp:213,224
+            if (fabs(y) < 1.0e-12) y = 0.0;          // :225
+            nonopt = __ballot(comp_ok && !passive && (y < 0.0));
+            infeas = __ballot(comp_ok && passive && (x < 0.0));
+            ng = __popcll(nonopt) + __popcll(infeas);
+            ++iter;
+        }
+        if (comp_ok) {
+            X[col * KP + lane] = x;
+            if (Y) Y[col * KP + lane] = y;
+        }
+        failed_any |= failed;
+    }
+    if (failed_any && lane == 0) atomicMin(fail_flag, iter_tag);
+}
+
+size_t nnls_scratch_elems(int k) { return (size_t)kp_of(k) * kp_of(k) + 8; }
+
+// solves columns [col_begin, col_end) of X (col_end <= N); other columns are untouched.
+// `scratch`: nnls_scratch_elems(k) doubles (the inverse of G and the path selector for KP = 64).
+int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
+                    int* fail_flag, int iter_tag, double* scratch, int num_cus, hipStream_t st)
+{
+    const int KPv = kp_of(k);
+    const int gpb = 256 / KPv;
+    const i64 ncols = col_end - col_begin;
+    if (ncols <= 0) return 0;
+    const int grid = (int)((ncols + gpb - 1) / gpb);
+    const i64 N = col_end;
+    static const int inv_mode = [] { const char* e = getenv("SMK_NNLS_INV"); return e ? atoi(e) : 1; }();
+    const int* skip_if = nullptr;
+    if (KPv == 64 && inv_mode && scratch) {
+        constexpr int NT = 512;
+        double* Ginv = scratch;
+        int* status = (int*)(scratch + 64 * 64);
+        gram_inverse_kernel<64><<<1, 256, 0, st>>>(G, k, Ginv, status);
+        SMK_HIP(hipGetLastError());
+        const int lds = (2 * 64 * 64 + (NT / 64) * 2 * 64) * (int)sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) {
+            SMK_HIP(hipFuncSetAttribute((const void*)nnls_bpp_inv_kernel<64, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
+        const i64 cap = (i64)num_cus * 2 * 4;          // 2 resident workgroups per CU, a few rounds for balance
+        if (g2 > cap) g2 = cap;
+        nnls_bpp_inv_kernel<64, NT><<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin);
+        SMK_HIP(hipGetLastError());
+        skip_if = status;
+    }
+    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if)));
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace smk

@@ -79,6 +79,7 @@ struct smk_solver {
     double *H = nullptr, *Wt = nullptr, *Gw = nullptr, *Gh = nullptr, *gram_scratch = nullptr;
     double *Wprev = nullptr, *hals_scratch = nullptr, *pg_partials = nullptr, *scal = nullptr, *tmpW = nullptr;
     double* tmpH = nullptr;               // k x n compact copy of H for the host (get_factors)
+    double* nnls_scratch = nullptr;       // BPP: inverse of the Gram matrix + path selector (k > 32)
     double *Gh_own = nullptr, *scal_own = nullptr, *Wt_own = nullptr;
     void *packW = nullptr, *packH = nullptr;
     double *P1 = nullptr, *P2 = nullptr;
@@ -625,6 +626,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     rc |= dev_alloc(&s->P1, s->pl1.p_elems);
     rc |= dev_alloc(&s->P2, s->pl2.p_elems);
     if (opts->algorithm == SMK_ALG_HALS) rc |= dev_alloc(&s->hals_scratch, hals_w_scratch_elems(s->k, s->m));
+    if (opts->algorithm == SMK_ALG_BPP) rc |= dev_alloc(&s->nnls_scratch, nnls_scratch_elems(s->k));
     if (opts->prog_est_algorithm == SMK_PROG_DELTA_FNORM) rc |= dev_alloc(&s->Wprev, (size_t)s->KP * s->m);
     if (rc) { smk_solver_destroy(s); return SMK_DEVICE_ERROR; }
     s->Gh = s->Gh_own;
@@ -638,7 +640,7 @@ void smk_solver_destroy(smk_solver* s)
 {
     if (!s) return;
     void* ptrs[] = {s->H, s->Wt_own, s->Gw, s->Gh_own, s->gram_scratch, s->tmpW, s->pg_partials, s->scal_own,
-                    s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH};
+                    s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH, s->nnls_scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int w = 0; w < 2; ++w)
@@ -831,7 +833,7 @@ static int solver_iteration(smk_solver* s)
             rc = prod2(s);    if (rc) return rc;
             break;
         case SMK_ALG_BPP:  // nmf_solver_bpp.hpp:342-377
-            rc = launch_nnls_bpp(s->H, nullptr, s->k, 0, s->n, r1, s->Gw, s->fail_flag, s->iter, s->st); if (rc) return rc;
+            rc = launch_nnls_bpp(s->H, nullptr, s->k, 0, s->n, r1, s->Gw, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
             rc = gram_h(s);   if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
             if (s->ar && s->world > 1) {
@@ -840,12 +842,12 @@ static int solver_iteration(smk_solver* s)
                 const i64 base = s->m / s->world, extra = s->m % s->world;
                 const i64 i0 = s->rank * base + (s->rank < extra ? s->rank : extra);
                 const i64 i1 = i0 + base + (s->rank < extra ? 1 : 0);
-                rc = launch_nnls_bpp(s->Wt, nullptr, s->k, i0, i1, view2(s), s->Gh, s->fail_flag, s->iter, s->st); if (rc) return rc;
+                rc = launch_nnls_bpp(s->Wt, nullptr, s->k, i0, i1, view2(s), s->Gh, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
                 if (i0 > 0) SMK_HIP(hipMemsetAsync(s->Wt, 0, (size_t)i0 * s->KP * sizeof(double), s->st));
                 if (i1 < s->m) SMK_HIP(hipMemsetAsync(s->Wt + i1 * s->KP, 0, (size_t)(s->m - i1) * s->KP * sizeof(double), s->st));
                 if (s->ar(s->ar_user, s->Wt, (int64_t)s->KP * s->m, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
             } else {
-                rc = launch_nnls_bpp(s->Wt, nullptr, s->k, 0, s->m, view2(s), s->Gh, s->fail_flag, s->iter, s->st); if (rc) return rc;
+                rc = launch_nnls_bpp(s->Wt, nullptr, s->k, 0, s->m, view2(s), s->Gh, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
             }
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
@@ -1187,6 +1189,56 @@ int smk_solver_nnls_hals(smk_solver* s, double tol, int verbose, int max_iter, i
     if (rc) return rc;
     if (!success) fprintf(stderr, "NNLS solver reached iteration limit.\n");
     return success ? SMK_OK : SMK_FAILURE;
+}
+
+// NnlsBlockpivot(LHS, RHS, X, Y), common/include/nnls.hpp:144-244, on its own: min ||.|| s.t. X >= 0 for
+// LHS X = RHS with LHS k x k SPD, warm start X (passive set = X > 0), dual Y = LHS X - RHS.
+int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, const double* RHS, int64_t ldR, double* X,
+                        int64_t ldX, double* Y, int64_t ldY)
+{
+    if (!g_init) { set_error("smk_initialize() has not been called"); return SMK_NOTINITIALIZED; }
+    if (k <= 0 || ncols <= 0 || !LHS || !RHS || !X || ldL < k || ldR < k || ldX < k || (Y && ldY < k)) return SMK_BAD_PARAM;
+    if (k > 64) { set_error("device path supports k <= 64"); return SMK_UNSUPPORTED; }
+    const int KP = kp_of(k);
+    std::vector<double> hg((size_t)KP * KP, 0.0), hr((size_t)KP * ncols, 0.0), hx((size_t)KP * ncols, 0.0);
+    for (int c = 0; c < k; ++c)
+        for (int r = 0; r < k; ++r) hg[(size_t)c * KP + r] = LHS[(size_t)c * ldL + r];
+    for (int64_t c = 0; c < ncols; ++c)
+        for (int r = 0; r < k; ++r) {
+            hr[(size_t)c * KP + r] = RHS[(size_t)c * ldR + r];
+            hx[(size_t)c * KP + r] = X[(size_t)c * ldX + r];
+        }
+    double *dg = nullptr, *dr = nullptr, *dx = nullptr, *dy = nullptr, *dscratch = nullptr;
+    int* dflag = nullptr;
+    int rc = 0;
+    rc |= dev_alloc(&dg, hg.size());
+    rc |= dev_alloc(&dr, hr.size());
+    rc |= dev_alloc(&dx, hx.size());
+    rc |= dev_alloc(&dy, hx.size());
+    rc |= dev_alloc(&dscratch, nnls_scratch_elems(k));
+    rc |= dev_alloc(&dflag, (size_t)1);
+    struct Free { std::vector<void*> p; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } guard{{dg, dr, dx, dy, dscratch, dflag}};
+    if (rc) return SMK_DEVICE_ERROR;
+    const int big = INT_MAX;
+    SMK_HIP(hipMemcpyAsync(dg, hg.data(), hg.size() * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    SMK_HIP(hipMemcpyAsync(dr, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    SMK_HIP(hipMemcpyAsync(dx, hx.data(), hx.size() * sizeof(double), hipMemcpyHostToDevice, g_stream));
+    SMK_HIP(hipMemsetAsync(dy, 0, hx.size() * sizeof(double), g_stream));
+    SMK_HIP(hipMemcpyAsync(dflag, &big, sizeof(int), hipMemcpyHostToDevice, g_stream));
+    const PartialView pv{dr, 1, 0, KP, 1};
+    rc = launch_nnls_bpp(dx, dy, k, 0, ncols, pv, dg, dflag, 0, dscratch, g_cus, g_stream);
+    if (rc) return rc;
+    int flag = INT_MAX;
+    SMK_HIP(hipMemcpyAsync(hx.data(), dx, hx.size() * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    SMK_HIP(hipMemcpyAsync(hr.data(), dy, hx.size() * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    SMK_HIP(hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+    SMK_HIP(hipStreamSynchronize(g_stream));
+    for (int64_t c = 0; c < ncols; ++c)
+        for (int r = 0; r < k; ++r) {
+            X[(size_t)c * ldX + r] = hx[(size_t)c * KP + r];
+            if (Y) Y[(size_t)c * ldY + r] = hr[(size_t)c * KP + r];
+        }
+    return flag == INT_MAX ? SMK_OK : SMK_FAILURE;
 }
 
 int smk_solver_get_factors(smk_solver* s, int normalize, double* W, int64_t ldW, double* H, int64_t ldH)

@@ -268,3 +268,19 @@ def nmf(A, W0, H0, algorithm, *, storage="f32", **kw) -> NmfResult:
     if rc not in (L.OK, L.FAILURE, L.BAD_PARAM, L.NOTINITIALIZED, L.SIZE_TOO_LARGE):
         L.check(rc, "smk_nmf_dense")
     return NmfResult(rc, W, H, st.iteration_count, st.elapsed_us)
+
+
+def nnls_blockpivot(LHS, RHS, Xinit):
+    """``NnlsBlockpivot`` (common/include/nnls.hpp:144-244) on the device, by itself.
+
+    LHS k x k SPD, RHS k x ncols, Xinit the warm start (passive set = Xinit > 0).
+    Returns (ok, X, Y) with Y = LHS X - RHS; ok False = the reference's ``false``."""
+    G = _f(LHS)
+    B = _f(RHS)
+    X = _f(Xinit).copy(order="F")
+    k, ncols = B.shape
+    Y = np.zeros((k, ncols), order="F")
+    rc = L.lib().smk_nnls_blockpivot(k, ncols, _p(G), k, _p(B), k, _p(X), k, _p(Y), k)
+    if rc not in (L.OK, L.FAILURE):
+        L.check(rc, "smk_nnls_blockpivot")
+    return rc == L.OK, X, Y

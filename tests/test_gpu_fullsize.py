@@ -107,3 +107,26 @@ def test_c4_shard_f32_sampled(gpu, alg):
     ref = oracle.nmf(np.asfortranarray(Ar.T), np.asfortranarray(H1.T), np.asfortranarray(W0[rows, :].T), alg,
                      min_iter=1, max_iter=1, normalize=False)
     assert ref.result == 0 and relerr(W1[rows, :], ref.H.T) < 1e-4
+
+
+def test_c4_full_f32_bpp_sampled(gpu):
+    """configs[3] WHOLE on one MI355X: dense 262144 x 65536, k = 64, BPP, A in fp32 (A and A' resident:
+    137 GB of the 288 GB).  One iteration from a mean-matched start, checked exactly like the shard test:
+    the H update on sampled columns and the W update on sampled rows are small NNLS problems the oracle
+    solves from regenerated columns / rows of A; every sampled entry went through the full-length
+    streaming products (65536- and 262144-long contractions, all row splits) and the k = 64 NNLS kernel."""
+    import oracle
+    m, n, k, seed = 262144, 65536, 64, 301
+    W0, H0, W1, H1 = _one_iteration(gpu, m, n, k, "BPP", "f32", (seed, 302, 303))
+    assert np.isfinite(W1).all() and np.isfinite(H1).all() and (W1 >= 0).all() and (H1 >= 0).all()
+    rng = np.random.default_rng(2)
+    cols = np.sort(rng.choice(n, size=k + 8, replace=False))
+    Ac = sampled_cols(oracle, m, seed, 0, cols)
+    ref = oracle.nmf(Ac, W0, H0[:, cols], "BPP", min_iter=1, max_iter=1, normalize=False)
+    assert ref.result == 0 and relerr(H1[:, cols], ref.H) < 1e-4
+    assert np.array_equal(H1[:, cols] > 0, ref.H > 0)                       # same passive sets
+    rows = np.sort(rng.choice(m, size=k + 8, replace=False))
+    Ar = sampled_rows(oracle, m, n, seed, 0, rows)
+    ref = oracle.nmf(np.asfortranarray(Ar.T), np.asfortranarray(H1.T), np.asfortranarray(W0[rows, :].T), "BPP",
+                     min_iter=1, max_iter=1, normalize=False)
+    assert ref.result == 0 and relerr(W1[rows, :], ref.H.T) < 1e-4

@@ -136,3 +136,19 @@ def test_rank2_requires_k2_and_solves_2x2_exactly():
     A2 = W0 @ Hs
     r = oracle.nmf(A2, W0, np.ones((2, 40)), "RANK2", min_iter=1, max_iter=1, normalize=False)
     assert np.linalg.norm(A2 - r.W @ r.H) / np.linalg.norm(A2) < 1e-10
+
+
+@pytest.mark.parametrize("alg,k", [("MU", 5), ("HALS", 4), ("BPP", 6), ("RANK2", 2)])
+def test_sparse_driver_equals_dense_driver(alg, k):
+    """orc_nmf_sparse (NmfSparse: products over the stored entries) against orc_nmf on the densified matrix:
+    the reference's own test (tests/src/test_dense_nmf.cpp:205-378) demands 1e-8 between the two."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(k)
+    m, n = 120, 90
+    A = sp.random(m, n, density=0.15, random_state=3, format="csc", data_rvs=lambda s: rng.random(s) + 0.1)
+    W0, H0 = oracle.fill_uniform(m, k, 5), oracle.fill_uniform(k, n, 6)
+    a = oracle.nmf_sparse(A, W0, H0, alg, min_iter=8, max_iter=8, tol=1e-12)
+    b = oracle.nmf(A.toarray(order="F"), W0, H0, alg, min_iter=8, max_iter=8, tol=1e-12)
+    assert a.result == b.result == 0 and a.iteration_count == b.iteration_count
+    assert np.abs(a.W - b.W).max() < 1e-10 * np.abs(b.W).max()
+    assert np.abs(a.H - b.H).max() < 1e-10 * np.abs(b.H).max()

@@ -1,6 +1,7 @@
 // phase profile of the streaming kernel (s_memtime stamps per stage): wait / barrier / issue / compute
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSMK_BP_PROFILE -I smallk_amd/csrc tools/mb/mb_bigprod.hip -o tools/mb/mb_bigprod
 #include "../../smallk_amd/csrc/kernels.hip"
+#include "../../smallk_amd/csrc/bigprod.hip"
 #include <cstdio>
 #include <vector>
 using namespace smk;
