@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const double* __restrict__ X,
 // blocks indexed by the global chunk-pair q; rows are padded to a multiple of 128.
 // operand format: bf16 fragments (E = 8) for bf16 storage and for the fp32 "bf16x3" emulation
 // (nsplit == 3); native fp32 fragments (E = 4, one term) otherwise
-static inline bool pack_is_bf16(int storage, int nsplit) { return storage == STORE_BF16 || nsplit == 3; }
+static inline bool pack_is_bf16(int storage, int nsplit) { return storage == STORE_BF16 || nsplit >= 2; }
 
 static inline i64 pack_nq(int storage, int nsplit, i64 N)
 {
@@ -464,6 +464,585 @@ int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* ou
     }
     SMK_HIP(hipGetLastError());
     return 0;
+}
+
+
+// ==========================================================================
+// fp32 A as three bf16 planes ("bf16x3"), second generation.
+//
+// Same staging (LDS ring filled by global_load_lds, XOR-swizzled 16-byte chunks, packed X fragments) and
+// the same result layout as bigprod_kernel, but organised around what limited that kernel for fp32 input
+// at k in (32, 64] (VALU issue, not HBM -- DESIGN.md 5.1):
+//   * a compute wave owns 32 columns and ALL k tiles, so the fp32 -> bf16 hi/mid/lo split of a tile is done
+//     once (it was done once per k-tile wave group) and each B fragment is read from LDS once;
+//   * the five small products (significance 2^-8 and 2^-16) share ONE fp32 accumulator per tile;
+//   * the leading product is folded into the fp64 sums every FOLD stages (FOLD * MB rows, the chain length the
+//     bf16 path has) by plain VALU adds, and the first MFMA after a fold takes C = 0, so there is no second
+//     accumulator set and no zeroing;
+//   * 4 compute waves (+ NWL loader waves) per 128-column tile.
+// ==========================================================================
+template <int KT, int MB_, int NSTAGE_, int NWL_, int NS = 3>
+struct F3Cfg {
+    static constexpr int MB = MB_;
+    static constexpr int NWC = 4;
+    static constexpr int NWL = NWL_;
+    static constexpr int NLD = NWL_ > 0 ? NWL_ : NWC;
+    static constexpr int NW = NWC + NWL_;
+    static constexpr int CPC = MB / 4;              // 16-byte chunks per column per stage
+    static constexpr int SWZ_SH = (CPC >= 16) ? 0 : (CPC == 8) ? 1 : (CPC == 4) ? 2 : 3;
+    static constexpr int SWZ_MASK = (CPC >= 16 ? 16 : CPC) - 1;
+    static constexpr int QS = MB / 16;              // 16-row MFMA steps per stage
+    static constexpr int NB = 128;
+    static constexpr int B_BYTES = NB * MB * 4;
+    static constexpr int X_BYTES = QS * NS * KT * 1024;
+    static constexpr int STAGE_BYTES = B_BYTES + X_BYTES;
+    static constexpr int NSTAGE = NSTAGE_;
+    static constexpr int PD = NSTAGE_ - 1;
+    static constexpr int TI = STAGE_BYTES / 1024;
+    static constexpr int LPS = TI / NLD;
+    static constexpr bool OK = (TI % NLD == 0) && (LPS * PD <= 63) && (STAGE_BYTES * NSTAGE <= 160 * 1024);
+};
+
+template <int KT, int MB, int NSTAGE, int NWL, int FOLD, int WPS, int NS>
+__global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
+                                                                        const unsigned char* __restrict__ Xp,
+                                                                        double* __restrict__ P, i64 stages, i64 nst,
+                                                                        i64 tiles, i64 ncols_pad, int S, int logS)
+{
+    using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const i64 grp = bid >> 3;
+    i64 tile;
+    int split;
+    if (S <= 8) {
+        split = xcd & (S - 1);
+        tile = grp * (8 >> logS) + (xcd >> logS);
+    } else {
+        const int sub = S >> 3;
+        split = (int)(grp % sub) * 8 + xcd;
+        tile = grp / sub;
+    }
+    if (tile >= tiles) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = (NWL == 0) || (wave >= C::NWC);
+    const bool is_compute = wave < C::NWC;
+    const int lw = (NWL == 0) ? wave : (wave - C::NWC);
+
+    i64 st0 = (i64)split * nst;
+    i64 st1 = st0 + nst;
+    if (st1 > stages) st1 = stages;
+    const int my_nst = (st1 > st0) ? (int)(st1 - st0) : 0;
+
+    const i64 col0 = tile * C::NB;
+    i64 src_off[C::LPS];
+    int is_b[C::LPS];
+#pragma unroll
+    for (int i = 0; i < C::LPS; ++i) {
+        const int t = lw + C::NLD * i;
+        if (t * 1024 < C::B_BYTES) {
+            const int p = t * 64 + lane;
+            const int j = p / C::CPC;
+            const int pc = p % C::CPC;
+            const int swz = (j >> C::SWZ_SH) & C::SWZ_MASK;
+            src_off[i] = (col0 + j) * ldb_bytes + (i64)(pc ^ swz) * 16;
+            is_b[i] = 1;
+        } else {
+            src_off[i] = (i64)(t * 1024 - C::B_BYTES) + lane * 16;
+            is_b[i] = 0;
+        }
+    }
+    auto issue = [&](int s_local) {
+        const i64 stage = st0 + s_local;
+        unsigned char* lbase = smem + (s_local % C::NSTAGE) * C::STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::LPS; ++i) {
+            const int t = lw + C::NLD * i;
+            const unsigned char* g = is_b[i] ? (B + src_off[i] + stage * (C::MB * 4)) : (Xp + stage * C::X_BYTES + src_off[i]);
+            if (is_b[i])
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
+            else
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16_t hi[KT], sm[KT];
+    double dacc[KT][16];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hi[kt][r] = 0.f; sm[kt][r] = 0.f; dacc[kt][r] = 0.0; }
+
+    const int h = lane >> 5;
+    const int jl = wave * 32 + (lane & 31);                  // this lane's column inside the tile (compute waves)
+    const int swz_r = (jl >> C::SWZ_SH) & C::SWZ_MASK;
+    const int bfrag_base = jl * C::CPC * 16;
+
+    auto fold = [&]() {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[kt][r] += (double)hi[kt][r];
+    };
+
+#ifdef SMK_BP_PROFILE
+    unsigned long long prof_[4] = {0, 0, 0, 0};
+#endif
+    // one stage; FIRST: the leading accumulators restart from zero (C = 0 on their first MFMA)
+    auto stage_body = [&](int t, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        int ahead = my_nst - 1 - t;
+        if (ahead > C::PD - 1) ahead = C::PD - 1;
+        BP_T(t0_);
+        if (is_loader) wait_stage<C::LPS, C::PD>(ahead);
+        BP_T(t1_);
+        __builtin_amdgcn_s_barrier();
+        BP_T(t2_);
+        if (is_loader && t + C::PD < my_nst) issue(t + C::PD);
+        BP_T(t3_);
+#ifdef SMK_BP_PROFILE
+        prof_[0] += t1_ - t0_; prof_[1] += t2_ - t1_; prof_[2] += t3_ - t2_;
+#endif
+        if (!is_compute) return;
+        const unsigned char* sb = smem + (t % C::NSTAGE) * C::STAGE_BYTES;
+        const unsigned char* sx = sb + C::B_BYTES;
+#pragma unroll
+        for (int q = 0; q < C::QS; ++q) {
+            // rows 16q + 8h .. +7 of this lane's column = fp32 chunks 4q + 2h, 4q + 2h + 1
+            const int lc0 = 4 * q + 2 * h;
+            const f32x4_t f0 = *(const f32x4_t*)(sb + bfrag_base + (((lc0) ^ swz_r) << 4));
+            const f32x4_t f1 = *(const f32x4_t*)(sb + bfrag_base + (((lc0 + 1) ^ swz_r) << 4));
+            bf16x8_t a[KT][NS];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    a[kt][s] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(sx + ((q * NS + s) * KT + kt) * 1024 + lane * 16));
+            f32x8_t x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = f0[e]; x[4 + e] = f1[e]; }
+            const bf16x8_t bhi = __builtin_convertvector(x, bf16x8_t);
+            x -= __builtin_convertvector(bhi, f32x8_t);
+            const bf16x8_t bmid = __builtin_convertvector(x, bf16x8_t);
+            bf16x8_t blo = bmid;
+            if constexpr (NS == 3) {
+                x -= __builtin_convertvector(bmid, f32x8_t);
+                blo = __builtin_convertvector(x, bf16x8_t);
+            }
+            // independent accumulators alternate so that no MFMA waits on the one just issued
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                if (FIRST && q == 0) {
+                    const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    hi[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][0], bhi, zero, 0, 0, 0);
+                } else {
+                    hi[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][0], bhi, hi[kt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][0], bmid, sm[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][1], bhi, sm[kt], 0, 0, 0);
+            if constexpr (NS == 3) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][0], blo, sm[kt], 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][1], bmid, sm[kt], 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][NS - 1], bhi, sm[kt], 0, 0, 0);
+            }
+        }
+#ifdef SMK_BP_PROFILE
+        asm volatile("s_nop 0" ::: "memory");
+        prof_[3] += __builtin_readcyclecounter() - t3_;
+#endif
+    };
+
+    if (is_loader) {
+#pragma unroll
+        for (int i = 0; i < C::PD; ++i)
+            if (i < my_nst) issue(i);
+    }
+
+    int t = 0;
+    for (; t + FOLD <= my_nst; t += FOLD) {
+        stage_body(t, std::true_type{});
+#pragma unroll
+        for (int u = 1; u < FOLD; ++u) stage_body(t + u, std::false_type{});
+        if (is_compute) fold();
+    }
+    if (t < my_nst) {
+        stage_body(t, std::true_type{});
+        for (++t; t < my_nst; ++t) stage_body(t, std::false_type{});
+        if (is_compute) fold();
+    }
+#ifdef SMK_BP_PROFILE
+    if (g_bp_prof && lane == 0) {
+        unsigned long long* o = g_bp_prof + ((size_t)blockIdx.x * C::NW + wave) * 4;
+        o[0] = prof_[0]; o[1] = prof_[1]; o[2] = prof_[2]; o[3] = prof_[3];
+    }
+#endif
+    if (!is_compute) return;
+
+    // epilogue (same layout as bigprod_kernel): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const i64 jg = col0 + jl;
+    double* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                f64x2_t v;
+                v[0] = dacc[kt][4 * g + i] + (double)sm[kt][4 * g + i];
+                v[1] = dacc[kt][4 * g + i + 1] + (double)sm[kt][4 * g + i + 1];
+                *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
+            }
+}
+
+
+// --------------------------------------------------------------------------
+// Software-pipelined form of the kernel above (MB = 32: two 16-row steps per stage).  Measured on the
+// non-pipelined form with one compute wave per SIMD: 90 % of a wave's time is its compute phase, ~1400
+// cycles per stage for 24 MFMAs (768 cycles of matrix pipe) -- the fragment reads and the bf16 split of a
+// step sit in front of its MFMAs instead of beside them.  Here the reads + split of step u + 1 are issued
+// behind the MFMAs of step u (register double buffer), across stages too: the barrier that publishes stage
+// t + 1 sits between the two steps of stage t, so a ring slot is reused two barriers after its last read
+// (in flight: NSTAGE - 2 stages).  sched_group_barrier pins the interleave: 1 MFMA : 1 LDS read : 4 VALU.
+// --------------------------------------------------------------------------
+template <int KT, int NSTAGE, int NWL, int FOLD, int PIN, int NS>
+__global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
+                                                                        const unsigned char* __restrict__ Xp,
+                                                                        double* __restrict__ P, i64 stages, i64 nst,
+                                                                        i64 tiles, i64 ncols_pad, int S, int logS)
+{
+    using C = F3Cfg<KT, 32, NSTAGE, NWL, NS>;
+    constexpr int PDN = NSTAGE - 2;                 // stages in flight ahead of the published one
+    static_assert(PDN >= 1, "ring too shallow");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const i64 grp = bid >> 3;
+    i64 tile;
+    int split;
+    if (S <= 8) {
+        split = xcd & (S - 1);
+        tile = grp * (8 >> logS) + (xcd >> logS);
+    } else {
+        const int sub = S >> 3;
+        split = (int)(grp % sub) * 8 + xcd;
+        tile = grp / sub;
+    }
+    if (tile >= tiles) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_compute = wave < C::NWC;
+    const int lw = (NWL == 0) ? wave : (wave - C::NWC);
+
+    i64 st0 = (i64)split * nst;
+    i64 st1 = st0 + nst;
+    if (st1 > stages) st1 = stages;
+    const int my_nst = (st1 > st0) ? (int)(st1 - st0) : 0;
+
+    const i64 col0 = tile * C::NB;
+    i64 src_off[C::LPS];
+    int is_b[C::LPS];
+#pragma unroll
+    for (int i = 0; i < C::LPS; ++i) {
+        const int t = lw + C::NLD * i;
+        if (t * 1024 < C::B_BYTES) {
+            const int p = t * 64 + lane;
+            const int j = p / C::CPC;
+            const int pc = p % C::CPC;
+            const int swz = (j >> C::SWZ_SH) & C::SWZ_MASK;
+            src_off[i] = (col0 + j) * ldb_bytes + (i64)(pc ^ swz) * 16;
+            is_b[i] = 1;
+        } else {
+            src_off[i] = (i64)(t * 1024 - C::B_BYTES) + lane * 16;
+            is_b[i] = 0;
+        }
+    }
+    auto issue = [&](int s_local) {
+        const i64 stage = st0 + s_local;
+        unsigned char* lbase = smem + (s_local % C::NSTAGE) * C::STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::LPS; ++i) {
+            const int t = lw + C::NLD * i;
+            const unsigned char* g = is_b[i] ? (B + src_off[i] + stage * (C::MB * 4)) : (Xp + stage * C::X_BYTES + src_off[i]);
+            if (is_b[i])
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
+            else
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
+        }
+    };
+    f32x16_t hi[KT], sm[KT];
+    double dacc[KT][16];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hi[kt][r] = 0.f; sm[kt][r] = 0.f; dacc[kt][r] = 0.0; }
+
+    const int h = lane >> 5;
+    const int jl = (wave & 3) * 32 + (lane & 31);
+    const int swz_r = (jl >> C::SWZ_SH) & C::SWZ_MASK;
+    const int bfrag_base = jl * C::CPC * 16;
+
+    struct Frag { bf16x8_t bh, bm, bl; bf16x8_t a[KT][NS]; };
+    auto lds_read = [&](int slot, int q, f32x4_t& r0, f32x4_t& r1, Frag& f) {
+        const unsigned char* sb = smem + slot * C::STAGE_BYTES;
+        const unsigned char* sx = sb + C::B_BYTES;
+        const int lc0 = 4 * q + 2 * h;             // rows 16q + 8h .. +7 = fp32 chunks lc0, lc0 + 1
+        r0 = *(const f32x4_t*)(sb + bfrag_base + (((lc0) ^ swz_r) << 4));
+        r1 = *(const f32x4_t*)(sb + bfrag_base + (((lc0 + 1) ^ swz_r) << 4));
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                f.a[kt][s] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(sx + ((q * NS + s) * KT + kt) * 1024 + lane * 16));
+    };
+    auto split3 = [&](const f32x4_t& r0, const f32x4_t& r1, Frag& f) {
+        f32x8_t x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = r0[e]; x[4 + e] = r1[e]; }
+        if constexpr ((PIN & 2) != 0) {             // experiment: no split (wrong numbers, same traffic)
+            f.bh = __builtin_bit_cast(bf16x8_t, r0);
+            f.bm = __builtin_bit_cast(bf16x8_t, r1);
+            f.bl = f.bh;
+            return;
+        }
+        f.bh = __builtin_convertvector(x, bf16x8_t);
+        x -= __builtin_convertvector(f.bh, f32x8_t);
+        f.bm = __builtin_convertvector(x, bf16x8_t);
+        f.bl = f.bm;
+        if constexpr (NS == 3) {
+            x -= __builtin_convertvector(f.bm, f32x8_t);
+            f.bl = __builtin_convertvector(x, bf16x8_t);
+        }
+    };
+    auto mma = [&](const Frag& f) {
+        if constexpr ((PIN & 4) != 0) {             // experiment: no matrix work, keep every read alive
+            u32x4_t acc = __builtin_bit_cast(u32x4_t, f.bh) ^ __builtin_bit_cast(u32x4_t, f.bm) ^ __builtin_bit_cast(u32x4_t, f.bl);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int s3 = 0; s3 < NS; ++s3) acc ^= __builtin_bit_cast(u32x4_t, f.a[kt][s3]);
+            hi[0][0] += __builtin_bit_cast(float, acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+            return;
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) hi[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][0], f.bh, hi[kt], 0, 0, 0);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][0], f.bm, sm[kt], 0, 0, 0);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][1], f.bh, sm[kt], 0, 0, 0);
+        if constexpr (NS == 3) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][0], f.bl, sm[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][1], f.bm, sm[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][NS - 1], f.bh, sm[kt], 0, 0, 0);
+        }
+    };
+    // interleave of one half stage: 6 KT MFMAs, 2 + 3 KT fragment reads, ~44 VALU of the split
+    auto pin_schedule = [&]() {
+        if constexpr ((PIN & 1) == 0) return;
+#pragma unroll
+        for (int i = 0; i < (NS == 3 ? 6 : 3) * KT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA
+            if (i < 2 + NS * KT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);              // four VALU
+        }
+    };
+
+    static_assert(NWL > 0, "the pipelined kernel keeps loading and computing on different waves");
+    if (!is_compute) {
+        // ---- loader waves: one barrier per stage, in step with the compute waves below ----
+        if constexpr ((PIN & 8) != 0) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int i = 0; i < PDN; ++i)
+            if (i < my_nst) issue(i);
+        for (int s = 0; s < my_nst; ++s) {
+            int ahead = my_nst - 1 - s;
+            if (ahead > PDN - 1) ahead = PDN - 1;
+            wait_stage<C::LPS, PDN>(ahead);
+            __builtin_amdgcn_s_barrier();                       // publishes stage s; stage s - 2 is consumed
+            if (s + PDN < my_nst) issue(s + PDN);
+        }
+        return;
+    }
+    if (my_nst > 0) {
+        __builtin_amdgcn_s_barrier();                           // stage 0 published
+        Frag fA, fB;
+        f32x4_t r0, r1;
+        lds_read(0, 0, r0, r1, fA);
+        split3(r0, r1, fA);
+        for (int t = 0; t < my_nst; ++t) {
+            const int slot = t % C::NSTAGE;
+            const int slot_next = (t + 1) % C::NSTAGE;         // past the end: stale but valid LDS, never used
+            lds_read(slot, 1, r0, r1, fB);
+            mma(fA);
+            split3(r0, r1, fB);
+            pin_schedule();
+            if (t + 1 < my_nst) __builtin_amdgcn_s_barrier();   // stage t + 1 published
+            lds_read(slot_next, 0, r0, r1, fA);
+            mma(fB);
+            split3(r0, r1, fA);
+            pin_schedule();
+            if ((t % FOLD) == FOLD - 1 || t == my_nst - 1) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { dacc[kt][r] += (double)hi[kt][r]; hi[kt][r] = 0.f; }
+            }
+        }
+    }
+
+    const i64 jg = col0 + jl;
+    double* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                f64x2_t v;
+                v[0] = dacc[kt][4 * g + i] + (double)sm[kt][4 * g + i];
+                v[1] = dacc[kt][4 * g + i + 1] + (double)sm[kt][4 * g + i + 1];
+                *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
+            }
+}
+
+template <int KT, int NS, int NSTAGE, int NWL, int FOLD, int PIN = 1>
+static int launch_f3p_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
+{
+    using C = F3Cfg<KT, 32, NSTAGE, NWL, NS>;
+    if constexpr (!C::OK) {
+        set_error("bigprod f3p variant does not fit");
+        return -100;
+    } else {
+        constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
+        static bool attr_set = false;
+        auto kern = bigprod_f3p_kernel<KT, NSTAGE, NWL, FOLD, PIN, NS>;
+        if (!attr_set) {
+            SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        int logS = 0;
+        while ((1 << logS) < pl.S) ++logS;
+        i64 grid;
+        if (pl.S <= 8) {
+            const i64 per = 8 >> logS;
+            grid = (pl.tiles + per - 1) / per * 8;
+        } else {
+            grid = pl.tiles * pl.S;
+        }
+        kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS);
+        SMK_HIP(hipGetLastError());
+        return 0;
+    }
+}
+
+struct F3Variant { int mb, nstage, nwl, fold, wps; };
+static const F3Variant kF3Variants[] = {
+    {32, 2, 0, 2, 2},   // 100: no loader waves, two workgroups per CU
+    {32, 3, 0, 2, 2},   // 101
+    {32, 4, 4, 2, 2},   // 102: 4 loader waves, one workgroup per CU, deep ring
+    {32, 5, 4, 2, 2},   // 103
+    {32, 2, 2, 2, 3},   // 104: 2 loader waves, two workgroups per CU (168 registers)
+    {64, 2, 0, 1, 2},   // 105: 64-row stages
+    {64, 2, 4, 1, 2},   // 106
+    {32, 4, 4, 4, 2},   // 107: fold every 4 stages (128-row chains)
+    {32, 2, 0, 4, 2},   // 108
+    {32, 4, 2, 2, 2},   // 109
+    // software-pipelined kernel (bigprod_f3p_kernel); wps unused
+    {32, 4, 4, 4, 0},   // 110: 4 loader waves, 4-deep ring, fold every 4 stages
+    {32, 5, 4, 4, 0},   // 111
+    {32, 5, 4, 2, 0},   // 112
+    {32, 4, 2, 4, 0},   // 113: 2 loader waves
+    {32, 5, 2, 4, 0},   // 114
+    {32, 3, 2, 4, 0},   // 115: shallow ring, two workgroups per CU fit
+    {32, 5, 4, 8, 0},   // 116: fold every 8 stages
+    {32, 5, 4, 4, 0},   // 117: as 111 without the pinned interleave (compiler's own schedule)
+    {32, 5, 4, 4, 0},   // 118: EXPERIMENT no bf16 split
+    {32, 5, 4, 4, 0},   // 119: EXPERIMENT no MFMA
+    {32, 5, 4, 4, 0},   // 120: EXPERIMENT neither
+    {32, 5, 4, 4, 0},   // 121: loader waves at priority 3
+    {32, 5, 4, 4, 0},   // 122: loader priority, compiler schedule
+};
+static const int kNumF3 = (int)(sizeof(kF3Variants) / sizeof(kF3Variants[0]));
+
+template <int KT, int NS, int MB, int NSTAGE, int NWL, int FOLD, int WPS>
+static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
+{
+    using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
+    if constexpr (!C::OK) {
+        set_error("bigprod f3 variant does not fit");
+        return -100;
+    } else {
+        constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
+        static bool attr_set = false;
+        auto kern = bigprod_f3_kernel<KT, MB, NSTAGE, NWL, FOLD, WPS, NS>;
+        if (!attr_set) {
+            SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        int logS = 0;
+        while ((1 << logS) < pl.S) ++logS;
+        i64 grid;
+        if (pl.S <= 8) {
+            const i64 per = 8 >> logS;
+            grid = (pl.tiles + per - 1) / per * 8;
+        } else {
+            grid = pl.tiles * pl.S;
+        }
+        kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS);
+        SMK_HIP(hipGetLastError());
+        return 0;
+    }
+}
+
+template <int KT, int NS>
+static int launch_f3(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
+{
+    switch (pl.variant - 100) {
+        case 0: return launch_f3_t<KT, NS, 32, 2, 0, 2, 2>(pl, B, ldb, Xp, P, st);
+        case 1: return launch_f3_t<KT, NS, 32, 3, 0, 2, 2>(pl, B, ldb, Xp, P, st);
+        case 2: return launch_f3_t<KT, NS, 32, 4, 4, 2, 2>(pl, B, ldb, Xp, P, st);
+        case 3: return launch_f3_t<KT, NS, 32, 5, 4, 2, 2>(pl, B, ldb, Xp, P, st);
+        case 4: return launch_f3_t<KT, NS, 32, 2, 2, 2, 3>(pl, B, ldb, Xp, P, st);
+        case 5: return launch_f3_t<KT, NS, 64, 2, 0, 1, 2>(pl, B, ldb, Xp, P, st);
+        case 6: return launch_f3_t<KT, NS, 64, 2, 4, 1, 2>(pl, B, ldb, Xp, P, st);
+        case 7: return launch_f3_t<KT, NS, 32, 4, 4, 4, 2>(pl, B, ldb, Xp, P, st);
+        case 8: return launch_f3_t<KT, NS, 32, 2, 0, 4, 2>(pl, B, ldb, Xp, P, st);
+        case 9: return launch_f3_t<KT, NS, 32, 4, 2, 2, 2>(pl, B, ldb, Xp, P, st);
+        case 10: return launch_f3p_t<KT, NS, 4, 4, 4>(pl, B, ldb, Xp, P, st);
+        case 11: return launch_f3p_t<KT, NS, 5, 4, 4>(pl, B, ldb, Xp, P, st);
+        case 12: return launch_f3p_t<KT, NS, 5, 4, 2>(pl, B, ldb, Xp, P, st);
+        case 13: return launch_f3p_t<KT, NS, 4, 2, 4>(pl, B, ldb, Xp, P, st);
+        case 14: return launch_f3p_t<KT, NS, 5, 2, 4>(pl, B, ldb, Xp, P, st);
+        case 15: return launch_f3p_t<KT, NS, 3, 2, 4>(pl, B, ldb, Xp, P, st);
+        case 16: return launch_f3p_t<KT, NS, 5, 4, 8>(pl, B, ldb, Xp, P, st);
+        case 17: return launch_f3p_t<KT, NS, 5, 4, 4, 0>(pl, B, ldb, Xp, P, st);
+        case 18: return launch_f3p_t<KT, NS, 5, 4, 4, 2>(pl, B, ldb, Xp, P, st);
+        case 19: return launch_f3p_t<KT, NS, 5, 4, 4, 4>(pl, B, ldb, Xp, P, st);
+        case 20: return launch_f3p_t<KT, NS, 5, 4, 4, 6>(pl, B, ldb, Xp, P, st);
+        case 21: return launch_f3p_t<KT, NS, 5, 4, 4, 9>(pl, B, ldb, Xp, P, st);
+        case 22: return launch_f3p_t<KT, NS, 5, 4, 4, 8>(pl, B, ldb, Xp, P, st);
+        default: break;
+    }
+    set_error("unknown bigprod f3 variant");
+    return -100;
 }
 
 constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw, int wk, int nwl);
@@ -504,13 +1083,43 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     pl.storage = storage;
     pl.kt = kt_of(k);
     // fp32 storage: nsplit 3 selects the bf16x3 emulation (default), 1 the native fp32 MFMA
-    pl.nsplit = storage == STORE_BF16 ? nsplit : (nsplit == 3 ? 3 : 1);
+    pl.nsplit = storage == STORE_BF16 ? nsplit : (nsplit >= 2 ? nsplit : 1);
     // measured best on MI355X: bf16 -> 64-row stages, 2-deep ring, 2 workgroups per CU (C3: 5.98 TB/s)
     int v = (storage == STORE_BF16) ? 6 : 7;
     // k in (32,64]: 8 compute waves (one k tile each) + 4 loader waves
     if (pl.kt == 2) v = (storage == STORE_BF16) ? 18 : 21;
+    // fp32 A as bf16 planes: the second-generation kernels (power-bound at ~4.1 TB/s for k = 64)
+    if (storage == STORE_F32 && pl.nsplit >= 2) v = (pl.kt == 2) ? 108 : 115;
     const char* env = getenv("SMK_BP_VARIANT");
     if (env) v = atoi(env);
+    const char* env2 = getenv("SMK_BP_VARIANT_K64");       // only for k in (32, 64]
+    if (env2 && pl.kt == 2) v = atoi(env2);
+    if (storage == STORE_F32 && pl.nsplit == 2 && v < 100) v = (pl.kt == 2) ? 108 : 115;   // the 2-term form exists only there
+    if (v >= 100 && storage == STORE_F32 && pl.nsplit >= 2) {
+        auto f3_fits = [&](int vv) {
+            if (vv < 100 || vv >= 100 + kNumF3) return false;
+            const F3Variant& f = kF3Variants[vv - 100];
+            const int stage = 128 * f.mb * 4 + (f.mb / 16) * pl.nsplit * pl.kt * 1024;
+            const int ti = stage / 1024, nld = f.nwl > 0 ? f.nwl : 4;
+            return ti % nld == 0 && (ti / nld) * (f.nstage - 1) <= 63 && stage * f.nstage <= 160 * 1024;
+        };
+        if (!f3_fits(v)) v = 108;
+        if (!f3_fits(v)) v = 115;
+        if (!f3_fits(v)) v = 110;
+        pl.variant = v;
+        const int MB = kF3Variants[v - 100].mb;
+        pl.stages = (len + MB - 1) / MB;
+        pl.tiles = (ncols + 127) / 128;
+        pl.ncols_pad = round_up(ncols, COL_PAD);
+        int S = 1;
+        while (pl.tiles * S < 2 * (i64)num_cus && S < 64 && pl.stages / (2 * S) >= 8) S *= 2;
+        const char* envS = getenv("SMK_BP_SPLITS");
+        if (envS && atoi(envS) > 0) { S = 1; while (S < atoi(envS) && S < 64) S *= 2; }
+        pl.S = S;
+        pl.nst = (pl.stages + S - 1) / S;
+        pl.p_elems = (size_t)S * pl.ncols_pad * pl.kt * 32;
+        return pl;
+    }
     if (v < 0 || v >= kNumVariants) v = 6;
     // variants that do not fit the 160 KiB LDS for this dtype / k fall back to variant 0
     auto fits = [&](int vv) {
@@ -632,6 +1241,10 @@ int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp
             return launch_bigprod_v<2, 2, 1>(pl, B, ldb, Xp, P, st);
         }
     } else {
+        if (pl.variant >= 100) {
+            if (pl.nsplit == 3) return pl.kt == 1 ? launch_f3<1, 3>(pl, B, ldb, Xp, P, st) : launch_f3<2, 3>(pl, B, ldb, Xp, P, st);
+            return pl.kt == 1 ? launch_f3<1, 2>(pl, B, ldb, Xp, P, st) : launch_f3<2, 2>(pl, B, ldb, Xp, P, st);
+        }
         if (pl.nsplit == 3) {
             if (pl.kt == 1) return launch_bigprod_v<4, 1, 3>(pl, B, ldb, Xp, P, st);
             return launch_bigprod_v<4, 2, 3>(pl, B, ldb, Xp, P, st);
