@@ -167,9 +167,33 @@ int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* laun
 /* algorithmic bytes / flops one launch of pass `which` moves (len*ncols*sizeof(elt), 2*k*len*ncols) */
 int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double* flops);
 
-/* ---- multi-GPU: A and H column sharded, W replicated.  The only exchange steps are
- * sum-all-reduces of HH' (k x k), H*At (k x m) and one scalar; the host supplies the collective
- * (torch.distributed / RCCL).  `ptr` is device memory inside the registered workspace. */
+/* ---- multi-GPU: A and H column sharded, W replicated.  The exchange steps are sum-all-reduces of
+ * HH' (k x k, fp64) and H*At (k x m, fp32) per iteration, one 2-element all-reduce when the stopping rule is
+ * evaluated, and for BPP an all-gather of the row slices of W each rank solved.  They are issued from C on the
+ * solver's own HIP streams through a communicator object:
+ *   - RCCL over xGMI: one process per GPU (smk_comm_unique_id on rank 0, broadcast the 128 bytes by any means,
+ *     smk_comm_init_rank everywhere) or one process driving several GPUs (smk_comm_init_all, one host thread per
+ *     device -- what smk_nmf_dense_sharded does);
+ *   - an in-process stand-in with the same semantics for several shards on ONE device (smk_comm_init_local: RCCL
+ *     refuses two ranks on a device), used by the tests and by boxes with fewer GPUs than shards.
+ * The reference has no distributed mode (sphinx/source/pages_installation.rst:38). */
+typedef struct smk_comm smk_comm;
+int smk_comm_unique_id(void* id128 /* 128 bytes out */);
+int smk_comm_init_rank(smk_comm** out, const void* id128, int rank, int world);   /* on the CURRENT HIP device */
+int smk_comm_init_all(smk_comm** out /* ndev handles */, int ndev, const int* devices /* NULL: 0..ndev-1 */);
+int smk_comm_init_local(smk_comm** out /* nranks handles */, int nranks);
+int smk_comm_rank(const smk_comm* c);
+int smk_comm_world(const smk_comm* c);
+void smk_comm_destroy(smk_comm* c);
+/* attach before smk_solver_set_factors(); the communicator must outlive the solver */
+int smk_solver_attach_comm(smk_solver* s, smk_comm* comm);
+/* Result Nmf(...) (common/src/nmf.cpp:173-229) on `nshards` column shards, one host thread and one device per shard;
+ * devices NULL: shard r on device r; local_stub != 0: all shards on the current device through the stand-in. */
+int smk_nmf_dense_sharded(const smk_options* opts, const double* A, int64_t ldA, double* W, int64_t ldW, double* H,
+                          int64_t ldH, smk_stats* stats, int storage, int nshards, const int* devices, int local_stub);
+
+/* Test hook kept from round 1: the host supplies the all-reduce (e.g. torch.distributed on gloo);
+ * `ptr` is device memory inside the registered workspace. */
 typedef int (*smk_allreduce_fn)(void* user, void* ptr, int64_t count, int dtype /*0 f32, 1 f64*/);
 int smk_solver_comm_workspace_bytes(const smk_solver* s, size_t* bytes);
 int smk_solver_set_comm(smk_solver* s, int rank, int world, smk_allreduce_fn fn, void* user,

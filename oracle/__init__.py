@@ -186,6 +186,26 @@ def projected_gradient_norm(gradW, gradH, W, H) -> float:
     return lib().orc_projected_gradient_norm(m, n, k, _p(gradW), m, _p(gradH), k, _p(W), m, _p(H), k)
 
 
+def gemm_tn(X, A) -> np.ndarray:
+    """X' A with the oracle's own GEMM loops (timing of the plain port in bench.py's cpu_baseline)."""
+    X, A = _f(X), _f(A)
+    m, k = X.shape
+    n = A.shape[1]
+    out = np.zeros((k, n), order="F")
+    lib().orc_gemm(1, 0, k, n, m, 1.0, _p(X), m, _p(A), m, 0.0, _p(out), k)
+    return out
+
+
+def gemm_nt(A, H) -> np.ndarray:
+    """A H' with the oracle's own GEMM loops."""
+    A, H = _f(A), _f(H)
+    m, n = A.shape
+    k = H.shape[0]
+    out = np.zeros((m, k), order="F")
+    lib().orc_gemm(0, 1, m, k, n, 1.0, _p(A), m, _p(H), k, 0.0, _p(out), m)
+    return out
+
+
 def num_threads() -> int:
     return lib().orc_num_threads()
 

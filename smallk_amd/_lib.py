@@ -102,6 +102,16 @@ SYMBOLS = {
     "smk_solver_kernel_time": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int)]),
     "smk_solver_kernel_work": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "smk_solver_comm_workspace_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
+    "smk_comm_unique_id": (C.c_int, [_vp]),
+    "smk_comm_init_rank": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
+    "smk_comm_init_all": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int)]),
+    "smk_comm_init_local": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "smk_comm_rank": (C.c_int, [_vp]),
+    "smk_comm_world": (C.c_int, [_vp]),
+    "smk_comm_destroy": (None, [_vp]),
+    "smk_solver_attach_comm": (C.c_int, [_vp, _vp]),
+    "smk_nmf_dense_sharded": (C.c_int, [C.POINTER(Options), _dp, _i64, _dp, _i64, _dp, _i64, C.POINTER(Stats), C.c_int,
+                                        C.c_int, C.POINTER(C.c_int), C.c_int]),
     "smk_solver_set_comm": (C.c_int, [_vp, C.c_int, C.c_int, ALLREDUCE_FN, _vp, _vp, C.c_size_t]),
     # CSV helpers (facade.cpp; reference delimited_file.hpp:49-135)
     "smk_write_csv": (C.c_int, [_dp, C.c_uint, C.c_uint, C.c_uint, C.c_char_p, C.c_uint]),

@@ -111,6 +111,9 @@ int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int*
 // delta-fnorm: out[0] = sum (W - Wprev)^2, out[1] = sum W^2 ; then Wprev = W
 int launch_delta_fnorm(const double* W, double* Wprev, i64 count, double* partials, double* out2, hipStream_t st);
 int launch_zero_f64(double* p, i64 n, hipStream_t st);
+// sharded runs: scal[6..7] <- (scal[1], failed ? 1 : 0) before the all-reduce (unpack = 0); scal[1] <- scal[6] and
+// flag <- min(flag, tag) when any rank failed, after it (unpack = 1)
+int launch_dist_scalars(double* scal, int* flag, int tag, int unpack, hipStream_t st);
 // dst (k x N, ld k) = first k rows of src (KP x N, ld KP)
 int launch_compact_rows(const double* src, int KP, double* dst, int k, i64 N, hipStream_t st);
 // live rows of W' and H + the Gram matrix <-> one compact buffer (pack != 0: factors -> buffer)

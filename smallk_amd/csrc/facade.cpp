@@ -250,6 +250,20 @@ static Result to_result(int rc)
     }
 }
 
+// Column shards of a dense factorisation: SMK_NUM_GPUS=N runs Nmf() / smallk::Nmf() / the nmf tool on N
+// GPUs of this node (one host thread per device, RCCL collectives issued from C); SMK_SHARDS_ON_ONE_GPU=1 keeps the N
+// shards on the current device with the in-process stand-in for RCCL (boxes with fewer GPUs, tests).
+static void requested_shards(int* shards, int* stub)
+{
+    *shards = 1;
+    *stub = 0;
+    const char* e = getenv("SMK_NUM_GPUS");
+    if (!e || atoi(e) <= 1) return;
+    *shards = atoi(e) > 16 ? 16 : atoi(e);
+    const char* s1 = getenv("SMK_SHARDS_ON_ONE_GPU");
+    *stub = (s1 && atoi(s1) != 0) ? 1 : 0;
+}
+
 Result Nmf(const NmfOptions& options, double* buf_a, int ldim_a, double* buf_w, int ldim_w, double* buf_h,
            int ldim_h, NmfStats& stats)
 {
@@ -264,7 +278,10 @@ Result Nmf(const NmfOptions& options, double* buf_a, int ldim_a, double* buf_w, 
     if (options.algorithm == NmfAlgorithm::RANK2 && options.k != 2) throw std::runtime_error("rank2 algorithm requires k == 2");
     smk_options c = to_c(options);
     smk_stats st{0, 0};
-    int rc = smk_nmf_dense(&c, buf_a, ldim_a, buf_w, ldim_w, buf_h, ldim_h, &st, g_nmf_storage);
+    int shards = 1, stub = 0;
+    requested_shards(&shards, &stub);
+    int rc = shards > 1 ? smk_nmf_dense_sharded(&c, buf_a, ldim_a, buf_w, ldim_w, buf_h, ldim_h, &st, g_nmf_storage, shards, nullptr, stub)
+                        : smk_nmf_dense(&c, buf_a, ldim_a, buf_w, ldim_w, buf_h, ldim_h, &st, g_nmf_storage);
     stats.elapsed_us = st.elapsed_us;
     stats.iteration_count = st.iteration_count;
     return to_result(rc);
@@ -679,6 +696,13 @@ void Nmf(const unsigned int kval, const Algorithm algorithm, const std::string& 
             result = Result::NOTINITIALIZED;
         } else if (!smk_is_valid(&c, 1)) {
             result = Result::BAD_PARAM;
+        } else if (int shards = 1, stub = 0; !is_sparse && (requested_shards(&shards, &stub), shards > 1)) {
+            smk_stats st{0, 0};
+            const int rc = smk_nmf_dense_sharded(&c, &buf_a[0], ldim_a, &buf_w[0], ldim_w, &buf_h[0], ldim_h, &st,
+                                                 (int)device_storage, shards, nullptr, stub);
+            stats.elapsed_us = st.elapsed_us;
+            stats.iteration_count = st.iteration_count;
+            result = to_result(rc);
         } else {
             smk_matrix* a = ensure_resident();
             smk_solver* sv = nullptr;

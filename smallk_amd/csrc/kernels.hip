@@ -217,6 +217,74 @@ int launch_zero_f64(double* p, i64 n, hipStream_t st)
     return 0;
 }
 
+// Sharded runs: the H-side projected-gradient sum and a "some rank failed" indicator travel in one 2-element
+// all-reduce (scal[6..7]); afterwards every rank holds the global sum in scal[1] and a consistent failure flag.
+__global__ void dist_scalars_kernel(double* __restrict__ scal, int* __restrict__ flag, int tag, int unpack)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!unpack) {
+        scal[6] = scal[1];
+        scal[7] = (*flag != 0x7FFFFFFF) ? 1.0 : 0.0;
+    } else {
+        scal[1] = scal[6];
+        if (scal[7] > 0.0) atomicMin(flag, tag);
+    }
+}
+int launch_dist_scalars(double* scal, int* flag, int tag, int unpack, hipStream_t st)
+{
+    dist_scalars_kernel<<<1, 64, 0, st>>>(scal, flag, tag, unpack);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- in-process stand-in for the RCCL collectives (comm.cpp: several shards on one device) ----
+struct RankPtrs { void* p[16]; };
+template <typename T>
+__global__ __launch_bounds__(256) void local_allreduce_kernel(RankPtrs rp, int world, i64 count)
+{
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < count; i += (i64)gridDim.x * 256) {
+        T s = ((const T*)rp.p[0])[i];
+        for (int r = 1; r < world; ++r) s += ((const T*)rp.p[r])[i];        // fixed rank order
+        for (int r = 0; r < world; ++r) ((T*)rp.p[r])[i] = s;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void local_allgather_kernel(RankPtrs rp, int world, i64 per)
+{
+    const i64 total = per * world;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
+        const int src = (int)(i / per);
+        const T v = ((const T*)rp.p[src])[i];
+        for (int r = 0; r < world; ++r)
+            if (r != src) ((T*)rp.p[r])[i] = v;
+    }
+}
+int launch_local_allreduce(void* const* ptrs, int world, i64 count, int f64, hipStream_t st)
+{
+    if (world > 16) { set_error("local communicator: at most 16 ranks"); return -100; }
+    RankPtrs rp;
+    for (int r = 0; r < 16; ++r) rp.p[r] = r < world ? ptrs[r] : nullptr;
+    const int grid = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+    if (grid < 1) return 0;
+    if (f64) local_allreduce_kernel<double><<<grid, 256, 0, st>>>(rp, world, count);
+    else local_allreduce_kernel<float><<<grid, 256, 0, st>>>(rp, world, count);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_local_allgather(void* const* ptrs, int world, i64 count_per_rank, int f64, hipStream_t st)
+{
+    if (world > 16) { set_error("local communicator: at most 16 ranks"); return -100; }
+    RankPtrs rp;
+    for (int r = 0; r < 16; ++r) rp.p[r] = r < world ? ptrs[r] : nullptr;
+    const i64 total = count_per_rank * world;
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (grid < 1) return 0;
+    if (f64) local_allgather_kernel<double><<<grid, 256, 0, st>>>(rp, world, count_per_rank);
+    else local_allgather_kernel<float><<<grid, 256, 0, st>>>(rp, world, count_per_rank);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 // sum the S slabs into one fp32 slab (used before a cross-GPU all-reduce)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ p, int S, i64 slab, i64 count,
                                                               float* __restrict__ out)

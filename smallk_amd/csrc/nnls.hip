@@ -188,51 +188,89 @@ __device__ __forceinline__ double fast_rcp(double x)
     return __builtin_fma(r, e, r);
 }
 
-// Ginv = G^-1 (k x k live, KP x KP storage, pads zero) by in-place Gauss-Jordan in LDS, one workgroup.
+// Ginv = G^-1 (k x k live, 64 x 64 storage, pads zero) by in-place Gauss-Jordan, one workgroup of 256 threads:
+// thread (r, cq) keeps the 16 entries a[r][16 cq .. 16 cq + 15] in registers; per pivot only the pivot row and
+// column travel through LDS (double buffered: one barrier per step).  ~10 us; the LDS-resident version it
+// replaces spent 180 us in 64 x 16 dependent LDS round trips.
 // status = 1 when every pivot p_j satisfies p_j > 1e-9 * G[j][j] (SPD and usable), else 0.
 template <int KP>
 __global__ __launch_bounds__(256) void gram_inverse_kernel(const double* __restrict__ G, int k,
                                                            double* __restrict__ Ginv, int* __restrict__ status)
 {
-    __shared__ double a[KP][KP + 1];
-    __shared__ double colj[KP], rowj[KP], diag0[KP];
+    static_assert(KP == 64, "256 threads x 16 entries");
+    __shared__ __attribute__((aligned(16))) double rowj[2][KP];
+    __shared__ double colj[2][KP];
+    __shared__ double diag0[KP];
     __shared__ int bad;
     const int tid = threadIdx.x;
+    const int r = tid >> 2, cq = tid & 3;
     if (tid == 0) bad = 0;
     if (tid < KP) diag0[tid] = (tid < k) ? G[tid * KP + tid] : 1.0;
-    for (int e = tid; e < KP * KP; e += 256) {
-        const int r = e % KP, c = e / KP;
-        a[r][c] = (r < k && c < k) ? G[c * KP + r] : ((r == c) ? 1.0 : 0.0);
+    double a[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = cq * 16 + e;
+        a[e] = (r < k && c < k) ? G[c * KP + r] : ((r == c) ? 1.0 : 0.0);
     }
+    auto publish = [&](int j) {                 // row j and column j of the current matrix -> LDS buffer j & 1
+        const int buf = j & 1, jq = j >> 4, je = j & 15;
+        if (r == j) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rowj[buf][cq * 16 + e] = a[e];
+        }
+        if (cq == jq) {
+            double v = a[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) v = (e == je) ? a[e] : v;
+            colj[buf][r] = v;
+        }
+    };
+    publish(0);
     __syncthreads();
     for (int j = 0; j < k; ++j) {
-        // row j and column j of the current matrix, staged so that the update below touches only a[r][c]
-        if (tid < KP) { colj[tid] = a[tid][j]; rowj[tid] = a[j][tid]; }
-        __syncthreads();
-        const double piv = rowj[j];
+        const int buf = j & 1;
+        const double piv = rowj[buf][j];
         if (tid == 0 && !(piv > 1.0e-9 * diag0[j])) bad = 1;
         const double ip = 1.0 / piv;
-        for (int e = tid; e < KP * KP; e += 256) {
-            const int r = e / KP, c = e % KP;           // consecutive threads walk a row: conflict-free
-            double val;
-            if (r == j) val = (c == j) ? ip : rowj[c] * ip;
-            else {
-                const double f = colj[r] * ip;
-                val = (c == j) ? -f : a[r][c] - f * rowj[c];
+        const double f = colj[buf][r] * ip;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const f64x2_t rr = *(const f64x2_t*)&rowj[buf][cq * 16 + e];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = cq * 16 + e + u;
+                double val;
+                if (r == j) val = (c == j) ? ip : rr[u] * ip;
+                else val = (c == j) ? -f : __builtin_fma(-f, rr[u], a[e + u]);
+                a[e + u] = val;
             }
-            a[r][c] = val;
         }
+        if (j + 1 < k) publish(j + 1);
         __syncthreads();
     }
-    for (int e = tid; e < KP * KP; e += 256) {
-        const int r = e % KP, c = e / KP;
-        Ginv[c * KP + r] = (r < k && c < k) ? 0.5 * (a[r][c] + a[c][r]) : 0.0;     // exactly symmetric
+    // symmetrise through LDS-free exchange: Ginv[r][c] = (a[r][c] + a[c][r]) / 2 needs the transposed entry,
+    // so write the matrix out and average in a second pass over global memory
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = cq * 16 + e;
+        Ginv[c * KP + r] = (r < k && c < k) ? a[e] : 0.0;
     }
+    __syncthreads();
+    __threadfence_block();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = cq * 16 + e;
+        const double up = Ginv[c * KP + r], lo = Ginv[r * KP + c];
+        a[e] = 0.5 * (up + lo);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Ginv[(cq * 16 + e) * KP + r] = a[e];
     if (tid == 0) *status = bad ? 0 : 1;
 }
 
-template <int KP, int NT>
-__global__ __launch_bounds__(NT, 4) void nnls_bpp_inv_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N,
+template <int KP, int NT, int WPS>
+__global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N,
                                                           PartialView R, const double* __restrict__ G,
                                                           const double* __restrict__ Ginv,
                                                           const int* __restrict__ status,
@@ -240,7 +278,6 @@ __global__ __launch_bounds__(NT, 4) void nnls_bpp_inv_kernel(double* __restrict_
 {
     static_assert(KP == 64, "one wave per column");
     constexpr int NW = NT / 64;
-    constexpr int TM = 32;                          // max compact dimension = min(|F|, |Z|) <= k/2
     if (*status == 0) return;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* gs = lds;                               // gs[c*KP + i]  = G[i][c]
@@ -280,7 +317,41 @@ __global__ __launch_bounds__(NT, 4) void nnls_bpp_inv_kernel(double* __restrict_
         }
 
         int failed = 0;
-        // one block-pivot solve for the passive set F: leaves x (zero outside F) and y (zero inside F)
+        // compact solve of M[T,T] u = s_T on the first TB lanes (rows >= t are identity rows), then
+        // out = base + M[:,T] u.  TB is a compile-time bound: no branch inside the elimination.
+        auto compact = [&](auto tb_tag, const double* M, int t, int tl, double sc, double base, double& u_out) -> double {
+            constexpr int TB = decltype(tb_tag)::value;
+            const bool live = lane < t;
+            double a[TB];
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const int tb = __builtin_amdgcn_readlane(tl, b);           // lanes >= t carry tl = 0: harmless
+                const double mv = M[tb * KP + tl];
+                a[b] = (live && b < t) ? mv : ((b == lane) ? 1.0 : 0.0);
+            }
+            double d = 1.0;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const double piv = readlane_f64(a[j], j);
+                if (!(piv > 0.0)) failed = 1;
+                const double ip = fast_rcp(piv);
+                if (lane == j) d = a[j];
+                const double f = (lane == j) ? 0.0 : a[j] * ip;
+#pragma unroll
+                for (int c = j + 1; c < TB; ++c) a[c] = __builtin_fma(-f, readlane_f64(a[c], j), a[c]);
+                sc = __builtin_fma(-f, readlane_f64(sc, j), sc);
+            }
+            const double u = live ? sc * fast_rcp(d) : 0.0;
+            double out = base;
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const int tb = __builtin_amdgcn_readlane(tl, b);
+                out = __builtin_fma(M[tb * KP + lane], readlane_f64(u, b), out);     // u = 0 beyond t
+            }
+            u_out = u;
+            return out;
+        };
+        // one block-pivot solve for the passive set Fs: leaves x (zero outside Fs) and y (zero inside Fs)
         auto solve = [&](unsigned long long Fs) {
             const unsigned long long Zs = ~Fs & kmask;
             const int p = __popcll(Fs), q = __popcll(Zs);
@@ -297,43 +368,13 @@ __global__ __launch_bounds__(NT, 4) void nnls_bpp_inv_kernel(double* __restrict_
             if (inT) sidx[rank] = lane;
             sv[lane] = comp ? -v : rhs;
             const int tl = (lane < t) ? sidx[lane] : 0;
-            double sc = (lane < t) ? sv[tl] : 0.0;
-            // row l of M[T,T]
-            double a[TM];
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                a[b] = 0.0;
-                if (b < t) {
-                    const int tb = __builtin_amdgcn_readlane(tl, b);
-                    a[b] = M[tb * KP + tl];
-                }
-            }
-            // Gauss-Jordan, pivots in order (= the Cholesky pivots of the SPD block)
-            double d = 1.0;
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                if (j < t) {
-                    const double piv = readlane_f64(a[j], j);
-                    if (!(piv > 0.0)) failed = 1;
-                    const double ip = fast_rcp(piv);
-                    if (lane == j) d = a[j];
-                    const double f = (lane == j) ? 0.0 : a[j] * ip;
-#pragma unroll
-                    for (int c = j + 1; c < TM; ++c)
-                        if (c < t) a[c] = __builtin_fma(-f, readlane_f64(a[c], j), a[c]);
-                    sc = __builtin_fma(-f, readlane_f64(sc, j), sc);
-                }
-            }
-            const double u = (lane < t) ? sc * fast_rcp(d) : 0.0;
-            // out = base + M[:,T] u
-            double out = comp ? v : -rhs;
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                if (b < t) {
-                    const int tb = __builtin_amdgcn_readlane(tl, b);
-                    out = __builtin_fma(M[tb * KP + lane], readlane_f64(u, b), out);
-                }
-            }
+            const double sc = (lane < t) ? sv[tl] : 0.0;
+            const double base = comp ? v : -rhs;
+            double u = 0.0, out;
+            if (t <= 8) out = compact(std::integral_constant<int, 8>{}, M, t, tl, sc, base, u);
+            else if (t <= 16) out = compact(std::integral_constant<int, 16>{}, M, t, tl, sc, base, u);
+            else if (t <= 24) out = compact(std::integral_constant<int, 24>{}, M, t, tl, sc, base, u);
+            else out = compact(std::integral_constant<int, 32>{}, M, t, tl, sc, base, u);
             // u back to component positions
             if (lane < t) sv[tl] = u;
             const double ut = inT ? sv[lane] : 0.0;
@@ -393,22 +434,25 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
     static const int inv_mode = [] { const char* e = getenv("SMK_NNLS_INV"); return e ? atoi(e) : 1; }();
     const int* skip_if = nullptr;
     if (KPv == 64 && inv_mode && scratch) {
-        constexpr int NT = 512;
         double* Ginv = scratch;
         int* status = (int*)(scratch + 64 * 64);
         gram_inverse_kernel<64><<<1, 256, 0, st>>>(G, k, Ginv, status);
         SMK_HIP(hipGetLastError());
-        const int lds = (2 * 64 * 64 + (NT / 64) * 2 * 64) * (int)sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {
-            SMK_HIP(hipFuncSetAttribute((const void*)nnls_bpp_inv_kernel<64, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
-        i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
-        const i64 cap = (i64)num_cus * 2 * 4;          // 2 resident workgroups per CU, a few rounds for balance
-        if (g2 > cap) g2 = cap;
-        nnls_bpp_inv_kernel<64, NT><<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin);
-        SMK_HIP(hipGetLastError());
+        auto run = [&](auto kern, int NT, int wg_per_cu) -> int {
+            const int lds = (2 * 64 * 64 + (NT / 64) * 2 * 64) * (int)sizeof(double);
+            SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
+            const i64 cap = (i64)num_cus * wg_per_cu * 4;      // resident workgroups x a few rounds for balance
+            if (g2 > cap) g2 = cap;
+            kern<<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin);
+            SMK_HIP(hipGetLastError());
+            return 0;
+        };
+        int rc;
+        if (inv_mode == 2) rc = run(nnls_bpp_inv_kernel<64, 768, 3>, 768, 1);
+        else if (inv_mode == 3) rc = run(nnls_bpp_inv_kernel<64, 512, 2>, 512, 1);
+        else rc = run(nnls_bpp_inv_kernel<64, 512, 4>, 512, 2);
+        if (rc) return rc;
         skip_if = status;
     }
     KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if)));

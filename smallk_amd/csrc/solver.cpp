@@ -13,6 +13,7 @@
 //   P1 : S1 slabs of n_pad x kpp fp64 = W'A partials,   P2 : S2 slabs of m_pad x kpp = (AH')' partials
 //   packW / packH : MFMA operand fragments of W' / H
 #include "common.h"
+#include "comm.h"
 #include "../../include/smallk_amd.h"
 
 #include <chrono>
@@ -23,15 +24,28 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <thread>
 
 namespace smk {
 
-static std::string g_err;
-static bool g_init = false;
-static int g_cus = 256;
-static hipStream_t g_stream = nullptr;
-static bool g_own_stream = false;
-static int g_live_solvers = 0;          // solver handles cache the stream: it cannot change under them
+// One device context per process by default; the single-process multi-GPU driver (smk_nmf_dense_sharded) runs
+// one host thread per shard and gives each its own context through t_ctx.
+struct DeviceCtx {
+    bool init = false;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int live_solvers = 0;               // solver handles cache the stream: it cannot change under them
+};
+static DeviceCtx g_ctx;
+static thread_local DeviceCtx* t_ctx = nullptr;
+static inline DeviceCtx& ctx() { return t_ctx ? *t_ctx : g_ctx; }
+#define g_init (ctx().init)
+#define g_cus (ctx().cus)
+#define g_stream (ctx().stream)
+#define g_own_stream (ctx().own_stream)
+#define g_live_solvers (ctx().live_solvers)
+static thread_local std::string g_err;
 
 void set_error(const std::string& msg) { g_err = msg; }
 
@@ -57,6 +71,7 @@ using namespace smk;
 struct smk_matrix {
     i64 m = 0, n_global = 0, c0 = 0, n = 0;
     int storage = SMK_STORE_F32;
+    hipStream_t st = nullptr;                        // stream of the context that created it
     void* A = nullptr;  i64 ldA = 0, colsA = 0;      // m_pad x n_pad
     void* At = nullptr; i64 ldAt = 0, colsAt = 0;    // n_pad x m_pad
     // sparse A: CSC of the local columns and CSC of its transpose (fp64 values, 64-bit offsets)
@@ -90,10 +105,16 @@ struct smk_solver {
     bool have_factors = false, inited = false, normalized = false;
     double pg0 = 1.0, last_metric = 1.0;
     size_t pg_half = 2048;
-    // comm
+    // comm: a native communicator (RCCL or the in-process stand-in, comm.cpp) or -- test hook -- a host callback
     int rank = 0, world = 1;
     smk_allreduce_fn ar = nullptr;
     void* ar_user = nullptr;
+    smk_comm* comm = nullptr;
+    void* comm_ws = nullptr;              // owned workspace when a native communicator is attached
+    i64 w_chunk = 0;                      // rows of W per rank in the BPP all-gather (ceil(m / world))
+    hipStream_t st2 = nullptr;            // the small HH' all-reduce runs here, beside the H*At pass
+    hipEvent_t ev_gram = nullptr, ev_gh = nullptr;
+    bool gh_pending = false;
     // stopping rule evaluated one iteration late (smk_solver_run): pinned result slots, events, and a
     // snapshot of (W, H, W'W) per checked iteration so that a speculative iteration can be undone
     struct ProgSlot { double h[8]; int flag; int fused; };     // fused: the flag travels in h[5]
@@ -218,6 +239,7 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
         return SMK_BAD_PARAM;
     smk_matrix* a = new smk_matrix;
     a->m = height; a->n_global = width_global; a->c0 = col0; a->n = ncols_local; a->storage = storage;
+    a->st = g_stream;
     a->ldA = round_up(height, ROW_PAD);      a->colsA = round_up(ncols_local, COL_PAD);
     a->ldAt = round_up(ncols_local, ROW_PAD); a->colsAt = round_up(height, COL_PAD);
     const size_t es = (size_t)elem_size(storage);
@@ -440,6 +462,7 @@ int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_glo
     smk_matrix* a = new smk_matrix;
     a->m = height; a->n_global = width_global; a->c0 = col0; a->n = ncols_local; a->storage = SMK_STORE_F32;
     a->sparse = true; a->nnz = nnz;
+    a->st = g_stream;
     a->h_colptr.resize((size_t)ncols_local + 1);
     for (int64_t c = 0; c <= ncols_local; ++c) a->h_colptr[(size_t)c] = col_offsets[c] - base;
     a->h_rowidx.assign(row_indices + base, row_indices + base + nnz);
@@ -522,6 +545,7 @@ int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t 
         smk_matrix* a = new smk_matrix;
         a->m = od.m; a->n_global = ncols; a->c0 = 0; a->n = ncols; a->storage = SMK_STORE_F32;
         a->sparse = true; a->nnz = od.nnz;
+        a->st = g_stream;
         a->colptr = od.colptr; a->rowidx = od.rowidx; a->val = od.val;
         a->colptr_t = od.colptr_t; a->rowidx_t = od.rowidx_t; a->val_t = od.val_t;
         if (new_height) *new_height = od.m;
@@ -548,9 +572,11 @@ static PartialView view1(const smk_solver* s)
 {
     return PartialView{s->P1, s->pl1.S, (i64)s->pl1.ncols_pad * s->kpp, s->kpp, 1};
 }
+static inline bool is_dist(const smk_solver* s) { return s->ar != nullptr || s->comm != nullptr; }
+
 static PartialView view2(const smk_solver* s)
 {
-    if (s->ar) return PartialView{s->R2red, 1, 0, s->kpp, 0};
+    if (is_dist(s)) return PartialView{s->R2red, 1, 0, s->kpp, 0};
     return PartialView{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
 }
 
@@ -563,7 +589,10 @@ static size_t comm_bytes(const smk_solver* s)
     b = (b + 255) / 256 * 256;
     b += 8 * sizeof(double);
     b = (b + 255) / 256 * 256;
-    b += (size_t)s->KP * s->m * sizeof(double);     // Wt: row-sharded W-side NNLS gathers through an all-reduce
+    // Wt: the row-sharded W-side NNLS gathers equal chunks of ceil(m / world) rows (the last one is padded)
+    const i64 world = s->comm ? s->comm->world : (s->world > 0 ? s->world : 1);
+    const i64 chunk = (s->m + world - 1) / world;
+    b += (size_t)s->KP * (size_t)std::max<i64>(chunk * world, s->m) * sizeof(double);
     return b;
 }
 
@@ -589,7 +618,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     s->kpp = kt_of(s->k) * 32;
     s->m = a->m;
     s->n = a->n;
-    s->st = g_stream;
+    s->st = a->st ? a->st : g_stream;
     const char* env = getenv("SMK_NSPLIT");
     s->nsplit = env ? atoi(env) : 3;
     if (s->nsplit < 1 || s->nsplit > 3) s->nsplit = 3;
@@ -650,6 +679,10 @@ void smk_solver_destroy(smk_solver* s)
         if (s->pev[b]) (void)hipEventDestroy(s->pev[b]);
     }
     if (s->pin) (void)hipHostFree(s->pin);
+    if (s->comm_ws) (void)hipFree(s->comm_ws);
+    if (s->st2) (void)hipStreamDestroy(s->st2);
+    if (s->ev_gram) (void)hipEventDestroy(s->ev_gram);
+    if (s->ev_gh) (void)hipEventDestroy(s->ev_gh);
     --g_live_solvers;
     delete s;
 }
@@ -661,30 +694,56 @@ int smk_solver_comm_workspace_bytes(const smk_solver* s, size_t* bytes)
     return SMK_OK;
 }
 
+static void carve_workspace(smk_solver* s, void* workspace)
+{
+    unsigned char* p = (unsigned char*)workspace;
+    s->R2red = (float*)p;
+    size_t b = (size_t)s->pl2.ncols_pad * s->kpp * sizeof(float);
+    b = (b + 255) / 256 * 256;
+    s->Gh = (double*)(p + b);
+    b += (size_t)s->KP * s->KP * sizeof(double);
+    b = (b + 255) / 256 * 256;
+    s->scal = (double*)(p + b);
+    b += 8 * sizeof(double);
+    b = (b + 255) / 256 * 256;
+    s->Wt = (double*)(p + b);
+}
+
 int smk_solver_set_comm(smk_solver* s, int rank, int world, smk_allreduce_fn fn, void* user, void* workspace,
                         size_t workspace_bytes)
 {
     if (!s || world < 1 || rank < 0 || rank >= world) return SMK_BAD_PARAM;
     if (world > 1 && !fn) return SMK_BAD_PARAM;
+    if (s->comm) { set_error("a native communicator is attached"); return SMK_BAD_PARAM; }
+    s->rank = rank; s->world = world;
     if (fn && (!workspace || workspace_bytes < comm_bytes(s))) return SMK_BAD_PARAM;
-    s->rank = rank; s->world = world; s->ar = fn; s->ar_user = user;
+    s->ar = fn; s->ar_user = user;
     if (fn) {
-        unsigned char* p = (unsigned char*)workspace;
-        s->R2red = (float*)p;
-        size_t b = (size_t)s->pl2.ncols_pad * s->kpp * sizeof(float);
-        b = (b + 255) / 256 * 256;
-        s->Gh = (double*)(p + b);
-        b += (size_t)s->KP * s->KP * sizeof(double);
-        b = (b + 255) / 256 * 256;
-        s->scal = (double*)(p + b);
-        b += 8 * sizeof(double);
-        b = (b + 255) / 256 * 256;
-        s->Wt = (double*)(p + b);
+        carve_workspace(s, workspace);
     } else {
         s->Gh = s->Gh_own;
         s->scal = s->scal_own;
         s->Wt = s->Wt_own;
     }
+    return SMK_OK;
+}
+
+// Native path: every collective is issued from C on the solver's streams (RCCL over xGMI, or the in-process
+// stand-in).  Call before set_factors().  The communicator must outlive the solver.
+int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
+{
+    if (!s || !comm) return SMK_BAD_PARAM;
+    if (s->ar || s->comm) { set_error("solver already has a communicator"); return SMK_BAD_PARAM; }
+    s->comm = comm;
+    s->rank = comm->rank; s->world = comm->world;
+    s->w_chunk = (s->m + comm->world - 1) / comm->world;
+    const size_t bytes = comm_bytes(s);
+    if (hipMalloc(&s->comm_ws, bytes) != hipSuccess) { s->comm = nullptr; set_error("hipMalloc(comm workspace)"); return SMK_DEVICE_ERROR; }
+    SMK_HIP(hipMemsetAsync(s->comm_ws, 0, bytes, s->st));
+    carve_workspace(s, s->comm_ws);
+    SMK_HIP(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
+    SMK_HIP(hipEventCreateWithFlags(&s->ev_gram, hipEventDisableTiming));
+    SMK_HIP(hipEventCreateWithFlags(&s->ev_gh, hipEventDisableTiming));
     return SMK_OK;
 }
 
@@ -712,6 +771,38 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
     s->pg0 = 1.0;
     s->last_metric = 1.0;
     return SMK_OK;
+}
+
+// ---- collectives -------------------------------------------------------------------------------
+static int dist_allreduce(smk_solver* s, void* ptr, i64 count, int f64, hipStream_t st)
+{
+    if (s->comm) return comm_allreduce(s->comm, ptr, count, f64, st);
+    if (s->ar) {
+        if (s->ar(s->ar_user, ptr, (int64_t)count, f64)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
+    }
+    return 0;
+}
+
+// HH' is needed only after the H*At pass: with a native communicator its all-reduce runs on a second stream
+// beside that pass; wait_gh() joins it back.
+static int allreduce_gh(smk_solver* s)
+{
+    if (!is_dist(s)) return 0;
+    if (!s->comm) return dist_allreduce(s, s->Gh, (i64)s->KP * s->KP, 1, s->st);
+    SMK_HIP(hipEventRecord(s->ev_gram, s->st));
+    SMK_HIP(hipStreamWaitEvent(s->st2, s->ev_gram, 0));
+    int rc = comm_allreduce(s->comm, s->Gh, (i64)s->KP * s->KP, 1, s->st2);
+    if (rc) return rc;
+    SMK_HIP(hipEventRecord(s->ev_gh, s->st2));
+    s->gh_pending = true;
+    return 0;
+}
+static int wait_gh(smk_solver* s)
+{
+    if (!s->gh_pending) return 0;
+    SMK_HIP(hipStreamWaitEvent(s->st, s->ev_gh, 0));
+    s->gh_pending = false;
+    return 0;
 }
 
 // ---- building blocks -----------------------------------------------------------------------
@@ -771,11 +862,14 @@ static int prod2(smk_solver* s)
         rc = timed_bigprod(s, 1, s->pl2, s->a->At, s->a->ldAt, s->packH, s->P2);
     }
     if (rc) return rc;
-    if (s->ar) {
+    rc = wait_gh(s);
+    if (rc) return rc;
+    if (is_dist(s)) {
         PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
         rc = launch_reduce_partials(pv, s->k, s->pl2.ncols_pad, s->R2red, s->st);
         if (rc) return rc;
-        if (s->ar(s->ar_user, s->R2red, (int64_t)s->pl2.ncols_pad * s->kpp, 0)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
+        rc = dist_allreduce(s, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, 0, s->st);
+        if (rc) return rc;
     }
     return 0;
 }
@@ -786,9 +880,7 @@ static int gram_h(smk_solver* s)
 {
     int rc = launch_gram(s->H, s->k, s->n, s->Gh, s->gram_scratch, GRAM_BLOCKS, s->st);
     if (rc) return rc;
-    if (s->ar)
-        if (s->ar(s->ar_user, s->Gh, (int64_t)s->KP * s->KP, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
-    return 0;
+    return allreduce_gh(s);
 }
 
 // solver.Init (mu :98-114, hals :142-159, bpp :310-335) + progress_est->Init
@@ -836,16 +928,24 @@ static int solver_iteration(smk_solver* s)
             rc = launch_nnls_bpp(s->H, nullptr, s->k, 0, s->n, r1, s->Gw, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
             rc = gram_h(s);   if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
-            if (s->ar && s->world > 1) {
-                // W is replicated but its rows are independent NNLS problems: every rank solves the rows
-                // [i0, i1) only, zeroes the rest and the slices are gathered by a sum-all-reduce of Wt.
-                const i64 base = s->m / s->world, extra = s->m % s->world;
-                const i64 i0 = s->rank * base + (s->rank < extra ? s->rank : extra);
-                const i64 i1 = i0 + base + (s->rank < extra ? 1 : 0);
-                rc = launch_nnls_bpp(s->Wt, nullptr, s->k, i0, i1, view2(s), s->Gh, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
-                if (i0 > 0) SMK_HIP(hipMemsetAsync(s->Wt, 0, (size_t)i0 * s->KP * sizeof(double), s->st));
-                if (i1 < s->m) SMK_HIP(hipMemsetAsync(s->Wt + i1 * s->KP, 0, (size_t)(s->m - i1) * s->KP * sizeof(double), s->st));
-                if (s->ar(s->ar_user, s->Wt, (int64_t)s->KP * s->m, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
+            if (is_dist(s) && s->world > 1) {
+                // W is replicated but its rows are independent NNLS problems: every rank solves its own rows only.
+                if (s->comm) {
+                    // equal chunks of ceil(m / world) rows, gathered in place (ncclAllGather: 1/world of the bytes a
+                    // sum-all-reduce of the whole matrix would move)
+                    const i64 i0 = std::min<i64>(s->m, s->rank * s->w_chunk), i1 = std::min<i64>(s->m, i0 + s->w_chunk);
+                    rc = launch_nnls_bpp(s->Wt, nullptr, s->k, i0, i1, view2(s), s->Gh, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
+                    rc = comm_allgather(s->comm, s->Wt, s->w_chunk * s->KP, 1, s->st); if (rc) return rc;
+                } else {
+                    // callback hook (one primitive only): zero the other rows and sum-all-reduce
+                    const i64 base = s->m / s->world, extra = s->m % s->world;
+                    const i64 i0 = s->rank * base + (s->rank < extra ? s->rank : extra);
+                    const i64 i1 = i0 + base + (s->rank < extra ? 1 : 0);
+                    rc = launch_nnls_bpp(s->Wt, nullptr, s->k, i0, i1, view2(s), s->Gh, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
+                    if (i0 > 0) SMK_HIP(hipMemsetAsync(s->Wt, 0, (size_t)i0 * s->KP * sizeof(double), s->st));
+                    if (i1 < s->m) SMK_HIP(hipMemsetAsync(s->Wt + i1 * s->KP, 0, (size_t)(s->m - i1) * s->KP * sizeof(double), s->st));
+                    rc = dist_allreduce(s, s->Wt, (i64)s->KP * s->m, 1, s->st); if (rc) return rc;
+                }
             } else {
                 rc = launch_nnls_bpp(s->Wt, nullptr, s->k, 0, s->m, view2(s), s->Gh, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
             }
@@ -855,8 +955,7 @@ static int solver_iteration(smk_solver* s)
         case SMK_ALG_RANK2:  // nmf_solver_rank2.hpp:353-455
             // each closed-form solve also emits the Gram matrix of its result (no second pass over H / W)
             rc = launch_rank2_solve(s->H, s->n, r1, s->Gw, 0, s->fail_flag, s->iter, s->Gh, s->gram_scratch, s->st); if (rc) return rc;
-            if (s->ar)
-                if (s->ar(s->ar_user, s->Gh, (int64_t)s->KP * s->KP, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
+            rc = allreduce_gh(s); if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
             rc = launch_rank2_solve(s->Wt, s->m, view2(s), s->Gh, 1, s->fail_flag, s->iter, s->Gw, s->gram_scratch, s->st); if (rc) return rc;
             // NormalizeAndScale(W, H, ScaleFactors) every iteration, norms from the Gram matrix of the new W;
@@ -900,6 +999,17 @@ static int sync_and_check(smk_solver* s, int* fail_iter)
     return SMK_OK;
 }
 
+// sharded: sum the H-side scalar over the ranks and make the failure flag the same everywhere, so that every
+// rank takes the same branch of the driver loop (a rank that stopped alone would strand the others in a collective)
+static int dist_agree(smk_solver* s)
+{
+    int rc = launch_dist_scalars(s->scal, s->fail_flag, s->iter > 0 ? s->iter - 1 : 0, 0, s->st);
+    if (rc) return rc;
+    rc = dist_allreduce(s, s->scal + 6, 2, 1, s->st);
+    if (rc) return rc;
+    return launch_dist_scalars(s->scal, s->fail_flag, s->iter > 0 ? s->iter - 1 : 0, 1, s->st);
+}
+
 // progress_est->Update(iter, W, H, gradW, gradH): returns the metric (synchronises)
 // the kernels (and, sharded, the scalar all-reduce) of one progress evaluation; results land in s->scal
 static int enqueue_progress_kernels(smk_solver* s)
@@ -914,9 +1024,8 @@ static int enqueue_progress_kernels(smk_solver* s)
         if (rc) return rc;
         rc = launch_grad_pg(s->H, s->k, s->n, view1(s), s->Gw, nullptr, s->pg_partials + s->pg_half, s->scal, 1, s->st);
         if (rc) return rc;
-        if (s->ar)
-            if (s->ar(s->ar_user, s->scal + 1, 1, 1)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
     }
+    if (is_dist(s)) { rc = dist_agree(s); if (rc) return rc; }
     return 0;
 }
 
@@ -959,7 +1068,7 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
         for (int i = 0; i < 2; ++i) SMK_HIP(hipEventCreateWithFlags(&s->pev[i], hipEventDisableTiming));
     }
     int rc = 0;
-    if (s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !s->ar) {
+    if (s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s)) {
         // both gradients in one launch, both sums + the failure flag in a second, one 64-byte read-back
         rc = launch_grad_pg2(s->Wt, s->m, view2(s), s->Gh, s->pg_partials, s->H, s->n, view1(s), s->Gw,
                              s->pg_partials + s->pg_half, s->k, s->scal, s->fail_flag, 5, s->st);
@@ -1119,6 +1228,7 @@ int smk_solver_run(smk_solver* s, smk_stats* stats)
     }
 
     if (o.normalize) { rc = normalize_device(s); if (rc) { result = rc; goto done; } }
+    if (is_dist(s)) { rc = dist_agree(s); if (rc) { result = rc; goto done; } }
     rc = sync_and_check(s, &fail_iter);
     if (rc) { result = rc; goto failed_check; }
     if (!success && iter == o.max_iter) success = true;
@@ -1152,7 +1262,7 @@ int smk_solver_nnls_hals(smk_solver* s, double tol, int verbose, int max_iter, i
 {
     if (!s || max_iter < 0) return SMK_BAD_PARAM;
     if (!s->have_factors) { set_error("set_factors() first"); return SMK_BAD_PARAM; }
-    if (s->ar) { set_error("NnlsHals: not available on a sharded solver"); return SMK_UNSUPPORTED; }
+    if (is_dist(s)) { set_error("NnlsHals: not available on a sharded solver"); return SMK_UNSUPPORTED; }
     if (verbose) printf("\nRunning NNLS solver...\n");
     int rc = prod1(s);
     if (!rc) rc = gram_w(s);
@@ -1336,6 +1446,95 @@ int smk_nmf_dense(const smk_options* opts, const double* A, int64_t ldA, double*
     smk_solver_destroy(s);
     smk_matrix_destroy(a);
     return rc;
+}
+
+// Result Nmf(...) on `nshards` column shards of A, one host thread + one HIP device per shard: A and H
+// column-sharded, W replicated, RCCL collectives issued from C on each shard's streams.  `devices` NULL: shard r on
+// device r.  local_stub != 0: every shard on the CURRENT device with the in-process stand-in for RCCL (which refuses
+// two ranks on one device) -- for boxes with fewer GPUs than shards, and for the tests.
+int smk_nmf_dense_sharded(const smk_options* opts, const double* A, int64_t ldA, double* W, int64_t ldW, double* H,
+                          int64_t ldH, smk_stats* stats, int storage, int nshards, const int* devices, int local_stub)
+{
+    if (!ctx().init) {
+        fprintf(stderr, "nmflib error: nmf_initialize() must be called prior to any factorization routine\n\n");
+        return SMK_NOTINITIALIZED;
+    }
+    if (!opts || !smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
+    if (!A || !W || !H || nshards < 1 || nshards > 16) return SMK_BAD_PARAM;
+    const int64_t m = opts->height, n = opts->width;
+    if (ldA < m || ldW < m || ldH < opts->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
+    if (nshards > n) nshards = (int)n;
+    if (nshards == 1) return smk_nmf_dense(opts, A, ldA, W, ldW, H, ldH, stats, storage);
+    int dev0 = 0;
+    SMK_HIP(hipGetDevice(&dev0));
+    if (!local_stub) {
+        int ndev = 0;
+        SMK_HIP(hipGetDeviceCount(&ndev));
+        for (int r = 0; r < nshards; ++r)
+            if ((devices ? devices[r] : r) >= ndev) { set_error("smk_nmf_dense_sharded: not enough devices for the shards"); return SMK_BAD_PARAM; }
+    }
+    std::vector<smk_comm*> comms((size_t)nshards, nullptr);
+    std::vector<int> devs((size_t)nshards);
+    for (int r = 0; r < nshards; ++r) devs[(size_t)r] = local_stub ? dev0 : (devices ? devices[r] : r);
+    int rc = local_stub ? smk_comm_init_local(comms.data(), nshards) : smk_comm_init_all(comms.data(), nshards, devs.data());
+    if (rc != SMK_OK) return rc;
+
+    std::vector<int> rcs((size_t)nshards, SMK_OK);
+    std::vector<smk_stats> sts((size_t)nshards, smk_stats{0, 0});
+    std::vector<std::string> errs((size_t)nshards);
+    std::vector<double> Wcopy((size_t)m * opts->k);          // every shard starts from the same W0
+    for (int c = 0; c < opts->k; ++c) std::copy(W + (size_t)c * ldW, W + (size_t)c * ldW + m, Wcopy.begin() + (size_t)c * m);
+    auto worker = [&](int r) {
+        DeviceCtx local;
+        t_ctx = &local;
+        int wrc = SMK_OK;
+        smk_matrix* a = nullptr;
+        smk_solver* s = nullptr;
+        const int64_t base = n / nshards, extra = n % nshards;
+        const int64_t c0 = r * base + std::min<int64_t>(r, extra), nc = base + (r < extra ? 1 : 0);
+        wrc = smk_initialize(devs[(size_t)r]);
+        if (wrc == SMK_OK) wrc = smk_matrix_create(&a, m, n, c0, nc, storage);
+        if (wrc == SMK_OK) wrc = smk_matrix_upload_f64(a, A + (size_t)c0 * ldA, ldA);
+        if (wrc == SMK_OK) wrc = smk_solver_create(&s, opts, a);
+        if (wrc == SMK_OK) wrc = smk_solver_attach_comm(s, comms[(size_t)r]);
+        if (wrc == SMK_OK) wrc = smk_solver_set_factors(s, Wcopy.data(), m, H + (size_t)c0 * ldH, ldH);
+        // a shard that failed before the first collective would strand the others: agree on the setup first
+        {
+            double ok = (wrc == SMK_OK) ? 0.0 : 1.0, *dflag = nullptr;
+            if (hipMalloc((void**)&dflag, sizeof(double)) == hipSuccess) {
+                (void)hipMemcpy(dflag, &ok, sizeof(double), hipMemcpyHostToDevice);
+                (void)comm_allreduce(comms[(size_t)r], dflag, 1, 1, ctx().stream);
+                (void)hipStreamSynchronize(ctx().stream);
+                (void)hipMemcpy(&ok, dflag, sizeof(double), hipMemcpyDeviceToHost);
+                (void)hipFree(dflag);
+            }
+            if (ok != 0.0 && wrc == SMK_OK) wrc = SMK_FAILURE;
+        }
+        if (wrc == SMK_OK) {
+            wrc = smk_solver_run(s, &sts[(size_t)r]);
+            if (wrc == SMK_OK || wrc == SMK_FAILURE) {
+                // W is replicated: rank 0 returns it; every rank returns its own columns of H
+                std::vector<double> Wl(r == 0 ? 0 : (size_t)m * opts->k);
+                (void)smk_solver_get_factors(s, 0, r == 0 ? W : Wl.data(), r == 0 ? ldW : m, H + (size_t)c0 * ldH, ldH);
+            }
+        }
+        errs[(size_t)r] = g_err;
+        smk_solver_destroy(s);
+        smk_matrix_destroy(a);
+        smk_finalize();
+        rcs[(size_t)r] = wrc;
+        t_ctx = nullptr;
+    };
+    std::vector<std::thread> th;
+    for (int r = 0; r < nshards; ++r) th.emplace_back(worker, r);
+    for (auto& t : th) t.join();
+    for (smk_comm* c : comms) smk_comm_destroy(c);
+    (void)hipSetDevice(dev0);
+    int result = SMK_OK;
+    for (int r = 0; r < nshards; ++r)
+        if (rcs[(size_t)r] != SMK_OK && result == SMK_OK) { result = rcs[(size_t)r]; set_error(errs[(size_t)r]); }
+    if (stats) *stats = sts[0];
+    return result;
 }
 
 // Result NmfSparse(...), common/src/nmf.cpp:232-300 (CSC input, 32-bit indices as in the reference)

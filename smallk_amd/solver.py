@@ -242,6 +242,11 @@ class NmfSolver:
         L.check(L.lib().smk_solver_set_comm(self._h, rank, world, self._cb, None, C.c_void_p(workspace_ptr),
                                             workspace_bytes), "smk_solver_set_comm")
 
+    def attach_comm(self, comm):
+        """Native collectives (RCCL / in-process stand-in); call before set_factors()."""
+        L.check(L.lib().smk_solver_attach_comm(self._h, comm._h), "smk_solver_attach_comm")
+        self._comm = comm          # keep alive
+
     def close(self):
         if self._h:
             L.lib().smk_solver_destroy(self._h)
@@ -284,3 +289,68 @@ def nnls_blockpivot(LHS, RHS, Xinit):
     if rc not in (L.OK, L.FAILURE):
         L.check(rc, "smk_nnls_blockpivot")
     return rc == L.OK, X, Y
+
+
+class Comm:
+    """A communicator of the column-sharded solver (include/smallk_amd.h, multi-GPU section): RCCL, or the
+    in-process stand-in for several shards on one device."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def unique_id(cls) -> bytes:
+        buf = C.create_string_buffer(128)
+        L.check(L.lib().smk_comm_unique_id(buf), "smk_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, uid: bytes, rank: int, world: int):
+        h = C.c_void_p()
+        L.check(L.lib().smk_comm_init_rank(C.byref(h), C.create_string_buffer(uid, 128), rank, world), "smk_comm_init_rank")
+        return cls(h)
+
+    @classmethod
+    def init_all(cls, ndev: int, devices=None):
+        hs = (C.c_void_p * ndev)()
+        dv = (C.c_int * ndev)(*devices) if devices is not None else None
+        L.check(L.lib().smk_comm_init_all(hs, ndev, dv), "smk_comm_init_all")
+        return [cls(C.c_void_p(h)) for h in hs]
+
+    @classmethod
+    def init_local(cls, nranks: int):
+        hs = (C.c_void_p * nranks)()
+        L.check(L.lib().smk_comm_init_local(hs, nranks), "smk_comm_init_local")
+        return [cls(C.c_void_p(h)) for h in hs]
+
+    @property
+    def rank(self):
+        return L.lib().smk_comm_rank(self._h)
+
+    @property
+    def world(self):
+        return L.lib().smk_comm_world(self._h)
+
+    def close(self):
+        if self._h:
+            L.lib().smk_comm_destroy(self._h)
+            self._h = None
+
+
+def nmf_sharded(A, W0, H0, algorithm, nshards, *, storage="f32", devices=None, local_stub=False, **kw) -> NmfResult:
+    """``Nmf(...)`` on ``nshards`` column shards, one host thread and one device per shard (RCCL), or all shards on
+    the current device through the in-process stand-in (``local_stub=True``)."""
+    A = _f(A)
+    W = _f(W0).copy(order="F")
+    H = _f(H0).copy(order="F")
+    m, n = A.shape
+    k = W.shape[1]
+    o = make_options(m, n, k, algorithm, **kw)
+    st = L.Stats()
+    stg = STORAGE[storage] if isinstance(storage, str) else int(storage)
+    dv = (C.c_int * nshards)(*devices) if devices is not None else None
+    rc = L.lib().smk_nmf_dense_sharded(C.byref(o), _p(A), m, _p(W), m, _p(H), k, C.byref(st), stg, nshards, dv,
+                                       1 if local_stub else 0)
+    if rc not in (L.OK, L.FAILURE, L.BAD_PARAM, L.NOTINITIALIZED, L.SIZE_TOO_LARGE):
+        L.check(rc, "smk_nmf_dense_sharded")
+    return NmfResult(rc, W, H, st.iteration_count, st.elapsed_us)

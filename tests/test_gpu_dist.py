@@ -140,3 +140,74 @@ def test_bench_two_processes_match_one(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["config"]["parallelism"] == "column-shard x2"
     W1, W2 = np.load(tmp_path / "w1.npy"), np.load(tmp_path / "w2.npy")
     assert np.linalg.norm(W1 - W2) / np.linalg.norm(W1) < 1e-5
+
+
+# ---- native communicators (comm.cpp): collectives issued from C on the solver's streams ------------------------
+@pytest.mark.parametrize("alg,storage,quant,k,shards", [("HALS", "bf16", 1, 12, 2), ("MU", "f32", 0, 12, 3), ("BPP", "f32", 0, 12, 2),
+                                                        ("BPP", "f32", 0, 40, 3), ("HALS", "f32", 0, 33, 4), ("BPP", "bf16", 1, 64, 2)])
+def test_sharded_one_shot_matches_single_and_oracle(gpu, alg, storage, quant, k, shards):
+    """smk_nmf_dense_sharded with the in-process stand-in for RCCL: `shards` host threads, each with its own
+    device context, column shard (uneven: 701 columns), solver and streams, all on this box's one GPU.  The code
+    path is the multi-GPU one -- only ncclAllReduce / ncclAllGather are replaced.  Sharded vs unsharded <= 1e-5
+    (summation order only), each vs the oracle <= 1e-4, equal iteration counts."""
+    m, n, iters = 1500, 701, 6
+    A = oracle.fill_uniform(m, n, 42, quant=quant)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    kw = dict(min_iter=iters, max_iter=iters, tol=1e-9)
+    ref = oracle.nmf(A, W0, H0, alg, **kw)
+    one = gpu.nmf(A, W0, H0, alg, storage=storage, **kw)
+    many = gpu.nmf_sharded(A, W0, H0, alg, shards, storage=storage, local_stub=True, **kw)
+    assert one.result == many.result == ref.result == 0
+    assert one.iteration_count == many.iteration_count == ref.iteration_count == iters
+    assert rel(many.W, one.W) < 1e-5 and rel(many.H, one.H) < 1e-5
+    assert rel(many.W, ref.W) < TOL and rel(many.H, ref.H) < TOL
+
+
+@pytest.mark.parametrize("alg", ["MU", "HALS", "BPP"])
+def test_sharded_stopping_rule_agrees_on_every_rank(gpu, alg):
+    """tolerance-based stop: every rank must leave the loop at the same iteration (the H-side projected-gradient
+    sum and the failure flag are all-reduced), which is also the oracle's."""
+    import make_golden as mg
+    m, n, k = 900, 500, 8
+    A = mg.make_A(m, n, k, True, 0)                           # planted low rank: converges in tens of iterations
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    kw = dict(min_iter=3, max_iter=400, tol=0.02)
+    ref = oracle.nmf(A, W0, H0, alg, **kw)
+    many = gpu.nmf_sharded(A, W0, H0, alg, 3, local_stub=True, **kw)
+    assert many.result == ref.result == 0
+    assert 3 < ref.iteration_count < 400 and many.iteration_count == ref.iteration_count
+    assert rel(many.W, ref.W) < TOL and rel(many.H, ref.H) < TOL
+
+
+def test_sharded_failure_is_reported_by_all_ranks(gpu):
+    """A rank-deficient start makes one NNLS sub-problem non-SPD: every shard returns FAILURE (none hangs)."""
+    A = np.ones((64, 40), order="F")
+    r = gpu.nmf_sharded(A, np.ones((64, 3)), np.ones((3, 40)), "BPP", 2, local_stub=True, min_iter=1, max_iter=3)
+    assert r.result == -4
+
+
+def test_rccl_world_of_one_native(gpu):
+    """The RCCL objects themselves on this box's single GPU: ncclCommInitAll(1) and the unique-id route, attached
+    to a solver (ncclAllReduce / ncclAllGather return immediately for one rank inside comm.cpp, communicator
+    creation and destruction are real)."""
+    from smallk_amd import Comm, NmfSolver, DenseMatrix, make_options
+    m, n, k, iters = 1024, 512, 16, 4
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    ref = oracle.nmf(A, W0, H0, "BPP", min_iter=iters, max_iter=iters)
+    for make in (lambda: Comm.init_all(1)[0], lambda: Comm.init_rank(Comm.unique_id(), 0, 1)):
+        comm = make()
+        assert (comm.rank, comm.world) == (0, 1)
+        D = DenseMatrix.from_host(A)
+        s = NmfSolver(D, make_options(m, n, k, "BPP", min_iter=iters, max_iter=iters))
+        s.attach_comm(comm)
+        s.set_factors(W0, H0)
+        rc, it, _ = s.run()
+        W, H = s.factors()
+        s.close()
+        D.close()
+        comm.close()
+        assert rc == 0 and it == iters and rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
