@@ -85,7 +85,7 @@ template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK, in
 __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                          const unsigned char* __restrict__ Xp,
                                                          double* __restrict__ P, i64 stages, i64 nst,
-                                                         i64 tiles, i64 ncols_pad, int S, int logS)
+                                                         i64 tiles, i64 ncols_pad, int S, int logS, int pstride)
 {
     using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
     constexpr int KTW = C::KTW;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
         const i64 jg = col0 + (cwv * CW + c) * 32 + (lane & 31);
-        double* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32) + kw * KTW * 32;
+        double* pout = P + ((i64)split * ncols_pad + jg) * pstride + kw * KTW * 32;
 #pragma unroll
         for (int kt = 0; kt < KTW; ++kt) {
             const int n = c * KTW + kt;
@@ -445,24 +445,41 @@ static inline i64 pack_nq(int storage, int nsplit, i64 N)
 size_t packed_bytes(int storage, int k, i64 N, int nsplit)
 {
     if (!pack_is_bf16(storage, nsplit)) nsplit = 1;
-    return (size_t)pack_nq(storage, nsplit, N) * nsplit * kt_of(k) * 1024;
+    size_t total = 0;
+    for (int k0 = 0; k0 < k; k0 += 64)          // groups of 64 factor rows, each packed with its own k-tile count
+        total += (size_t)pack_nq(storage, nsplit, N) * nsplit * kt_of(k - k0 < 64 ? k - k0 : 64) * 1024;
+    return total;
 }
 
-int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st)
+int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st)
 {
-    const int KT = kt_of(k);
+    const int KT = kt_of(kg);
     const i64 nq = pack_nq(storage, nsplit, N);
     const i64 threads = nq * KT * 64;
     const int grid = (int)((threads + 255) / 256);
     if (grid == 0) return 0;
+    const double* Xg = X + k0;                   // the kernel sees rows [k0, k0 + kg) as rows [0, kg)
     if (pack_is_bf16(storage, nsplit)) {
-        if (nsplit == 3) pack_kernel<2, 3><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
-        else if (nsplit == 2) pack_kernel<2, 2><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
-        else pack_kernel<2, 1><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
+        if (nsplit == 3) pack_kernel<2, 3><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
+        else if (nsplit == 2) pack_kernel<2, 2><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
+        else pack_kernel<2, 1><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
     } else {
-        pack_kernel<4, 1><<<grid, 256, 0, st>>>(X, k, kp_of(k), N, KT, nq, (unsigned char*)out);
+        pack_kernel<4, 1><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
     }
     SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st)
+{
+    // all groups of a k-row factor, back to back (group g: rows [64 g, 64 g + 64) of [0, k))
+    size_t off = 0;
+    for (int k0 = 0; k0 < k; k0 += 64) {
+        const int kg = k - k0 < 64 ? k - k0 : 64;
+        int rc = launch_pack_rows(X, kp_of(k), k0, kg, N, storage, nsplit, (unsigned char*)out + off, st);
+        if (rc) return rc;
+        off += packed_bytes(storage, kg, N, nsplit);
+    }
     return 0;
 }
 
@@ -507,7 +524,7 @@ template <int KT, int MB, int NSTAGE, int NWL, int FOLD, int WPS, int NS>
 __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                                         const unsigned char* __restrict__ Xp,
                                                                         double* __restrict__ P, i64 stages, i64 nst,
-                                                                        i64 tiles, i64 ncols_pad, int S, int logS)
+                                                                        i64 tiles, i64 ncols_pad, int S, int logS, int pstride)
 {
     using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -691,7 +708,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
 
     // epilogue (same layout as bigprod_kernel): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const i64 jg = col0 + jl;
-    double* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32);
+    double* pout = P + ((i64)split * ncols_pad + jg) * pstride;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -719,7 +736,7 @@ template <int KT, int NSTAGE, int NWL, int FOLD, int PIN, int NS>
 __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                                         const unsigned char* __restrict__ Xp,
                                                                         double* __restrict__ P, i64 stages, i64 nst,
-                                                                        i64 tiles, i64 ncols_pad, int S, int logS)
+                                                                        i64 tiles, i64 ncols_pad, int S, int logS, int pstride)
 {
     using C = F3Cfg<KT, 32, NSTAGE, NWL, NS>;
     constexpr int PDN = NSTAGE - 2;                 // stages in flight ahead of the published one
@@ -907,7 +924,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
     }
 
     const i64 jg = col0 + jl;
-    double* pout = P + ((i64)split * ncols_pad + jg) * (KT * 32);
+    double* pout = P + ((i64)split * ncols_pad + jg) * pstride;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -946,7 +963,7 @@ static int launch_f3p_t(const BigProdPlan& pl, const void* B, i64 ldb, const voi
             grid = pl.tiles * pl.S;
         }
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
-                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS);
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride);
         SMK_HIP(hipGetLastError());
         return 0;
     }
@@ -1006,7 +1023,7 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
             grid = pl.tiles * pl.S;
         }
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
-                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS);
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride);
         SMK_HIP(hipGetLastError());
         return 0;
     }
@@ -1077,11 +1094,32 @@ static const BPVariant kVariants[] = {
 };
 static const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
+int plan_bigprod_groups(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out)
+{
+    int ng = 0;
+    size_t off = 0;
+    const int pstride = kt_of(k) * 32;
+    for (int k0 = 0; k0 < k; k0 += 64, ++ng) {
+        const int kg = k - k0 < 64 ? k - k0 : 64;
+        BigProdPlan pl = plan_bigprod(storage, kg, len, ncols, nsplit, num_cus);
+        pl.k0 = k0; pl.kg = kg; pl.pstride = pstride; pl.pack_offset = off;
+        if (ng > 0) {                              // one P layout for all groups: the first group's row splits
+            pl.S = out[0].S;
+            pl.nst = (pl.stages + pl.S - 1) / pl.S;
+        }
+        off += packed_bytes(storage, kg, len, nsplit);
+        out[ng] = pl;
+    }
+    for (int g = 0; g < ng; ++g) out[g].p_elems = (size_t)out[0].S * out[0].ncols_pad * pstride;
+    return ng;
+}
+
 BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus)
 {
     BigProdPlan pl;
     pl.storage = storage;
     pl.kt = kt_of(k);
+    pl.k0 = 0; pl.kg = k; pl.pstride = kt_of(k) * 32; pl.pack_offset = 0;
     // fp32 storage: nsplit 3 selects the bf16x3 emulation (default), 1 the native fp32 MFMA
     pl.nsplit = storage == STORE_BF16 ? nsplit : (nsplit >= 2 ? nsplit : 1);
     // measured best on MI355X: bf16 -> 64-row stages, 2-deep ring, 2 workgroups per CU (C3: 5.98 TB/s)
@@ -1168,7 +1206,7 @@ static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const
         grid = pl.tiles * pl.S;
     }
     kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * EBYTES, (const unsigned char*)Xp, P,
-                                           pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS);
+                                           pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride);
     SMK_HIP(hipGetLastError());
     return 0;
 }

@@ -23,7 +23,8 @@ constexpr i64 COL_PAD = 256;
 inline i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
 
 // padded k handled by the column-per-thread kernels
-inline int kp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64; }
+inline int kp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : 128; }
+constexpr int MAX_K = 128;                     // larger ranks: SMK_UNSUPPORTED
 // number of 32-wide k tiles of the streaming product
 inline int kt_of(int k) { return (k + 31) / 32; }
 
@@ -66,9 +67,15 @@ int launch_transpose_f64(const double* src, i64 ld_src, double* dst, i64 ld_dst,
 // packed MFMA operand of X (k x N): bytes needed
 size_t packed_bytes(int storage, int k, i64 N, int nsplit);
 int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st);
+// rows [k0, k0 + kg) of a factor stored with leading dimension ldx
+int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st);
 
 // streaming product: P[s][j][:] = sum over the rows of split s of X[:,row] * B[row, j]
 struct BigProdPlan {
+    // k > 64 runs as groups of 64 factor rows (one pass over the big matrix per group); this plan describes ONE group:
+    // k0 = first factor row, pstride = doubles per column of P (the padded k of the whole factor)
+    int k0 = 0, kg = 0, pstride = 0;
+    size_t pack_offset = 0;   // bytes from the start of the packed operand to this group's fragments
     int S;          // row splits
     i64 stages;     // total stages = ceil(len / MB)
     i64 nst;        // stages per split
@@ -78,6 +85,8 @@ struct BigProdPlan {
     size_t p_elems; // doubles needed for P
 };
 BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus);
+// the groups of a k-row factor (1 for k <= 64, 2 up to 128): same row splits, P laid out [S][ncols_pad][32 kt_of(k)]
+int plan_bigprod_groups(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out /* 2 */);
 int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st);
 
 int launch_reduce_partials(PartialView pv, int k, i64 N, float* out /* [N][kpp] */, hipStream_t st);
@@ -99,7 +108,8 @@ int launch_pg_from_grad(const double* X, const double* Y, int k, i64 N, double* 
                         int slot, hipStream_t st);
 // HALS W update (all k columns, k+1 launches); norms scratch: [k][nblocks] + ...
 int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, int num_cus,
-                         int* fail_flag, hipStream_t st);
+                         int* fail_flag, int parity, int force_multi, hipStream_t st);
+int hals_w_scratch_init(double* scratch, int k, i64 M, hipStream_t st);
 size_t hals_w_scratch_elems(int k, i64 M);
 // BPP / NNLS block principal pivoting over all columns
 // scratch: nnls_scratch_elems(k) doubles (k > 32: inverse of G + path selector), may be NULL (slow path only)

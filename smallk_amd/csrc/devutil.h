@@ -79,6 +79,7 @@ __device__ __forceinline__ double group_sum(double v)
     if constexpr (LPC >= 4) v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
     if constexpr (LPC >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
     if constexpr (LPC >= 16) v += dpp_f64<0x140>(v);  // row_mirror
+    if constexpr (LPC >= 32) v += __shfl_xor(v, 16, 64);   // the neighbouring DPP row (LDS crossbar; KP = 128 only)
     return v;
 }
 
@@ -178,6 +179,15 @@ __device__ __forceinline__ double block_sum_array(const double* __restrict__ p, 
         case 16: { constexpr int KP = 16; CALL; } break; \
         case 32: { constexpr int KP = 32; CALL; } break; \
         default: { constexpr int KP = 64; CALL; } break; \
+    }
+// kernels that also exist for k in (64, 128]
+#define KP_DISPATCH128(KPV, CALL)           \
+    switch (KPV) {                          \
+        case 8: { constexpr int KP = 8; CALL; } break;   \
+        case 16: { constexpr int KP = 16; CALL; } break; \
+        case 32: { constexpr int KP = 32; CALL; } break; \
+        case 64: { constexpr int KP = 64; CALL; } break; \
+        default: { constexpr int KP = 128; CALL; } break; \
     }
 
 }  // namespace smk

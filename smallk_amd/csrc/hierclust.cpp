@@ -505,7 +505,7 @@ int clust_flat(Run& r, smk_tree& t)
         set_error("Insufficient number of leaf nodes for flat clustering.");
         return SMK_FLATCLUST_FAILURE;
     }
-    if (k > 64) { set_error("flat clustering: more than 64 clusters is not built on the device path"); return SMK_UNSUPPORTED; }
+    if (k > 128) { set_error("flat clustering: more than 128 clusters is not built on the device path"); return SMK_UNSUPPORTED; }
     std::vector<double> W((size_t)m * k), H((size_t)k * n);
     int c = 0;
     for (size_t q = 0; q < t.nodes.size(); ++q)

@@ -442,6 +442,62 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
     for (int i = threadIdx.x; i < KP * KP; i += 256) out[i] = red[i];
 }
 
+// KP = 128 (k in (64, 128]): the 8 x 8 grid of 16 x 16 tiles does not fit one wave's registers, so a workgroup
+// computes TA = 2 tile rows (blockIdx.y picks them) against all 8 tile columns; 4 passes over X share the launch.
+template <int KP, int TA>
+__global__ __launch_bounds__(256) void gram_mfma_rows_kernel(const double* __restrict__ X, i64 N, i64 cols_per_wave,
+                                                             double* __restrict__ Gp)
+{
+    constexpr int T = KP / 16;
+    __shared__ double red[TA * 16 * KP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int a0 = blockIdx.y * TA;
+    const i64 wg = (i64)blockIdx.x * 4 + wave;
+    const i64 c_begin = wg * cols_per_wave;
+    i64 c_end = c_begin + cols_per_wave;
+    if (c_end > N) c_end = N;
+    f64x4_t acc[TA][T];
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b) acc[a][b] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const int kc = lane >> 4, r16 = lane & 15;
+    for (i64 c0 = c_begin; c0 < c_end; c0 += 4) {
+        const i64 col = c0 + kc;
+        const bool ok = col < c_end;
+        double f[T], fa[TA];
+#pragma unroll
+        for (int t = 0; t < T; ++t) f[t] = ok ? X[col * KP + 16 * t + r16] : 0.0;
+#pragma unroll
+        for (int a = 0; a < TA; ++a) fa[a] = ok ? X[col * KP + 16 * (a0 + a) + r16] : 0.0;   // same cache lines as f[]
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int b = 0; b < T; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], f[b], acc[a][b], 0, 0, 0);
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < TA; ++a)
+#pragma unroll
+                for (int b = 0; b < T; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * a + kc + 4 * r, colm = 16 * b + r16;       // row inside this pass
+                        const int idx = colm * (TA * 16) + row;
+                        red[idx] = (w == 0) ? acc[a][b][r] : red[idx] + acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    double* out = Gp + (i64)blockIdx.x * KP * KP;
+    for (int i = threadIdx.x; i < TA * 16 * KP; i += 256) {
+        const int colm = i / (TA * 16), row = i % (TA * 16);
+        out[colm * KP + a0 * 16 + row] = red[i];
+    }
+}
+
 // G[e] = sum_b Gp[b][e]: 16 elements per block, 16 thread groups stride the partials, fixed order
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ Gp, int nblk, int elems,
                                                           double* __restrict__ G)
@@ -524,7 +580,8 @@ int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int m
         switch (KP) {
             case 16: gram_mfma_kernel<16><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
             case 32: gram_mfma_kernel<32><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
-            default: gram_mfma_kernel<64><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
+            case 64: gram_mfma_kernel<64><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
+            default: gram_mfma_rows_kernel<128, 2><<<dim3(nblk, 4), 256, 0, st>>>(X, N, cpw, scratch); break;
         }
     } else {
         nblk = (int)((N + 255) / 256);
@@ -545,7 +602,7 @@ int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int m
 // ==========================================================================
 #define COLTILE_PROLOGUE(KP)                                                          \
     constexpr int LPC = KP / 4;                                                       \
-    __shared__ __attribute__((aligned(16))) double gs[KP * KP];                       \
+    extern __shared__ __attribute__((aligned(16))) double gs[];   /* KP * KP doubles */ \
     for (int i_ = threadIdx.x; i_ < KP * KP; i_ += blockDim.x) gs[i_] = G[i_];        \
     __syncthreads();                                                                  \
     const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;                      \
@@ -651,7 +708,7 @@ __global__ __launch_bounds__(256) void grad_pg_kernel(const double* __restrict__
                                                       double* __restrict__ partials)
 {
     __shared__ double sh[16];
-    __shared__ __attribute__((aligned(16))) double gs[KP * KP];
+    extern __shared__ __attribute__((aligned(16))) double gs[];      // KP * KP doubles
     grad_pg_body<KP>(X, k, N, R, G, grad_out, partials, blockIdx.x, gs, sh);
 }
 
@@ -663,7 +720,7 @@ __global__ __launch_bounds__(256) void grad_pg2_kernel(const double* __restrict_
                                                        const double* __restrict__ G2, double* __restrict__ part2, int k)
 {
     __shared__ double sh[16];
-    __shared__ __attribute__((aligned(16))) double gs[KP * KP];
+    extern __shared__ __attribute__((aligned(16))) double gs[];      // KP * KP doubles
     if ((int)blockIdx.x < grid1) grad_pg_body<KP>(X1, k, N1, R1, G1, nullptr, part1, blockIdx.x, gs, sh);
     else grad_pg_body<KP>(X2, k, N2, R2, G2, nullptr, part2, blockIdx.x - grid1, gs, sh);
 }
@@ -683,11 +740,33 @@ __global__ __launch_bounds__(256) void pg_from_grad_kernel(const double* __restr
 
 
 static inline int coltile_grid(int KP, i64 N) { return (int)((N * (KP / 4) + 255) / 256); }
+// the column-tile kernels keep G in dynamic LDS: KP * KP doubles (128 KiB for KP = 128: opt in once per kernel)
+template <typename K>
+static int coltile_lds(K kern, int KP)
+{
+    const int bytes = KP * KP * (int)sizeof(double);
+    if (bytes > 48 * 1024) SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return bytes;
+}
+#define COLTILE_CASE(KPX, KERN, GRID, ...)                                                \
+    case KPX: {                                                                           \
+        const int lds_ = coltile_lds(KERN<KPX>, KPX);                                     \
+        if (lds_ < 0) return lds_;                                                        \
+        KERN<KPX><<<(GRID), 256, lds_, st>>>(__VA_ARGS__);                                \
+    } break;
+#define COLTILE_LAUNCH(KERN, GRID, ...)                                                   \
+    switch (KPv) {                                                                        \
+        COLTILE_CASE(8, KERN, GRID, __VA_ARGS__)                                          \
+        COLTILE_CASE(16, KERN, GRID, __VA_ARGS__)                                         \
+        COLTILE_CASE(32, KERN, GRID, __VA_ARGS__)                                         \
+        COLTILE_CASE(64, KERN, GRID, __VA_ARGS__)                                         \
+        default: { COLTILE_CASE(128, KERN, GRID, __VA_ARGS__) }                           \
+    }
 
 int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st)
 {
     const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
-    KP_DISPATCH(KPv, (mu_update_kernel<KP><<<grid, 256, 0, st>>>(X, k, N, R, G)));
+    COLTILE_LAUNCH(mu_update_kernel, grid, X, k, N, R, G);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -695,7 +774,7 @@ int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hi
 int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st)
 {
     const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
-    KP_DISPATCH(KPv, (hals_sweep_kernel<KP><<<grid, 256, 0, st>>>(X, k, N, R, G)));
+    COLTILE_LAUNCH(hals_sweep_kernel, grid, X, k, N, R, G);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -704,7 +783,7 @@ int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G
                    double* pg_partials, double* pg_accum, int slot, hipStream_t st)
 {
     const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
-    KP_DISPATCH(KPv, (grad_pg_kernel<KP><<<grid, 256, 0, st>>>(X, k, N, R, G, grad_out, pg_partials)));
+    COLTILE_LAUNCH(grad_pg_kernel, grid, X, k, N, R, G, grad_out, pg_partials);
     SMK_HIP(hipGetLastError());
     sum_partials_kernel<<<1, 256, 0, st>>>(pg_partials, grid, pg_accum + slot);
     SMK_HIP(hipGetLastError());
@@ -718,7 +797,7 @@ int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, 
                     int flag_slot, hipStream_t st)
 {
     const int KPv = kp_of(k), g1 = coltile_grid(KPv, N1), g2 = coltile_grid(KPv, N2);
-    KP_DISPATCH(KPv, (grad_pg2_kernel<KP><<<g1 + g2, 256, 0, st>>>(X1, N1, R1, G1, part1, g1, X2, N2, R2, G2, part2, k)));
+    COLTILE_LAUNCH(grad_pg2_kernel, g1 + g2, X1, N1, R1, G1, part1, g1, X2, N2, R2, G2, part2, k);
     SMK_HIP(hipGetLastError());
     sum_partials2_kernel<<<2, 256, 0, st>>>(part1, g1, part2, g2, pg_accum, flag, flag_slot);
     SMK_HIP(hipGetLastError());
@@ -881,7 +960,7 @@ template <int KP, int NT, int C>
 __device__ __forceinline__ void hals_w_fused_step(double (&w)[KP], double& rhs, bool& dead, const double* gs,
                                                   double* sh, int k, i64 M, i64 row, bool valid,
                                                   const PartialView& R, unsigned long long* __restrict__ slots,
-                                                  int nblk, int lane, int wave)
+                                                  int nblk, int lane, int wave, unsigned spin_max)
 {
     constexpr int NW = NT / 64;
     if (C >= k || dead) return;                     // uniform
@@ -919,7 +998,7 @@ __device__ __forceinline__ void hals_w_fused_step(double (&w)[KP], double& rhs, 
             bool have[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { have[u] = (b0 + u * 64 + lane) < nblk; bits[u] = have[u] ? kSlotEmpty : 0ull; }
-            for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+            for (unsigned spin = 0; spin < spin_max; ++spin) {
                 bool pending = false;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -956,20 +1035,25 @@ template <int KP, int NT, int... Cs>
 __device__ __forceinline__ void hals_w_fused_all(std::integer_sequence<int, Cs...>, double (&w)[KP], double& rhs,
                                                  bool& dead, const double* gs, double* sh, int k, i64 M, i64 row,
                                                  bool valid, const PartialView& R,
-                                                 unsigned long long* __restrict__ slots, int nblk, int lane, int wave)
+                                                 unsigned long long* __restrict__ slots, int nblk, int lane, int wave,
+                                                 unsigned spin_max)
 {
-    (hals_w_fused_step<KP, NT, Cs>(w, rhs, dead, gs, sh, k, M, row, valid, R, slots, nblk, lane, wave), ...);
+    (hals_w_fused_step<KP, NT, Cs>(w, rhs, dead, gs, sh, k, M, row, valid, R, slots, nblk, lane, wave, spin_max), ...);
 }
 
 template <int KP, int NT>
 __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ Wt, int k, i64 M, PartialView R,
                                                           const double* __restrict__ G,
-                                                          unsigned long long* __restrict__ slots, int nblk,
-                                                          int* __restrict__ fail_flag)
+                                                          unsigned long long* __restrict__ slots,
+                                                          unsigned long long* __restrict__ slots_other, int nblk,
+                                                          int* __restrict__ fail_flag, unsigned spin_max)
 {
     __shared__ __attribute__((aligned(16))) double gs[KP * KP];
     __shared__ double sh[40];
     for (int t = threadIdx.x; t < KP * KP; t += NT) gs[t] = G[t];
+    // the other slot buffer (used by the previous sweep, which is complete) is re-armed for the next one: no memset
+    // launch per iteration
+    if ((int)threadIdx.x < k) slots_other[(i64)threadIdx.x * nblk + blockIdx.x] = kSlotEmpty;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const i64 row = (i64)blockIdx.x * NT + threadIdx.x;
@@ -989,7 +1073,7 @@ __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ W
 
     bool dead = false;
     hals_w_fused_all<KP, NT>(std::make_integer_sequence<int, KP>{}, w, rhs, dead, gs, sh, k, M, row, valid, R, slots,
-                             nblk, lane, wave);
+                             nblk, lane, wave, spin_max);
     if (dead) {
         if (threadIdx.x == 0) atomicMin(fail_flag, -3);
         return;
@@ -1009,18 +1093,29 @@ __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ W
 size_t hals_w_scratch_elems(int k, i64 M)
 {
     const size_t multi = (size_t)(2 * (i64)k * hals_w_blocks(kp_of(k), M));
-    const size_t fused = (size_t)k * 1024;          // slots (8 bytes each), generous
+    const size_t fused = (size_t)2 * k * 1024;      // two slot buffers (8 bytes per slot), generous
     return multi > fused ? multi : fused;
 }
 
+// `parity` alternates between the two slot buffers of the fused sweep (both must be all-ones before the first call:
+// hals_w_scratch_init); force_multi: the one-launch-per-column path (also SMK_HALS_W=multi).
+int hals_w_scratch_init(double* scratch, int k, i64 M, hipStream_t st)
+{
+    SMK_HIP(hipMemsetAsync(scratch, 0xFF, hals_w_scratch_elems(k, M) * sizeof(double), st));
+    return 0;
+}
+
 int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, int num_cus,
-                         int* fail_flag, hipStream_t st)
+                         int* fail_flag, int parity, int force_multi, hipStream_t st)
 {
     const int KPv = kp_of(k);
     static int mode = -1;                            // SMK_HALS_W=multi forces the one-launch-per-column path
+    static unsigned spin_max = 1u << 22;             // SMK_HALS_SPIN=<n>: bound of the exchange polls (tests)
     if (mode < 0) {
         const char* env = getenv("SMK_HALS_W");
         mode = (env && env[0] == 'm') ? 0 : 1;
+        const char* sp = getenv("SMK_HALS_SPIN");
+        if (sp && atoi(sp) > 0) spin_max = (unsigned)atoi(sp);
     }
     // fused path: at most one workgroup per CU so that all of them are resident by construction.
     // Smallest workgroup (256 threads: cheapest in-block sync, measured best) that still covers M
@@ -1029,12 +1124,12 @@ int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* 
     const int nt_max = (KPv == 64) ? 256 : (KPv == 32) ? 512 : 1024;
     for (int cand = 256; cand <= nt_max; cand *= 2)
         if ((M + cand - 1) / cand <= (i64)num_cus) { nt = cand; break; }
-    if (mode == 1 && nt != 0) {
+    if (mode == 1 && nt != 0 && !force_multi && KPv <= 64) {
         const i64 nblk_f = (M + nt - 1) / nt;
-        unsigned long long* slots = (unsigned long long*)scratch;
-        SMK_HIP(hipMemsetAsync(slots, 0xFF, (size_t)k * nblk_f * sizeof(unsigned long long), st));
+        unsigned long long* slots = (unsigned long long*)scratch + (size_t)(parity & 1) * k * 1024;
+        unsigned long long* other = (unsigned long long*)scratch + (size_t)((parity & 1) ^ 1) * k * 1024;
         const int nb = (int)nblk_f;
-#define SMK_FUSED(KPX, NTX) hals_w_fused_kernel<KPX, NTX><<<nb, NTX, 0, st>>>(Wt, k, M, R, G, slots, nb, fail_flag)
+#define SMK_FUSED(KPX, NTX) hals_w_fused_kernel<KPX, NTX><<<nb, NTX, 0, st>>>(Wt, k, M, R, G, slots, other, nb, fail_flag, spin_max)
         switch (KPv) {
             case 8: if (nt == 256) SMK_FUSED(8, 256); else if (nt == 512) SMK_FUSED(8, 512); else SMK_FUSED(8, 1024); break;
             case 16: if (nt == 256) SMK_FUSED(16, 256); else if (nt == 512) SMK_FUSED(16, 512); else SMK_FUSED(16, 1024); break;
@@ -1049,7 +1144,7 @@ int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* 
     double* ss = scratch;
     double* nz = scratch + (i64)k * nblk;
     for (int c = 0; c <= k; ++c) {
-        KP_DISPATCH(KPv, (hals_w_col_kernel<KP><<<nblk, 1024, 0, st>>>(Wt, k, M, R, G, c, nblk, ss, nz)));
+        KP_DISPATCH128(KPv, (hals_w_col_kernel<KP><<<nblk, 1024, 0, st>>>(Wt, k, M, R, G, c, nblk, ss, nz)));
     }
     SMK_HIP(hipGetLastError());
     return 0;
@@ -1135,7 +1230,7 @@ int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* 
     }
     const int grid = (int)((ncols * (KPv / 4) + 255) / 256);
     if (grid == 0) return 0;
-    KP_DISPATCH(KPv, (spmm_gather_kernel<KP><<<grid, 256, 0, st>>>(colptr, rowidx, val, ncols, X, P, kpp)));
+    KP_DISPATCH128(KPv, (spmm_gather_kernel<KP><<<grid, 256, 0, st>>>(colptr, rowidx, val, ncols, X, P, kpp)));
     SMK_HIP(hipGetLastError());
     return 0;
 }

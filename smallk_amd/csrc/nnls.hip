@@ -197,31 +197,33 @@ template <int KP>
 __global__ __launch_bounds__(256) void gram_inverse_kernel(const double* __restrict__ G, int k,
                                                            double* __restrict__ Ginv, int* __restrict__ status)
 {
-    static_assert(KP == 64, "256 threads x 16 entries");
+    static_assert(KP == 64 || KP == 128, "256 threads x (KP * KP / 256) entries");
+    constexpr int CQ = 256 / KP;                 // threads per matrix row
+    constexpr int EPT = KP / CQ;                 // entries per thread: a[r][EPT cq .. EPT cq + EPT - 1]
     __shared__ __attribute__((aligned(16))) double rowj[2][KP];
     __shared__ double colj[2][KP];
     __shared__ double diag0[KP];
     __shared__ int bad;
     const int tid = threadIdx.x;
-    const int r = tid >> 2, cq = tid & 3;
+    const int r = tid / CQ, cq = tid % CQ;
     if (tid == 0) bad = 0;
     if (tid < KP) diag0[tid] = (tid < k) ? G[tid * KP + tid] : 1.0;
-    double a[16];
+    double a[EPT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int c = cq * 16 + e;
+    for (int e = 0; e < EPT; ++e) {
+        const int c = cq * EPT + e;
         a[e] = (r < k && c < k) ? G[c * KP + r] : ((r == c) ? 1.0 : 0.0);
     }
     auto publish = [&](int j) {                 // row j and column j of the current matrix -> LDS buffer j & 1
-        const int buf = j & 1, jq = j >> 4, je = j & 15;
+        const int buf = j & 1, jq = j / EPT, je = j % EPT;
         if (r == j) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) rowj[buf][cq * 16 + e] = a[e];
+            for (int e = 0; e < EPT; ++e) rowj[buf][cq * EPT + e] = a[e];
         }
         if (cq == jq) {
             double v = a[0];
 #pragma unroll
-            for (int e = 1; e < 16; ++e) v = (e == je) ? a[e] : v;
+            for (int e = 1; e < EPT; ++e) v = (e == je) ? a[e] : v;
             colj[buf][r] = v;
         }
     };
@@ -234,11 +236,11 @@ __global__ __launch_bounds__(256) void gram_inverse_kernel(const double* __restr
         const double ip = 1.0 / piv;
         const double f = colj[buf][r] * ip;
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const f64x2_t rr = *(const f64x2_t*)&rowj[buf][cq * 16 + e];
+        for (int e = 0; e < EPT; e += 2) {
+            const f64x2_t rr = *(const f64x2_t*)&rowj[buf][cq * EPT + e];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int c = cq * 16 + e + u;
+                const int c = cq * EPT + e + u;
                 double val;
                 if (r == j) val = (c == j) ? ip : rr[u] * ip;
                 else val = (c == j) ? -f : __builtin_fma(-f, rr[u], a[e + u]);
@@ -248,24 +250,23 @@ __global__ __launch_bounds__(256) void gram_inverse_kernel(const double* __restr
         if (j + 1 < k) publish(j + 1);
         __syncthreads();
     }
-    // symmetrise through LDS-free exchange: Ginv[r][c] = (a[r][c] + a[c][r]) / 2 needs the transposed entry,
-    // so write the matrix out and average in a second pass over global memory
+    // symmetrise: write the matrix out, then average each entry with its transposed partner
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int c = cq * 16 + e;
+    for (int e = 0; e < EPT; ++e) {
+        const int c = cq * EPT + e;
         Ginv[c * KP + r] = (r < k && c < k) ? a[e] : 0.0;
     }
     __syncthreads();
     __threadfence_block();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int c = cq * 16 + e;
+    for (int e = 0; e < EPT; ++e) {
+        const int c = cq * EPT + e;
         const double up = Ginv[c * KP + r], lo = Ginv[r * KP + c];
         a[e] = 0.5 * (up + lo);
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) Ginv[(cq * 16 + e) * KP + r] = a[e];
+    for (int e = 0; e < EPT; ++e) Ginv[(cq * EPT + e) * KP + r] = a[e];
     if (tid == 0) *status = bad ? 0 : 1;
 }
 
@@ -418,6 +419,170 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
     if (failed_any && lane == 0) atomicMin(fail_flag, iter_tag);
 }
 
+// k in (64, 128]: the same algorithm with two components per lane (lane i owns i and 64 + i), passive sets as two
+// 64-bit words, Ginv (128 KiB) in LDS and G read through the caches (it is needed only by the direct form, i.e. for
+// solutions with more zeros than positives).  The compact dimension min(|F|, |Z|) is at most 64 = one row per lane.
+// There is no masked Gauss-Jordan fallback at this width: a Gram matrix that is not (numerically) positive definite
+// reports failure for the whole launch -- the reference fails only when a passive block it actually meets is not
+// SPD (normal_eq.hpp:35-50), which for a rank-deficient factor is the usual case.
+template <int NT>
+__global__ __launch_bounds__(NT) void nnls_bpp_inv128_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N,
+                                                             PartialView R, const double* __restrict__ G,
+                                                             const double* __restrict__ Ginv,
+                                                             const int* __restrict__ status,
+                                                             int* __restrict__ fail_flag, int iter_tag, i64 col_begin)
+{
+    constexpr int KP = 128;
+    constexpr int NW = NT / 64;
+    if (*status == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMin(fail_flag, iter_tag);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* gis = lds;                              // gis[c*KP + i] = Ginv[i][c]
+    for (int t = threadIdx.x; t < KP * KP; t += NT) gis[t] = Ginv[t];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* sv = lds + KP * KP + wave * (KP + KP / 2);          // wave-private: 128 doubles of values
+    int* sidx = (int*)(sv + KP);                                //               128 ints of indices
+    __syncthreads();
+
+    const int k1 = k - 64;                                       // live components in the upper word (k > 64 here)
+    const unsigned long long m0 = ~0ull, m1 = (k1 >= 64) ? ~0ull : ((1ull << k1) - 1ull);
+    const bool ok0 = true, ok1 = lane < k1;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int max_iter = 5 * k;
+    int failed_any = 0;
+
+    for (i64 col = col_begin + (i64)blockIdx.x * NW + wave; col < N; col += (i64)gridDim.x * NW) {
+        const double r0 = rhs_elem(R, col, lane), r1 = ok1 ? rhs_elem(R, col, 64 + lane) : 0.0;
+        double x0 = X[col * KP + lane], x1 = ok1 ? X[col * KP + 64 + lane] : 0.0;
+        double y0 = 0.0, y1 = 0.0;
+        unsigned long long F0 = __ballot(ok0 && x0 > 0.0) & m0, F1 = __ballot(ok1 && x1 > 0.0) & m1;
+
+        sv[lane] = r0;
+        sv[64 + lane] = r1;
+        double v0 = 0.0, v1 = 0.0;
+#pragma unroll 4
+        for (int c = 0; c < KP; c += 2) {
+            const f64x2_t rr = *(const f64x2_t*)(sv + c);
+            v0 = __builtin_fma(gis[c * KP + lane], rr[0], v0);
+            v1 = __builtin_fma(gis[c * KP + 64 + lane], rr[0], v1);
+            v0 = __builtin_fma(gis[(c + 1) * KP + lane], rr[1], v0);
+            v1 = __builtin_fma(gis[(c + 1) * KP + 64 + lane], rr[1], v1);
+        }
+
+        int failed = 0;
+        auto compact = [&](auto tb_tag, const double* M, int t, int tl, double sc, double b0, double b1, double& u_out,
+                           double& o0, double& o1) {
+            constexpr int TB = decltype(tb_tag)::value;
+            const bool live = lane < t;
+            double a[TB];
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const int tb = __builtin_amdgcn_readlane(tl, b);
+                const double mv = M[tb * KP + tl];
+                a[b] = (live && b < t) ? mv : ((b == lane) ? 1.0 : 0.0);
+            }
+            double d = 1.0;
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const double piv = readlane_f64(a[j], j);
+                if (!(piv > 0.0)) failed = 1;
+                const double ip = fast_rcp(piv);
+                if (lane == j) d = a[j];
+                const double f = (lane == j) ? 0.0 : a[j] * ip;
+#pragma unroll
+                for (int c = j + 1; c < TB; ++c) a[c] = __builtin_fma(-f, readlane_f64(a[c], j), a[c]);
+                sc = __builtin_fma(-f, readlane_f64(sc, j), sc);
+            }
+            const double u = live ? sc * fast_rcp(d) : 0.0;
+            o0 = b0;
+            o1 = b1;
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const int tb = __builtin_amdgcn_readlane(tl, b);
+                const double ub = readlane_f64(u, b);
+                o0 = __builtin_fma(M[tb * KP + lane], ub, o0);
+                o1 = __builtin_fma(M[tb * KP + 64 + lane], ub, o1);
+            }
+            u_out = u;
+        };
+        auto solve = [&](unsigned long long Fa, unsigned long long Fb) {
+            const unsigned long long Za = ~Fa & m0, Zb = ~Fb & m1;
+            const int p = __popcll(Fa) + __popcll(Fb), q = __popcll(Za) + __popcll(Zb);
+            const bool inF0 = (Fa >> lane) & 1ull, inF1 = (Fb >> lane) & 1ull;
+            if (q == 0) { x0 = v0; x1 = v1; y0 = y1 = 0.0; return; }
+            if (p == 0) { x0 = x1 = 0.0; y0 = -r0; y1 = ok1 ? -r1 : 0.0; return; }
+            const bool comp = q <= p;
+            const unsigned long long Ta = comp ? Za : Fa, Tb = comp ? Zb : Fb;
+            const int t = comp ? q : p;
+            const double* M = comp ? gis : G;
+            const bool inT0 = (Ta >> lane) & 1ull, inT1 = (Tb >> lane) & 1ull;
+            const int rank0 = __popcll(Ta & below), rank1 = __popcll(Ta) + __popcll(Tb & below);
+            if (inT0) sidx[rank0] = lane;
+            if (inT1) sidx[rank1] = 64 + lane;
+            sv[lane] = comp ? -v0 : r0;
+            sv[64 + lane] = comp ? -v1 : r1;
+            const int tl = (lane < t) ? sidx[lane] : 0;
+            const double sc = (lane < t) ? sv[tl] : 0.0;
+            double u = 0.0, o0 = 0.0, o1 = 0.0;
+            const double b0 = comp ? v0 : -r0, b1 = comp ? v1 : -r1;
+            if (t <= 8) compact(std::integral_constant<int, 8>{}, M, t, tl, sc, b0, b1, u, o0, o1);
+            else if (t <= 16) compact(std::integral_constant<int, 16>{}, M, t, tl, sc, b0, b1, u, o0, o1);
+            else if (t <= 32) compact(std::integral_constant<int, 32>{}, M, t, tl, sc, b0, b1, u, o0, o1);
+            else compact(std::integral_constant<int, 64>{}, M, t, tl, sc, b0, b1, u, o0, o1);
+            if (lane < t) sv[tl] = u;
+            const double ut0 = inT0 ? sv[lane] : 0.0, ut1 = inT1 ? sv[64 + lane] : 0.0;
+            if (comp) { x0 = inF0 ? o0 : 0.0; x1 = inF1 ? o1 : 0.0; y0 = ut0; y1 = ut1; }
+            else      { x0 = ut0; x1 = ut1; y0 = !inF0 ? o0 : 0.0; y1 = (ok1 && !inF1) ? o1 : 0.0; }
+        };
+
+        solve(F0, F1);
+        auto sets = [&](unsigned long long& no0, unsigned long long& no1, unsigned long long& in0, unsigned long long& in1) {
+            const bool pa = (F0 >> lane) & 1ull, pb = (F1 >> lane) & 1ull;
+            no0 = __ballot(ok0 && !pa && (y0 < 0.0));
+            no1 = __ballot(ok1 && !pb && (y1 < 0.0));
+            in0 = __ballot(ok0 && pa && (x0 < 0.0));
+            in1 = __ballot(ok1 && pb && (x1 < 0.0));
+        };
+        unsigned long long no0, no1, in0, in1;
+        sets(no0, no1, in0, in1);
+        int ng = __popcll(no0) + __popcll(no1) + __popcll(in0) + __popcll(in1);
+        int Pc = 3, Ninf = k + 1;
+        int iter = 0;
+        while (ng > 0) {
+            if (iter >= max_iter) { failed = 1; break; }
+            if (ng < Ninf) { Pc = 3; Ninf = ng; F0 = (F0 | no0) & ~in0; F1 = (F1 | no1) & ~in1; }
+            else if (Pc >= 1) { Pc -= 1; F0 = (F0 | no0) & ~in0; F1 = (F1 | no1) & ~in1; }
+            else {
+                // backup rule: the largest index among the non-optimal / infeasible components changes sides
+                const unsigned long long hi = no1 | in1, lo = no0 | in0;
+                if (hi) F1 ^= 1ull << (63 - __clzll(hi));
+                else F0 ^= 1ull << (63 - __clzll(lo));
+            }
+            F0 &= m0;
+            F1 &= m1;
+            solve(F0, F1);
+            if (fabs(x0) < 1.0e-12) x0 = 0.0;
+            if (fabs(x1) < 1.0e-12) x1 = 0.0;
+            if (fabs(y0) < 1.0e-12) y0 = 0.0;
+            if (fabs(y1) < 1.0e-12) y1 = 0.0;
+            sets(no0, no1, in0, in1);
+            ng = __popcll(no0) + __popcll(no1) + __popcll(in0) + __popcll(in1);
+            ++iter;
+        }
+        X[col * KP + lane] = x0;
+        if (ok1) X[col * KP + 64 + lane] = x1;
+        if (Y) {
+            Y[col * KP + lane] = y0;
+            if (ok1) Y[col * KP + 64 + lane] = y1;
+        }
+        failed_any |= failed;
+    }
+    if (failed_any && lane == 0) atomicMin(fail_flag, iter_tag);
+}
+
 size_t nnls_scratch_elems(int k) { return (size_t)kp_of(k) * kp_of(k) + 8; }
 
 // solves columns [col_begin, col_end) of X (col_end <= N); other columns are untouched.
@@ -433,6 +598,21 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
     const i64 N = col_end;
     static const int inv_mode = [] { const char* e = getenv("SMK_NNLS_INV"); return e ? atoi(e) : 1; }();
     const int* skip_if = nullptr;
+    if (KPv == 128) {
+        if (!scratch) { set_error("nnls: k > 64 needs the scratch buffer"); return -100; }
+        constexpr int NT = 1024;
+        double* Ginv = scratch;
+        int* status = (int*)(scratch + 128 * 128);
+        gram_inverse_kernel<128><<<1, 256, 0, st>>>(G, k, Ginv, status);
+        SMK_HIP(hipGetLastError());
+        const int lds = (128 * 128 + (NT / 64) * (128 + 64)) * (int)sizeof(double);
+        SMK_HIP(hipFuncSetAttribute((const void*)nnls_bpp_inv128_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
+        if (g2 > (i64)num_cus * 4) g2 = (i64)num_cus * 4;
+        nnls_bpp_inv128_kernel<NT><<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin);
+        SMK_HIP(hipGetLastError());
+        return 0;
+    }
     if (KPv == 64 && inv_mode && scratch) {
         double* Ginv = scratch;
         int* status = (int*)(scratch + 64 * 64);

@@ -95,11 +95,18 @@ struct smk_solver {
     double *Wprev = nullptr, *hals_scratch = nullptr, *pg_partials = nullptr, *scal = nullptr, *tmpW = nullptr;
     double* tmpH = nullptr;               // k x n compact copy of H for the host (get_factors)
     double* nnls_scratch = nullptr;       // BPP: inverse of the Gram matrix + path selector (k > 32)
+    // HALS: the fused W sweep needs every workgroup resident; if its bounded polls ever expire (flag -3) the run is
+    // repeated from the initial factors on the one-launch-per-column path, latched for the life of the handle
+    double *W0c = nullptr, *H0c = nullptr;
+    bool hals_multi = false;
+    int hals_calls = 0;
     double *Gh_own = nullptr, *scal_own = nullptr, *Wt_own = nullptr;
     void *packW = nullptr, *packH = nullptr;
     double *P1 = nullptr, *P2 = nullptr;
     float* R2red = nullptr;
-    BigProdPlan pl1, pl2;
+    BigProdPlan pl1, pl2;                 // first group of each pass (row splits, P layout)
+    BigProdPlan pg1[2], pg2[2];           // all groups: k > 64 streams the big matrix once per 64 factor rows
+    int ng = 1;
     int* fail_flag = nullptr;
     int iter = 0;
     bool have_factors = false, inited = false, normalized = false;
@@ -604,7 +611,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if (!opts || !a) return SMK_BAD_PARAM;
     if (!smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
     if (opts->height != a->m || opts->width != a->n_global) { set_error("options/matrix dimension mismatch"); return SMK_BAD_PARAM; }
-    if (opts->k > 64) { set_error("device path supports k <= 64"); return SMK_UNSUPPORTED; }
+    if (opts->k > MAX_K) { set_error("device path supports k <= 128"); return SMK_UNSUPPORTED; }
     // W and H element counts must fit the reference's 32-bit index (nmf.cpp:194-210)
     if ((uint64_t)a->m * (uint64_t)opts->k > 0x7FFFFFFFull) { fprintf(stderr, "W matrix size too large\n"); return SMK_SIZE_TOO_LARGE; }
     if ((uint64_t)a->n_global * (uint64_t)opts->k > 0x7FFFFFFFull) { fprintf(stderr, "H matrix size too large\n"); return SMK_SIZE_TOO_LARGE; }
@@ -622,8 +629,10 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     const char* env = getenv("SMK_NSPLIT");
     s->nsplit = env ? atoi(env) : 3;
     if (s->nsplit < 1 || s->nsplit > 3) s->nsplit = 3;
-    s->pl1 = plan_bigprod(a->storage, s->k, s->m, s->n, s->nsplit, g_cus);
-    s->pl2 = plan_bigprod(a->storage, s->k, s->n, s->m, s->nsplit, g_cus);
+    s->ng = plan_bigprod_groups(a->storage, s->k, s->m, s->n, s->nsplit, g_cus, s->pg1);
+    (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
+    s->pl1 = s->pg1[0];
+    s->pl2 = s->pg2[0];
     if (a->sparse) {   // gather products write one slab, as dense as the factor layout (KP values per column)
         s->kpp = s->KP;
         s->pl1.S = 1; s->pl1.p_elems = (size_t)s->pl1.ncols_pad * s->kpp;
@@ -654,7 +663,12 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     }
     rc |= dev_alloc(&s->P1, s->pl1.p_elems);
     rc |= dev_alloc(&s->P2, s->pl2.p_elems);
-    if (opts->algorithm == SMK_ALG_HALS) rc |= dev_alloc(&s->hals_scratch, hals_w_scratch_elems(s->k, s->m));
+    if (opts->algorithm == SMK_ALG_HALS) {
+        rc |= dev_alloc(&s->hals_scratch, hals_w_scratch_elems(s->k, s->m));
+        rc |= dev_alloc(&s->W0c, (size_t)s->KP * s->m);
+        rc |= dev_alloc(&s->H0c, (size_t)s->KP * s->n);
+        if (!rc) rc = hals_w_scratch_init(s->hals_scratch, s->k, s->m, s->st);
+    }
     if (opts->algorithm == SMK_ALG_BPP) rc |= dev_alloc(&s->nnls_scratch, nnls_scratch_elems(s->k));
     if (opts->prog_est_algorithm == SMK_PROG_DELTA_FNORM) rc |= dev_alloc(&s->Wprev, (size_t)s->KP * s->m);
     if (rc) { smk_solver_destroy(s); return SMK_DEVICE_ERROR; }
@@ -669,7 +683,7 @@ void smk_solver_destroy(smk_solver* s)
 {
     if (!s) return;
     void* ptrs[] = {s->H, s->Wt_own, s->Gw, s->Gh_own, s->gram_scratch, s->tmpW, s->pg_partials, s->scal_own,
-                    s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH, s->nnls_scratch};
+                    s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH, s->nnls_scratch, s->W0c, s->H0c};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int w = 0; w < 2; ++w)
@@ -763,6 +777,10 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
                              (size_t)s->k * sizeof(double), (size_t)s->n, hipMemcpyHostToDevice, s->st));
     const int big = INT_MAX;
     SMK_HIP(hipMemcpyAsync(s->fail_flag, &big, sizeof(int), hipMemcpyHostToDevice, s->st));
+    if (s->W0c) {
+        SMK_HIP(hipMemcpyAsync(s->W0c, s->Wt, (size_t)s->KP * s->m * sizeof(double), hipMemcpyDeviceToDevice, s->st));
+        SMK_HIP(hipMemcpyAsync(s->H0c, s->H, (size_t)s->KP * s->n * sizeof(double), hipMemcpyDeviceToDevice, s->st));
+    }
     SMK_HIP(hipStreamSynchronize(s->st));
     s->have_factors = true;
     s->inited = false;
@@ -847,7 +865,11 @@ static int prod1(smk_solver* s)
     if (s->a->sparse) return timed_spmm(s, 0, s->a->colptr, s->a->rowidx, s->a->val, s->n, s->Wt, s->P1);
     int rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st);
     if (rc) return rc;
-    return timed_bigprod(s, 0, s->pl1, s->a->A, s->a->ldA, s->packW, s->P1);
+    for (int g = 0; g < s->ng; ++g) {
+        rc = timed_bigprod(s, 0, s->pg1[g], s->a->A, s->a->ldA, (const unsigned char*)s->packW + s->pg1[g].pack_offset, s->P1 + s->pg1[g].k0);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // R2 = H At = (A H')'  (k x m), summed over ranks when sharded
@@ -859,7 +881,8 @@ static int prod2(smk_solver* s)
     } else {
         rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st);
         if (rc) return rc;
-        rc = timed_bigprod(s, 1, s->pl2, s->a->At, s->a->ldAt, s->packH, s->P2);
+        for (int g = 0; g < s->ng && !rc; ++g)
+            rc = timed_bigprod(s, 1, s->pg2[g], s->a->At, s->a->ldAt, (const unsigned char*)s->packH + s->pg2[g].pack_offset, s->P2 + s->pg2[g].k0);
     }
     if (rc) return rc;
     rc = wait_gh(s);
@@ -917,7 +940,7 @@ static int solver_iteration(smk_solver* s)
             rc = gram_w(s);   if (rc) return rc;
             break;
         case SMK_ALG_HALS: // nmf_solver_hals.hpp:166-199
-            rc = launch_hals_w_update(s->Wt, s->k, s->m, r2, s->Gh, s->hals_scratch, g_cus, s->fail_flag, s->st); if (rc) return rc;
+            rc = launch_hals_w_update(s->Wt, s->k, s->m, r2, s->Gh, s->hals_scratch, g_cus, s->fail_flag, s->hals_calls++, s->hals_multi ? 1 : 0, s->st); if (rc) return rc;
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
             rc = launch_hals_sweep(s->H, s->k, s->n, r1, s->Gw, s->st); if (rc) return rc;
@@ -1127,6 +1150,29 @@ static int normalize_device(smk_solver* s)
     return 0;
 }
 
+// The fused HALS W sweep reported expired polls (-3: some workgroup was not resident): go back to the initial
+// factors and latch the one-launch-per-column path.  Returns 1 when the caller should repeat its work.
+static int hals_fail_soft(smk_solver* s)
+{
+    if (s->o.algorithm != SMK_ALG_HALS || s->hals_multi || !s->W0c) return 0;
+    int flag = INT_MAX;
+    if (hipMemcpy(&flag, s->fail_flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || flag != -3) return 0;
+    fprintf(stderr, "smallk_amd: fused HALS W sweep could not keep its workgroups resident; repeating the run on the per-column path\n");
+    s->hals_multi = true;
+    const int big = INT_MAX;
+    (void)hipMemcpyAsync(s->Wt, s->W0c, (size_t)s->KP * s->m * sizeof(double), hipMemcpyDeviceToDevice, s->st);
+    (void)hipMemcpyAsync(s->H, s->H0c, (size_t)s->KP * s->n * sizeof(double), hipMemcpyDeviceToDevice, s->st);
+    (void)hipMemcpyAsync(s->fail_flag, &big, sizeof(int), hipMemcpyHostToDevice, s->st);
+    (void)hals_w_scratch_init(s->hals_scratch, s->k, s->m, s->st);
+    (void)hipStreamSynchronize(s->st);
+    s->inited = false;
+    s->normalized = false;
+    s->iter = 0;
+    s->pg0 = 1.0;
+    s->last_metric = 1.0;
+    return 1;
+}
+
 int smk_solver_iterate(smk_solver* s, int iters)
 {
     if (!s || iters < 0) return SMK_BAD_PARAM;
@@ -1143,7 +1189,13 @@ int smk_solver_iterate(smk_solver* s, int iters)
 int smk_solver_sync(smk_solver* s)
 {
     if (!s) return SMK_BAD_PARAM;
-    return sync_and_check(s, nullptr);
+    const int target = s->iter;
+    int rc = sync_and_check(s, nullptr);
+    if (rc == SMK_FAILURE && !is_dist(s) && hals_fail_soft(s)) {
+        rc = smk_solver_iterate(s, target);
+        if (rc == SMK_OK) rc = sync_and_check(s, nullptr);
+    }
+    return rc;
 }
 
 int smk_solver_progress(smk_solver* s, double* metric)
@@ -1155,8 +1207,17 @@ int smk_solver_progress(smk_solver* s, double* metric)
 
 int smk_solver_iteration_count(const smk_solver* s) { return s ? s->iter : 0; }
 
+static int solver_run_once(smk_solver* s, smk_stats* stats);
+
 // NmfSolve<>, common/include/nmf_solve_generic.hpp:34-140
 int smk_solver_run(smk_solver* s, smk_stats* stats)
+{
+    int rc = solver_run_once(s, stats);
+    if (rc == SMK_FAILURE && s && !is_dist(s) && hals_fail_soft(s)) rc = solver_run_once(s, stats);
+    return rc;
+}
+
+static int solver_run_once(smk_solver* s, smk_stats* stats)
 {
     if (!s) return SMK_BAD_PARAM;
     if (!s->have_factors) { set_error("set_factors() first"); return SMK_BAD_PARAM; }
@@ -1308,7 +1369,7 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
 {
     if (!g_init) { set_error("smk_initialize() has not been called"); return SMK_NOTINITIALIZED; }
     if (k <= 0 || ncols <= 0 || !LHS || !RHS || !X || ldL < k || ldR < k || ldX < k || (Y && ldY < k)) return SMK_BAD_PARAM;
-    if (k > 64) { set_error("device path supports k <= 64"); return SMK_UNSUPPORTED; }
+    if (k > MAX_K) { set_error("device path supports k <= 128"); return SMK_UNSUPPORTED; }
     const int KP = kp_of(k);
     std::vector<double> hg((size_t)KP * KP, 0.0), hr((size_t)KP * ncols, 0.0), hx((size_t)KP * ncols, 0.0);
     for (int c = 0; c < k; ++c)
@@ -1414,7 +1475,7 @@ int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double
     }
     const double mn = (double)s->m * (double)s->n;
     if (bytes) *bytes = mn * elem_size(s->a->storage);
-    if (flops) *flops = 2.0 * mn * s->k;
+    if (flops) *flops = 2.0 * mn * s->k / s->ng;      // per launch: k > 64 streams the matrix once per group of 64 rows
     return SMK_OK;
 }
 

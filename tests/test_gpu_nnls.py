@@ -90,7 +90,19 @@ def test_ill_conditioned_gram_takes_the_slow_path_and_agrees(gpu, k):
         assert np.abs(Xg - Xo).max() <= 1e-3 * np.abs(Xo).max()
 
 
-@pytest.mark.parametrize("k", [4, 16, 40, 64])
+@pytest.mark.parametrize("k", [65, 80, 100, 128])
+@pytest.mark.parametrize("fill", [0.0, 0.2, 0.5, 0.8, 1.0])
+def test_k_above_64_every_passive_density(gpu, k, fill):
+    """k in (64, 128]: two components per lane, passive sets as two 64-bit words, compact solves up to 64 rows."""
+    rng = np.random.default_rng(int(k * 10 + fill * 100))
+    ncols = 200
+    G, B = problem(rng, 4 * k + 5, k, ncols, shift=False)
+    B -= np.quantile(B, 1.0 - fill) if 0.0 < fill < 1.0 else (np.abs(B).max() * 2 if fill == 0.0 else 0.0)
+    X0 = rng.random((k, ncols)) * (rng.random((k, ncols)) < fill)
+    compare(gpu, G, B, np.asfortranarray(X0))
+
+
+@pytest.mark.parametrize("k", [4, 16, 40, 64, 100])
 def test_not_positive_definite_is_failure(gpu, k):
     """Rank-one Gram matrix: the passive block is not SPD -> false (normal_eq.hpp:35-50)."""
     G = np.ones((k, k), order="F")

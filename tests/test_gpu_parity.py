@@ -166,7 +166,7 @@ def test_failure_and_bad_params(gpu):
     assert gpu.nmf(A, np.ones((12, 3)), np.ones((3, 6)), "MU", tol=2.0).result == L.BAD_PARAM
     assert gpu.nmf(A[:, :2], np.ones((12, 3)), np.ones((3, 2)), "MU").result == L.BAD_PARAM   # k > n
     with pytest.raises(L.SmallkError):
-        gpu.nmf(np.ones((200, 100)), np.ones((200, 65)), np.ones((65, 100)), "MU")            # k > 64
+        gpu.nmf(np.ones((200, 150)), np.ones((200, 129)), np.ones((129, 150)), "MU")          # k > 128
 
 
 @pytest.mark.parametrize("alg,storage,quant,m,n,k,iters", [
@@ -290,12 +290,31 @@ def test_hals_mean_matched_start(gpu, m, n, k, storage, quant):
         assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
 
 
-def test_rank_above_64_is_refused_loudly(gpu):
-    """k > 64 is valid for the reference and not built on the device path: SMK_UNSUPPORTED with a message,
+@pytest.mark.parametrize("alg", ["MU", "HALS", "BPP"])
+@pytest.mark.parametrize("m,n,k,storage,quant", [(700, 400, 65, "f32", 0), (900, 500, 96, "bf16", 1), (1200, 640, 128, "f32", 0),
+                                                  (300, 129, 100, "f32", 0)])
+def test_rank_above_64(gpu, alg, m, n, k, storage, quant):
+    """k in (64, 128] (valid in the reference: only k <= n is required, common/src/nmf_options.cpp:47-52): the big
+    matrix is streamed once per group of 64 factor rows, the column kernels run 32 lanes per column, NNLS keeps two
+    components per lane.  Same bar as everywhere: 1e-4 relative Frobenius against the oracle after equal iterations."""
+    import oracle
+    import make_golden as mg
+    iters = 5
+    A = mg.make_A(m, n, k, True, quant)                       # planted rank k (pure noise at k ~ n kills HALS rows)
+    W0, H0 = oracle.fill_uniform(m, k, 43), oracle.fill_uniform(k, n, 44)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters)
+    r = gpu.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, storage=storage)
+    assert r.result == ref.result == 0 and r.iteration_count == ref.iteration_count == iters
+    assert np.linalg.norm(r.W - ref.W) / np.linalg.norm(ref.W) < 1e-4
+    assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
+
+
+def test_rank_above_128_is_refused_loudly(gpu):
+    """k > 128 is valid for the reference and not built on the device path: SMK_UNSUPPORTED with a message,
     never a silent fallback."""
     import oracle
     from smallk_amd import _lib as L
     A = oracle.fill_uniform(200, 150, 1)
     with pytest.raises(L.SmallkError) as e:
-        gpu.nmf(A, oracle.fill_uniform(200, 65, 2), oracle.fill_uniform(65, 150, 3), "HALS", min_iter=1, max_iter=2)
-    assert e.value.code == L.UNSUPPORTED and "k <= 64" in str(e.value)
+        gpu.nmf(A, oracle.fill_uniform(200, 129, 2), oracle.fill_uniform(129, 150, 3), "HALS", min_iter=1, max_iter=2)
+    assert e.value.code == L.UNSUPPORTED and "k <= 128" in str(e.value)

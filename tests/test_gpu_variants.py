@@ -22,7 +22,7 @@ def run_quick_parity(env_extra):
     return last
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7, 9, 11, 13, 14, 15, 18, 20, 21])
+@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7, 9, 11, 13, 14, 15, 18, 20, 21, 100, 102, 106, 108, 111, 115, 117])
 def test_streaming_kernel_variants(variant):
     run_quick_parity({"SMK_BP_VARIANT": str(variant)})
 
@@ -59,3 +59,38 @@ def test_check_every_iteration_loop():
                        text=True, cwd=ROOT, timeout=600, env=dict(os.environ, SMK_SYNC_PROGRESS="1"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "converged early" in r.stdout
+
+
+def test_fused_hals_sweep_fails_soft(tmp_path):
+    """SMK_HALS_SPIN=1 makes the grid-wide exchange of the fused W sweep give up at once (what would happen if a
+    workgroup could not be resident): the run is repeated from the initial factors on the one-launch-per-column
+    path, the caller sees OK and the oracle's factors, and the fallback is announced once on stderr."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import numpy as np, oracle, smallk_amd
+smallk_amd.initialize(0)
+m, n, k, iters = 3000, 900, 20, 6
+A = oracle.fill_uniform(m, n, 42); W0 = oracle.fill_uniform(m, k, 43); H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+ref = oracle.nmf(A, W0, H0, "HALS", min_iter=iters, max_iter=iters)
+got = smallk_amd.nmf(A, W0, H0, "HALS", min_iter=iters, max_iter=iters)
+e = max(np.linalg.norm(got.W - ref.W) / np.linalg.norm(ref.W), np.linalg.norm(got.H - ref.H) / np.linalg.norm(ref.H))
+print("RESULT", got.result, got.iteration_count, e)
+# the stepwise interface recovers too
+D = smallk_amd.DenseMatrix.from_host(A)
+s = smallk_amd.NmfSolver(D, smallk_amd.make_options(m, n, k, "HALS", min_iter=iters, max_iter=iters, normalize=False))
+s.set_factors(W0, H0); s.iterate(iters); rc = s.sync(); W, H = s.factors()
+ref2 = oracle.nmf(A, W0, H0, "HALS", min_iter=iters, max_iter=iters, normalize=False)
+print("STEPWISE", rc, np.linalg.norm(W - ref2.W) / np.linalg.norm(ref2.W))
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SMK_HALS_SPIN="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert int(line[1]) == 0 and int(line[2]) == 6 and float(line[3]) < 1e-4
+    step = [l for l in r.stdout.splitlines() if l.startswith("STEPWISE")][0].split()
+    assert int(step[1]) == 0 and float(step[2]) < 1e-4
+    assert r.stderr.count("repeating the run on the per-column path") == 2
