@@ -4,8 +4,9 @@
 // (same names, argument meaning, defaults and exception behaviour) so that a program written
 // against libsmallk -- e.g. examples/smallk_example.cpp or pysmallk's cdef extern block
 // (pysmallk/interface/smallk_lib.pyx:42-88) -- links against libsmallk_amd.so instead.
-// NMF (MU / HALS / BPP / RANK2, dense or sparse A) runs on the GPU; the clustering entry points
-// (HierNmf2, dictionaries) are declared and throw std::runtime_error until they are built.
+// NMF (MU / HALS / BPP / RANK2, dense or sparse A) and the clustering entry points (LoadDictionary,
+// HierNmf2, HierNmf2WithFlat) all run on the GPU through include/smallk_amd.h; SMK_NUM_GPUS=N shards a
+// dense Nmf() over N devices of the node.
 #pragma once
 
 #include <string>

@@ -625,55 +625,100 @@ static void print_opts(const NmfOptions& o)
     cout << endl;
 }
 
-// smallk.cpp:471-650
+// ---- smallk::Nmf (smallk.cpp:471-650) in four steps: rank + algorithm, initial factors, device run, result files ----
+
+// public algorithm id -> the inner seam's (the two enums are numbered differently, smallk.cpp:497-513)
+static NmfAlgorithm inner_algorithm(const Algorithm algorithm)
+{
+    switch (algorithm) {
+        case Algorithm::MU: return NmfAlgorithm::MU;
+        case Algorithm::HALS: return NmfAlgorithm::HALS;
+        case Algorithm::RANK2: return NmfAlgorithm::RANK2;
+        case Algorithm::BPP: return NmfAlgorithm::BPP;
+    }
+    throw std::logic_error("smallk error (NMF): unknown NMF algorithm.");
+}
+
+// One initial factor, rows x cols with leading dimension rows: drawn from the generator when `file` is empty,
+// else read from a CSV file.  The file goes into a scratch vector first, so a file of the wrong shape leaves
+// `dst` (and the sizes LockedBufferW/H report) consistent.
+static void initial_factor(const char* name, const std::string& file, unsigned rows, unsigned cols, std::vector<double>& dst)
+{
+    std::cout << "Initializing matrix " << name << "..." << std::endl;
+    dst.resize((size_t)rows * cols);
+    if (file.empty()) {
+        RandomMatrix(dst.data(), rows, rows, cols);
+        return;
+    }
+    std::vector<double> loaded;
+    unsigned fh = 0, fw = 0;
+    if (!smallk_amd_io::LoadCsv(loaded, fh, fw, file))
+        throw std::runtime_error("smallk error (Nmf): load failed for file \"" + file + "\"");
+    if (fh != rows || fw != cols) {
+        std::cerr << "\tdimensions of matrix " << name << " are " << fh << " x " << fw << std::endl;
+        std::cerr << "\texpected " << rows << " x " << cols << std::endl;
+        throw std::logic_error(std::string("smallk error (Nmf): non-conformant matrix ") + name + ".");
+    }
+    std::copy(loaded.begin(), loaded.begin() + (size_t)rows * cols, dst.begin());
+}
+
+// the inner seam's checks (::Nmf, nmf.cpp:173-229) without its per-call upload: A stays resident in HBM;
+// SMK_NUM_GPUS > 1 shards a dense matrix over that many devices instead
+static Result run_on_device(const NmfOptions& opts, NmfStats& stats)
+{
+    smk_options c = to_c(opts);
+    if (smk_is_initialized() != SMK_INITIALIZED) {
+        std::cerr << "nmflib error: nmf_initialize() must be called prior to any factorization routine\n" << std::endl;
+        return Result::NOTINITIALIZED;
+    }
+    if (!smk_is_valid(&c, 1)) return Result::BAD_PARAM;
+    smk_stats st{0, 0};
+    int rc, shards = 1, stub = 0;
+    requested_shards(&shards, &stub);
+    if (!is_sparse && shards > 1) {
+        rc = smk_nmf_dense_sharded(&c, &buf_a[0], ldim_a, &buf_w[0], ldim_w, &buf_h[0], ldim_h, &st, (int)device_storage,
+                                   shards, nullptr, stub);
+    } else {
+        smk_solver* sv = nullptr;
+        rc = smk_solver_create(&sv, &c, ensure_resident());
+        if (rc == SMK_OK) rc = smk_solver_set_factors(sv, &buf_w[0], ldim_w, &buf_h[0], ldim_h);
+        if (rc == SMK_OK) {
+            rc = smk_solver_run(sv, &st);
+            // like the reference, W/H hold the last iterate even when the solver reports failure
+            if (rc == SMK_OK || rc == SMK_FAILURE) (void)smk_solver_get_factors(sv, 0, &buf_w[0], ldim_w, &buf_h[0], ldim_h);
+        }
+        smk_solver_destroy(sv);
+    }
+    stats.elapsed_us = st.elapsed_us;
+    stats.iteration_count = st.iteration_count;
+    return to_result(rc);
+}
+
 void Nmf(const unsigned int kval, const Algorithm algorithm, const std::string& csv_file_w, const std::string& csv_file_h)
 {
     if (!matrix_loaded) throw std::logic_error("smallk error (NMF): no matrix has been loaded.");
     if (max_iter < min_iter) throw std::logic_error("smallk error (NMF): min_iterations exceeds max_iterations.");
     if (0 == kval) throw std::logic_error("smallk error (NMF): k must be greater than 0.");
-    if ((uint64_t)m * kval > (uint64_t)std::numeric_limits<int>::max())
-        throw std::logic_error("smallk error (Nmf): mxk matrix W is too large.");
-    if ((uint64_t)kval * n > (uint64_t)std::numeric_limits<int>::max())
-        throw std::logic_error("smallk error (Nmf): kxn matrix H is too large.");
-    k = kval;
+    const NmfAlgorithm alg = inner_algorithm(algorithm);
+    const unsigned int rank = (NmfAlgorithm::RANK2 == alg) ? 2u : kval;
+    const uint64_t int_max = (uint64_t)std::numeric_limits<int>::max();
+    if ((uint64_t)m * kval > int_max) throw std::logic_error("smallk error (Nmf): mxk matrix W is too large.");
+    if ((uint64_t)kval * n > int_max) throw std::logic_error("smallk error (Nmf): kxn matrix H is too large.");
 
-    NmfOptions opts;
-    switch (algorithm) {      // smallk::Algorithm and NmfAlgorithm are numbered differently (:497-513)
-        case Algorithm::MU: opts.algorithm = NmfAlgorithm::MU; break;
-        case Algorithm::HALS: opts.algorithm = NmfAlgorithm::HALS; break;
-        case Algorithm::RANK2: opts.algorithm = NmfAlgorithm::RANK2; break;
-        case Algorithm::BPP: opts.algorithm = NmfAlgorithm::BPP; break;
-        default: throw std::logic_error("smallk error (NMF): unknown NMF algorithm.");
-    }
-    if (NmfAlgorithm::RANK2 == opts.algorithm) k = 2;
+    // W first, then H: the generator's draw order is part of the interface (clust_hier_util.hpp:196-203 relies on it too)
+    std::vector<double> w0, h0;
+    initial_factor("W", csv_file_w, m, rank, w0);
+    initial_factor("H", csv_file_h, rank, n, h0);
+    k = rank;
     ldim_w = m;
     ldim_h = k;
-    if (buf_w.size() < (size_t)m * k) buf_w.resize((size_t)m * k);
-    if (buf_h.size() < (size_t)k * n) buf_h.resize((size_t)k * n);
+    buf_w.swap(w0);
+    buf_h.swap(h0);
 
-    bool ok = true;
-    unsigned int height_w = m, width_w = k, height_h = k, width_h = n;
-    std::cout << "Initializing matrix W..." << std::endl;
-    if (csv_file_w.empty()) RandomMatrix(&buf_w[0], ldim_w, m, k);
-    else ok = smallk_amd_io::LoadCsv(buf_w, height_w, width_w, csv_file_w);
-    if (!ok) throw std::runtime_error("smallk error (Nmf): load failed for file \"" + csv_file_w + "\"");
-    if ((height_w != m) || (width_w != k)) {
-        std::cerr << "\tdimensions of matrix W are " << height_w << " x " << width_w << std::endl;
-        std::cerr << "\texpected " << m << " x " << k << std::endl;
-        throw std::logic_error("smallk error (Nmf): non-conformant matrix W.");
-    }
-    std::cout << "Initializing matrix H..." << std::endl;
-    if (csv_file_h.empty()) RandomMatrix(&buf_h[0], ldim_h, k, n);
-    else ok = smallk_amd_io::LoadCsv(buf_h, height_h, width_h, csv_file_h);
-    if (!ok) throw std::runtime_error("smallk error (Nmf): load failed for file \"" + csv_file_h + "\"");
-    if ((height_h != k) || (width_h != n)) {
-        std::cerr << "\tdimensions of matrix H are " << height_h << " x " << width_h << std::endl;
-        std::cerr << "\texpected " << k << " x " << n << std::endl;
-        throw std::logic_error("smallk error (Nmf): non-conformant matrix H.");
-    }
-
-    // MU -> DELTA_FNORM, everything else PG_RATIO (:581-584)
-    opts.prog_est_algorithm = (NmfAlgorithm::MU == opts.algorithm) ? NmfProgressAlgorithm::DELTA_FNORM : NmfProgressAlgorithm::PG_RATIO;
+    NmfOptions opts;
+    opts.algorithm = alg;
+    // MU -> DELTA_FNORM, everything else PG_RATIO (smallk.cpp:581-584)
+    opts.prog_est_algorithm = (NmfAlgorithm::MU == alg) ? NmfProgressAlgorithm::DELTA_FNORM : NmfProgressAlgorithm::PG_RATIO;
     opts.tol = nmf_tolerance;
     opts.height = m;
     opts.width = n;
@@ -686,51 +731,19 @@ void Nmf(const unsigned int kval, const Algorithm algorithm, const std::string& 
     opts.normalize = true;
     print_opts(opts);
 
-    // the inner seam's checks (::Nmf, nmf.cpp:173-229) without its per-call upload: A is resident
     NmfStats stats;
-    Result result = Result::OK;
-    {
-        smk_options c = to_c(opts);
-        if (smk_is_initialized() != SMK_INITIALIZED) {
-            std::cerr << "nmflib error: nmf_initialize() must be called prior to any factorization routine\n" << std::endl;
-            result = Result::NOTINITIALIZED;
-        } else if (!smk_is_valid(&c, 1)) {
-            result = Result::BAD_PARAM;
-        } else if (int shards = 1, stub = 0; !is_sparse && (requested_shards(&shards, &stub), shards > 1)) {
-            smk_stats st{0, 0};
-            const int rc = smk_nmf_dense_sharded(&c, &buf_a[0], ldim_a, &buf_w[0], ldim_w, &buf_h[0], ldim_h, &st,
-                                                 (int)device_storage, shards, nullptr, stub);
-            stats.elapsed_us = st.elapsed_us;
-            stats.iteration_count = st.iteration_count;
-            result = to_result(rc);
-        } else {
-            smk_matrix* a = ensure_resident();
-            smk_solver* sv = nullptr;
-            smk_stats st{0, 0};
-            int rc = smk_solver_create(&sv, &c, a);
-            if (rc == SMK_OK) rc = smk_solver_set_factors(sv, &buf_w[0], ldim_w, &buf_h[0], ldim_h);
-            if (rc == SMK_OK) {
-                rc = smk_solver_run(sv, &st);
-                if (rc == SMK_OK || rc == SMK_FAILURE) (void)smk_solver_get_factors(sv, 0, &buf_w[0], ldim_w, &buf_h[0], ldim_h);
-            }
-            smk_solver_destroy(sv);
-            stats.elapsed_us = st.elapsed_us;
-            stats.iteration_count = st.iteration_count;
-            result = to_result(rc);
-        }
-    }
+    const Result result = run_on_device(opts, stats);
     last_stats = stats;
-
     std::cout << "Elapsed wall clock time: " << elapsed_string(stats.elapsed_us) << std::endl << std::endl;
     if (Result::OK != result) throw std::runtime_error("smallk error (Nmf): NMF solver failure.");
 
-    const std::string outfile_w = outdir.empty() ? DEFAULT_FILENAME_W : outdir + DEFAULT_FILENAME_W;
-    const std::string outfile_h = outdir.empty() ? DEFAULT_FILENAME_H : outdir + DEFAULT_FILENAME_H;
     std::cout << "Writing output files..." << std::endl;
-    if (!smallk_amd_io::WriteCsv(&buf_w[0], ldim_w, m, k, outfile_w, outprecision))
-        throw std::runtime_error("smallk error (Nmf): could not write W result.");
-    if (!smallk_amd_io::WriteCsv(&buf_h[0], ldim_h, k, n, outfile_h, outprecision))
-        throw std::runtime_error("smallk error (Nmf): could not write H result.");
+    const struct { const char* what; const std::string file; const double* buf; unsigned ld, rows, cols; } outputs[] = {
+        {"W", outdir + DEFAULT_FILENAME_W, &buf_w[0], ldim_w, m, k},
+        {"H", outdir + DEFAULT_FILENAME_H, &buf_h[0], ldim_h, k, n}};
+    for (const auto& o : outputs)
+        if (!smallk_amd_io::WriteCsv(o.buf, o.ld, o.rows, o.cols, o.file, outprecision))
+            throw std::runtime_error(std::string("smallk error (Nmf): could not write ") + o.what + " result.");
 }
 
 const double* LockedBufferW(unsigned int& ldim, unsigned int& height, unsigned int& width)
