@@ -114,7 +114,9 @@ size_t hals_w_scratch_elems(int k, i64 M);
 // BPP / NNLS block principal pivoting over all columns
 // scratch: nnls_scratch_elems(k) doubles (k > 32: inverse of G + path selector), may be NULL (slow path only)
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
-                    int* fail_flag, int iter_tag, double* scratch, int num_cus, hipStream_t st);
+                    int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st);
+// k > 32: the inverse of G into scratch, ahead of launch_nnls_bpp(..., inverse_ready = 1, ...) (any stream)
+int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st);
 size_t nnls_scratch_elems(int k);
 // normalisation: scale Wt rows by 1/nu_c, H rows by nu_c where nu_c^2 = G[c][c]
 int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int* fail_flag, hipStream_t st);

@@ -585,10 +585,23 @@ __global__ __launch_bounds__(NT) void nnls_bpp_inv128_kernel(double* __restrict_
 
 size_t nnls_scratch_elems(int k) { return (size_t)kp_of(k) * kp_of(k) + 8; }
 
+// k > 32: Ginv and the path selector into `scratch` (nnls_scratch_elems(k) doubles).  One workgroup, ~0.1 ms: the
+// solver runs it on a side stream beside the streaming product that separates the Gram matrix from its NNLS.
+int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st)
+{
+    const int KPv = kp_of(k);
+    if (KPv < 64 || !scratch) return 0;
+    if (KPv == 64) gram_inverse_kernel<64><<<1, 256, 0, st>>>(G, k, scratch, (int*)(scratch + 64 * 64));
+    else gram_inverse_kernel<128><<<1, 256, 0, st>>>(G, k, scratch, (int*)(scratch + 128 * 128));
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 // solves columns [col_begin, col_end) of X (col_end <= N); other columns are untouched.
-// `scratch`: nnls_scratch_elems(k) doubles (the inverse of G and the path selector for KP = 64).
+// `scratch`: nnls_scratch_elems(k) doubles (the inverse of G and the path selector for k > 32);
+// inverse_ready != 0: launch_gram_inverse(G, ...) has already been ordered before this call.
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
-                    int* fail_flag, int iter_tag, double* scratch, int num_cus, hipStream_t st)
+                    int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st)
 {
     const int KPv = kp_of(k);
     const int gpb = 256 / KPv;
@@ -603,8 +616,7 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
         constexpr int NT = 1024;
         double* Ginv = scratch;
         int* status = (int*)(scratch + 128 * 128);
-        gram_inverse_kernel<128><<<1, 256, 0, st>>>(G, k, Ginv, status);
-        SMK_HIP(hipGetLastError());
+        if (!inverse_ready) { int irc = launch_gram_inverse(G, k, scratch, st); if (irc) return irc; }
         const int lds = (128 * 128 + (NT / 64) * (128 + 64)) * (int)sizeof(double);
         SMK_HIP(hipFuncSetAttribute((const void*)nnls_bpp_inv128_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
@@ -616,8 +628,7 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
     if (KPv == 64 && inv_mode && scratch) {
         double* Ginv = scratch;
         int* status = (int*)(scratch + 64 * 64);
-        gram_inverse_kernel<64><<<1, 256, 0, st>>>(G, k, Ginv, status);
-        SMK_HIP(hipGetLastError());
+        if (!inverse_ready) { int irc = launch_gram_inverse(G, k, scratch, st); if (irc) return irc; }
         auto run = [&](auto kern, int NT, int wg_per_cu) -> int {
             const int lds = (2 * 64 * 64 + (NT / 64) * 2 * 64) * (int)sizeof(double);
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -94,7 +94,10 @@ struct smk_solver {
     double *H = nullptr, *Wt = nullptr, *Gw = nullptr, *Gh = nullptr, *gram_scratch = nullptr;
     double *Wprev = nullptr, *hals_scratch = nullptr, *pg_partials = nullptr, *scal = nullptr, *tmpW = nullptr;
     double* tmpH = nullptr;               // k x n compact copy of H for the host (get_factors)
-    double* nnls_scratch = nullptr;       // BPP: inverse of the Gram matrix + path selector (k > 32)
+    double* nnls_scratch = nullptr;       // BPP: inverses of W'W and HH' + path selectors (k > 32), two halves
+    hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
+    hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
+    bool inv_pending[2] = {false, false};
     // HALS: the fused W sweep needs every workgroup resident; if its bounded polls ever expire (flag -3) the run is
     // repeated from the initial factors on the one-launch-per-column path, latched for the life of the handle
     double *W0c = nullptr, *H0c = nullptr;
@@ -669,7 +672,16 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
         rc |= dev_alloc(&s->H0c, (size_t)s->KP * s->n);
         if (!rc) rc = hals_w_scratch_init(s->hals_scratch, s->k, s->m, s->st);
     }
-    if (opts->algorithm == SMK_ALG_BPP) rc |= dev_alloc(&s->nnls_scratch, nnls_scratch_elems(s->k));
+    if (opts->algorithm == SMK_ALG_BPP) {
+        rc |= dev_alloc(&s->nnls_scratch, 2 * nnls_scratch_elems(s->k));
+        if (s->KP >= 64) {
+            if (hipStreamCreateWithFlags(&s->st_inv, hipStreamNonBlocking) != hipSuccess) rc |= 1;
+            for (int i = 0; i < 2 && !rc; ++i) {
+                if (hipEventCreateWithFlags(&s->ev_g[i], hipEventDisableTiming) != hipSuccess) rc |= 1;
+                if (hipEventCreateWithFlags(&s->ev_inv[i], hipEventDisableTiming) != hipSuccess) rc |= 1;
+            }
+        }
+    }
     if (opts->prog_est_algorithm == SMK_PROG_DELTA_FNORM) rc |= dev_alloc(&s->Wprev, (size_t)s->KP * s->m);
     if (rc) { smk_solver_destroy(s); return SMK_DEVICE_ERROR; }
     s->Gh = s->Gh_own;
@@ -695,6 +707,11 @@ void smk_solver_destroy(smk_solver* s)
     if (s->pin) (void)hipHostFree(s->pin);
     if (s->comm_ws) (void)hipFree(s->comm_ws);
     if (s->st2) (void)hipStreamDestroy(s->st2);
+    if (s->st_inv) (void)hipStreamDestroy(s->st_inv);
+    for (int i = 0; i < 2; ++i) {
+        if (s->ev_g[i]) (void)hipEventDestroy(s->ev_g[i]);
+        if (s->ev_inv[i]) (void)hipEventDestroy(s->ev_inv[i]);
+    }
     if (s->ev_gram) (void)hipEventDestroy(s->ev_gram);
     if (s->ev_gh) (void)hipEventDestroy(s->ev_gh);
     --g_live_solvers;
@@ -823,6 +840,31 @@ static int wait_gh(smk_solver* s)
     return 0;
 }
 
+// BPP, k > 32: the inverse of a Gram matrix (side 0: W'W for the H solve, side 1: HH' for the W solve) is taken on a
+// side stream as soon as the matrix exists; the streaming product that follows on the main stream hides it.
+static inline double* inv_scratch(smk_solver* s, int side) { return s->nnls_scratch + (size_t)side * nnls_scratch_elems(s->k); }
+static int start_inverse(smk_solver* s, int side, const double* G)
+{
+    if (!s->st_inv || s->o.algorithm != SMK_ALG_BPP) return 0;
+    SMK_HIP(hipEventRecord(s->ev_g[side], s->st));
+    SMK_HIP(hipStreamWaitEvent(s->st_inv, s->ev_g[side], 0));
+    int rc = launch_gram_inverse(G, s->k, inv_scratch(s, side), s->st_inv);
+    if (rc) return rc;
+    SMK_HIP(hipEventRecord(s->ev_inv[side], s->st_inv));
+    s->inv_pending[side] = true;
+    return 0;
+}
+static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, PartialView R, const double* G)
+{
+    int ready = 0;
+    if (s->inv_pending[side]) {
+        SMK_HIP(hipStreamWaitEvent(s->st, s->ev_inv[side], 0));
+        s->inv_pending[side] = false;
+        ready = 1;
+    }
+    return launch_nnls_bpp(X, nullptr, s->k, c0, c1, R, G, s->fail_flag, s->iter, inv_scratch(s, side), ready, g_cus, s->st);
+}
+
 // ---- building blocks -----------------------------------------------------------------------
 static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp,
                          double* P)
@@ -897,13 +939,21 @@ static int prod2(smk_solver* s)
     return 0;
 }
 
-static int gram_w(smk_solver* s) { return launch_gram(s->Wt, s->k, s->m, s->Gw, s->gram_scratch, GRAM_BLOCKS, s->st); }
+static int gram_w(smk_solver* s)
+{
+    int rc = launch_gram(s->Wt, s->k, s->m, s->Gw, s->gram_scratch, GRAM_BLOCKS, s->st);
+    if (rc) return rc;
+    return start_inverse(s, 0, s->Gw);
+}
 
 static int gram_h(smk_solver* s)
 {
     int rc = launch_gram(s->H, s->k, s->n, s->Gh, s->gram_scratch, GRAM_BLOCKS, s->st);
     if (rc) return rc;
-    return allreduce_gh(s);
+    rc = allreduce_gh(s);
+    if (rc) return rc;
+    // sharded: HH' is final only after its all-reduce (joined in prod2); the inverse is taken in line then
+    return is_dist(s) ? 0 : start_inverse(s, 1, s->Gh);
 }
 
 // solver.Init (mu :98-114, hals :142-159, bpp :310-335) + progress_est->Init
@@ -948,7 +998,7 @@ static int solver_iteration(smk_solver* s)
             rc = prod2(s);    if (rc) return rc;
             break;
         case SMK_ALG_BPP:  // nmf_solver_bpp.hpp:342-377
-            rc = launch_nnls_bpp(s->H, nullptr, s->k, 0, s->n, r1, s->Gw, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
+            rc = nnls_side(s, 0, s->H, 0, s->n, r1, s->Gw); if (rc) return rc;
             rc = gram_h(s);   if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
             if (is_dist(s) && s->world > 1) {
@@ -957,20 +1007,20 @@ static int solver_iteration(smk_solver* s)
                     // equal chunks of ceil(m / world) rows, gathered in place (ncclAllGather: 1/world of the bytes a
                     // sum-all-reduce of the whole matrix would move)
                     const i64 i0 = std::min<i64>(s->m, s->rank * s->w_chunk), i1 = std::min<i64>(s->m, i0 + s->w_chunk);
-                    rc = launch_nnls_bpp(s->Wt, nullptr, s->k, i0, i1, view2(s), s->Gh, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
+                    rc = nnls_side(s, 1, s->Wt, i0, i1, view2(s), s->Gh); if (rc) return rc;
                     rc = comm_allgather(s->comm, s->Wt, s->w_chunk * s->KP, 1, s->st); if (rc) return rc;
                 } else {
                     // callback hook (one primitive only): zero the other rows and sum-all-reduce
                     const i64 base = s->m / s->world, extra = s->m % s->world;
                     const i64 i0 = s->rank * base + (s->rank < extra ? s->rank : extra);
                     const i64 i1 = i0 + base + (s->rank < extra ? 1 : 0);
-                    rc = launch_nnls_bpp(s->Wt, nullptr, s->k, i0, i1, view2(s), s->Gh, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
+                    rc = nnls_side(s, 1, s->Wt, i0, i1, view2(s), s->Gh); if (rc) return rc;
                     if (i0 > 0) SMK_HIP(hipMemsetAsync(s->Wt, 0, (size_t)i0 * s->KP * sizeof(double), s->st));
                     if (i1 < s->m) SMK_HIP(hipMemsetAsync(s->Wt + i1 * s->KP, 0, (size_t)(s->m - i1) * s->KP * sizeof(double), s->st));
                     rc = dist_allreduce(s, s->Wt, (i64)s->KP * s->m, 1, s->st); if (rc) return rc;
                 }
             } else {
-                rc = launch_nnls_bpp(s->Wt, nullptr, s->k, 0, s->m, view2(s), s->Gh, s->fail_flag, s->iter, s->nnls_scratch, g_cus, s->st); if (rc) return rc;
+                rc = nnls_side(s, 1, s->Wt, 0, s->m, view2(s), s->Gh); if (rc) return rc;
             }
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
@@ -1397,7 +1447,7 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
     SMK_HIP(hipMemsetAsync(dy, 0, hx.size() * sizeof(double), g_stream));
     SMK_HIP(hipMemcpyAsync(dflag, &big, sizeof(int), hipMemcpyHostToDevice, g_stream));
     const PartialView pv{dr, 1, 0, KP, 1};
-    rc = launch_nnls_bpp(dx, dy, k, 0, ncols, pv, dg, dflag, 0, dscratch, g_cus, g_stream);
+    rc = launch_nnls_bpp(dx, dy, k, 0, ncols, pv, dg, dflag, 0, dscratch, 0, g_cus, g_stream);
     if (rc) return rc;
     int flag = INT_MAX;
     SMK_HIP(hipMemcpyAsync(hx.data(), dx, hx.size() * sizeof(double), hipMemcpyDeviceToHost, g_stream));
