@@ -139,6 +139,32 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("gloo")                 # CPU side channel only: unique id, barrier, max of the clocks
     smallk_amd.initialize(device_index)
+    comm, fallback_group, collectives = None, None, "none"
+    if world > 1 and native:
+        # RCCL communicator created by libsmallk_amd.so itself; every collective of the iteration is issued from C
+        ok = 1
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.tensor(list(smallk_amd.Comm.unique_id()), dtype=torch.uint8)
+            torch.distributed.broadcast(uid, 0)
+            comm = smallk_amd.Comm.init_rank(bytes(uid.tolist()), rank, world)
+        except Exception as e:              # pragma: no cover  (multi-GPU nodes only)
+            print(f"[bench rank {rank}] native RCCL communicator failed: {e}", file=sys.stderr, flush=True)
+            ok = 0
+        agreed = torch.tensor([ok], dtype=torch.int32)
+        torch.distributed.all_reduce(agreed, op=torch.distributed.ReduceOp.MIN)
+        if int(agreed.item()) == 1:
+            collectives = "RCCL from C (comm.cpp)"
+        else:                               # plan B, all ranks together: torch's own RCCL through the callback hook
+            if comm is not None:
+                comm.close()
+                comm = None
+            native = False
+            fallback_group = torch.distributed.new_group(backend="nccl")
+            collectives = "torch.distributed nccl through the callback hook (native communicator failed)"
+    elif world > 1:
+        collectives = "callback hook (" + backend + ")"
     if world > 1 and not native:
         # callback hook: the solver launches on torch's current stream so that the all-reduces order against it
         smallk_amd.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -155,16 +181,10 @@ def main():
     H0 = smallk_amd.uniform_host(k, ncols, 44, c0=col0, gheight=k) * (2.0 / k)
     opts = smallk_amd.make_options(m, n, k, alg, min_iter=total_iters, max_iter=total_iters)
     solver = smallk_amd.NmfSolver(A, opts)
-    comm = None
-    if world > 1 and native:
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.tensor(list(smallk_amd.Comm.unique_id()), dtype=torch.uint8)
-        torch.distributed.broadcast(uid, 0)
-        comm = smallk_amd.Comm.init_rank(bytes(uid.tolist()), rank, world)
+    if comm is not None:
         solver.attach_comm(comm)
     elif world > 1:
-        sdist.attach(solver, rank, world, dev)
+        sdist.attach(solver, rank, world, dev, group=fallback_group)
     solver.set_factors(W0, H0)
 
     def barrier():
@@ -230,7 +250,7 @@ def main():
             "config": {"workload": desc, "m": m, "n": n, "k": k, "algorithm": alg, "A_storage": storage,
                        "state": "W,H,Gram fp64; big products fp32-accumulate MFMA",
                        "parallelism": f"column-shard x{world}" if world > 1 else "single GPU",
-                       "collectives": ("RCCL from C (comm.cpp)" if native else "callback hook") if world > 1 else "none"},
+                       "collectives": collectives},
             "mfma_tflops_big_products": mfma_tf,
             "mfma_frac_of_peak": mfma_tf / MFMA_PEAK_TF[storage],
             "whole_iteration_tflops": 4.0 * m * n * k / (elapsed / args.steps) / 1e12,

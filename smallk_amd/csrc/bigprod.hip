@@ -796,7 +796,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
             const unsigned char* g = is_b[i] ? (B + src_off[i] + stage * (C::MB * 4)) : (Xp + stage * C::X_BYTES + src_off[i]);
             if (is_b[i])
                 __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
-            else
+            else if constexpr ((PIN & 16) == 0)     // experiment bit 16: the X fragments are not fetched at all
                 __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
         }
     };
@@ -995,6 +995,8 @@ static const F3Variant kF3Variants[] = {
     {32, 5, 4, 4, 0},   // 120: EXPERIMENT neither
     {32, 5, 4, 4, 0},   // 121: loader waves at priority 3
     {32, 5, 4, 4, 0},   // 122: loader priority, compiler schedule
+    {32, 5, 4, 4, 0},   // 123: EXPERIMENT no X fetch (full compute)
+    {32, 5, 4, 4, 0},   // 124: EXPERIMENT no X fetch, no MFMA, no split
 };
 static const int kNumF3 = (int)(sizeof(kF3Variants) / sizeof(kF3Variants[0]));
 
@@ -1056,6 +1058,8 @@ static int launch_f3(const BigProdPlan& pl, const void* B, i64 ldb, const void* 
         case 20: return launch_f3p_t<KT, NS, 5, 4, 4, 6>(pl, B, ldb, Xp, P, st);
         case 21: return launch_f3p_t<KT, NS, 5, 4, 4, 9>(pl, B, ldb, Xp, P, st);
         case 22: return launch_f3p_t<KT, NS, 5, 4, 4, 8>(pl, B, ldb, Xp, P, st);
+        case 23: return launch_f3p_t<KT, NS, 5, 4, 4, 16>(pl, B, ldb, Xp, P, st);
+        case 24: return launch_f3p_t<KT, NS, 5, 4, 4, 22>(pl, B, ldb, Xp, P, st);
         default: break;
     }
     set_error("unknown bigprod f3 variant");

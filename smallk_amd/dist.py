@@ -22,9 +22,10 @@ def shard_columns(n: int, world: int, rank: int):
 class TorchAllReduce:
     """Owns the comm workspace (a torch uint8 tensor on the GPU) and all-reduces views of it."""
 
-    def __init__(self, nbytes: int, device):
+    def __init__(self, nbytes: int, device, group=None):
         import torch
         self.torch = torch
+        self.group = group
         self.ws = torch.zeros(int(nbytes) + 256, dtype=torch.uint8, device=device)
         self.base = self.ws.data_ptr()
         pad = (-self.base) % 256
@@ -39,13 +40,13 @@ class TorchAllReduce:
         off = ptr - self.base
         assert 0 <= off and off + count * esz <= self.ws.numel(), "pointer outside the comm workspace"
         view = self.ws[off:off + count * esz].view(torch.float32 if dtype == 0 else torch.float64)
-        dist.all_reduce(view, op=dist.ReduceOp.SUM)
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         return 0
 
 
-def attach(solver, rank: int, world: int, device):
+def attach(solver, rank: int, world: int, device, group=None):
     """Register the torch-backed all-reduce with an NmfSolver.  Call before set_factors()."""
-    ar = TorchAllReduce(solver.comm_workspace_bytes(), device)
+    ar = TorchAllReduce(solver.comm_workspace_bytes(), device, group)
     solver.set_comm(rank, world, ar, ar.ptr, ar.nbytes)
     solver._allreduce = ar          # keep alive
     return ar

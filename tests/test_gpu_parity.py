@@ -318,3 +318,35 @@ def test_rank_above_128_is_refused_loudly(gpu):
     with pytest.raises(L.SmallkError) as e:
         gpu.nmf(A, oracle.fill_uniform(200, 129, 2), oracle.fill_uniform(129, 150, 3), "HALS", min_iter=1, max_iter=2)
     assert e.value.code == L.UNSUPPORTED and "k <= 128" in str(e.value)
+
+
+@pytest.mark.parametrize("alg", ["MU", "HALS", "BPP"])
+def test_handle_reuse_after_normalised_run(gpu, alg):
+    """run() with normalize rescales W and H in place; a second run() on the SAME handle must start from solver.Init
+    on the scaled factors (Gram matrices and stored products of the first run describe the un-normalised ones) and
+    normalise again at its end -- i.e. behave exactly like a fresh solver given the first run's output."""
+    import oracle
+    from smallk_amd import DenseMatrix, NmfSolver, make_options
+    m, n, k = 600, 400, 12
+    A = oracle.fill_uniform(m, n, 42)
+    W0, H0 = oracle.fill_uniform(m, k, 43), oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    D = DenseMatrix.from_host(A)
+    o = make_options(m, n, k, alg, min_iter=4, max_iter=4, normalize=True)
+    s = NmfSolver(D, o)
+    s.set_factors(W0, H0)
+    rc1, it1, _ = s.run()
+    W1, H1 = s.factors()
+    rc2, it2, _ = s.run()                       # same handle, continues from (W1, H1)
+    W2, H2 = s.factors()
+    s.close()
+    f = NmfSolver(D, o)
+    f.set_factors(W1, H1)
+    rcf, itf, _ = f.run()
+    Wf, Hf = f.factors()
+    f.close()
+    D.close()
+    assert rc1 == rc2 == rcf == 0 and it1 == it2 == itf == 4
+    assert np.linalg.norm(W2 - Wf) <= 1e-10 * np.linalg.norm(Wf) and np.linalg.norm(H2 - Hf) <= 1e-10 * np.linalg.norm(Hf)
+    assert np.allclose(np.linalg.norm(W2, axis=0), 1.0, atol=1e-10)
+    ref = oracle.nmf(A, W1, H1, alg, min_iter=4, max_iter=4)
+    assert np.linalg.norm(W2 - ref.W) / np.linalg.norm(ref.W) < 1e-4
