@@ -93,6 +93,10 @@ int launch_reduce_partials(PartialView pv, int k, i64 N, float* out /* [N][kpp] 
 
 int launch_gram(const double* X, int k, i64 N, double* G /* KP x KP */, double* scratch, int max_blocks, hipStream_t st);
 size_t gram_scratch_elems(int k, int max_blocks);
+// G = X X' and the packed streaming operand of X in one launch (k <= 64, bf16 fragments); returns 1 if this shape has
+// no fused kernel.  The ticket word at scratch[max_blocks * KP * KP] must be zero before the first call.
+int launch_gram_pack(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, int storage, int nsplit,
+                     void* packed, hipStream_t st);
 
 int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
 int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);

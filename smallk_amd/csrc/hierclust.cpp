@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <cstdio>
 #include <fstream>
 #include <functional>
@@ -350,6 +351,9 @@ int factor_node(Run& r, const smk_matrix* a, i64 h, i64 w, const unsigned* rows,
             return SMK_OK;
         }
         if (rc != SMK_FAILURE) return rc;
+        // a NaN projected gradient is an exception in the reference (projected_gradient.hpp:94-121 throws through
+        // NmfSolve), not a solver `false`: no retry
+        if (strstr(smk_last_error(), "ProjectedGradientNorm: NaN")) return SMK_FAILURE;
         printf("\n%s factorization failed, retrying with new initializers...\n", what);
     }
     set_error(std::string("HierNMF2: ") + (rows || cols ? "node" : "root node") +

@@ -498,6 +498,99 @@ __global__ __launch_bounds__(256) void gram_mfma_rows_kernel(const double* __res
     }
 }
 
+// Gram partials AND the packed MFMA operand of the same factor in one pass (k <= 64, bf16 fragments): a wave walks
+// its column range once for the fp64-MFMA Gram partials and once more (L1/L2-warm) for the hi/mid/lo fragments;
+// gram_reduce_kernel then sums the partials.  Replaces gram_mfma + pack (two launches, two reads of the factor).
+// (A last-arriver reduce inside this kernel was tried: one workgroup summing 64-256 partials is slower than the
+// separate 4.7 us reduce launch.)
+template <int KP, int NSPLIT>
+__global__ __launch_bounds__(256) void gram_pack_kernel(const double* __restrict__ X, int k, i64 N, i64 cols_per_wave,
+                                                        double* __restrict__ Gp, int KT, i64 nq,
+                                                        unsigned char* __restrict__ out)
+{
+    constexpr int T = KP / 16;
+    __shared__ double red[KP * KP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 wg = (i64)blockIdx.x * 4 + wave;
+    const i64 c_begin = wg * cols_per_wave;             // multiple of 16
+    i64 c_end = c_begin + cols_per_wave;
+    if (c_end > N) c_end = N;
+    f64x4_t acc[T][T];
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b) acc[a][b] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const int kc = lane >> 4, r16 = lane & 15;
+    for (i64 c0 = c_begin; c0 < c_end; c0 += 16) {
+        double f[4][T];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const i64 col = c0 + 4 * u + kc;
+            const bool ok = col < c_end;
+#pragma unroll
+            for (int t = 0; t < T; ++t) f[u][t] = ok ? X[col * KP + 16 * t + r16] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int b = 0; b < T; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[u][a], f[u][b], acc[a][b], 0, 0, 0);
+    }
+    // ---- fragments of the same columns: chunk pair q covers rows 16 q .. 16 q + 15 of the operand (= columns of X)
+    {
+        const i64 q0 = c_begin / 16;
+        i64 q1 = (c_begin + cols_per_wave) / 16;
+        if (q1 > nq) q1 = nq;
+        // the very last wave also writes the zero padding up to nq
+        if (c_begin < N && c_begin + cols_per_wave >= N) q1 = nq;
+        const int h = lane >> 5;
+        for (i64 q = q0; q < q1; ++q)
+            for (int kt = 0; kt < KT; ++kt) {
+                const int r = kt * 32 + (lane & 31);
+                const i64 row0 = (2 * q + h) * 8;
+                double res[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const i64 row = row0 + e;
+                    res[e] = (row < N && r < k) ? X[row * KP + r] : 0.0;
+                }
+#pragma unroll
+                for (int sp = 0; sp < NSPLIT; ++sp) {
+                    unsigned short hb[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        hb[e] = f32_to_bf16_rne((float)res[e]);
+                        res[e] -= (double)bf16_bits_to_f32(hb[e]);
+                    }
+                    u32x4_t w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (unsigned)hb[2 * e] | ((unsigned)hb[2 * e + 1] << 16);
+                    *(u32x4_t*)(out + (((q * NSPLIT + sp) * KT + kt) * 64 + lane) * 16) = w;
+                }
+            }
+    }
+    // ---- deterministic in-block sum of the 4 waves, then the last workgroup sums the blocks in order
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int b = 0; b < T; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * a + kc + 4 * r, colm = 16 * b + r16;
+                        const int idx = colm * KP + row;
+                        red[idx] = (w == 0) ? acc[a][b][r] : red[idx] + acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    double* mine = Gp + (i64)blockIdx.x * KP * KP;
+    for (int i = threadIdx.x; i < KP * KP; i += 256) mine[i] = red[i];
+}
+
 // G[e] = sum_b Gp[b][e]: 16 elements per block, 16 thread groups stride the partials, fixed order
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ Gp, int nblk, int elems,
                                                           double* __restrict__ G)
@@ -563,7 +656,7 @@ __global__ __launch_bounds__(256) void gram_stream8_kernel(const double* __restr
 size_t gram_scratch_elems(int k, int max_blocks)
 {
     int KP = kp_of(k);
-    return (size_t)max_blocks * KP * KP;
+    return (size_t)max_blocks * KP * KP + 8;             // + the ticket word of the fused Gram/pack kernel
 }
 
 int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, hipStream_t st)
@@ -591,6 +684,36 @@ int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int m
     }
     SMK_HIP(hipGetLastError());
     gram_reduce_kernel<<<(elems + 15) / 16, 256, 0, st>>>(scratch, nblk, elems, G);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// gram scratch: [max_blocks][KP*KP] partials followed by one ticket word.  Returns 1 when this shape has no fused
+// kernel (the caller then runs launch_gram + launch_pack).
+int launch_gram_pack(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, int storage, int nsplit,
+                     void* packed, hipStream_t st)
+{
+    const int KP = kp_of(k);
+    const bool bf16_frag = storage == STORE_BF16 || nsplit >= 2;
+    if (KP < 16 || KP > 64 || !bf16_frag || nsplit < 1 || nsplit > 3) return 1;
+    static const bool enabled = [] { const char* e = getenv("SMK_FUSED_GRAM"); return !(e && e[0] == '0'); }();
+    if (!enabled) return 1;
+    int nblk = (int)((N + 255) / 256);                   // >= 64 columns per wave, as launch_gram
+    if (nblk > max_blocks) nblk = max_blocks;
+    if (nblk < 1) nblk = 1;
+    i64 cpw = (N + (i64)nblk * 4 - 1) / ((i64)nblk * 4);
+    cpw = (cpw + 15) / 16 * 16;
+    const int KT = kt_of(k);
+    const i64 nq = round_up(N, ROW_PAD) / 16;
+#define SMK_GP(KPX, NSX) gram_pack_kernel<KPX, NSX><<<nblk, 256, 0, st>>>(X, k, N, cpw, scratch, KT, nq, (unsigned char*)packed)
+    switch (KP * 10 + nsplit) {
+        case 161: SMK_GP(16, 1); break; case 162: SMK_GP(16, 2); break; case 163: SMK_GP(16, 3); break;
+        case 321: SMK_GP(32, 1); break; case 322: SMK_GP(32, 2); break; case 323: SMK_GP(32, 3); break;
+        case 641: SMK_GP(64, 1); break; case 642: SMK_GP(64, 2); break; default: SMK_GP(64, 3); break;
+    }
+#undef SMK_GP
+    SMK_HIP(hipGetLastError());
+    gram_reduce_kernel<<<(KP * KP + 15) / 16, 256, 0, st>>>(scratch, nblk, KP * KP, G);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -1121,9 +1244,10 @@ int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* 
     // Smallest workgroup (256 threads: cheapest in-block sync, measured best) that still covers M
     // rows with <= num_cus workgroups; the register budget caps it at 512 for KP = 32 and 256 for 64.
     int nt = 0;
-    const int nt_max = (KPv == 64) ? 256 : (KPv == 32) ? 512 : 1024;
+    const int nt_max = (KPv == 64) ? 256 : 1024;
+    static const int nt_min = [] { const char* e = getenv("SMK_HALS_NT"); return e ? atoi(e) : 256; }();
     for (int cand = 256; cand <= nt_max; cand *= 2)
-        if ((M + cand - 1) / cand <= (i64)num_cus) { nt = cand; break; }
+        if (cand >= nt_min && (M + cand - 1) / cand <= (i64)num_cus) { nt = cand; break; }
     if (mode == 1 && nt != 0 && !force_multi && KPv <= 64) {
         const i64 nblk_f = (M + nt - 1) / nt;
         unsigned long long* slots = (unsigned long long*)scratch + (size_t)(parity & 1) * k * 1024;
@@ -1133,7 +1257,7 @@ int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* 
         switch (KPv) {
             case 8: if (nt == 256) SMK_FUSED(8, 256); else if (nt == 512) SMK_FUSED(8, 512); else SMK_FUSED(8, 1024); break;
             case 16: if (nt == 256) SMK_FUSED(16, 256); else if (nt == 512) SMK_FUSED(16, 512); else SMK_FUSED(16, 1024); break;
-            case 32: if (nt == 256) SMK_FUSED(32, 256); else SMK_FUSED(32, 512); break;
+            case 32: if (nt == 256) SMK_FUSED(32, 256); else if (nt == 512) SMK_FUSED(32, 512); else SMK_FUSED(32, 1024); break;
             default: SMK_FUSED(64, 256); break;
         }
 #undef SMK_FUSED

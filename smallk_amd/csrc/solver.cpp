@@ -98,6 +98,7 @@ struct smk_solver {
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
     bool inv_pending[2] = {false, false};
+    bool packed_fresh[2] = {false, false};   // the fused Gram kernel has already written packW / packH for the next product
     // HALS: the fused W sweep needs every workgroup resident; if its bounded polls ever expire (flag -3) the run is
     // repeated from the initial factors on the one-launch-per-column path, latched for the life of the handle
     double *W0c = nullptr, *H0c = nullptr;
@@ -652,6 +653,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
         size_t gs = gram_scratch_elems(s->k, GRAM_BLOCKS);
         if (s->o.algorithm == SMK_ALG_RANK2) gs = std::max(gs, rank2_gram_scratch_elems(std::max(s->m, s->n)));
         rc |= dev_alloc(&s->gram_scratch, gs);
+        if (!rc && hipMemsetAsync(s->gram_scratch, 0, gs * sizeof(double), s->st) != hipSuccess) rc |= 1;   // incl. the ticket word
     }
     rc |= dev_alloc(&s->tmpW, (size_t)s->KP * s->m);
     // one partial per workgroup of the column-tile kernels (grid = N*(KP/4)/256 blocks) and at most
@@ -905,7 +907,9 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
 static int prod1(smk_solver* s)
 {
     if (s->a->sparse) return timed_spmm(s, 0, s->a->colptr, s->a->rowidx, s->a->val, s->n, s->Wt, s->P1);
-    int rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st);
+    int rc = 0;
+    if (!s->packed_fresh[0]) rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st);
+    s->packed_fresh[0] = false;
     if (rc) return rc;
     for (int g = 0; g < s->ng; ++g) {
         rc = timed_bigprod(s, 0, s->pg1[g], s->a->A, s->a->ldA, (const unsigned char*)s->packW + s->pg1[g].pack_offset, s->P1 + s->pg1[g].k0);
@@ -921,7 +925,8 @@ static int prod2(smk_solver* s)
     if (s->a->sparse) {
         rc = timed_spmm(s, 1, s->a->colptr_t, s->a->rowidx_t, s->a->val_t, s->m, s->H, s->P2);
     } else {
-        rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st);
+        if (!s->packed_fresh[1]) rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st);
+        s->packed_fresh[1] = false;
         if (rc) return rc;
         for (int g = 0; g < s->ng && !rc; ++g)
             rc = timed_bigprod(s, 1, s->pg2[g], s->a->At, s->a->ldAt, (const unsigned char*)s->packH + s->pg2[g].pack_offset, s->P2 + s->pg2[g].k0);
@@ -939,16 +944,33 @@ static int prod2(smk_solver* s)
     return 0;
 }
 
+// Gram matrix of a factor; for dense A the same launch also writes the packed operand of the product that follows
+// (every schedule calls gram_x and prod_x back to back)
+static int gram_factor(smk_solver* s, int side)
+{
+    const double* X = side == 0 ? s->Wt : s->H;
+    const i64 N = side == 0 ? s->m : s->n;
+    double* G = side == 0 ? s->Gw : s->Gh;
+    s->packed_fresh[side] = false;
+    if (!s->a->sparse && s->o.algorithm != SMK_ALG_RANK2) {
+        const int rc = launch_gram_pack(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->a->storage, s->nsplit,
+                                        side == 0 ? s->packW : s->packH, s->st);
+        if (rc == 0) { s->packed_fresh[side] = true; return 0; }
+        if (rc != 1) return rc;
+    }
+    return launch_gram(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->st);
+}
+
 static int gram_w(smk_solver* s)
 {
-    int rc = launch_gram(s->Wt, s->k, s->m, s->Gw, s->gram_scratch, GRAM_BLOCKS, s->st);
+    int rc = gram_factor(s, 0);
     if (rc) return rc;
     return start_inverse(s, 0, s->Gw);
 }
 
 static int gram_h(smk_solver* s)
 {
-    int rc = launch_gram(s->H, s->k, s->n, s->Gh, s->gram_scratch, GRAM_BLOCKS, s->st);
+    int rc = gram_factor(s, 1);
     if (rc) return rc;
     rc = allreduce_gh(s);
     if (rc) return rc;
@@ -964,8 +986,8 @@ static int solver_init(smk_solver* s)
         rc = gram_h(s);  if (rc) return rc;
         rc = prod2(s);   if (rc) return rc;
     } else {   // MU, BPP, RANK2: WtA and WtW from W0
-        rc = prod1(s);   if (rc) return rc;
         rc = gram_w(s);  if (rc) return rc;
+        rc = prod1(s);   if (rc) return rc;
     }
     if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM)
         SMK_HIP(hipMemcpyAsync(s->Wprev, s->Wt, (size_t)s->KP * s->m * sizeof(double), hipMemcpyDeviceToDevice, s->st));
@@ -986,8 +1008,8 @@ static int solver_iteration(smk_solver* s)
             rc = gram_h(s);   if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
             rc = launch_mu_update(s->Wt, s->k, s->m, r2, s->Gh, s->st); if (rc) return rc;
-            rc = prod1(s);    if (rc) return rc;
             rc = gram_w(s);   if (rc) return rc;
+            rc = prod1(s);    if (rc) return rc;
             break;
         case SMK_ALG_HALS: // nmf_solver_hals.hpp:166-199
             rc = launch_hals_w_update(s->Wt, s->k, s->m, r2, s->Gh, s->hals_scratch, g_cus, s->fail_flag, s->hals_calls++, s->hals_multi ? 1 : 0, s->st); if (rc) return rc;
@@ -1270,6 +1292,7 @@ int smk_solver_run(smk_solver* s, smk_stats* stats)
 static int solver_run_once(smk_solver* s, smk_stats* stats)
 {
     if (!s) return SMK_BAD_PARAM;
+    set_error("");                                  // smk_last_error() describes THIS run afterwards
     if (!s->have_factors) { set_error("set_factors() first"); return SMK_BAD_PARAM; }
     const smk_options& o = s->o;
     const double t0 = wall_us();
@@ -1375,8 +1398,8 @@ int smk_solver_nnls_hals(smk_solver* s, double tol, int verbose, int max_iter, i
     if (!s->have_factors) { set_error("set_factors() first"); return SMK_BAD_PARAM; }
     if (is_dist(s)) { set_error("NnlsHals: not available on a sharded solver"); return SMK_UNSUPPORTED; }
     if (verbose) printf("\nRunning NNLS solver...\n");
-    int rc = prod1(s);
-    if (!rc) rc = gram_w(s);
+    int rc = gram_w(s);
+    if (!rc) rc = prod1(s);
     if (rc) return rc;
     bool success = false;
     double pg0 = 0.0;
