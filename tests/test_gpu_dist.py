@@ -211,3 +211,51 @@ def test_rccl_world_of_one_native(gpu):
         D.close()
         comm.close()
         assert rc == 0 and it == iters and rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
+
+
+def test_nmf_tool_and_facade_shard_over_smk_num_gpus(tmp_path):
+    """SMK_NUM_GPUS=N reaches smk_nmf_dense_sharded from the unchanged callers: the `nmf` command line tool (which
+    calls Nmf(NmfOptions...), nmf/src/main.cpp:218-233) and smallk::Nmf through the flat API.  On this one-GPU box
+    the shards stay on device 0 (SMK_SHARDS_ON_ONE_GPU=1); results must match the single-shard run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(4)
+    m, n, k = 300, 221, 6
+    A = rng.random((m, n))          # well conditioned: the (AH')' all-reduce travels as fp32, which a nearly
+                                    # rank-deficient Gram matrix would amplify beyond the 1e-5 of SURVEY 8e
+    np.savetxt(tmp_path / "a.csv", A, delimiter=",")
+    np.savetxt(tmp_path / "w0.csv", rng.random((m, k)), delimiter=",")
+    np.savetxt(tmp_path / "h0.csv", rng.random((k, n)), delimiter=",")
+    tool = os.path.join(root, "smallk_amd", "bin", "nmf")
+    outs = {}
+    for tag, env in (("one", {}), ("three", {"SMK_NUM_GPUS": "3", "SMK_SHARDS_ON_ONE_GPU": "1"})):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([tool, "--matrixfile", str(tmp_path / "a.csv"), "--k", str(k), "--algorithm", "BPP", "--miniter", "1",
+                            "--maxiter", "8", "--tol", "1e-9", "--infile_W", str(tmp_path / "w0.csv"), "--infile_H",
+                            str(tmp_path / "h0.csv"), "--outprecision", "15", "--verbose", "0"],
+                           cwd=str(d), capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[tag] = (np.loadtxt(d / "w.csv", delimiter=","), np.loadtxt(d / "h.csv", delimiter=","))
+    assert rel(outs["three"][0], outs["one"][0]) < 1e-5 and rel(outs["three"][1], outs["one"][1]) < 1e-5
+    # smallk::Nmf through the flat handles, in a fresh process (the environment is read per call)
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import numpy as np
+from smallk_amd import SmallkAPI
+api = SmallkAPI()
+api.load_matrix(filepath=%r)
+api.nmf(%d, "HALS", infile_W=%r, infile_H=%r, min_iter=1, max_iter=6, tol=1e-9, outdir=%r)
+np.save(%r, api.get_W())
+""" 
+    Ws = {}
+    for tag, env in (("one", {}), ("two", {"SMK_NUM_GPUS": "2", "SMK_SHARDS_ON_ONE_GPU": "1"})):
+        out = tmp_path / ("api_" + tag)
+        out.mkdir()
+        src = code % (root, str(tmp_path / "a.csv"), k, str(tmp_path / "w0.csv"), str(tmp_path / "h0.csv"), str(out) + "/",
+                      str(out / "W.npy"))
+        r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        Ws[tag] = np.load(out / "W.npy")
+    assert rel(Ws["two"], Ws["one"]) < 1e-5
