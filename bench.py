@@ -248,11 +248,14 @@ def main():
             "dtype": storage if storage == "bf16" else "f32",
             "data": "synthetic",
             "config": {"workload": desc, "m": m, "n": n, "k": k, "algorithm": alg, "A_storage": storage,
-                       "state": "W,H,Gram fp64; big products fp32-accumulate MFMA",
+                       "state": "W,H,Gram fp64; big products: MFMA with fp32 accumulation folded into fp64",
                        "parallelism": f"column-shard x{world}" if world > 1 else "single GPU",
                        "collectives": collectives},
-            "mfma_tflops_big_products": mfma_tf,
-            "mfma_frac_of_peak": mfma_tf / MFMA_PEAK_TF[storage],
+            # useful flops (2 k per matrix entry) of the streaming products.  fp32 storage computes them as three fp16
+            # MFMAs per product, so its ratio is against the NATIVE fp32 matrix peak that this replaces
+            # and may exceed 1; the bound that matters for this path is roofline.frac (HBM).
+            "useful_tflops_big_products": mfma_tf,
+            "useful_tflops_vs_native_mfma_peak": mfma_tf / MFMA_PEAK_TF[storage],
             "whole_iteration_tflops": 4.0 * m * n * k / (elapsed / args.steps) / 1e12,
             "windows": len(windows), "windows_ms": [round(w * 1e3, 4) for w in windows],
             "timed_region_s": sum(windows),

@@ -430,11 +430,49 @@ __global__ __launch_bounds__(256) void pack_kernel(const double* __restrict__ X,
     }
 }
 
+// The low terms of both operands are stored multiplied by 2^11 (so that they are normal fp16 numbers whenever the
+// high term is: full 22-bit operands over a 2^28 range below the scale) and the cross-term accumulator is divided
+// by 2^11 once, in the epilogue.
+constexpr float F16X2_LO_SCALE = 2048.f;
+// fp16 two-term form: the same fragment layout with _Float16 entries; row r of the operand (factor row k0 + r) is
+// multiplied by xscale[k0 + r] (a power of two from the Gram diagonal, gram_reduce_kernel) before the split so that its
+// entries sit in fp16's range with full 11-bit precision: hi = fp16(x), lo = fp16(x - hi)  (22 significant bits).
+__global__ __launch_bounds__(256) void pack_f16x2_kernel(const double* __restrict__ X, int k, int ldx, i64 N, int KT, i64 nq,
+                                                         const double* __restrict__ xscale, unsigned char* __restrict__ out)
+{
+    const i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const i64 rest = gid >> 6;
+    const int kt = (int)(rest % KT);
+    const i64 q = rest / KT;
+    if (q >= nq) return;
+    const int r = kt * 32 + (lane & 31);
+    const i64 row0 = (2 * q + (lane >> 5)) * 8;
+    const double sc = (r < k) ? xscale[r] : 0.0;
+    double res[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const i64 row = row0 + e;
+        res[e] = (row < N && r < k) ? X[row * ldx + r] * sc : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f16x8_t h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h[e] = (_Float16)(float)res[e];
+            res[e] = (res[e] - (double)(float)h[e]) * F16X2_LO_SCALE;     // the low term is carried 2^11 up
+        }
+        *(f16x8_t*)(out + (((q * 2 + s) * KT + kt) * 64 + lane) * 16) = h;
+    }
+}
+
 // The packed operand layout does not depend on the stage height: it is a sequence of 1-KiB
 // blocks indexed by the global chunk-pair q; rows are padded to a multiple of 128.
 // operand format: bf16 fragments (E = 8) for bf16 storage and for the fp32 "bf16x3" emulation
 // (nsplit == 3); native fp32 fragments (E = 4, one term) otherwise
 static inline bool pack_is_bf16(int storage, int nsplit) { return storage == STORE_BF16 || nsplit >= 2; }
+static inline int pack_terms(int nsplit) { return nsplit == NSPLIT_F16X2 ? 2 : nsplit; }
 
 static inline i64 pack_nq(int storage, int nsplit, i64 N)
 {
@@ -447,11 +485,12 @@ size_t packed_bytes(int storage, int k, i64 N, int nsplit)
     if (!pack_is_bf16(storage, nsplit)) nsplit = 1;
     size_t total = 0;
     for (int k0 = 0; k0 < k; k0 += 64)          // groups of 64 factor rows, each packed with its own k-tile count
-        total += (size_t)pack_nq(storage, nsplit, N) * nsplit * kt_of(k - k0 < 64 ? k - k0 : 64) * 1024;
+        total += (size_t)pack_nq(storage, nsplit, N) * pack_terms(nsplit) * kt_of(k - k0 < 64 ? k - k0 : 64) * 1024;
     return total;
 }
 
-int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st)
+int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st,
+                     const double* xscale)
 {
     const int KT = kt_of(kg);
     const i64 nq = pack_nq(storage, nsplit, N);
@@ -459,7 +498,10 @@ int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storag
     const int grid = (int)((threads + 255) / 256);
     if (grid == 0) return 0;
     const double* Xg = X + k0;                   // the kernel sees rows [k0, k0 + kg) as rows [0, kg)
-    if (pack_is_bf16(storage, nsplit)) {
+    if (nsplit == NSPLIT_F16X2) {
+        if (!xscale) { set_error("pack: the fp16 two-term form needs the row scales"); return -100; }
+        pack_f16x2_kernel<<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, xscale + k0, (unsigned char*)out);
+    } else if (pack_is_bf16(storage, nsplit)) {
         if (nsplit == 3) pack_kernel<2, 3><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
         else if (nsplit == 2) pack_kernel<2, 2><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
         else pack_kernel<2, 1><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
@@ -470,13 +512,13 @@ int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storag
     return 0;
 }
 
-int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st)
+int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st, const double* xscale)
 {
     // all groups of a k-row factor, back to back (group g: rows [64 g, 64 g + 64) of [0, k))
     size_t off = 0;
     for (int k0 = 0; k0 < k; k0 += 64) {
         const int kg = k - k0 < 64 ? k - k0 : 64;
-        int rc = launch_pack_rows(X, kp_of(k), k0, kg, N, storage, nsplit, (unsigned char*)out + off, st);
+        int rc = launch_pack_rows(X, kp_of(k), k0, kg, N, storage, nsplit, (unsigned char*)out + off, st, xscale);
         if (rc) return rc;
         off += packed_bytes(storage, kg, N, nsplit);
     }
@@ -520,11 +562,12 @@ struct F3Cfg {
     static constexpr bool OK = (TI % NLD == 0) && (LPS * PD <= 63) && (STAGE_BYTES * NSTAGE <= 160 * 1024);
 };
 
-template <int KT, int MB, int NSTAGE, int NWL, int FOLD, int WPS, int NS>
+template <int KT, int MB, int NSTAGE, int NWL, int FOLD, int WPS, int NS, int FMT>
 __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                                         const unsigned char* __restrict__ Xp,
                                                                         double* __restrict__ P, i64 stages, i64 nst,
-                                                                        i64 tiles, i64 ncols_pad, int S, int logS, int pstride)
+                                                                        i64 tiles, i64 ncols_pad, int S, int logS, int pstride,
+                                                                        const double* __restrict__ oscale, float ascale)
 {
     using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -634,15 +677,41 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
             const int lc0 = 4 * q + 2 * h;
             const f32x4_t f0 = *(const f32x4_t*)(sb + bfrag_base + (((lc0) ^ swz_r) << 4));
             const f32x4_t f1 = *(const f32x4_t*)(sb + bfrag_base + (((lc0 + 1) ^ swz_r) << 4));
+            f32x8_t x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = f0[e]; x[4 + e] = f1[e]; }
+            if constexpr (FMT == 1) {
+                // fp16 two-term form: hi = fp16(a s), lo = fp16(a s - hi); products hi*hi | hi*lo + lo*hi
+                f16x8_t a[KT][2];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        a[kt][s] = __builtin_bit_cast(f16x8_t, *(const u32x4_t*)(sx + ((q * 2 + s) * KT + kt) * 1024 + lane * 16));
+                if (ascale != 1.0f) x *= ascale;
+                const f16x8_t bh = __builtin_convertvector(x, f16x8_t);
+                x = (x - __builtin_convertvector(bh, f32x8_t)) * F16X2_LO_SCALE;
+                const f16x8_t bl = __builtin_convertvector(x, f16x8_t);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    if (FIRST && q == 0) {
+                        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        hi[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kt][0], bh, zero, 0, 0, 0);
+                    } else {
+                        hi[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kt][0], bh, hi[kt], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kt][0], bl, sm[kt], 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kt][1], bh, sm[kt], 0, 0, 0);
+            } else {
             bf16x8_t a[KT][NS];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
                     a[kt][s] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(sx + ((q * NS + s) * KT + kt) * 1024 + lane * 16));
-            f32x8_t x;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { x[e] = f0[e]; x[4 + e] = f1[e]; }
             const bf16x8_t bhi = __builtin_convertvector(x, bf16x8_t);
             x -= __builtin_convertvector(bhi, f32x8_t);
             const bf16x8_t bmid = __builtin_convertvector(x, bf16x8_t);
@@ -672,6 +741,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
                 for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][1], bmid, sm[kt], 0, 0, 0);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kt][NS - 1], bhi, sm[kt], 0, 0, 0);
+            }
             }
         }
 #ifdef SMK_BP_PROFILE
@@ -716,8 +786,14 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
 #pragma unroll
             for (int i = 0; i < 4; i += 2) {
                 f64x2_t v;
-                v[0] = dacc[kt][4 * g + i] + (double)sm[kt][4 * g + i];
-                v[1] = dacc[kt][4 * g + i + 1] + (double)sm[kt][4 * g + i + 1];
+                constexpr double cross = (FMT == 1) ? 1.0 / F16X2_LO_SCALE : 1.0;
+                v[0] = dacc[kt][4 * g + i] + cross * (double)sm[kt][4 * g + i];
+                v[1] = dacc[kt][4 * g + i + 1] + cross * (double)sm[kt][4 * g + i + 1];
+                if constexpr (FMT == 1) {
+                    const f64x2_t os = *(const f64x2_t*)(oscale + kt * 32 + 8 * g + 4 * h + i);
+                    v[0] *= os[0];
+                    v[1] *= os[1];
+                }
                 *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
             }
 }
@@ -732,11 +808,20 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
 // t + 1 sits between the two steps of stage t, so a ring slot is reused two barriers after its last read
 // (in flight: NSTAGE - 2 stages).  sched_group_barrier pins the interleave: 1 MFMA : 1 LDS read : 4 VALU.
 // --------------------------------------------------------------------------
-template <int KT, int NSTAGE, int NWL, int FOLD, int PIN, int NS>
+static __device__ __forceinline__ f32x16_t mfma16(bf16x8_t a, bf16x8_t b, f32x16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+static __device__ __forceinline__ f32x16_t mfma16(f16x8_t a, f16x8_t b, f32x16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <int KT, int NSTAGE, int NWL, int FOLD, int PIN, int NS, int FMT>
 __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                                         const unsigned char* __restrict__ Xp,
                                                                         double* __restrict__ P, i64 stages, i64 nst,
-                                                                        i64 tiles, i64 ncols_pad, int S, int logS, int pstride)
+                                                                        i64 tiles, i64 ncols_pad, int S, int logS, int pstride,
+                                                                        const double* __restrict__ oscale, float ascale)
 {
     using C = F3Cfg<KT, 32, NSTAGE, NWL, NS>;
     constexpr int PDN = NSTAGE - 2;                 // stages in flight ahead of the published one
@@ -812,7 +897,8 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
     const int swz_r = (jl >> C::SWZ_SH) & C::SWZ_MASK;
     const int bfrag_base = jl * C::CPC * 16;
 
-    struct Frag { bf16x8_t bh, bm, bl; bf16x8_t a[KT][NS]; };
+    using V = std::conditional_t<FMT == 1, f16x8_t, bf16x8_t>;   // fp16 two-term form or bf16 terms
+    struct Frag { V bh, bm, bl; V a[KT][NS]; };
     auto lds_read = [&](int slot, int q, f32x4_t& r0, f32x4_t& r1, Frag& f) {
         const unsigned char* sb = smem + slot * C::STAGE_BYTES;
         const unsigned char* sx = sb + C::B_BYTES;
@@ -823,25 +909,29 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-                f.a[kt][s] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(sx + ((q * NS + s) * KT + kt) * 1024 + lane * 16));
+                f.a[kt][s] = __builtin_bit_cast(V, *(const u32x4_t*)(sx + ((q * NS + s) * KT + kt) * 1024 + lane * 16));
     };
     auto split3 = [&](const f32x4_t& r0, const f32x4_t& r1, Frag& f) {
         f32x8_t x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { x[e] = r0[e]; x[4 + e] = r1[e]; }
         if constexpr ((PIN & 2) != 0) {             // experiment: no split (wrong numbers, same traffic)
-            f.bh = __builtin_bit_cast(bf16x8_t, r0);
-            f.bm = __builtin_bit_cast(bf16x8_t, r1);
+            f.bh = __builtin_bit_cast(V, r0);
+            f.bm = __builtin_bit_cast(V, r1);
             f.bl = f.bh;
             return;
         }
-        f.bh = __builtin_convertvector(x, bf16x8_t);
+        if constexpr (FMT == 1) {
+            if (ascale != 1.0f) x *= ascale;
+        }
+        f.bh = __builtin_convertvector(x, V);
         x -= __builtin_convertvector(f.bh, f32x8_t);
-        f.bm = __builtin_convertvector(x, bf16x8_t);
+        if constexpr (FMT == 1) x *= F16X2_LO_SCALE;
+        f.bm = __builtin_convertvector(x, V);
         f.bl = f.bm;
         if constexpr (NS == 3) {
             x -= __builtin_convertvector(f.bm, f32x8_t);
-            f.bl = __builtin_convertvector(x, bf16x8_t);
+            f.bl = __builtin_convertvector(x, V);
         }
     };
     auto mma = [&](const Frag& f) {
@@ -855,18 +945,18 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
             return;
         }
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) hi[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][0], f.bh, hi[kt], 0, 0, 0);
+        for (int kt = 0; kt < KT; ++kt) hi[kt] = mfma16(f.a[kt][0], f.bh, hi[kt]);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][0], f.bm, sm[kt], 0, 0, 0);
+        for (int kt = 0; kt < KT; ++kt) sm[kt] = mfma16(f.a[kt][0], f.bm, sm[kt]);
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][1], f.bh, sm[kt], 0, 0, 0);
+        for (int kt = 0; kt < KT; ++kt) sm[kt] = mfma16(f.a[kt][1], f.bh, sm[kt]);
         if constexpr (NS == 3) {
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][0], f.bl, sm[kt], 0, 0, 0);
+            for (int kt = 0; kt < KT; ++kt) sm[kt] = mfma16(f.a[kt][0], f.bl, sm[kt]);
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][1], f.bm, sm[kt], 0, 0, 0);
+            for (int kt = 0; kt < KT; ++kt) sm[kt] = mfma16(f.a[kt][1], f.bm, sm[kt]);
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) sm[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[kt][NS - 1], f.bh, sm[kt], 0, 0, 0);
+            for (int kt = 0; kt < KT; ++kt) sm[kt] = mfma16(f.a[kt][NS - 1], f.bh, sm[kt]);
         }
     };
     // interleave of one half stage: 6 KT MFMAs, 2 + 3 KT fragment reads, ~44 VALU of the split
@@ -932,13 +1022,19 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
 #pragma unroll
             for (int i = 0; i < 4; i += 2) {
                 f64x2_t v;
-                v[0] = dacc[kt][4 * g + i] + (double)sm[kt][4 * g + i];
-                v[1] = dacc[kt][4 * g + i + 1] + (double)sm[kt][4 * g + i + 1];
+                constexpr double cross = (FMT == 1) ? 1.0 / F16X2_LO_SCALE : 1.0;
+                v[0] = dacc[kt][4 * g + i] + cross * (double)sm[kt][4 * g + i];
+                v[1] = dacc[kt][4 * g + i + 1] + cross * (double)sm[kt][4 * g + i + 1];
+                if constexpr (FMT == 1) {
+                    const f64x2_t os = *(const f64x2_t*)(oscale + kt * 32 + 8 * g + 4 * h + i);
+                    v[0] *= os[0];
+                    v[1] *= os[1];
+                }
                 *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
             }
 }
 
-template <int KT, int NS, int NSTAGE, int NWL, int FOLD, int PIN = 1>
+template <int KT, int NS, int NSTAGE, int NWL, int FOLD, int PIN = 1, int FMT = 0>
 static int launch_f3p_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
     using C = F3Cfg<KT, 32, NSTAGE, NWL, NS>;
@@ -948,7 +1044,7 @@ static int launch_f3p_t(const BigProdPlan& pl, const void* B, i64 ldb, const voi
     } else {
         constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
         static bool attr_set = false;
-        auto kern = bigprod_f3p_kernel<KT, NSTAGE, NWL, FOLD, PIN, NS>;
+        auto kern = bigprod_f3p_kernel<KT, NSTAGE, NWL, FOLD, PIN, NS, FMT>;
         if (!attr_set) {
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr_set = true;
@@ -963,7 +1059,7 @@ static int launch_f3p_t(const BigProdPlan& pl, const void* B, i64 ldb, const voi
             grid = pl.tiles * pl.S;
         }
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
-                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride);
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale);
         SMK_HIP(hipGetLastError());
         return 0;
     }
@@ -1000,7 +1096,7 @@ static const F3Variant kF3Variants[] = {
 };
 static const int kNumF3 = (int)(sizeof(kF3Variants) / sizeof(kF3Variants[0]));
 
-template <int KT, int NS, int MB, int NSTAGE, int NWL, int FOLD, int WPS>
+template <int KT, int NS, int MB, int NSTAGE, int NWL, int FOLD, int WPS, int FMT = 0>
 static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
     using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
@@ -1010,7 +1106,7 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
     } else {
         constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
         static bool attr_set = false;
-        auto kern = bigprod_f3_kernel<KT, MB, NSTAGE, NWL, FOLD, WPS, NS>;
+        auto kern = bigprod_f3_kernel<KT, MB, NSTAGE, NWL, FOLD, WPS, NS, FMT>;
         if (!attr_set) {
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             attr_set = true;
@@ -1025,7 +1121,7 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
             grid = pl.tiles * pl.S;
         }
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
-                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride);
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale);
         SMK_HIP(hipGetLastError());
         return 0;
     }
@@ -1063,6 +1159,21 @@ static int launch_f3(const BigProdPlan& pl, const void* B, i64 ldb, const void* 
         default: break;
     }
     set_error("unknown bigprod f3 variant");
+    return -100;
+}
+
+// fp16 two-term form: the variants that won for the bf16 forms
+template <int KT>
+static int launch_f3_f16(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
+{
+    switch (pl.variant - 100) {
+        case 8: return launch_f3_t<KT, 2, 32, 2, 0, 4, 2, 1>(pl, B, ldb, Xp, P, st);
+        case 10: return launch_f3p_t<KT, 2, 4, 4, 4, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 11: return launch_f3p_t<KT, 2, 5, 4, 4, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 15: return launch_f3p_t<KT, 2, 3, 2, 4, 1, 1>(pl, B, ldb, Xp, P, st);
+        default: break;
+    }
+    set_error("unknown bigprod f16 variant");
     return -100;
 }
 
@@ -1136,12 +1247,14 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     if (env) v = atoi(env);
     const char* env2 = getenv("SMK_BP_VARIANT_K64");       // only for k in (32, 64]
     if (env2 && pl.kt == 2) v = atoi(env2);
-    if (storage == STORE_F32 && pl.nsplit == 2 && v < 100) v = (pl.kt == 2) ? 108 : 115;   // the 2-term form exists only there
+    if (storage == STORE_F32 && (pl.nsplit == 2 || pl.nsplit == NSPLIT_F16X2) && v < 100)
+        v = (pl.kt == 2) ? 108 : 115;                       // the 2-term forms exist only there
+    if (pl.nsplit == NSPLIT_F16X2 && v != 108 && v != 110 && v != 111 && v != 115) v = (pl.kt == 2) ? 108 : 115;
     if (v >= 100 && storage == STORE_F32 && pl.nsplit >= 2) {
         auto f3_fits = [&](int vv) {
             if (vv < 100 || vv >= 100 + kNumF3) return false;
             const F3Variant& f = kF3Variants[vv - 100];
-            const int stage = 128 * f.mb * 4 + (f.mb / 16) * pl.nsplit * pl.kt * 1024;
+            const int stage = 128 * f.mb * 4 + (f.mb / 16) * pack_terms(pl.nsplit) * pl.kt * 1024;
             const int ti = stage / 1024, nld = f.nwl > 0 ? f.nwl : 4;
             return ti % nld == 0 && (ti / nld) * (f.nstage - 1) <= 63 && stage * f.nstage <= 160 * 1024;
         };
@@ -1284,6 +1397,10 @@ int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp
         }
     } else {
         if (pl.variant >= 100) {
+            if (pl.nsplit == NSPLIT_F16X2) {
+                if (!pl.oscale) { set_error("bigprod: the fp16 two-term form needs the output scales"); return -100; }
+                return pl.kt == 1 ? launch_f3_f16<1>(pl, B, ldb, Xp, P, st) : launch_f3_f16<2>(pl, B, ldb, Xp, P, st);
+            }
             if (pl.nsplit == 3) return pl.kt == 1 ? launch_f3<1, 3>(pl, B, ldb, Xp, P, st) : launch_f3<2, 3>(pl, B, ldb, Xp, P, st);
             return pl.kt == 1 ? launch_f3<1, 2>(pl, B, ldb, Xp, P, st) : launch_f3<2, 2>(pl, B, ldb, Xp, P, st);
         }

@@ -65,10 +65,13 @@ int launch_gather_cols(const void* src, i64 ld_src_bytes, const unsigned* cols_d
 int launch_transpose_f64(const double* src, i64 ld_src, double* dst, i64 ld_dst, i64 rows, i64 cols, hipStream_t st);
 
 // packed MFMA operand of X (k x N): bytes needed
+// nsplit: 1..3 = bf16 terms of the skinny operand; NSPLIT_F16X2 = two fp16 terms with per-row power-of-two scales
+constexpr int NSPLIT_F16X2 = 4;
 size_t packed_bytes(int storage, int k, i64 N, int nsplit);
-int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st);
+int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st, const double* xscale = nullptr);
 // rows [k0, k0 + kg) of a factor stored with leading dimension ldx
-int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st);
+int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st,
+                     const double* xscale = nullptr);
 
 // streaming product: P[s][j][:] = sum over the rows of split s of X[:,row] * B[row, j]
 struct BigProdPlan {
@@ -76,6 +79,10 @@ struct BigProdPlan {
     // k0 = first factor row, pstride = doubles per column of P (the padded k of the whole factor)
     int k0 = 0, kg = 0, pstride = 0;
     size_t pack_offset = 0;   // bytes from the start of the packed operand to this group's fragments
+    // fp16 two-term form (nsplit == NSPLIT_F16X2): A is multiplied by ascale (a power of two) before the split, the
+    // packed operand carries per-row scales, and row r of the result is multiplied by oscale[r] = 1 / (xscale[r] ascale)
+    const double* oscale = nullptr;   // device, indexed by the factor row (0 .. k-1 of the WHOLE factor)
+    float ascale = 1.0f;
     int S;          // row splits
     i64 stages;     // total stages = ceil(len / MB)
     i64 nst;        // stages per split
@@ -91,8 +98,13 @@ int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp
 
 int launch_reduce_partials(PartialView pv, int k, i64 N, float* out /* [N][kpp] */, hipStream_t st);
 
-int launch_gram(const double* X, int k, i64 N, double* G /* KP x KP */, double* scratch, int max_blocks, hipStream_t st);
+// xscale / oscale (KP doubles each, optional): per-row scales of the fp16 two-term operand, derived from the diagonal
+// in the same reduce launch: xscale[r] = 2^e with sqrt(G_rr) 2^e in [2^13, 2^14], oscale[r] = 1 / (xscale[r] * ascale)
+int launch_gram(const double* X, int k, i64 N, double* G /* KP x KP */, double* scratch, int max_blocks, hipStream_t st,
+                double* xscale = nullptr, double* oscale = nullptr, double ascale = 1.0);
 size_t gram_scratch_elems(int k, int max_blocks);
+// *out = bits of max |A[i]| (NaN entries are ignored by fmaxf)
+int launch_absmax_f32(const float* A, i64 elems, unsigned* out, hipStream_t st);
 // G = X X' and the packed streaming operand of X in one launch (k <= 64, bf16 fragments); returns 1 if this shape has
 // no fused kernel.  The ticket word at scratch[max_blocks * KP * KP] must be zero before the first call.
 int launch_gram_pack(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, int storage, int nsplit,

@@ -593,7 +593,9 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const double* __restrict
 
 // G[e] = sum_b Gp[b][e]: 16 elements per block, 16 thread groups stride the partials, fixed order
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ Gp, int nblk, int elems,
-                                                          double* __restrict__ G)
+                                                          double* __restrict__ G, int KP = 0,
+                                                          double* __restrict__ xscale = nullptr,
+                                                          double* __restrict__ oscale = nullptr, double ascale = 1.0)
 {
     __shared__ double sh[16][17];
     const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -610,6 +612,20 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += sh[i][el];
         G[e] = t;
+        // fp16 two-term operand: every entry of row r is bounded by sqrt(G_rr); scale the row so that this bound lands
+        // in [2^13, 2^14] (fp16 tops out at 65504, its 11-bit precision holds down to 2^-14)
+        if (xscale && KP > 0 && e % (KP + 1) == 0) {
+            const int r = e / (KP + 1);
+            int ex = 0;
+            double xs = 1.0;
+            if (t > 0.0 && t < 1.0e300) {
+                (void)frexp(t, &ex);                    // t = f 2^ex, f in [0.5, 1)  ->  sqrt(t) <= 2^ceil(ex / 2)
+                const int half = (ex >= 0) ? (ex + 1) / 2 : -((-ex) / 2);
+                xs = ldexp(1.0, 14 - half);
+            }
+            xscale[r] = xs;
+            if (oscale) oscale[r] = 1.0 / (xs * ascale);
+        }
     }
 }
 
@@ -653,13 +669,40 @@ __global__ __launch_bounds__(256) void gram_stream8_kernel(const double* __restr
     }
 }
 
+// max |A| over a padded fp32 allocation (padding is zero): picks the power-of-two scale of the fp16 two-term product
+__global__ __launch_bounds__(256) void absmax_f32_kernel(const float* __restrict__ A, i64 elems, unsigned* __restrict__ out)
+{
+    float m = 0.f;
+    const i64 n4 = elems >> 2;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n4; i += (i64)gridDim.x * 256) {
+        const f32x4_t v = ((const f32x4_t*)A)[i];
+        m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(elems & 3)) m = fmaxf(m, fabsf(A[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bits
+}
+
+int launch_absmax_f32(const float* A, i64 elems, unsigned* out, hipStream_t st)
+{
+    SMK_HIP(hipMemsetAsync(out, 0, sizeof(unsigned), st));
+    i64 grid = (elems / 4 + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    absmax_f32_kernel<<<(unsigned)grid, 256, 0, st>>>(A, elems, out);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 size_t gram_scratch_elems(int k, int max_blocks)
 {
     int KP = kp_of(k);
     return (size_t)max_blocks * KP * KP + 8;             // + the ticket word of the fused Gram/pack kernel
 }
 
-int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, hipStream_t st)
+int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, hipStream_t st, double* xscale,
+                double* oscale, double ascale)
 {
     const int KP = kp_of(k);
     const int elems = KP * KP;
@@ -683,7 +726,7 @@ int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int m
         gram_stream8_kernel<<<nblk, 256, 0, st>>>(X, N, scratch);
     }
     SMK_HIP(hipGetLastError());
-    gram_reduce_kernel<<<(elems + 15) / 16, 256, 0, st>>>(scratch, nblk, elems, G);
+    gram_reduce_kernel<<<(elems + 15) / 16, 256, 0, st>>>(scratch, nblk, elems, G, KP, xscale, oscale, ascale);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -695,7 +738,7 @@ int launch_gram_pack(const double* X, int k, i64 N, double* G, double* scratch, 
 {
     const int KP = kp_of(k);
     const bool bf16_frag = storage == STORE_BF16 || nsplit >= 2;
-    if (KP < 16 || KP > 64 || !bf16_frag || nsplit < 1 || nsplit > 3) return 1;
+    if (KP < 16 || KP > 64 || !bf16_frag || nsplit < 1 || nsplit > 3) return 1;     // (the fp16 form needs the finished Gram diagonal first)
     static const bool enabled = [] { const char* e = getenv("SMK_FUSED_GRAM"); return !(e && e[0] == '0'); }();
     if (!enabled) return 1;
     int nblk = (int)((N + 255) / 256);                   // >= 64 columns per wave, as launch_gram

@@ -72,6 +72,7 @@ struct smk_matrix {
     i64 m = 0, n_global = 0, c0 = 0, n = 0;
     int storage = SMK_STORE_F32;
     hipStream_t st = nullptr;                        // stream of the context that created it
+    mutable float ascale = 0.f;                      // fp16 two-term products: power of two with max|A| ascale in [2^13, 2^14); 0 = not yet measured
     void* A = nullptr;  i64 ldA = 0, colsA = 0;      // m_pad x n_pad
     void* At = nullptr; i64 ldAt = 0, colsAt = 0;    // n_pad x m_pad
     // sparse A: CSC of the local columns and CSC of its transpose (fp64 values, 64-bit offsets)
@@ -98,6 +99,7 @@ struct smk_solver {
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
     bool inv_pending[2] = {false, false};
+    double *xscale[2] = {nullptr, nullptr}, *oscale[2] = {nullptr, nullptr};   // fp16 two-term products: row scales of W / H (from the Gram diagonal) and their inverses
     bool packed_fresh[2] = {false, false};   // the fused Gram kernel has already written packW / packH for the next product
     // HALS: the fused W sweep needs every workgroup resident; if its bounded polls ever expire (flag -3) the run is
     // repeated from the initial factors on the one-launch-per-column path, latched for the life of the handle
@@ -607,6 +609,30 @@ static size_t comm_bytes(const smk_solver* s)
     return b;
 }
 
+// max |A| of a dense fp32 matrix -> ascale (power of two, max |A| ascale in [2^13, 2^14)); 1 for an all-zero or
+// non-finite matrix.  One pass over A at HBM rate, once per matrix.
+static int matrix_measure_scale(const smk_matrix* a, hipStream_t st)
+{
+    unsigned* d = nullptr;
+    SMK_HIP(hipMalloc((void**)&d, sizeof(unsigned)));
+    unsigned bits = 0;
+    int rc = launch_absmax_f32((const float*)a->A, a->ldA * a->colsA, d, st);
+    if (!rc && hipMemcpyAsync(&bits, d, sizeof(bits), hipMemcpyDeviceToHost, st) != hipSuccess) rc = SMK_DEVICE_ERROR;
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = SMK_DEVICE_ERROR;
+    (void)hipFree(d);
+    if (rc) { set_error("could not measure max |A|"); return rc; }
+    float mx;
+    memcpy(&mx, &bits, sizeof(mx));
+    float sc = 1.f;
+    if (mx > 0.f && std::isfinite(mx)) {
+        int ex = 0;
+        (void)frexpf(mx, &ex);                     // mx = f 2^ex, f in [0.5, 1)
+        sc = ldexpf(1.f, 14 - ex);
+    }
+    a->ascale = sc;
+    return 0;
+}
+
 int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matrix* a)
 {
     if (!out) return SMK_BAD_PARAM;
@@ -631,19 +657,39 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     s->n = a->n;
     s->st = a->st ? a->st : g_stream;
     const char* env = getenv("SMK_NSPLIT");
-    s->nsplit = env ? atoi(env) : 3;
-    if (s->nsplit < 1 || s->nsplit > 3) s->nsplit = 3;
+    // fp32 A: the fp16 two-term form (3 MFMAs per product, 2^-22 operand error) unless SMK_NSPLIT picks the bf16 forms
+    // (3 = bf16x3, 6 MFMAs, power-bound; 2 = two bf16 terms, 2^-16); bf16 A: three bf16 terms of the factor
+    const int nsplit_default = (a->storage == SMK_STORE_F32) ? NSPLIT_F16X2 : 3;
+    s->nsplit = env ? atoi(env) : nsplit_default;
+    if (s->nsplit < 1 || s->nsplit > NSPLIT_F16X2) s->nsplit = nsplit_default;
+    // the fp16 two-term form applies to fp32 storage; RANK2 keeps its Gram matrices inside its own solve kernel
+    if (s->nsplit == NSPLIT_F16X2 && (a->storage != SMK_STORE_F32 || a->sparse || opts->algorithm == SMK_ALG_RANK2)) s->nsplit = 3;
+    if (s->nsplit == NSPLIT_F16X2 && a->ascale == 0.f) {
+        const int rc0 = matrix_measure_scale(a, s->st);
+        if (rc0) { --g_live_solvers; delete s; return rc0; }
+    }
     s->ng = plan_bigprod_groups(a->storage, s->k, s->m, s->n, s->nsplit, g_cus, s->pg1);
     (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
     s->pl1 = s->pg1[0];
     s->pl2 = s->pg2[0];
+    int rc = 0;
+    if (s->nsplit == NSPLIT_F16X2) {
+        for (int side = 0; side < 2 && !rc; ++side) {
+            rc |= dev_alloc(&s->xscale[side], (size_t)MAX_K);
+            rc |= dev_alloc(&s->oscale[side], (size_t)MAX_K);
+        }
+        if (rc) { smk_solver_destroy(s); return SMK_DEVICE_ERROR; }
+        for (int g = 0; g < s->ng; ++g) {
+            s->pg1[g].oscale = s->oscale[0] + s->pg1[g].k0;  s->pg1[g].ascale = a->ascale;
+            s->pg2[g].oscale = s->oscale[1] + s->pg2[g].k0;  s->pg2[g].ascale = a->ascale;
+        }
+    }
     if (a->sparse) {   // gather products write one slab, as dense as the factor layout (KP values per column)
         s->kpp = s->KP;
         s->pl1.S = 1; s->pl1.p_elems = (size_t)s->pl1.ncols_pad * s->kpp;
         s->pl2.S = 1; s->pl2.p_elems = (size_t)s->pl2.ncols_pad * s->kpp;
     }
 
-    int rc = 0;
     const size_t kk = (size_t)s->KP * s->KP;
     rc |= dev_alloc(&s->H, (size_t)s->KP * s->n);
     rc |= dev_alloc(&s->Wt_own, (size_t)s->KP * s->m);
@@ -697,7 +743,8 @@ void smk_solver_destroy(smk_solver* s)
 {
     if (!s) return;
     void* ptrs[] = {s->H, s->Wt_own, s->Gw, s->Gh_own, s->gram_scratch, s->tmpW, s->pg_partials, s->scal_own,
-                    s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH, s->nnls_scratch, s->W0c, s->H0c};
+                    s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH, s->nnls_scratch, s->W0c, s->H0c,
+                    s->xscale[0], s->xscale[1], s->oscale[0], s->oscale[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int w = 0; w < 2; ++w)
@@ -908,7 +955,7 @@ static int prod1(smk_solver* s)
 {
     if (s->a->sparse) return timed_spmm(s, 0, s->a->colptr, s->a->rowidx, s->a->val, s->n, s->Wt, s->P1);
     int rc = 0;
-    if (!s->packed_fresh[0]) rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st);
+    if (!s->packed_fresh[0]) rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st, s->xscale[0]);
     s->packed_fresh[0] = false;
     if (rc) return rc;
     for (int g = 0; g < s->ng; ++g) {
@@ -925,7 +972,7 @@ static int prod2(smk_solver* s)
     if (s->a->sparse) {
         rc = timed_spmm(s, 1, s->a->colptr_t, s->a->rowidx_t, s->a->val_t, s->m, s->H, s->P2);
     } else {
-        if (!s->packed_fresh[1]) rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st);
+        if (!s->packed_fresh[1]) rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st, s->xscale[1]);
         s->packed_fresh[1] = false;
         if (rc) return rc;
         for (int g = 0; g < s->ng && !rc; ++g)
@@ -952,6 +999,8 @@ static int gram_factor(smk_solver* s, int side)
     const i64 N = side == 0 ? s->m : s->n;
     double* G = side == 0 ? s->Gw : s->Gh;
     s->packed_fresh[side] = false;
+    if (s->nsplit == NSPLIT_F16X2)       // the reduce launch also derives the row scales of the operand packed next
+        return launch_gram(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->st, s->xscale[side], s->oscale[side], (double)s->a->ascale);
     if (!s->a->sparse && s->o.algorithm != SMK_ALG_RANK2) {
         const int rc = launch_gram_pack(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->a->storage, s->nsplit,
                                         side == 0 ? s->packW : s->packH, s->st);

@@ -350,3 +350,60 @@ def test_handle_reuse_after_normalised_run(gpu, alg):
     assert np.allclose(np.linalg.norm(W2, axis=0), 1.0, atol=1e-10)
     ref = oracle.nmf(A, W1, H1, alg, min_iter=4, max_iter=4)
     assert np.linalg.norm(W2 - ref.W) / np.linalg.norm(ref.W) < 1e-4
+
+
+# ---- fp32 A: the products run as two fp16 terms per operand with power-of-two scales --------------
+@pytest.mark.parametrize("alg,log2scale", [("HALS", s) for s in (-60, -20, 20, 60)] + [("MU", s) for s in (-20, 20)]
+                         + [("BPP", s) for s in (-20, 20)])
+def test_fp32_products_at_any_magnitude(gpu, alg, log2scale):
+    """A 2^s and H0 2^s: magnitudes far outside fp16's range (6e-5 .. 65504) on both sides of the product.  (The
+    reference's own absolute thresholds -- 1e-12 zeroing in BPP, the 1e-13 of MU -- bound the scales that make sense.)"""
+    m, n, k = 384, 256, 24
+    A = oracle.quantize(np.asfortranarray(np.ldexp(mg.make_A(m, n, k, True, 0), log2scale)), 0)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = np.ldexp(oracle.fill_uniform(k, n, 44), log2scale)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=5, max_iter=5)
+    got = gpu.nmf(A, W0, H0, alg, min_iter=5, max_iter=5, storage="f32")
+    assert ref.result == 0 and got.result == 0
+    assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL
+
+
+@pytest.mark.parametrize("alg", ["HALS", "BPP"])
+@pytest.mark.parametrize("span", [12, 20])
+def test_fp32_products_with_wide_dynamic_range(gpu, alg, span):
+    """columns of A spanning 2^-span .. 2^span and rows of H0 spanning 2^-6 .. 2^6.  The two-term fp16 operands are exact
+    to 22 bits for entries down to 2^-28 max|A|: inside that range (span 12) every column of H is held to
+    the tolerance against its own norm; beyond it (span 20) the small columns lose bits and the bar is the normwise one."""
+    m, n, k = 512, 320, 16
+    rng = np.random.default_rng(7)
+    A = oracle.fill_uniform(m, n, 42, quant=0) * np.exp2(rng.integers(-span, span + 1, size=n))[None, :]
+    A = oracle.quantize(np.asfortranarray(A), 0)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * np.exp2(rng.integers(-6, 7, size=k))[:, None]
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=6, max_iter=6)
+    got = gpu.nmf(A, W0, H0, alg, min_iter=6, max_iter=6, storage="f32")
+    assert ref.result == 0 and got.result == 0
+    # span 20: the iteration itself is this sensitive to fp32-class products (the bf16x3 form measures 1.6e-4 here)
+    bar = TOL if span <= 12 else 1e-3
+    assert rel(got.W, ref.W) < bar and rel(got.H, ref.H) < bar
+    if span <= 12:
+        cn = np.linalg.norm(ref.H, axis=0)
+        live = cn > 0
+        assert (np.linalg.norm(got.H - ref.H, axis=0)[live] / cn[live]).max() < 1e-3
+
+
+def test_fp32_product_forms_agree(gpu, monkeypatch):
+    """SMK_NSPLIT selects the emulation of the fp32 product: 4 (default, fp16 two-term), 3 (bf16x3), 2 (fast two-term
+    bf16, 2^-16).  The first two agree to fp32 class; the fast form to its documented 1e-3."""
+    m, n, k = 640, 512, 48
+    A = mg.make_A(m, n, k, True, 0)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    out = {}
+    for ns in ("4", "3", "2"):
+        monkeypatch.setenv("SMK_NSPLIT", ns)
+        out[ns] = gpu.nmf(A, W0, H0, "HALS", min_iter=5, max_iter=5, storage="f32")
+    ref = oracle.nmf(A, W0, H0, "HALS", min_iter=5, max_iter=5)
+    assert rel(out["4"].W, ref.W) < TOL and rel(out["3"].W, ref.W) < TOL
+    assert rel(out["4"].W, out["3"].W) < 1e-5
+    assert rel(out["2"].W, ref.W) < 1e-2
