@@ -51,6 +51,7 @@ def main():
 
     # the SmallkAPI facade on the same data: plain NMF with BPP
     api = SmallkAPI()
+    api.seed_rng(1)              # initial factors are random; without a seed they come from the clock
     if len(sys.argv) == 3:
         api.load_matrix(filepath=sys.argv[1])
     else:

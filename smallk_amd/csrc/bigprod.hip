@@ -434,6 +434,25 @@ __global__ __launch_bounds__(256) void pack_kernel(const double* __restrict__ X,
 // high term is: full 22-bit operands over a 2^28 range below the scale) and the cross-term accumulator is divided
 // by 2^11 once, in the epilogue.
 constexpr float F16X2_LO_SCALE = 2048.f;
+// residual of the fp16 two-term split, (a s - hi) 2^11, for both halves of a packed fp16 pair: one v_fma_mix_f32 each
+// (fp16 source read in place, fp32 accumulate; exact because a s - hi is representable)
+static __device__ __forceinline__ void f16x2_residual(unsigned hi_pair, float xl0, float xl1, float& r0, float& r1)
+{
+#ifndef SMK_F16_RESID_ASM
+#define SMK_F16_RESID_ASM 1
+#endif
+#if SMK_F16_RESID_ASM
+    const float neg = -F16X2_LO_SCALE;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi_pair), "v"(neg), "v"(xl0));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi_pair), "v"(neg), "v"(xl1));
+#else
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t h = __builtin_bit_cast(h2_t, hi_pair);
+    r0 = __builtin_fmaf((float)h[0], -F16X2_LO_SCALE, xl0);
+    r1 = __builtin_fmaf((float)h[1], -F16X2_LO_SCALE, xl1);
+#endif
+}
+
 // fp16 two-term form: the same fragment layout with _Float16 entries; row r of the operand (factor row k0 + r) is
 // multiplied by xscale[k0 + r] (a power of two from the Gram diagonal, gram_reduce_kernel) before the split so that its
 // entries sit in fp16's range with full 11-bit precision: hi = fp16(x), lo = fp16(x - hi)  (22 significant bits).
@@ -600,7 +619,9 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
     const int my_nst = (st1 > st0) ? (int)(st1 - st0) : 0;
 
     const i64 col0 = tile * C::NB;
-    i64 src_off[C::LPS];
+    // one running pointer per load of a stage: issue() is called for consecutive stages only, so each call costs one
+    // 64-bit add per load (the select between the two operands and the stage multiply are paid once, here)
+    const unsigned char* gsrc[C::LPS];
     int is_b[C::LPS];
 #pragma unroll
     for (int i = 0; i < C::LPS; ++i) {
@@ -610,24 +631,25 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
             const int j = p / C::CPC;
             const int pc = p % C::CPC;
             const int swz = (j >> C::SWZ_SH) & C::SWZ_MASK;
-            src_off[i] = (col0 + j) * ldb_bytes + (i64)(pc ^ swz) * 16;
+            gsrc[i] = B + (col0 + j) * ldb_bytes + (i64)(pc ^ swz) * 16 + st0 * (C::MB * 4);
             is_b[i] = 1;
         } else {
-            src_off[i] = (i64)(t * 1024 - C::B_BYTES) + lane * 16;
+            gsrc[i] = Xp + st0 * C::X_BYTES + (i64)(t * 1024 - C::B_BYTES) + lane * 16;
             is_b[i] = 0;
         }
     }
     auto issue = [&](int s_local) {
-        const i64 stage = st0 + s_local;
         unsigned char* lbase = smem + (s_local % C::NSTAGE) * C::STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < C::LPS; ++i) {
             const int t = lw + C::NLD * i;
-            const unsigned char* g = is_b[i] ? (B + src_off[i] + stage * (C::MB * 4)) : (Xp + stage * C::X_BYTES + src_off[i]);
-            if (is_b[i])
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
-            else
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
+            if (is_b[i]) {
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
+                gsrc[i] += C::MB * 4;
+            } else {
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
+                gsrc[i] += C::X_BYTES;
+            }
         }
     };
 
@@ -688,9 +710,19 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
                         a[kt][s] = __builtin_bit_cast(f16x8_t, *(const u32x4_t*)(sx + ((q * 2 + s) * KT + kt) * 1024 + lane * 16));
-                if (ascale != 1.0f) x *= ascale;
-                const f16x8_t bh = __builtin_convertvector(x, f16x8_t);
-                x = (x - __builtin_convertvector(bh, f32x8_t)) * F16X2_LO_SCALE;
+                // hi = fp16(a s); lo = fp16((a s - hi) 2^11), the residual as one mixed-precision fma per entry (exact)
+                const f32x8_t xs = x * ascale, xl = x * (ascale * F16X2_LO_SCALE);
+                const f16x8_t bh = __builtin_convertvector(xs, f16x8_t);
+                {
+                    const u32x4_t hp = __builtin_bit_cast(u32x4_t, bh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float r0, r1;
+                        f16x2_residual(hp[e], xl[2 * e], xl[2 * e + 1], r0, r1);
+                        x[2 * e] = r0;
+                        x[2 * e + 1] = r1;
+                    }
+                }
                 const f16x8_t bl = __builtin_convertvector(x, f16x8_t);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
@@ -855,7 +887,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
     const int my_nst = (st1 > st0) ? (int)(st1 - st0) : 0;
 
     const i64 col0 = tile * C::NB;
-    i64 src_off[C::LPS];
+    const unsigned char* gsrc[C::LPS];             // running pointers, as in bigprod_f3_kernel
     int is_b[C::LPS];
 #pragma unroll
     for (int i = 0; i < C::LPS; ++i) {
@@ -865,24 +897,26 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
             const int j = p / C::CPC;
             const int pc = p % C::CPC;
             const int swz = (j >> C::SWZ_SH) & C::SWZ_MASK;
-            src_off[i] = (col0 + j) * ldb_bytes + (i64)(pc ^ swz) * 16;
+            gsrc[i] = B + (col0 + j) * ldb_bytes + (i64)(pc ^ swz) * 16 + st0 * (C::MB * 4);
             is_b[i] = 1;
         } else {
-            src_off[i] = (i64)(t * 1024 - C::B_BYTES) + lane * 16;
+            gsrc[i] = Xp + st0 * C::X_BYTES + (i64)(t * 1024 - C::B_BYTES) + lane * 16;
             is_b[i] = 0;
         }
     }
     auto issue = [&](int s_local) {
-        const i64 stage = st0 + s_local;
         unsigned char* lbase = smem + (s_local % C::NSTAGE) * C::STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < C::LPS; ++i) {
             const int t = lw + C::NLD * i;
-            const unsigned char* g = is_b[i] ? (B + src_off[i] + stage * (C::MB * 4)) : (Xp + stage * C::X_BYTES + src_off[i]);
-            if (is_b[i])
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
-            else if constexpr ((PIN & 16) == 0)     // experiment bit 16: the X fragments are not fetched at all
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
+            if (is_b[i]) {
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
+                gsrc[i] += C::MB * 4;
+            } else {
+                if constexpr ((PIN & 16) == 0)      // experiment bit 16: the X fragments are not fetched at all
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
+                gsrc[i] += C::X_BYTES;
+            }
         }
     };
     f32x16_t hi[KT], sm[KT];
@@ -921,12 +955,23 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
             f.bl = f.bh;
             return;
         }
-        if constexpr (FMT == 1) {
-            if (ascale != 1.0f) x *= ascale;
+        if constexpr (FMT == 1) {       // as in bigprod_f3_kernel
+            const f32x8_t xs = x * ascale, xl = x * (ascale * F16X2_LO_SCALE);
+            f.bh = __builtin_convertvector(xs, V);
+            const u32x4_t hp = __builtin_bit_cast(u32x4_t, f.bh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                        float r0, r1;
+                        f16x2_residual(hp[e], xl[2 * e], xl[2 * e + 1], r0, r1);
+                        x[2 * e] = r0;
+                        x[2 * e + 1] = r1;
+                    }
+            f.bm = __builtin_convertvector(x, V);
+            f.bl = f.bm;
+            return;
         }
         f.bh = __builtin_convertvector(x, V);
         x -= __builtin_convertvector(f.bh, f32x8_t);
-        if constexpr (FMT == 1) x *= F16X2_LO_SCALE;
         f.bm = __builtin_convertvector(x, V);
         f.bl = f.bm;
         if constexpr (NS == 3) {
@@ -1093,6 +1138,8 @@ static const F3Variant kF3Variants[] = {
     {32, 5, 4, 4, 0},   // 122: loader priority, compiler schedule
     {32, 5, 4, 4, 0},   // 123: EXPERIMENT no X fetch (full compute)
     {32, 5, 4, 4, 0},   // 124: EXPERIMENT no X fetch, no MFMA, no split
+    {32, 2, 0, 8, 2},   // 125: as 108, folding into fp64 every 8 stages (256-row fp32 chains)
+    {32, 3, 0, 4, 2},   // 126: as 108 with a 3-deep ring
 };
 static const int kNumF3 = (int)(sizeof(kF3Variants) / sizeof(kF3Variants[0]));
 
@@ -1156,6 +1203,8 @@ static int launch_f3(const BigProdPlan& pl, const void* B, i64 ldb, const void* 
         case 22: return launch_f3p_t<KT, NS, 5, 4, 4, 8>(pl, B, ldb, Xp, P, st);
         case 23: return launch_f3p_t<KT, NS, 5, 4, 4, 16>(pl, B, ldb, Xp, P, st);
         case 24: return launch_f3p_t<KT, NS, 5, 4, 4, 22>(pl, B, ldb, Xp, P, st);
+        case 25: return launch_f3_t<KT, NS, 32, 2, 0, 8, 2>(pl, B, ldb, Xp, P, st);
+        case 26: return launch_f3_t<KT, NS, 32, 3, 0, 4, 2>(pl, B, ldb, Xp, P, st);
         default: break;
     }
     set_error("unknown bigprod f3 variant");
@@ -1171,6 +1220,8 @@ static int launch_f3_f16(const BigProdPlan& pl, const void* B, i64 ldb, const vo
         case 10: return launch_f3p_t<KT, 2, 4, 4, 4, 1, 1>(pl, B, ldb, Xp, P, st);
         case 11: return launch_f3p_t<KT, 2, 5, 4, 4, 1, 1>(pl, B, ldb, Xp, P, st);
         case 15: return launch_f3p_t<KT, 2, 3, 2, 4, 1, 1>(pl, B, ldb, Xp, P, st);
+        case 25: return launch_f3_t<KT, 2, 32, 2, 0, 8, 2, 1>(pl, B, ldb, Xp, P, st);
+        case 26: return launch_f3_t<KT, 2, 32, 3, 0, 4, 2, 1>(pl, B, ldb, Xp, P, st);
         default: break;
     }
     set_error("unknown bigprod f16 variant");
@@ -1243,13 +1294,17 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     if (pl.kt == 2) v = (storage == STORE_BF16) ? 18 : 21;
     // fp32 A as bf16 planes: the second-generation kernels (power-bound at ~4.1 TB/s for k = 64)
     if (storage == STORE_F32 && pl.nsplit >= 2) v = (pl.kt == 2) ? 108 : 115;
+    // fp16 two-term form: the two-workgroup kernel wins or ties at every shape measured (C2, 32768 x 8192 k = 32, both
+    // passes of a C4 shard); the pipelined ones stay selectable (110, 111, 115)
+    // folding the fp32 accumulators into fp64 every 8 stages (variant 125) instead of 4 is worth 0.5 .. 6 % and keeps the
+    // product at 4e-8 of the exact one (2^-24 = 6e-8; measured by tools/mb/mb_bp_sweep against an fp64 host product)
+    if (storage == STORE_F32 && pl.nsplit == NSPLIT_F16X2) v = 125;
     const char* env = getenv("SMK_BP_VARIANT");
     if (env) v = atoi(env);
     const char* env2 = getenv("SMK_BP_VARIANT_K64");       // only for k in (32, 64]
     if (env2 && pl.kt == 2) v = atoi(env2);
-    if (storage == STORE_F32 && (pl.nsplit == 2 || pl.nsplit == NSPLIT_F16X2) && v < 100)
-        v = (pl.kt == 2) ? 108 : 115;                       // the 2-term forms exist only there
-    if (pl.nsplit == NSPLIT_F16X2 && v != 108 && v != 110 && v != 111 && v != 115) v = (pl.kt == 2) ? 108 : 115;
+    if (storage == STORE_F32 && pl.nsplit == 2 && v < 100) v = (pl.kt == 2) ? 108 : 115;   // the 2-term forms exist only there
+    if (pl.nsplit == NSPLIT_F16X2 && v != 108 && v != 110 && v != 111 && v != 115 && v != 125 && v != 126) v = 125;
     if (v >= 100 && storage == STORE_F32 && pl.nsplit >= 2) {
         auto f3_fits = [&](int vv) {
             if (vv < 100 || vv >= 100 + kNumF3) return false;
@@ -1258,7 +1313,7 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
             const int ti = stage / 1024, nld = f.nwl > 0 ? f.nwl : 4;
             return ti % nld == 0 && (ti / nld) * (f.nstage - 1) <= 63 && stage * f.nstage <= 160 * 1024;
         };
-        if (!f3_fits(v)) v = 108;
+        if (!f3_fits(v)) v = (pl.nsplit == NSPLIT_F16X2) ? 125 : 108;
         if (!f3_fits(v)) v = 115;
         if (!f3_fits(v)) v = 110;
         pl.variant = v;

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -397,6 +398,9 @@ void Initialize(int& /*argc*/, char**& /*argv*/)
 {
     Reset();
     rng_seed = (uint64_t)std::chrono::high_resolution_clock::now().time_since_epoch().count();
+    // SMALLK_SEED pins the seed for callers that cannot be changed to call SeedRNG() (the reference's own example
+    // programs draw their initial factors right after Initialize)
+    if (const char* e = getenv("SMALLK_SEED")) rng_seed = (uint64_t)strtoull(e, nullptr, 10);
     rng_draws = 0;
     if (smk_initialize(-1) != SMK_OK) throw std::runtime_error(std::string("smallk error (Initialize): ") + smk_last_error());
 }

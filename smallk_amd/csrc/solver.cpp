@@ -61,6 +61,10 @@ static int dev_alloc(T** p, size_t count)
     *p = nullptr;
     if (count == 0) count = 1;
     SMK_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    // debugging aid: SMK_POISON=1 fills every fresh workspace with 0xFF bytes (NaN as fp64 / fp32, -1 as int), so that a
+    // kernel reading memory nobody wrote shows up in every run instead of once in a hundred
+    static const bool poison = [] { const char* e = getenv("SMK_POISON"); return e && atoi(e) != 0; }();
+    if (poison) { SMK_HIP(hipMemset(*p, 0xFF, count * sizeof(T))); SMK_HIP(hipDeviceSynchronize()); }   // the fill must not trail work on the non-blocking streams
     return 0;
 }
 

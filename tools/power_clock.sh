@@ -4,7 +4,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/r02; mkdir -p $OUT
 {
 echo "rocm-smi --showclocks --showpower sampled every ~0.9 s while tools/mb/mb_bp_sweep 64 8192 262144 0 <variant> loops (MB_REPS=5000)"
-echo "variants: 21 = round-1 kernel, 108 = round-2 kernel (6 products), 120 = the same data path with no MFMA and no bf16 split"
+echo "variants: 21 = round-1 kernel, 108 = round-2 kernel (bf16x3: 6 products), 120 = the same data path with no MFMA and no bf16 split"
+export MB_NSPLIT=3
 for v in 21 108 120; do
   (MB_REPS=5000 $ROOT/tools/mb/mb_bp_sweep 64 8192 262144 0 $v > $OUT/long_$v.log 2>&1 &)
   sleep 4
@@ -13,16 +14,17 @@ for v in 21 108 120; do
   while pgrep -x mb_bp_sweep > /dev/null; do sleep 0.5; done
   cat $OUT/long_$v.log; rm -f $OUT/long_$v.log
 done
+echo "== fp16 two-term form (MB_NSPLIT=4, the default for fp32 A), variant 125 (the default)"
+(MB_NSPLIT=4 MB_REPS=5000 $ROOT/tools/mb/mb_bp_sweep 64 8192 262144 0 125 > $OUT/long_f.log 2>&1 &)
+sleep 4
+for i in 1 2 3; do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Package Power" ; sleep 0.4; done
+while pgrep -x mb_bp_sweep > /dev/null; do sleep 0.5; done
+cat $OUT/long_f.log; rm -f $OUT/long_f.log
 echo "== 2-term fast form (MB_NSPLIT=2), variant 108"
 (MB_NSPLIT=2 MB_REPS=5000 $ROOT/tools/mb/mb_bp_sweep 64 8192 262144 0 108 > $OUT/long_f.log 2>&1 &)
 sleep 4
 for i in 1 2 3; do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Package Power" ; sleep 0.4; done
 while pgrep -x mb_bp_sweep > /dev/null; do sleep 0.5; done
 cat $OUT/long_f.log; rm -f $OUT/long_f.log
-echo "== C3 bench loop (bf16, k = 32)"
-(python3 $ROOT/bench.py --steps 2000 --warmup 3 --no-cpu-baseline > $OUT/long_c3.log 2>&1 &)
-sleep 14
-for i in 1 2 3; do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Package Power" ; sleep 0.4; done
-wait; sleep 12; tail -c 300 $OUT/long_c3.log; rm -f $OUT/long_c3.log
 } > $OUT/r02_k64_f32_power_clock.txt 2>&1
 cat $OUT/r02_k64_f32_power_clock.txt

@@ -31,6 +31,7 @@ for w in c3 c2 c4s c4; do
   python3 $ROOT/bench.py --workload $w --steps $([ $w = c4 ] && echo 4 || echo 20) --warmup 3 $([ $w = c3 ] || echo --no-cpu-baseline) 2> $OUT/bench_$w.err | tail -1 > $OUT/r02_bench_$w.json
 done
 SMK_NSPLIT=2 python3 $ROOT/bench.py --workload c4s --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/r02_bench_c4s_fast2term.json
+SMK_NSPLIT=3 python3 $ROOT/bench.py --workload c4s --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/r02_bench_c4s_bf16x3.json
 # ---- kernel tables ----
 kt c3_hals_bf16 $B --workload c3 --steps 20 --warmup 3
 kt c2_bpp_f32 $B --workload c2 --steps 50 --warmup 5
@@ -43,24 +44,21 @@ pmc c3_write WRITE_SIZE $B --workload c3 --steps 10 --warmup 2
 pmc c4s_fetch FETCH_SIZE $B --workload c4s --steps 5 --warmup 2
 pmc c4s_write WRITE_SIZE $B --workload c4s --steps 5 --warmup 2
 python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_c3_fetch.db $OUT/pmc_c3_write.db bigprod_kernel c3_n1 $OUT/hbm_traffic.json > /dev/null
-python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_c4s_fetch.db $OUT/pmc_c4s_write.db bigprod_f3_kernel c4s_n1 $OUT/hbm_traffic.json > /dev/null
-# ---- SQ counters, k = 64 fp32 streaming kernel: round-1 (21) vs round-2 (108) ----
+python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_c4s_fetch.db $OUT/pmc_c4s_write.db bigprod_f3 c4s_n1 $OUT/hbm_traffic.json > /dev/null
+# ---- SQ counters, k = 64 fp32 streaming kernel: round-1 (21, bf16x3), round-2 bf16x3 (108) and fp16 two-term (108, MB_NSPLIT=4) ----
 SW="$ROOT/tools/mb/mb_bp_sweep 64 8192 262144 0"
 for v in 21 108; do
+  export MB_NSPLIT=3
   pmc sq_a_v$v "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" $SW $v
   pmc sq_b_v$v "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" $SW $v
 done
+export MB_NSPLIT=4
+pmc sq_a_v125_f16x2 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" $SW 125
+pmc sq_b_v125_f16x2 "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" $SW 125
+unset MB_NSPLIT
 for f in $OUT/pmc_sq_*.db; do echo "== $f"; python3 $ROOT/tools/pmc_dump.py $f bigprod; done > $OUT/r02_k64_f32_sq_counters.txt 2>&1
 # ---- power / clock while the streaming kernels run ----
-{
-for v in 21 108 120; do
-  (MB_REPS=1200 $ROOT/tools/mb/mb_bp_sweep 64 8192 262144 0 $v > $OUT/long_$v.log 2>&1 &)
-  sleep 1.2
-  echo "== variant $v (21: round-1 kernel, 108: round-2 kernel, 120: loads only, no MFMA / no split)"
-  for i in 1 2 3; do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" ; sleep 0.4; done
-  sleep 2.5; cat $OUT/long_$v.log
-done
-} > $OUT/r02_k64_f32_power_clock.txt 2>&1
+bash $ROOT/tools/power_clock.sh > /dev/null 2>&1
 rm -f $OUT/long_*.log $OUT/pmc_sq_*.db $OUT/pmc_c4s_*.db
 ls -la $OUT
 for f in $OUT/r02_bench_*.json; do echo $f; python3 -c "
