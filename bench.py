@@ -149,6 +149,7 @@ def main():
                 uid = torch.tensor(list(smallk_amd.Comm.unique_id()), dtype=torch.uint8)
             torch.distributed.broadcast(uid, 0)
             comm = smallk_amd.Comm.init_rank(bytes(uid.tolist()), rank, world)
+            comm.selftest()                 # known sums through RCCL before the run is trusted to it
         except Exception as e:              # pragma: no cover  (multi-GPU nodes only)
             print(f"[bench rank {rank}] native RCCL communicator failed: {e}", file=sys.stderr, flush=True)
             ok = 0

@@ -106,6 +106,7 @@ SYMBOLS = {
     "smk_comm_init_rank": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
     "smk_comm_init_all": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int)]),
     "smk_comm_init_local": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "smk_comm_selftest": (C.c_int, [_vp]),
     "smk_comm_rank": (C.c_int, [_vp]),
     "smk_comm_world": (C.c_int, [_vp]),
     "smk_comm_destroy": (None, [_vp]),

@@ -144,6 +144,51 @@ int smk_comm_init_local(smk_comm** out, int nranks)
     return SMK_OK;
 }
 
+// One sum-all-reduce (fp64 and fp32) and one all-gather of known values on a private stream of the current device,
+// checked on the host.  Every rank of the communicator must call it.  SMK_OK, or SMK_DEVICE_ERROR with the reason in
+// smk_last_error(): callers (bench.py) use it to decide whether the native path can be trusted on this node.
+int smk_comm_selftest(smk_comm* c)
+{
+    if (!c) return SMK_BAD_PARAM;
+    const int W = c->world;
+    hipStream_t st = nullptr;
+    double* d = nullptr;
+    std::vector<double> h((size_t)(2 * W + 2), 0.0);
+    int rc = SMK_OK;
+    auto fail = [&](const std::string& m) { set_error("communicator self-test: " + m); rc = SMK_DEVICE_ERROR; };
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate"); return rc; }
+    if (hipMalloc((void**)&d, h.size() * sizeof(double)) != hipSuccess) { (void)hipStreamDestroy(st); fail("hipMalloc"); return rc; }
+    // layout: [0] fp64 sum slot, [1] two fp32 sum slots, [2 .. 2 + W) gather slots (fp64)
+    h[0] = (double)(c->rank + 1);
+    float f2[2] = {(float)(c->rank + 1), 0.5f};
+    std::memcpy(&h[1], f2, sizeof(f2));
+    h[(size_t)(2 + c->rank)] = 100.0 + c->rank;
+    if (hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) fail("upload");
+    if (!rc && c->nccl) {          // also with one rank: the calls must at least go through the library
+        ncclComm_t nc = (ncclComm_t)c->nccl;
+        ncclResult_t r = ncclAllReduce(d, d, 1, ncclDouble, ncclSum, nc, st);
+        if (r == ncclSuccess) r = ncclAllReduce(d + 1, d + 1, 2, ncclFloat, ncclSum, nc, st);
+        if (r == ncclSuccess) r = ncclAllGather(d + 2 + c->rank, d + 2, 1, ncclDouble, nc, st);
+        if (r != ncclSuccess) fail(std::string("RCCL: ") + ncclGetErrorString(r));
+    } else if (!rc) {
+        if (comm_allreduce(c, d, 1, 1, st) || comm_allreduce(c, d + 1, 2, 0, st) || comm_allgather(c, d + 2, 1, 1, st)) rc = SMK_DEVICE_ERROR;
+    }
+    if (!rc && hipMemcpyAsync(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) fail("download");
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) fail("synchronize");
+    if (!rc) {
+        std::memcpy(f2, &h[1], sizeof(f2));
+        const double want = 0.5 * W * (W + 1);
+        if (h[0] != want) fail("fp64 all-reduce returned " + std::to_string(h[0]) + ", expected " + std::to_string(want));
+        else if (f2[0] != (float)want || f2[1] != 0.5f * W) fail("fp32 all-reduce returned wrong sums");
+        else
+            for (int r = 0; r < W; ++r)
+                if (h[(size_t)(2 + r)] != 100.0 + r) { fail("all-gather slot " + std::to_string(r) + " is wrong"); break; }
+    }
+    (void)hipFree(d);
+    (void)hipStreamDestroy(st);
+    return rc;
+}
+
 int smk_comm_rank(const smk_comm* c) { return c ? c->rank : 0; }
 int smk_comm_world(const smk_comm* c) { return c ? c->world : 1; }
 

@@ -323,6 +323,10 @@ class Comm:
         L.check(L.lib().smk_comm_init_local(hs, nranks), "smk_comm_init_local")
         return [cls(C.c_void_p(h)) for h in hs]
 
+    def selftest(self):
+        """known values through one all-reduce and one all-gather; every rank calls it; raises on a wrong answer"""
+        L.check(L.lib().smk_comm_selftest(self._h), "smk_comm_selftest")
+
     @property
     def rank(self):
         return L.lib().smk_comm_rank(self._h)

@@ -201,6 +201,7 @@ def test_rccl_world_of_one_native(gpu):
     for make in (lambda: Comm.init_all(1)[0], lambda: Comm.init_rank(Comm.unique_id(), 0, 1)):
         comm = make()
         assert (comm.rank, comm.world) == (0, 1)
+        comm.selftest()                 # ncclAllReduce (fp64, fp32) + ncclAllGather really issued, sums checked
         D = DenseMatrix.from_host(A)
         s = NmfSolver(D, make_options(m, n, k, "BPP", min_iter=iters, max_iter=iters))
         s.attach_comm(comm)
@@ -211,6 +212,28 @@ def test_rccl_world_of_one_native(gpu):
         D.close()
         comm.close()
         assert rc == 0 and it == iters and rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
+
+
+def test_comm_selftest_on_the_stand_in(gpu):
+    """smk_comm_selftest through the in-process communicator: 3 ranks = 3 host threads on this device"""
+    import threading
+    from smallk_amd import Comm
+    comms = Comm.init_local(3)
+    errs = []
+
+    def run(c):
+        try:
+            c.selftest()
+        except Exception as e:      # noqa: BLE001
+            errs.append(str(e))
+    ts = [threading.Thread(target=run, args=(c,)) for c in comms]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for c in comms:
+        c.close()
+    assert errs == []
 
 
 def test_nmf_tool_and_facade_shard_over_smk_num_gpus(tmp_path):
