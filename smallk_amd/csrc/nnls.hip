@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
 
     const int lane = threadIdx.x & 63;
     const int i = threadIdx.x % GS;                 // component owned by this lane
-    const i64 col = col_begin + (i64)blockIdx.x * GPB + threadIdx.x / GS;
+    // grid-stride over blocks of GPB columns: the k in (32, 64] fallback is launched with a small grid so that its
+    // usual early exit costs 2 us, not one workgroup per 4 columns; every other launch covers its columns in one trip
+    for (i64 vb = blockIdx.x; vb * GPB < N - col_begin; vb += gridDim.x) {
+    const i64 col = col_begin + vb * GPB + threadIdx.x / GS;
     const bool col_ok = col < N;
     const bool comp_ok = i < k;
     const i64 cc = col_ok ? col : (N - 1);
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
     }
     bool passive = comp_ok && (x > 0.0);            // passive_set = (X > 0), nnls.hpp:157
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-    int failed = 0;
+    int failed = 0;                                 // per trip
 
     auto solve = [&](unsigned long long F) {
         // masked matrix row i
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
         if (Y) Y[col * KP + i] = y;
     }
     if (failed && col_ok) atomicMin(fail_flag, iter_tag);
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void gram_inverse_kernel(const double* __restr
     if (tid == 0) *status = bad ? 0 : 1;
 }
 
-template <int KP, int NT, int WPS>
+template <int KP, int NT, int WPS, bool FINE = true>
 __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N,
                                                           PartialView R, const double* __restrict__ G,
                                                           const double* __restrict__ Ginv,
@@ -372,9 +376,15 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
             const double sc = (lane < t) ? sv[tl] : 0.0;
             const double base = comp ? v : -rhs;
             double u = 0.0, out;
-            if (t <= 8) out = compact(std::integral_constant<int, 8>{}, M, t, tl, sc, base, u);
+            // the elimination costs ~TB^2 / 2 broadcast + FMA pairs: bounds in steps of 4 (FINE) waste a quarter less
+            // than steps of 8 on the |Z| = 6 .. 20 of noise-like data
+            if (FINE && t <= 4) out = compact(std::integral_constant<int, 4>{}, M, t, tl, sc, base, u);
+            else if (t <= 8) out = compact(std::integral_constant<int, 8>{}, M, t, tl, sc, base, u);
+            else if (FINE && t <= 12) out = compact(std::integral_constant<int, 12>{}, M, t, tl, sc, base, u);
             else if (t <= 16) out = compact(std::integral_constant<int, 16>{}, M, t, tl, sc, base, u);
+            else if (FINE && t <= 20) out = compact(std::integral_constant<int, 20>{}, M, t, tl, sc, base, u);
             else if (t <= 24) out = compact(std::integral_constant<int, 24>{}, M, t, tl, sc, base, u);
+            else if (FINE && t <= 28) out = compact(std::integral_constant<int, 28>{}, M, t, tl, sc, base, u);
             else out = compact(std::integral_constant<int, 32>{}, M, t, tl, sc, base, u);
             // u back to component positions
             if (lane < t) sv[tl] = u;
@@ -642,11 +652,14 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
         int rc;
         if (inv_mode == 2) rc = run(nnls_bpp_inv_kernel<64, 768, 3>, 768, 1);
         else if (inv_mode == 3) rc = run(nnls_bpp_inv_kernel<64, 512, 2>, 512, 1);
+        else if (inv_mode == 4) rc = run(nnls_bpp_inv_kernel<64, 512, 4, false>, 512, 2);   // solve bounds in steps of 8 (A/B)
         else rc = run(nnls_bpp_inv_kernel<64, 512, 4>, 512, 2);
         if (rc) return rc;
         skip_if = status;
     }
-    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if)));
+    int grid1 = grid;
+    if (skip_if && grid1 > num_cus * 12) grid1 = num_cus * 12;      // 3 resident workgroups per CU x 4 trips when it does run
+    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid1, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if)));
     SMK_HIP(hipGetLastError());
     return 0;
 }

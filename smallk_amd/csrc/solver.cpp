@@ -286,6 +286,7 @@ static int matrix_make_transpose(smk_matrix* a)
 
 int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
 {
+    if (a) a->ascale = 0.f;                 // new contents: the fp16 product scale is measured again on first use
     if (!a || !host || ld < a->m || a->sparse) return SMK_BAD_PARAM;
     const size_t budget = (size_t)64 << 20;   // staging bytes
     i64 chunk = (i64)(budget / ((size_t)a->m * sizeof(double)));
@@ -313,6 +314,7 @@ int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
 
 int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed)
 {
+    if (a) a->ascale = 0.f;
     if (!a || a->sparse) return SMK_BAD_PARAM;
     int rc = launch_fill_uniform(a->A, a->storage, a->ldA, a->m, a->n, a->ldA, a->colsA, 0, a->c0, a->m, seed,
                                  a->storage == SMK_STORE_BF16 ? 1 : 0, g_stream);
@@ -835,6 +837,12 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
 {
     if (!s || !W0 || !H0) return SMK_BAD_PARAM;
     if (ldW < s->m || ldH < s->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
+    if (s->nsplit == NSPLIT_F16X2 && (s->a->ascale == 0.f || s->a->ascale != s->pg1[0].ascale)) {
+        // the matrix was refilled after this solver was created: its fp16 product scale follows the new contents
+        if (s->a->ascale == 0.f) { const int rc0 = matrix_measure_scale(s->a, s->st); if (rc0) return rc0; }
+        for (int g = 0; g < s->ng; ++g) s->pg1[g].ascale = s->pg2[g].ascale = s->a->ascale;
+        s->pl1.ascale = s->pl2.ascale = s->a->ascale;
+    }
     // pad rows of the KP x N device layout must be (and stay) zero
     SMK_HIP(hipMemsetAsync(s->Wt, 0, (size_t)s->KP * s->m * sizeof(double), s->st));
     SMK_HIP(hipMemsetAsync(s->H, 0, (size_t)s->KP * s->n * sizeof(double), s->st));
