@@ -261,7 +261,9 @@ def main():
             "windows": len(windows), "windows_ms": [round(w * 1e3, 4) for w in windows],
             "timed_region_s": sum(windows),
             "roofline": {
-                "bound": "hbm", "kernel": "smk::bigprod_kernel (W'A and H*At passes)",
+                "bound": "hbm",
+                "kernel": ("smk::bigprod_kernel" if storage == "bf16" else "smk::bigprod_f3_kernel (fp32 A as two fp16 terms)")
+                          + " (W'A and H*At passes)",
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_ms": avg_ms, "launches": c0 + c1,
