@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- NMF iterations/sec of the MI355X dense NMF path on synthetic data.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c4|c1]
+  python bench.py --gpus N --steps K --warmup W [--workload c4|c3|c2|c1]
 
 A "step" is one NMF iteration (one pass of the hot path: both streaming products over A plus the
-factor updates).  Default workload = BASELINE.json configs[2] ("C3", the MFMA-roofline run):
-dense 65536 x 16384, k = 32, HALS, A held as bf16.  With N > 1 (launched by torch.distributed.run)
-the SAME matrix is column-sharded over the ranks ("strong" scaling, as north_star asks: the named
-(m,n,k) at 1/2/4/8 GPUs); exchange = RCCL all-reduce of HH' and (AH')' (+ an all-gather of W for BPP),
-issued from C by libsmallk_amd.so on the solver's streams -- no Python inside the iteration loop.
-torch.distributed (gloo, CPU) is used only to broadcast the RCCL unique id and for the timing barrier.
+factor updates).  Default workload = BASELINE.json configs[3] ("C4"): dense 262144 x 65536, k = 64, BPP, fp32 --
+the configuration north_star's 1/2/4/8-GPU throughput and >= 6x target are quoted on, and the largest one that
+fits a single MI355X (137 GB of A and A').  `--workload c3` is configs[2] (65536 x 16384, k = 32, HALS, bf16 A,
+the MFMA-roofline run; its line is kept in profiles/), c2 is configs[1].  With N > 1 (launched by
+torch.distributed.run) the SAME matrix is column-sharded over the ranks ("strong" scaling: the named (m,n,k) at
+1/2/4/8 GPUs); exchange = RCCL all-reduce of HH' and (AH')' (+ an all-gather of W for BPP), issued from C by
+libsmallk_amd.so on the solver's streams -- no Python inside the iteration loop.  torch.distributed (gloo, CPU)
+is used only to broadcast the RCCL unique id and for the timing barrier.
 
 The K timed steps are one window; the window is repeated (5 times, and until >= 0.5 s have been timed) and
 the MEDIAN window is reported, so `value`, `ms_per_step` are per K steps as the contract asks while short
@@ -112,7 +114,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
