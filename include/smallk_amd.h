@@ -182,7 +182,7 @@ int smk_comm_unique_id(void* id128 /* 128 bytes out */);
 int smk_comm_init_rank(smk_comm** out, const void* id128, int rank, int world);   /* on the CURRENT HIP device */
 int smk_comm_init_all(smk_comm** out /* ndev handles */, int ndev, const int* devices /* NULL: 0..ndev-1 */);
 int smk_comm_init_local(smk_comm** out /* nranks handles */, int nranks);
-/* every rank calls it: known values through one all-reduce (fp64, fp32) and one all-gather, checked on the host */
+/* every rank calls it: known values through an all-reduce (fp64, fp32), an all-gather and a reduce-scatter, checked on the host */
 int smk_comm_selftest(smk_comm* c);
 int smk_comm_rank(const smk_comm* c);
 int smk_comm_world(const smk_comm* c);

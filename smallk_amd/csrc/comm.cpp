@@ -41,8 +41,10 @@ struct LocalGroup {
 
 int launch_local_allreduce(void* const* ptrs, int world, i64 count, int f64, hipStream_t st);               // kernels.hip
 int launch_local_allgather(void* const* ptrs, int world, i64 count_per_rank, int f64, hipStream_t st);
+int launch_local_reduce_scatter(void* const* ptrs, int world, i64 count_per_rank, int f64, hipStream_t st);
 
-static int local_collective(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st, bool gather)
+enum { LOCAL_ALLREDUCE = 0, LOCAL_ALLGATHER = 1, LOCAL_REDUCE_SCATTER = 2 };
+static int local_collective(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st, int op)
 {
     LocalGroup* g = c->local;
     SMK_HIP(hipStreamSynchronize(st));          // this rank's contribution is complete
@@ -51,8 +53,9 @@ static int local_collective(smk_comm* c, void* ptr, i64 count, int f64, hipStrea
     g->barrier();
     int rc = 0;
     if (c->rank == 0) {
-        rc = gather ? launch_local_allgather(g->ptr.data(), g->world, count, f64, st)
-                    : launch_local_allreduce(g->ptr.data(), g->world, count, f64, st);
+        rc = op == LOCAL_ALLGATHER        ? launch_local_allgather(g->ptr.data(), g->world, count, f64, st)
+             : op == LOCAL_REDUCE_SCATTER ? launch_local_reduce_scatter(g->ptr.data(), g->world, count, f64, st)
+                                          : launch_local_allreduce(g->ptr.data(), g->world, count, f64, st);
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = SMK_DEVICE_ERROR;
     }
     g->barrier();                               // results are in every rank's buffer
@@ -62,7 +65,7 @@ static int local_collective(smk_comm* c, void* ptr, i64 count, int f64, hipStrea
 int comm_allreduce(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st)
 {
     if (!c || c->world == 1) return 0;
-    if (c->local) return local_collective(c, ptr, count, f64, st, false);
+    if (c->local) return local_collective(c, ptr, count, f64, st, LOCAL_ALLREDUCE);
     const ncclResult_t r = ncclAllReduce(ptr, ptr, (size_t)count, f64 ? ncclDouble : ncclFloat, ncclSum, (ncclComm_t)c->nccl, st);
     if (r != ncclSuccess) { set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return SMK_DEVICE_ERROR; }
     return 0;
@@ -72,11 +75,24 @@ int comm_allreduce(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st)
 int comm_allgather(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st)
 {
     if (!c || c->world == 1) return 0;
-    if (c->local) return local_collective(c, buf, count_per_rank, f64, st, true);
+    if (c->local) return local_collective(c, buf, count_per_rank, f64, st, LOCAL_ALLGATHER);
     const size_t es = f64 ? 8 : 4;
     const ncclResult_t r = ncclAllGather((const char*)buf + (size_t)c->rank * count_per_rank * es, buf, (size_t)count_per_rank,
                                          f64 ? ncclDouble : ncclFloat, (ncclComm_t)c->nccl, st);
     if (r != ncclSuccess) { set_error(std::string("ncclAllGather: ") + ncclGetErrorString(r)); return SMK_DEVICE_ERROR; }
+    return 0;
+}
+
+// in place: every rank holds world * count_per_rank elements; afterwards slice `rank` of this rank's buffer is the sum
+// over ranks of their slice `rank` (the other slices keep this rank's own contribution)
+int comm_reduce_scatter(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st)
+{
+    if (!c || c->world == 1) return 0;
+    if (c->local) return local_collective(c, buf, count_per_rank, f64, st, LOCAL_REDUCE_SCATTER);
+    const size_t es = f64 ? 8 : 4;
+    const ncclResult_t r = ncclReduceScatter(buf, (char*)buf + (size_t)c->rank * count_per_rank * es, (size_t)count_per_rank,
+                                             f64 ? ncclDouble : ncclFloat, ncclSum, (ncclComm_t)c->nccl, st);
+    if (r != ncclSuccess) { set_error(std::string("ncclReduceScatter: ") + ncclGetErrorString(r)); return SMK_DEVICE_ERROR; }
     return 0;
 }
 
@@ -153,7 +169,7 @@ int smk_comm_selftest(smk_comm* c)
     const int W = c->world;
     hipStream_t st = nullptr;
     double* d = nullptr;
-    std::vector<double> h((size_t)(2 * W + 2), 0.0);
+    std::vector<double> h((size_t)(2 * W + 2), 0.0);      // [0] sum f64, [1] 2 x f32, [2, 2+W) gather, [2+W, 2+2W) reduce-scatter
     int rc = SMK_OK;
     auto fail = [&](const std::string& m) { set_error("communicator self-test: " + m); rc = SMK_DEVICE_ERROR; };
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate"); return rc; }
@@ -163,15 +179,19 @@ int smk_comm_selftest(smk_comm* c)
     float f2[2] = {(float)(c->rank + 1), 0.5f};
     std::memcpy(&h[1], f2, sizeof(f2));
     h[(size_t)(2 + c->rank)] = 100.0 + c->rank;
+    for (int r = 0; r < W; ++r) h[(size_t)(2 + W + r)] = (double)((c->rank + 1) * (r + 1));     // slot r sums to (r+1) W (W+1) / 2
     if (hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) fail("upload");
     if (!rc && c->nccl) {          // also with one rank: the calls must at least go through the library
         ncclComm_t nc = (ncclComm_t)c->nccl;
         ncclResult_t r = ncclAllReduce(d, d, 1, ncclDouble, ncclSum, nc, st);
         if (r == ncclSuccess) r = ncclAllReduce(d + 1, d + 1, 2, ncclFloat, ncclSum, nc, st);
         if (r == ncclSuccess) r = ncclAllGather(d + 2 + c->rank, d + 2, 1, ncclDouble, nc, st);
+        if (r == ncclSuccess) r = ncclReduceScatter(d + 2 + W, d + 2 + W + c->rank, 1, ncclDouble, ncclSum, nc, st);
         if (r != ncclSuccess) fail(std::string("RCCL: ") + ncclGetErrorString(r));
     } else if (!rc) {
-        if (comm_allreduce(c, d, 1, 1, st) || comm_allreduce(c, d + 1, 2, 0, st) || comm_allgather(c, d + 2, 1, 1, st)) rc = SMK_DEVICE_ERROR;
+        if (comm_allreduce(c, d, 1, 1, st) || comm_allreduce(c, d + 1, 2, 0, st) || comm_allgather(c, d + 2, 1, 1, st) ||
+            comm_reduce_scatter(c, d + 2 + W, 1, 1, st))
+            rc = SMK_DEVICE_ERROR;
     }
     if (!rc && hipMemcpyAsync(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) fail("download");
     if (!rc && hipStreamSynchronize(st) != hipSuccess) fail("synchronize");
@@ -183,6 +203,7 @@ int smk_comm_selftest(smk_comm* c)
         else
             for (int r = 0; r < W; ++r)
                 if (h[(size_t)(2 + r)] != 100.0 + r) { fail("all-gather slot " + std::to_string(r) + " is wrong"); break; }
+        if (!rc && h[(size_t)(2 + W + c->rank)] != (c->rank + 1) * want) fail("reduce-scatter returned a wrong sum");
     }
     (void)hipFree(d);
     (void)hipStreamDestroy(st);

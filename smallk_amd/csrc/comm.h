@@ -16,4 +16,6 @@ namespace smk {
 int comm_allreduce(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st);
 // in place: rank r contributes buf[r * count_per_rank ...]; afterwards every rank holds all slices
 int comm_allgather(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st);
+// in place: afterwards slice `rank` (count_per_rank elements) of this rank's buffer holds the sum over ranks of that slice
+int comm_reduce_scatter(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st);
 }  // namespace smk

@@ -141,7 +141,7 @@ int launch_delta_fnorm(const double* W, double* Wprev, i64 count, double* partia
 int launch_zero_f64(double* p, i64 n, hipStream_t st);
 // sharded runs: scal[6..7] <- (scal[1], failed ? 1 : 0) before the all-reduce (unpack = 0); scal[1] <- scal[6] and
 // flag <- min(flag, tag) when any rank failed, after it (unpack = 1)
-int launch_dist_scalars(double* scal, int* flag, int tag, int unpack, hipStream_t st);
+int launch_dist_scalars(double* scal, int* flag, int tag, int unpack, int wpart, hipStream_t st);
 // dst (k x N, ld k) = first k rows of src (KP x N, ld KP)
 int launch_compact_rows(const double* src, int KP, double* dst, int k, i64 N, hipStream_t st);
 // live rows of W' and H + the Gram matrix <-> one compact buffer (pack != 0: factors -> buffer)

@@ -219,20 +219,23 @@ int launch_zero_f64(double* p, i64 n, hipStream_t st)
 
 // Sharded runs: the H-side projected-gradient sum and a "some rank failed" indicator travel in one 2-element
 // all-reduce (scal[6..7]); afterwards every rank holds the global sum in scal[1] and a consistent failure flag.
-__global__ void dist_scalars_kernel(double* __restrict__ scal, int* __restrict__ flag, int tag, int unpack)
+// wpart: the W-side projected-gradient sum is a partial one too (BPP with row-sharded W solves) and travels in scal[5]
+__global__ void dist_scalars_kernel(double* __restrict__ scal, int* __restrict__ flag, int tag, int unpack, int wpart)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (!unpack) {
+        scal[5] = wpart ? scal[0] : 0.0;
         scal[6] = scal[1];
         scal[7] = (*flag != 0x7FFFFFFF) ? 1.0 : 0.0;
     } else {
+        if (wpart) scal[0] = scal[5];
         scal[1] = scal[6];
         if (scal[7] > 0.0) atomicMin(flag, tag);
     }
 }
-int launch_dist_scalars(double* scal, int* flag, int tag, int unpack, hipStream_t st)
+int launch_dist_scalars(double* scal, int* flag, int tag, int unpack, int wpart, hipStream_t st)
 {
-    dist_scalars_kernel<<<1, 64, 0, st>>>(scal, flag, tag, unpack);
+    dist_scalars_kernel<<<1, 64, 0, st>>>(scal, flag, tag, unpack, wpart);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -258,6 +261,31 @@ __global__ __launch_bounds__(256) void local_allgather_kernel(RankPtrs rp, int w
         for (int r = 0; r < world; ++r)
             if (r != src) ((T*)rp.p[r])[i] = v;
     }
+}
+// slice r (per elements) of rank r's buffer <- sum over ranks of their slice r, fixed rank order; other slices untouched
+template <typename T>
+__global__ __launch_bounds__(256) void local_reduce_scatter_kernel(RankPtrs rp, int world, i64 per)
+{
+    const i64 total = per * world;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
+        const int dst = (int)(i / per);
+        T s = ((const T*)rp.p[0])[i];
+        for (int r = 1; r < world; ++r) s += ((const T*)rp.p[r])[i];
+        ((T*)rp.p[dst])[i] = s;
+    }
+}
+int launch_local_reduce_scatter(void* const* ptrs, int world, i64 per, int f64, hipStream_t st)
+{
+    if (world > 16) { set_error("local communicator: at most 16 ranks"); return -100; }
+    RankPtrs rp;
+    for (int r = 0; r < world; ++r) rp.p[r] = ptrs[r];
+    i64 grid = (per * world + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    if (f64) local_reduce_scatter_kernel<double><<<(unsigned)grid, 256, 0, st>>>(rp, world, per);
+    else local_reduce_scatter_kernel<float><<<(unsigned)grid, 256, 0, st>>>(rp, world, per);
+    SMK_HIP(hipGetLastError());
+    return 0;
 }
 int launch_local_allreduce(void* const* ptrs, int world, i64 count, int f64, hipStream_t st)
 {

@@ -592,6 +592,12 @@ static PartialView view1(const smk_solver* s)
     return PartialView{s->P1, s->pl1.S, (i64)s->pl1.ncols_pad * s->kpp, s->kpp, 1};
 }
 static inline bool is_dist(const smk_solver* s) { return s->ar != nullptr || s->comm != nullptr; }
+// BPP with a native communicator: every rank solves only its own rows of W, so it needs only those rows of the summed
+// (AH')' -- a reduce-scatter instead of an all-reduce (half the bytes on the wire) -- and W comes back by all-gather
+static inline bool w_rows_sharded(const smk_solver* s)
+{
+    return s->comm != nullptr && s->world > 1 && s->o.algorithm == SMK_ALG_BPP;
+}
 
 static PartialView view2(const smk_solver* s)
 {
@@ -601,16 +607,17 @@ static PartialView view2(const smk_solver* s)
 
 static size_t comm_bytes(const smk_solver* s)
 {
-    // [R2red: m_pad*kpp f32][Gh: KP*KP f64][scal: 8 f64]
-    size_t b = (size_t)s->pl2.ncols_pad * s->kpp * sizeof(float);
+    // [R2red: rows * kpp f32][Gh: KP*KP f64][scal: 8 f64]; rows = m_pad, or world equal chunks of ceil(m / world) rows
+    // when that is more (the reduce-scatter / all-gather of the row-sharded W solve work on equal chunks)
+    const i64 world = s->comm ? s->comm->world : (s->world > 0 ? s->world : 1);
+    const i64 chunk = (s->m + world - 1) / world;
+    size_t b = (size_t)std::max<i64>(s->pl2.ncols_pad, chunk * world) * s->kpp * sizeof(float);
     b = (b + 255) / 256 * 256;
     b += (size_t)s->KP * s->KP * sizeof(double);
     b = (b + 255) / 256 * 256;
     b += 8 * sizeof(double);
     b = (b + 255) / 256 * 256;
     // Wt: the row-sharded W-side NNLS gathers equal chunks of ceil(m / world) rows (the last one is padded)
-    const i64 world = s->comm ? s->comm->world : (s->world > 0 ? s->world : 1);
-    const i64 chunk = (s->m + world - 1) / world;
     b += (size_t)s->KP * (size_t)std::max<i64>(chunk * world, s->m) * sizeof(double);
     return b;
 }
@@ -784,7 +791,9 @@ static void carve_workspace(smk_solver* s, void* workspace)
 {
     unsigned char* p = (unsigned char*)workspace;
     s->R2red = (float*)p;
-    size_t b = (size_t)s->pl2.ncols_pad * s->kpp * sizeof(float);
+    const i64 world = s->comm ? s->comm->world : (s->world > 0 ? s->world : 1);      // same layout as comm_bytes()
+    const i64 chunk = (s->m + world - 1) / world;
+    size_t b = (size_t)std::max<i64>(s->pl2.ncols_pad, chunk * world) * s->kpp * sizeof(float);
     b = (b + 255) / 256 * 256;
     s->Gh = (double*)(p + b);
     b += (size_t)s->KP * s->KP * sizeof(double);
@@ -997,7 +1006,8 @@ static int prod2(smk_solver* s)
         PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
         rc = launch_reduce_partials(pv, s->k, s->pl2.ncols_pad, s->R2red, s->st);
         if (rc) return rc;
-        rc = dist_allreduce(s, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, 0, s->st);
+        if (w_rows_sharded(s)) rc = comm_reduce_scatter(s->comm, s->R2red, s->w_chunk * s->kpp, 0, s->st);   // own rows only
+        else rc = dist_allreduce(s, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, 0, s->st);
         if (rc) return rc;
     }
     return 0;
@@ -1159,11 +1169,12 @@ static int sync_and_check(smk_solver* s, int* fail_iter)
 // rank takes the same branch of the driver loop (a rank that stopped alone would strand the others in a collective)
 static int dist_agree(smk_solver* s)
 {
-    int rc = launch_dist_scalars(s->scal, s->fail_flag, s->iter > 0 ? s->iter - 1 : 0, 0, s->st);
+    const int wpart = w_rows_sharded(s) ? 1 : 0;      // the W-side sum covers this rank's rows only
+    int rc = launch_dist_scalars(s->scal, s->fail_flag, s->iter > 0 ? s->iter - 1 : 0, 0, wpart, s->st);
     if (rc) return rc;
-    rc = dist_allreduce(s, s->scal + 6, 2, 1, s->st);
+    rc = dist_allreduce(s, s->scal + 5, 3, 1, s->st);
     if (rc) return rc;
-    return launch_dist_scalars(s->scal, s->fail_flag, s->iter > 0 ? s->iter - 1 : 0, 1, s->st);
+    return launch_dist_scalars(s->scal, s->fail_flag, s->iter > 0 ? s->iter - 1 : 0, 1, wpart, s->st);
 }
 
 // progress_est->Update(iter, W, H, gradW, gradH): returns the metric (synchronises)
@@ -1176,7 +1187,15 @@ static int enqueue_progress_kernels(smk_solver* s)
         if (rc) return rc;
     } else {
         // gradW = W*HHt - AHt  (slot 0, replicated), gradH = WtW*H - WtA (slot 1, local shard)
-        rc = launch_grad_pg(s->Wt, s->k, s->m, view2(s), s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st);
+        if (w_rows_sharded(s)) {      // only this rank's rows of the summed (AH')' exist here: partial sum, joined in dist_agree
+            const i64 i0 = std::min<i64>(s->m, s->rank * s->w_chunk), i1 = std::min<i64>(s->m, i0 + s->w_chunk);
+            PartialView own = view2(s);
+            own.p = (const float*)own.p + i0 * s->kpp;
+            if (i1 > i0) rc = launch_grad_pg(s->Wt + i0 * s->KP, s->k, i1 - i0, own, s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st);
+            else rc = launch_zero_f64(s->scal, 1, s->st);
+        } else {
+            rc = launch_grad_pg(s->Wt, s->k, s->m, view2(s), s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st);
+        }
         if (rc) return rc;
         rc = launch_grad_pg(s->H, s->k, s->n, view1(s), s->Gw, nullptr, s->pg_partials + s->pg_half, s->scal, 1, s->st);
         if (rc) return rc;

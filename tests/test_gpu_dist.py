@@ -164,6 +164,22 @@ def test_sharded_one_shot_matches_single_and_oracle(gpu, alg, storage, quant, k,
     assert rel(many.W, ref.W) < TOL and rel(many.H, ref.H) < TOL
 
 
+@pytest.mark.parametrize("m,shards", [(1001, 3), (1001, 7), (1280, 5)])
+def test_sharded_bpp_rows_of_w_in_uneven_chunks(gpu, m, shards):
+    """BPP: (AH')' is reduce-scattered by row chunks of ceil(m / shards) rows, each rank solves its own rows of W and the
+    rows come back by all-gather; the last chunk is short (1001 = 2 x 334 + 333) or the chunks overrun the padded row
+    count (5 x 256 = 1280).  The stopping rule sums the W-side projected gradient over the ranks."""
+    n, k = 333, 20
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    for kw in (dict(min_iter=5, max_iter=5, tol=1e-9), dict(min_iter=2, max_iter=60, tol=0.05)):
+        ref = oracle.nmf(A, W0, H0, "BPP", **kw)
+        many = gpu.nmf_sharded(A, W0, H0, "BPP", shards, local_stub=True, **kw)
+        assert many.result == ref.result == 0 and many.iteration_count == ref.iteration_count
+        assert rel(many.W, ref.W) < TOL and rel(many.H, ref.H) < TOL
+
+
 @pytest.mark.parametrize("alg", ["MU", "HALS", "BPP"])
 def test_sharded_stopping_rule_agrees_on_every_rank(gpu, alg):
     """tolerance-based stop: every rank must leave the loop at the same iteration (the H-side projected-gradient
