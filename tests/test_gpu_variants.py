@@ -22,9 +22,16 @@ def run_quick_parity(env_extra):
     return last
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7, 9, 11, 13, 14, 15, 18, 20, 21, 100, 102, 106, 108, 111, 115, 117])
+@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7, 9, 11, 13, 14, 15, 18, 20, 21, 108, 110, 111, 115, 125, 126])
 def test_streaming_kernel_variants(variant):
+    """bf16 A: variants < 100; fp32 A (two fp16 terms, the default): the variants that form is built for"""
     run_quick_parity({"SMK_BP_VARIANT": str(variant)})
+
+
+@pytest.mark.parametrize("variant", [7, 21, 100, 102, 106, 108, 111, 115, 117])
+def test_streaming_kernel_variants_bf16x3(variant):
+    """fp32 A as three bf16 terms (SMK_NSPLIT=3): the round-1 kernel (7, 21) and the round-2 kernels"""
+    run_quick_parity({"SMK_BP_VARIANT": str(variant), "SMK_NSPLIT": "3"})
 
 
 @pytest.mark.parametrize("splits", [1, 8])
@@ -39,6 +46,13 @@ def test_hals_w_multi_launch_fallback():
 def test_two_term_operand_split():
     # 16-bit operand: looser but still inside the bar on these shapes
     run_quick_parity({"SMK_NSPLIT": "2"})
+
+
+def test_native_fp32_matrix_cores():
+    """SMK_NSPLIT=1: v_mfma_f32_32x32x2_f32 on the fp32 tile, no emulation; one iteration on five shapes"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "native_fp32_check.py")], capture_output=True, text=True,
+                       env=dict(os.environ, SMK_NSPLIT="1"), cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-1500:] + r.stderr[-1500:]
 
 
 def test_randomised_parity_sweep():
