@@ -20,6 +20,16 @@ namespace smk {
 // TRUE largest index (the reference's MaxRowIndex is off by 32 for k >= 64,
 // bit_matrix.cpp:456-468; the NNLS optimum is unique so results agree).
 // ==========================================================================
+// GS = 16: a column group is one DPP row, and row_newbcast:N (the one DPP control gfx90a+ keeps for 64-bit data) puts lane
+// N of every row into all 16 lanes of that row -- two VALU moves, no trip through the LDS crossbar
+template <int J>
+__device__ __forceinline__ double row16_bcast(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + J, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + J, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 template <int GS>
 __device__ __forceinline__ double group_bcast(double v, int src /* compile-time after unroll */)
 {
@@ -27,6 +37,14 @@ __device__ __forceinline__ double group_bcast(double v, int src /* compile-time 
         int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
         int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
         return __hiloint2double(hi, lo);
+    } else if constexpr (GS == 16) {
+        switch (src) {          // src is a constant after unrolling: one case survives
+#define SMK_BC(n) case n: return row16_bcast<n>(v);
+            SMK_BC(0) SMK_BC(1) SMK_BC(2) SMK_BC(3) SMK_BC(4) SMK_BC(5) SMK_BC(6) SMK_BC(7)
+            SMK_BC(8) SMK_BC(9) SMK_BC(10) SMK_BC(11) SMK_BC(12) SMK_BC(13) SMK_BC(14) SMK_BC(15)
+#undef SMK_BC
+            default: return v;
+        }
     } else {
         return __shfl(v, src, GS);
     }
