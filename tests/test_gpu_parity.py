@@ -429,3 +429,24 @@ def test_matrix_refilled_under_a_live_solver(gpu):
         assert rc == 0 and rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
     s.close()
     D.close()
+
+
+def test_smallk_seed_environment_pins_the_clock_seed(gpu, tmp_path):
+    """smallk::Initialize() seeds the RNG from the clock (smallk.cpp:114-119); SMALLK_SEED replaces that seed for callers
+    that never call SeedRNG() -- two fresh processes with the same value draw the same initial factors"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys; sys.path.insert(0, %r); import numpy as np\n"
+            "from smallk_amd.api import SmallkAPI\n"
+            "api = SmallkAPI(); A = np.asfortranarray(np.random.default_rng(0).random((60, 40)))\n"
+            "api.load_matrix(matrix=A); api.nmf(4, 'HALS', min_iter=3, max_iter=3, outdir=%r)\n"
+            "np.save(sys.argv[1], api.get_W())\n") % (root, str(tmp_path) + "/")
+    out = []
+    for i, seed in enumerate(("77", "77", "78")):
+        f = str(tmp_path / f"w{i}.npy")
+        r = subprocess.run([sys.executable, "-c", prog, f], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, SMALLK_SEED=seed))
+        assert r.returncode == 0, r.stderr[-1500:]
+        out.append(np.load(f))
+    assert np.array_equal(out[0], out[1]) and not np.array_equal(out[0], out[2])
