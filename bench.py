@@ -140,6 +140,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")                 # CPU side channel only: unique id, barrier, max of the clocks
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            # one node: RCCL's bootstrap sockets stay on the loopback interface (the container's hostname may not
+            # resolve) and no InfiniBand probing; the data path is xGMI either way.  The caller's settings win.
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_IB_DISABLE", "1")
     smallk_amd.initialize(device_index)
     comm, fallback_group, collectives = None, None, "none"
     if world > 1 and native:

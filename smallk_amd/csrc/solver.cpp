@@ -913,11 +913,17 @@ static int wait_gh(smk_solver* s)
 // BPP, k > 32: the inverse of a Gram matrix (side 0: W'W for the H solve, side 1: HH' for the W solve) is taken on a
 // side stream as soon as the matrix exists; the streaming product that follows on the main stream hides it.
 static inline double* inv_scratch(smk_solver* s, int side) { return s->nnls_scratch + (size_t)side * nnls_scratch_elems(s->k); }
-static int start_inverse(smk_solver* s, int side, const double* G)
+// `after`: the event that makes G final when that is not the main stream's current position (the HH' all-reduce of a
+// sharded run finishes on the second stream)
+static int start_inverse(smk_solver* s, int side, const double* G, hipEvent_t after = nullptr)
 {
     if (!s->st_inv || s->o.algorithm != SMK_ALG_BPP) return 0;
-    SMK_HIP(hipEventRecord(s->ev_g[side], s->st));
-    SMK_HIP(hipStreamWaitEvent(s->st_inv, s->ev_g[side], 0));
+    if (after) {
+        SMK_HIP(hipStreamWaitEvent(s->st_inv, after, 0));
+    } else {
+        SMK_HIP(hipEventRecord(s->ev_g[side], s->st));
+        SMK_HIP(hipStreamWaitEvent(s->st_inv, s->ev_g[side], 0));
+    }
     int rc = launch_gram_inverse(G, s->k, inv_scratch(s, side), s->st_inv);
     if (rc) return rc;
     SMK_HIP(hipEventRecord(s->ev_inv[side], s->st_inv));
@@ -1045,8 +1051,9 @@ static int gram_h(smk_solver* s)
     if (rc) return rc;
     rc = allreduce_gh(s);
     if (rc) return rc;
-    // sharded: HH' is final only after its all-reduce (joined in prod2); the inverse is taken in line then
-    return is_dist(s) ? 0 : start_inverse(s, 1, s->Gh);
+    // sharded: HH' is final only after its all-reduce -- in stream order with the callback hook, on the second stream
+    // (event ev_gh) with a native communicator; either way the inversion runs beside the H*At pass
+    return start_inverse(s, 1, s->Gh, (is_dist(s) && s->gh_pending) ? s->ev_gh : nullptr);
 }
 
 // solver.Init (mu :98-114, hals :142-159, bpp :310-335) + progress_est->Init
