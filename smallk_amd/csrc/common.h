@@ -23,8 +23,11 @@ constexpr i64 COL_PAD = 256;
 inline i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
 
 // padded k handled by the column-per-thread kernels
-inline int kp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : 128; }
-constexpr int MAX_K = 128;                     // larger ranks: SMK_UNSUPPORTED
+// padded rank: the narrow kernels are built for 8 / 16 / 32 / 64 / 128; above that ("wide", wide.hip) a multiple of 64
+inline int kp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : k <= 128 ? 128 : (k + 63) / 64 * 64; }
+constexpr int MAX_K = 512;                     // larger ranks: SMK_UNSUPPORTED
+constexpr int MAX_GROUPS = MAX_K / 64;         // the streaming product takes 64 factor rows per pass over A
+inline bool is_wide(int k) { return k > 128; }
 // number of 32-wide k tiles of the streaming product
 inline int kt_of(int k) { return (k + 31) / 32; }
 
@@ -109,6 +112,22 @@ int launch_absmax_f32(const float* A, i64 elems, unsigned* out, hipStream_t st);
 // no fused kernel.  The ticket word at scratch[max_blocks * KP * KP] must be zero before the first call.
 int launch_gram_pack(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, int storage, int nsplit,
                      void* packed, hipStream_t st);
+
+// ---- k > 128 (wide.hip): one wave per column, the Gram matrix through the caches; reached through the launch_*
+// functions below and in nnls.hip, which branch on is_wide(k)
+int launch_gram_wide_partials(const double* X, int KP, i64 N, double* scratch, int max_blocks, int* nblk_out, hipStream_t st);
+int gram_wide_blocks(int KP, i64 N, int max_blocks);
+int launch_mu_update_wide(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
+int launch_hals_sweep_wide(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
+int launch_grad_pg_wide(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out, double* pg_partials,
+                        int* grid_out, hipStream_t st);
+int hals_w_wide_blocks(i64 M);
+int launch_hals_w_update_wide(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, hipStream_t st);
+int launch_spmm_gather_wide(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X, int k,
+                            double* P, int kpp, hipStream_t st);
+size_t nnls_wide_scratch_elems(int k, int num_cus);
+int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G, int* fail_flag,
+                         int iter_tag, double* scratch, int num_cus, hipStream_t st);
 
 int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
 int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);

@@ -726,6 +726,7 @@ int launch_absmax_f32(const float* A, i64 elems, unsigned* out, hipStream_t st)
 size_t gram_scratch_elems(int k, int max_blocks)
 {
     int KP = kp_of(k);
+    if (is_wide(k)) return (size_t)gram_wide_blocks(KP, (i64)1 << 40, max_blocks) * KP * KP + 8;
     return (size_t)max_blocks * KP * KP + 8;             // + the ticket word of the fused Gram/pack kernel
 }
 
@@ -735,7 +736,10 @@ int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int m
     const int KP = kp_of(k);
     const int elems = KP * KP;
     int nblk;
-    if (KP >= 16) {
+    if (is_wide(k)) {
+        const int rc = launch_gram_wide_partials(X, KP, N, scratch, max_blocks, &nblk, st);
+        if (rc) return rc;
+    } else if (KP >= 16) {
         nblk = (int)((N + 255) / 256);               // >= 64 columns per wave
         if (nblk > max_blocks) nblk = max_blocks;
         if (nblk < 1) nblk = 1;
@@ -959,6 +963,7 @@ static int coltile_lds(K kern, int KP)
 
 int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st)
 {
+    if (is_wide(k)) return launch_mu_update_wide(X, k, N, R, G, st);
     const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
     COLTILE_LAUNCH(mu_update_kernel, grid, X, k, N, R, G);
     SMK_HIP(hipGetLastError());
@@ -967,6 +972,7 @@ int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hi
 
 int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st)
 {
+    if (is_wide(k)) return launch_hals_sweep_wide(X, k, N, R, G, st);
     const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
     COLTILE_LAUNCH(hals_sweep_kernel, grid, X, k, N, R, G);
     SMK_HIP(hipGetLastError());
@@ -976,6 +982,14 @@ int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, h
 int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
                    double* pg_partials, double* pg_accum, int slot, hipStream_t st)
 {
+    if (is_wide(k)) {
+        int g = 0;
+        const int rc = launch_grad_pg_wide(X, k, N, R, G, grad_out, pg_partials, &g, st);
+        if (rc) return rc;
+        sum_partials_kernel<<<1, 256, 0, st>>>(pg_partials, g, pg_accum + slot);
+        SMK_HIP(hipGetLastError());
+        return 0;
+    }
     const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
     COLTILE_LAUNCH(grad_pg_kernel, grid, X, k, N, R, G, grad_out, pg_partials);
     SMK_HIP(hipGetLastError());
@@ -1286,6 +1300,7 @@ __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ W
 
 size_t hals_w_scratch_elems(int k, i64 M)
 {
+    if (is_wide(k)) return (size_t)(2 * (i64)k * hals_w_wide_blocks(M));
     const size_t multi = (size_t)(2 * (i64)k * hals_w_blocks(kp_of(k), M));
     const size_t fused = (size_t)2 * k * 1024;      // two slot buffers (8 bytes per slot), generous
     return multi > fused ? multi : fused;
@@ -1302,6 +1317,7 @@ int hals_w_scratch_init(double* scratch, int k, i64 M, hipStream_t st)
 int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, int num_cus,
                          int* fail_flag, int parity, int force_multi, hipStream_t st)
 {
+    if (is_wide(k)) return launch_hals_w_update_wide(Wt, k, M, R, G, scratch, st);
     const int KPv = kp_of(k);
     static int mode = -1;                            // SMK_HALS_W=multi forces the one-launch-per-column path
     static unsigned spin_max = 1u << 22;             // SMK_HALS_SPIN=<n>: bound of the exchange polls (tests)
@@ -1414,6 +1430,7 @@ __global__ __launch_bounds__(256) void spmm_gather2_kernel(const i64* __restrict
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X,
                        int k, double* P, int kpp, hipStream_t st)
 {
+    if (is_wide(k)) return launch_spmm_gather_wide(colptr, rowidx, val, ncols, X, k, P, kpp, st);
     const int KPv = kp_of(k);
     static const bool rank2_path = [] { const char* e = getenv("SMK_SPMM2"); return !(e && e[0] == '0'); }();
     if (k <= 2 && rank2_path) {

@@ -611,14 +611,14 @@ __global__ __launch_bounds__(NT) void nnls_bpp_inv128_kernel(double* __restrict_
     if (failed_any && lane == 0) atomicMin(fail_flag, iter_tag);
 }
 
-size_t nnls_scratch_elems(int k) { return (size_t)kp_of(k) * kp_of(k) + 8; }
+size_t nnls_scratch_elems(int k) { return (size_t)kp_of(k) * kp_of(k) + 8; }     // k <= 128; above: nnls_wide_scratch_elems
 
 // k > 32: Ginv and the path selector into `scratch` (nnls_scratch_elems(k) doubles).  One workgroup, ~0.1 ms: the
 // solver runs it on a side stream beside the streaming product that separates the Gram matrix from its NNLS.
 int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st)
 {
     const int KPv = kp_of(k);
-    if (KPv < 64 || !scratch) return 0;
+    if (KPv < 64 || KPv > 128 || !scratch) return 0;
     if (KPv == 64) gram_inverse_kernel<64><<<1, 256, 0, st>>>(G, k, scratch, (int*)(scratch + 64 * 64));
     else gram_inverse_kernel<128><<<1, 256, 0, st>>>(G, k, scratch, (int*)(scratch + 128 * 128));
     SMK_HIP(hipGetLastError());
@@ -631,6 +631,7 @@ int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st)
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
                     int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st)
 {
+    if (is_wide(k)) return launch_nnls_bpp_wide(X, Y, k, col_begin, col_end, R, G, fail_flag, iter_tag, scratch, num_cus, st);
     const int KPv = kp_of(k);
     const int gpb = 256 / KPv;
     const i64 ncols = col_end - col_begin;

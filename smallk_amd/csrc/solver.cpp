@@ -115,7 +115,7 @@ struct smk_solver {
     double *P1 = nullptr, *P2 = nullptr;
     float* R2red = nullptr;
     BigProdPlan pl1, pl2;                 // first group of each pass (row splits, P layout)
-    BigProdPlan pg1[2], pg2[2];           // all groups: k > 64 streams the big matrix once per 64 factor rows
+    BigProdPlan pg1[MAX_GROUPS], pg2[MAX_GROUPS];   // all groups: k > 64 streams the big matrix once per 64 factor rows
     int ng = 1;
     int* fail_flag = nullptr;
     int iter = 0;
@@ -654,7 +654,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if (!opts || !a) return SMK_BAD_PARAM;
     if (!smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
     if (opts->height != a->m || opts->width != a->n_global) { set_error("options/matrix dimension mismatch"); return SMK_BAD_PARAM; }
-    if (opts->k > MAX_K) { set_error("device path supports k <= 128"); return SMK_UNSUPPORTED; }
+    if (opts->k > MAX_K) { set_error("device path supports k <= 512"); return SMK_UNSUPPORTED; }
     // W and H element counts must fit the reference's 32-bit index (nmf.cpp:194-210)
     if ((uint64_t)a->m * (uint64_t)opts->k > 0x7FFFFFFFull) { fprintf(stderr, "W matrix size too large\n"); return SMK_SIZE_TOO_LARGE; }
     if ((uint64_t)a->n_global * (uint64_t)opts->k > 0x7FFFFFFFull) { fprintf(stderr, "H matrix size too large\n"); return SMK_SIZE_TOO_LARGE; }
@@ -718,6 +718,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     // one partial per workgroup of the column-tile kernels (grid = N*(KP/4)/256 blocks) and at most
     // 2 x 512 for delta_fnorm
     s->pg_half = (size_t)((std::max(s->m, s->n) * (s->KP / 4) + 255) / 256) + 1024;
+    if (is_wide(s->k)) s->pg_half = std::max(s->pg_half, (size_t)((std::max(s->m, s->n) + 3) / 4) + 1024);   // one partial per 4 columns
     rc |= dev_alloc(&s->pg_partials, 2 * s->pg_half);
     rc |= dev_alloc(&s->scal_own, (size_t)8);
     rc |= dev_alloc(&s->fail_flag, (size_t)1);
@@ -734,8 +735,9 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
         if (!rc) rc = hals_w_scratch_init(s->hals_scratch, s->k, s->m, s->st);
     }
     if (opts->algorithm == SMK_ALG_BPP) {
-        rc |= dev_alloc(&s->nnls_scratch, 2 * nnls_scratch_elems(s->k));
-        if (s->KP >= 64) {
+        // k <= 128: two (inverse + selector) halves; above: one Cholesky panel per resident workgroup (wide.hip)
+        rc |= dev_alloc(&s->nnls_scratch, is_wide(s->k) ? nnls_wide_scratch_elems(s->k, g_cus) : 2 * nnls_scratch_elems(s->k));
+        if (s->KP >= 64 && !is_wide(s->k)) {
             if (hipStreamCreateWithFlags(&s->st_inv, hipStreamNonBlocking) != hipSuccess) rc |= 1;
             for (int i = 0; i < 2 && !rc; ++i) {
                 if (hipEventCreateWithFlags(&s->ev_g[i], hipEventDisableTiming) != hipSuccess) rc |= 1;
@@ -912,7 +914,10 @@ static int wait_gh(smk_solver* s)
 
 // BPP, k > 32: the inverse of a Gram matrix (side 0: W'W for the H solve, side 1: HH' for the W solve) is taken on a
 // side stream as soon as the matrix exists; the streaming product that follows on the main stream hides it.
-static inline double* inv_scratch(smk_solver* s, int side) { return s->nnls_scratch + (size_t)side * nnls_scratch_elems(s->k); }
+static inline double* inv_scratch(smk_solver* s, int side)
+{
+    return is_wide(s->k) ? s->nnls_scratch : s->nnls_scratch + (size_t)side * nnls_scratch_elems(s->k);
+}
 // `after`: the event that makes G final when that is not the main stream's current position (the HH' all-reduce of a
 // sharded run finishes on the second stream)
 static int start_inverse(smk_solver* s, int side, const double* G, hipEvent_t after = nullptr)
@@ -1250,7 +1255,7 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
         for (int i = 0; i < 2; ++i) SMK_HIP(hipEventCreateWithFlags(&s->pev[i], hipEventDisableTiming));
     }
     int rc = 0;
-    if (s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s)) {
+    if (s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s) && !is_wide(s->k)) {
         // both gradients in one launch, both sums + the failure flag in a second, one 64-byte read-back
         rc = launch_grad_pg2(s->Wt, s->m, view2(s), s->Gh, s->pg_partials, s->H, s->n, view1(s), s->Gw,
                              s->pg_partials + s->pg_half, s->k, s->scal, s->fail_flag, 5, s->st);
@@ -1529,7 +1534,7 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
 {
     if (!g_init) { set_error("smk_initialize() has not been called"); return SMK_NOTINITIALIZED; }
     if (k <= 0 || ncols <= 0 || !LHS || !RHS || !X || ldL < k || ldR < k || ldX < k || (Y && ldY < k)) return SMK_BAD_PARAM;
-    if (k > MAX_K) { set_error("device path supports k <= 128"); return SMK_UNSUPPORTED; }
+    if (k > MAX_K) { set_error("device path supports k <= 512"); return SMK_UNSUPPORTED; }
     const int KP = kp_of(k);
     std::vector<double> hg((size_t)KP * KP, 0.0), hr((size_t)KP * ncols, 0.0), hx((size_t)KP * ncols, 0.0);
     for (int c = 0; c < k; ++c)
@@ -1546,7 +1551,7 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
     rc |= dev_alloc(&dr, hr.size());
     rc |= dev_alloc(&dx, hx.size());
     rc |= dev_alloc(&dy, hx.size());
-    rc |= dev_alloc(&dscratch, nnls_scratch_elems(k));
+    rc |= dev_alloc(&dscratch, is_wide(k) ? nnls_wide_scratch_elems(k, g_cus) : nnls_scratch_elems(k));
     rc |= dev_alloc(&dflag, (size_t)1);
     struct Free { std::vector<void*> p; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } guard{{dg, dr, dx, dy, dscratch, dflag}};
     if (rc) return SMK_DEVICE_ERROR;

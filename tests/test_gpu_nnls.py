@@ -102,7 +102,19 @@ def test_k_above_64_every_passive_density(gpu, k, fill):
     compare(gpu, G, B, np.asfortranarray(X0))
 
 
-@pytest.mark.parametrize("k", [4, 16, 40, 64, 100])
+@pytest.mark.parametrize("k", [129, 192, 250, 400])
+@pytest.mark.parametrize("fill", [0.0, 0.3, 0.7, 1.0])
+def test_k_above_128_every_passive_density(gpu, k, fill):
+    """k in (128, 512]: a workgroup per column, Cholesky of the passive block in a global scratch panel (wide.hip)"""
+    rng = np.random.default_rng(int(k * 10 + fill * 100))
+    ncols = 60
+    G, B = problem(rng, 4 * k + 5, k, ncols, shift=False)
+    B -= np.quantile(B, 1.0 - fill) if 0.0 < fill < 1.0 else (np.abs(B).max() * 2 if fill == 0.0 else 0.0)
+    X0 = rng.random((k, ncols)) * (rng.random((k, ncols)) < fill)
+    compare(gpu, G, B, np.asfortranarray(X0))
+
+
+@pytest.mark.parametrize("k", [4, 16, 40, 64, 100, 130, 260])
 def test_not_positive_definite_is_failure(gpu, k):
     """Rank-one Gram matrix: the passive block is not SPD -> false (normal_eq.hpp:35-50)."""
     G = np.ones((k, k), order="F")
@@ -112,7 +124,7 @@ def test_not_positive_definite_is_failure(gpu, k):
     assert not oko and not okg
 
 
-@pytest.mark.parametrize("k", [12, 48, 64])
+@pytest.mark.parametrize("k", [12, 48, 64, 150])
 def test_hard_problems_use_backup_rule(gpu, k):
     """Strongly correlated columns and alternating-sign right-hand sides make full exchanges cycle, so P
     runs out and the single-variable backup rule decides (src/nnls.cpp:52-70).  Results still agree."""

@@ -58,7 +58,7 @@ def test_matrix_market_loader(tmp_path):
 @pytest.mark.parametrize("alg,m,n,k,density,iters", [
     ("MU", 300, 200, 8, 0.2, 20), ("BPP", 300, 200, 8, 0.2, 10), ("HALS", 300, 200, 8, 0.3, 10),
     ("RANK2", 300, 200, 2, 0.2, 20), ("BPP", 512, 400, 33, 0.1, 5), ("MU", 1000, 700, 64, 0.02, 10),
-    ("BPP", 2000, 1500, 16, 0.05, 5),
+    ("BPP", 2000, 1500, 16, 0.05, 5), ("MU", 900, 700, 200, 0.3, 4), ("BPP", 900, 700, 150, 0.5, 3),
     # HALS is exercised only on the denser small case: on very sparse data rows of H die and the
     # reference update is discontinuous there (see tests/golden/make_golden.py; the reference's own
     # sparse-vs-dense test skips HALS, test_dense_nmf.cpp:263-266)
