@@ -387,24 +387,143 @@ int launch_spmm_gather_wide(const i64* colptr, const unsigned* rowidx, const dou
 
 // --------------------------------------------------------------------------------------------------------------------
 // NNLS by block principal pivoting (nnls.hpp:144-244, src/nnls.cpp:18-74, normal_eq.hpp:27-54), one workgroup per column.
-// The passive block G[F,F] is gathered into this workgroup's panel of global scratch (column-major lower triangle, leading
-// dimension t = |F|), factored by a right-looking Cholesky (a pivot <= 0 is the reference's "not SPD" failure), and
-// solved by forward / back substitution on vectors in LDS; y = G x - r through the caches.  State machine as in
-// nnls_bpp_kernel: PBAR = 3, backup rule on the largest index, 5 k pivots at most, 1e-12 zeroing after every exchange.
+//
+// As for k in (32, 128] (nnls.hip) the common work is moved into the inverse of the Gram matrix: Ginv = G^-1 once per
+// launch (chol_wide_kernel + inv_cols_wide_kernel), v = Ginv r per column, and a passive set F is solved either
+// directly, G[F,F] x_F = r_F, y = G[:,F] x_F - r, or through its complement Z: y_Z = -(Ginv[Z,Z])^-1 v_Z,
+// x = v + Ginv[:,Z] y_Z -- whichever block is smaller.  The block (t = min(|F|, |Z|) rows) is gathered into a panel
+// (LDS when t <= 128, else this workgroup's panel of global scratch; the code is the same through generic pointers),
+// factored by a right-looking Cholesky and solved by forward / back substitution on an LDS vector.  A pivot <= 0 is the
+// reference's "not SPD" failure.  When G itself is not safely invertible (a pivot of its Cholesky below 1e-9 of the
+// diagonal) only the direct form is used, which is the reference's own computation.
+// State machine as in nnls_bpp_kernel: PBAR = 3, backup rule on the largest index, 5 k pivots at most, 1e-12 zeroing
+// after every exchange.
 // --------------------------------------------------------------------------------------------------------------------
 constexpr int WIDE_MAX = 512;
+constexpr int WIDE_TL = 128;                       // largest block kept in LDS (128 KiB)
+
+// in-place Cholesky of the column-major lower triangle Mp (leading dimension t), then L z = b, L' x = z on zs (LDS).
+// Every thread of the workgroup calls it; returns true when a pivot is not positive (uniform).
+__device__ __forceinline__ bool chol_solve_panel(double* Mp, int t, double* zs, int* s_bad)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) *s_bad = 0;
+    __syncthreads();
+    for (int j = 0; j < t; ++j) {
+        const double piv = Mp[(size_t)j * t + j];
+        if (!(piv > 0.0)) {                                     // uniform: every thread reads the same entry
+            if (tid == 0) *s_bad = 1;
+            break;
+        }
+        const double d = sqrt(piv), id = 1.0 / d;
+        __syncthreads();                                        // everyone has read the pivot
+        for (int i = j + 1 + tid; i < t; i += nt) Mp[(size_t)j * t + i] *= id;
+        if (tid == 0) Mp[(size_t)j * t + j] = d;
+        __syncthreads();
+        {   // trailing update on a 16 x (nt / 16) thread grid: entry (i, l), j < l <= i < t
+            const int ti = tid & 15, tl = tid >> 4, nl = nt >> 4;
+            for (int l = j + 1 + tl; l < t; l += nl) {
+                const double mlj = Mp[(size_t)j * t + l];
+                for (int i = l + ti; i < t; i += 16) Mp[(size_t)l * t + i] -= Mp[(size_t)j * t + i] * mlj;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (*s_bad) return true;
+    for (int j = 0; j < t; ++j) {                               // L z = b
+        const double zj = zs[j] / Mp[(size_t)j * t + j];
+        __syncthreads();
+        if (tid == 0) zs[j] = zj;
+        for (int i = j + 1 + tid; i < t; i += nt) zs[i] -= Mp[(size_t)j * t + i] * zj;
+        __syncthreads();
+    }
+    for (int j = t - 1; j >= 0; --j) {                          // L' x = z
+        const double xj = zs[j] / Mp[(size_t)j * t + j];
+        __syncthreads();
+        if (tid == 0) zs[j] = xj;
+        for (int i = tid; i < j; i += nt) zs[i] -= Mp[(size_t)i * t + j] * xj;
+        __syncthreads();
+    }
+    return false;
+}
+
+// L = chol(G) (lower, column-major, leading dimension KP) by one workgroup; status = 1 when every pivot exceeds 1e-9 of
+// its diagonal entry (the guard of gram_inverse_kernel), else 0
+__global__ __launch_bounds__(1024) void chol_wide_kernel(const double* __restrict__ G, int k, int KP, double* __restrict__ L,
+                                                         int* __restrict__ status)
+{
+    __shared__ int bad;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int q = tid; q < k * k; q += nt) {
+        const int i = q % k, l = q / k;
+        if (i >= l) L[(size_t)l * KP + i] = G[(size_t)l * KP + i];
+    }
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        const double piv = L[(size_t)j * KP + j];
+        if (!(piv > 1.0e-9 * G[(size_t)j * KP + j])) {
+            if (tid == 0) bad = 1;
+            break;
+        }
+        const double d = sqrt(piv), id = 1.0 / d;
+        __syncthreads();
+        for (int i = j + 1 + tid; i < k; i += nt) L[(size_t)j * KP + i] *= id;
+        if (tid == 0) L[(size_t)j * KP + j] = d;
+        __syncthreads();
+        const int w = k - j - 1;
+        for (int q = tid; q < w * w; q += nt) {
+            const int i = j + 1 + q % w, l = j + 1 + q / w;
+            if (i >= l) L[(size_t)l * KP + i] -= L[(size_t)j * KP + i] * L[(size_t)j * KP + l];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) *status = bad ? 0 : 1;
+}
+
+// column c of Ginv = G^-1 from L: L z = e_c, L' x = z; one workgroup per column
+__global__ __launch_bounds__(256) void inv_cols_wide_kernel(const double* __restrict__ L, int k, int KP, double* __restrict__ Ginv,
+                                                            const int* __restrict__ status)
+{
+    __shared__ double z[WIDE_MAX];
+    if (*status == 0) return;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < k; e += 256) z[e] = (e == c) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int j = c; j < k; ++j) {                               // z_j = 0 for j < c
+        const double zj = z[j] / L[(size_t)j * KP + j];
+        __syncthreads();
+        if (tid == 0) z[j] = zj;
+        for (int i = j + 1 + tid; i < k; i += 256) z[i] -= L[(size_t)j * KP + i] * zj;
+        __syncthreads();
+    }
+    for (int j = k - 1; j >= 0; --j) {
+        const double xj = z[j] / L[(size_t)j * KP + j];
+        __syncthreads();
+        if (tid == 0) z[j] = xj;
+        for (int i = tid; i < j; i += 256) z[i] -= L[(size_t)i * KP + j] * xj;
+        __syncthreads();
+    }
+    for (int e = tid; e < KP; e += 256) Ginv[(size_t)c * KP + e] = (e < k) ? z[e] : 0.0;
+}
 
 __global__ __launch_bounds__(256) void nnls_wide_kernel(double* __restrict__ X, double* __restrict__ Y, int k, int KP, i64 N,
                                                         PartialView R, const double* __restrict__ G,
+                                                        const double* __restrict__ Ginv, const int* __restrict__ status,
                                                         int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
-                                                        double* __restrict__ scratch)
+                                                        double* __restrict__ panels, int tl_cap, int skip_if_invertible)
 {
-    __shared__ double xs[WIDE_MAX], ys[WIDE_MAX], rs[WIDE_MAX], zs[WIDE_MAX];
+    extern __shared__ __attribute__((aligned(16))) double lds_panel[];          // tl_cap * tl_cap doubles
+    if (skip_if_invertible && Ginv != nullptr && *status != 0) return;          // the wave kernel took this launch
+    __shared__ double xs[WIDE_MAX], ys[WIDE_MAX], rs[WIDE_MAX], zs[WIDE_MAX], vs[WIDE_MAX];
     __shared__ int idx[WIDE_MAX];
     __shared__ unsigned char pas[WIDE_MAX], nonopt[WIDE_MAX], infeas[WIDE_MAX];
-    __shared__ int s_t, s_ng, s_bad, s_last;
-    double* M = scratch + (size_t)blockIdx.x * KP * KP;
+    __shared__ int s_t, s_ng, s_bad, s_last, s_comp;
+    double* gpanel = panels + (size_t)blockIdx.x * KP * KP;
     const int tid = threadIdx.x;
+    const bool use_inv = Ginv != nullptr && *status != 0;
     int failed_any = 0;
 
     for (i64 col = col_begin + blockIdx.x; col < N; col += gridDim.x) {
@@ -415,77 +534,87 @@ __global__ __launch_bounds__(256) void nnls_wide_kernel(double* __restrict__ X, 
             pas[e] = x0 > 0.0;                      // passive_set = (X > 0), nnls.hpp:157
         }
         __syncthreads();
+        if (use_inv) {                              // v = Ginv r
+            for (int e = tid; e < k; e += 256) {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;          // four chains: the loads of 8 rows are in flight together
+                int c = 0;
+#pragma unroll 2
+                for (; c + 4 <= k; c += 4) {
+                    a0 = __builtin_fma(Ginv[(size_t)c * KP + e], rs[c], a0);
+                    a1 = __builtin_fma(Ginv[(size_t)(c + 1) * KP + e], rs[c + 1], a1);
+                    a2 = __builtin_fma(Ginv[(size_t)(c + 2) * KP + e], rs[c + 2], a2);
+                    a3 = __builtin_fma(Ginv[(size_t)(c + 3) * KP + e], rs[c + 3], a3);
+                }
+                for (; c < k; ++c) a0 = __builtin_fma(Ginv[(size_t)c * KP + e], rs[c], a0);
+                vs[e] = (a0 + a1) + (a2 + a3);
+            }
+            __syncthreads();
+        }
 
-        // x_F = G[F,F]^-1 r_F, x elsewhere 0; y = G x - r; then the two violation sets and their size
-        auto solve_and_classify = [&](bool zeroize) {
+        // one block-pivot solve for the current passive set, then the two violation sets and their size
+        auto solve_and_classify = [&](bool zeroize) -> bool {
             if (tid == 0) {
+                int p = 0;
+                for (int e = 0; e < k; ++e) p += pas[e] ? 1 : 0;
+                const int comp = (use_inv && (k - p) <= p) ? 1 : 0;       // the smaller block
                 int t = 0;
                 for (int e = 0; e < k; ++e)
-                    if (pas[e]) idx[t++] = e;
+                    if ((pas[e] != 0) != (comp != 0)) idx[t++] = e;      // direct: the passive ones; complement: the others
                 s_t = t;
-                s_bad = 0;
+                s_comp = comp;
             }
             __syncthreads();
             const int t = s_t;
-            for (int q = tid; q < t * t; q += 256) {            // lower triangle, column-major: (i, l), i >= l, at M[l t + i]
+            const bool comp = s_comp != 0;
+            const double* Msrc = comp ? Ginv : G;
+            double* Mp = (t <= tl_cap) ? lds_panel : gpanel;
+#pragma unroll 4
+            for (int q = tid; q < t * t; q += 256) {            // lower triangle, column-major: (i, l), i >= l, at Mp[l t + i]
                 const int i = q % t, l = q / t;
-                if (i >= l) M[(size_t)l * t + i] = G[(i64)idx[l] * KP + idx[i]];
+                if (i >= l) Mp[(size_t)l * t + i] = Msrc[(size_t)idx[l] * KP + idx[i]];
             }
-            for (int a = tid; a < t; a += 256) zs[a] = rs[idx[a]];
+            for (int a = tid; a < t; a += 256) zs[a] = comp ? -vs[idx[a]] : rs[idx[a]];
             __syncthreads();
-            for (int j = 0; j < t; ++j) {
-                const double piv = M[(size_t)j * t + j];
-                if (!(piv > 0.0)) {                             // uniform: every thread reads the same entry
-                    if (tid == 0) s_bad = 1;
-                    break;
+            const bool bad = (t > 0) ? chol_solve_panel(Mp, t, zs, &s_bad) : false;
+            // out = base + Msrc[:, T] u  with base = v (complement) or -r (direct)
+            for (int e = tid; e < k; e += 256) {
+                double acc = comp ? vs[e] : -rs[e];
+                if (!bad) {
+                    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                    int a = 0;
+#pragma unroll 2
+                    for (; a + 4 <= t; a += 4) {
+                        acc = __builtin_fma(Msrc[(size_t)idx[a] * KP + e], zs[a], acc);
+                        a1 = __builtin_fma(Msrc[(size_t)idx[a + 1] * KP + e], zs[a + 1], a1);
+                        a2 = __builtin_fma(Msrc[(size_t)idx[a + 2] * KP + e], zs[a + 2], a2);
+                        a3 = __builtin_fma(Msrc[(size_t)idx[a + 3] * KP + e], zs[a + 3], a3);
+                    }
+                    for (; a < t; ++a) acc = __builtin_fma(Msrc[(size_t)idx[a] * KP + e], zs[a], acc);
+                    acc = (acc + a1) + (a2 + a3);
                 }
-                const double d = sqrt(piv), id = 1.0 / d;
-                __syncthreads();                                // everyone has read the pivot
-                for (int i = j + 1 + tid; i < t; i += 256) M[(size_t)j * t + i] *= id;
-                if (tid == 0) M[(size_t)j * t + j] = d;
-                __syncthreads();
-                const int w = t - j - 1;
-                for (int q = tid; q < w * w; q += 256) {
-                    const int i = j + 1 + q % w, l = j + 1 + q / w;
-                    if (i >= l) M[(size_t)l * t + i] -= M[(size_t)j * t + i] * M[(size_t)j * t + l];
-                }
-                __syncthreads();
+                double x, y;
+                if (comp) { x = pas[e] ? acc : 0.0; y = 0.0; }         // y on Z is u, scattered below
+                else      { x = 0.0; y = pas[e] ? 0.0 : acc; }         // x on F is u, scattered below
+                xs[e] = x;
+                ys[e] = y;
             }
-            __syncthreads();
-            const bool bad = s_bad != 0;
-            if (!bad) {
-                for (int j = 0; j < t; ++j) {                   // L z = b
-                    const double zj = zs[j] / M[(size_t)j * t + j];
-                    __syncthreads();
-                    if (tid == 0) zs[j] = zj;
-                    for (int i = j + 1 + tid; i < t; i += 256) zs[i] -= M[(size_t)j * t + i] * zj;
-                    __syncthreads();
-                }
-                for (int j = t - 1; j >= 0; --j) {              // L' x = z
-                    const double xj = zs[j] / M[(size_t)j * t + j];
-                    __syncthreads();
-                    if (tid == 0) zs[j] = xj;
-                    for (int i = tid; i < j; i += 256) zs[i] -= M[(size_t)i * t + j] * xj;
-                    __syncthreads();
-                }
-            }
-            for (int e = tid; e < k; e += 256) xs[e] = 0.0;
             __syncthreads();
             if (!bad)
                 for (int a = tid; a < t; a += 256) {
-                    double v = zs[a];
-                    if (zeroize && fabs(v) < 1.0e-12) v = 0.0;      // ZeroizeSmallValues, nnls.hpp:213,224
-                    xs[idx[a]] = v;
+                    if (comp) ys[idx[a]] = zs[a];
+                    else xs[idx[a]] = zs[a];
                 }
             __syncthreads();
-            for (int e = tid; e < k; e += 256) {                    // y = G x - r (G symmetric: row idx[a] read along e)
-                double acc = 0.0;
-                for (int a = 0; a < t; ++a) acc = __builtin_fma(G[(i64)idx[a] * KP + e], xs[idx[a]], acc);
-                double y = acc - rs[e];
-                if (zeroize && fabs(y) < 1.0e-12) y = 0.0;          // :225
-                ys[e] = y;
+            for (int e = tid; e < k; e += 256) {
+                double x = xs[e], y = ys[e];
+                if (zeroize) {                                         // ZeroizeSmallValues, nnls.hpp:213,224-225
+                    if (fabs(x) < 1.0e-12) x = 0.0;
+                    if (fabs(y) < 1.0e-12) y = 0.0;
+                    xs[e] = x;
+                    ys[e] = y;
+                }
                 nonopt[e] = (!pas[e]) && (y < 0.0);
-                infeas[e] = pas[e] && (xs[e] < 0.0);
+                infeas[e] = pas[e] && (x < 0.0);
             }
             __syncthreads();
             if (tid == 0) {
@@ -533,10 +662,266 @@ __global__ __launch_bounds__(256) void nnls_wide_kernel(double* __restrict__ X, 
     if (failed_any && tid == 0) atomicMin(fail_flag, iter_tag);
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// The same algorithm with one WAVE per column and no workgroup barrier at all (k <= 256, Gram matrix safely invertible):
+// the block solved per exchange has at most k / 2 rows (the smaller of F and Z), its lower triangle is kept PACKED in this
+// wave's slice of LDS (t (t + 1) / 2 doubles: 66 KB at t = 128), sets are built with ballots, and every step of the
+// Cholesky and of the substitutions is wave-synchronous (LDS operations of one wave execute in order; WAVE_SYNC only stops
+// the compiler from moving them).  The workgroup kernel above spends its time in ~7 t barriers per solve; here a solve
+// costs its ~t^3 / 6 multiply-adds over 64 lanes plus ~4 t LDS round trips.
+// --------------------------------------------------------------------------------------------------------------------
+#define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+__host__ __device__ static inline int tri_elems(int t) { return t * (t + 1) / 2; }
+__device__ __forceinline__ int tri_off(int l, int t) { return l * t - (l * (l - 1)) / 2; }      // start of column l (entry (l, l))
+
+// per-wave LDS slice: [panel: tri(tl)] [xs ys rs zs vs: 5 x kq doubles] [idx: kq ints] [pas: kq bytes], kq = k rounded up to 64
+static inline size_t wave_slice_bytes(int k)
+{
+    const int kq = (k + 63) / 64 * 64, tl = (k + 1) / 2;
+    return (size_t)tri_elems(tl) * 8 + (size_t)5 * kq * 8 + (size_t)kq * 4 + (size_t)kq;
+}
+
+__global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict__ X, double* __restrict__ Y, int k, int KP, i64 N,
+                                                             PartialView R, const double* __restrict__ G,
+                                                             const double* __restrict__ Ginv, const int* __restrict__ status,
+                                                             int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
+                                                             int slice_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wave_lds[];
+    if (*status == 0) return;                                   // the workgroup kernel takes this launch
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int kq = (k + 63) / 64 * 64, tl = (k + 1) / 2;
+    unsigned char* base = wave_lds + (size_t)wave * slice_bytes;
+    double* Mp = (double*)base;
+    double* xs = Mp + tri_elems(tl);
+    double* ys = xs + kq;
+    double* rs = ys + kq;
+    double* zs = rs + kq;
+    double* vs = zs + kq;
+    int* idx = (int*)(vs + kq);
+    unsigned char* pas = (unsigned char*)(idx + kq);
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int failed_any = 0;
+
+    for (i64 col = col_begin + (i64)blockIdx.x * nwaves + wave; col < N; col += (i64)gridDim.x * nwaves) {
+        for (int e = lane; e < kq; e += 64) {
+            const bool in = e < k;
+            const double x0 = in ? X[col * KP + e] : 0.0;
+            rs[e] = in ? rhs_elem(R, col, e) : 0.0;
+            xs[e] = x0;
+            pas[e] = in && x0 > 0.0;                            // passive_set = (X > 0), nnls.hpp:157
+        }
+        WAVE_SYNC();
+        for (int e = lane; e < kq; e += 64) {                   // v = Ginv r
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;      // 8 independent loads of Ginv in flight per lane
+            if (e < k) {
+                int c = 0;
+                for (; c + 8 <= k; c += 8) {
+                    double g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[u] = Ginv[(size_t)(c + u) * KP + e];
+                    a0 = __builtin_fma(g[0], rs[c], a0);     a1 = __builtin_fma(g[1], rs[c + 1], a1);
+                    a2 = __builtin_fma(g[2], rs[c + 2], a2); a3 = __builtin_fma(g[3], rs[c + 3], a3);
+                    a0 = __builtin_fma(g[4], rs[c + 4], a0); a1 = __builtin_fma(g[5], rs[c + 5], a1);
+                    a2 = __builtin_fma(g[6], rs[c + 6], a2); a3 = __builtin_fma(g[7], rs[c + 7], a3);
+                }
+                for (; c < k; ++c) a0 = __builtin_fma(Ginv[(size_t)c * KP + e], rs[c], a0);
+            }
+            vs[e] = (a0 + a1) + (a2 + a3);
+        }
+        WAVE_SYNC();
+
+        int ng = 0, last = -1;
+        // one block-pivot solve for the current passive set; leaves xs, ys and the violation count / largest violator
+        auto solve_and_classify = [&](bool zeroize) -> bool {
+            int p = 0;
+            for (int e0 = 0; e0 < kq; e0 += 64) p += __popcll(__ballot(pas[e0 + lane] != 0));
+            const bool comp = (k - p) <= p;                     // the smaller block
+            int t = 0;
+            for (int e0 = 0; e0 < kq; e0 += 64) {
+                const int e = e0 + lane;
+                const bool sel = (e < k) && ((pas[e] != 0) != comp);
+                const unsigned long long m = __ballot(sel);
+                if (sel) idx[t + __popcll(m & lt_mask)] = e;
+                t += __popcll(m);
+            }
+            WAVE_SYNC();
+            const double* Msrc = comp ? Ginv : G;
+            {   // packed lower triangle, column l: rows l .. t - 1; four columns' loads issued together
+                int l = 0;
+                for (; l + 4 <= t; l += 4) {
+                    double g[4][2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int i = l + u + lane + 64 * h;
+                            g[u][h] = (i < t) ? Msrc[(size_t)idx[l + u] * KP + idx[i]] : 0.0;
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int i = l + u + lane + 64 * h;
+                            if (i < t) Mp[tri_off(l + u, t) + (i - l - u)] = g[u][h];
+                        }
+                }
+                for (; l < t; ++l) {
+                    const int il = idx[l], o = tri_off(l, t);
+                    for (int i = l + lane; i < t; i += 64) Mp[o + (i - l)] = Msrc[(size_t)il * KP + idx[i]];
+                }
+            }
+            for (int a = lane; a < t; a += 64) zs[a] = comp ? -vs[idx[a]] : rs[idx[a]];
+            WAVE_SYNC();
+            bool bad = false;
+            for (int j = 0; j < t; ++j) {                       // right-looking Cholesky; the diagonal keeps 1 / L_jj
+                const int oj = tri_off(j, t);
+                const double piv = Mp[oj];
+                if (!(piv > 0.0)) { bad = true; break; }
+                double id = __builtin_amdgcn_rsq(piv);          // 1 / sqrt(piv): hardware estimate + two Newton steps
+                id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
+                id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
+                WAVE_SYNC();
+                for (int i = j + 1 + lane; i < t; i += 64) Mp[oj + (i - j)] *= id;
+                if (lane == 0) Mp[oj] = id;
+                WAVE_SYNC();
+                const int ti = lane & 15, tq = lane >> 4;       // 16 rows x 4 columns of the trailing block at a time
+                for (int l = j + 1 + tq; l < t; l += 4) {
+                    const double mlj = Mp[oj + (l - j)];
+                    const int ol = tri_off(l, t);
+                    for (int i = l + ti; i < t; i += 16) Mp[ol + (i - l)] -= Mp[oj + (i - j)] * mlj;
+                }
+                WAVE_SYNC();
+            }
+            if (!bad) {
+                // substitutions with the right-hand side in registers (t <= 128: two entries per lane): the value of step j
+                // is a lane broadcast, not an LDS round trip
+                double z0 = (lane < t) ? zs[lane] : 0.0, z1 = (64 + lane < t) ? zs[64 + lane] : 0.0;
+                for (int j = 0; j < t; ++j) {                   // L z = b
+                    const int oj = tri_off(j, t);
+                    const double zj = readlane_f64(j < 64 ? z0 : z1, j & 63) * Mp[oj];
+                    if (j < 64) { if (lane == j) z0 = zj; } else { if (lane == j - 64) z1 = zj; }
+                    const int i0 = lane, i1 = 64 + lane;
+                    if (i0 > j && i0 < t) z0 = __builtin_fma(-Mp[oj + (i0 - j)], zj, z0);
+                    if (i1 > j && i1 < t) z1 = __builtin_fma(-Mp[oj + (i1 - j)], zj, z1);
+                }
+                for (int j = t - 1; j >= 0; --j) {              // L' x = z
+                    const double xj = readlane_f64(j < 64 ? z0 : z1, j & 63) * Mp[tri_off(j, t)];
+                    if (j < 64) { if (lane == j) z0 = xj; } else { if (lane == j - 64) z1 = xj; }
+                    const int i0 = lane, i1 = 64 + lane;
+                    if (i0 < j) z0 = __builtin_fma(-Mp[tri_off(i0, t) + (j - i0)], xj, z0);
+                    if (i1 < j) z1 = __builtin_fma(-Mp[tri_off(i1, t) + (j - i1)], xj, z1);
+                }
+                WAVE_SYNC();
+                if (lane < t) zs[lane] = z0;
+                if (64 + lane < t) zs[64 + lane] = z1;
+                WAVE_SYNC();
+            }
+            // out = base + Msrc[:, T] u  with base = v (complement) or -r (direct)
+            for (int e = lane; e < kq; e += 64) {
+                double acc = comp ? vs[e] : -rs[e], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                if (!bad && e < k) {
+                    int a = 0;
+                    for (; a + 8 <= t; a += 8) {
+                        double g[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) g[u] = Msrc[(size_t)idx[a + u] * KP + e];
+                        acc = __builtin_fma(g[0], zs[a], acc);      a1 = __builtin_fma(g[1], zs[a + 1], a1);
+                        a2 = __builtin_fma(g[2], zs[a + 2], a2);    a3 = __builtin_fma(g[3], zs[a + 3], a3);
+                        acc = __builtin_fma(g[4], zs[a + 4], acc);  a1 = __builtin_fma(g[5], zs[a + 5], a1);
+                        a2 = __builtin_fma(g[6], zs[a + 6], a2);    a3 = __builtin_fma(g[7], zs[a + 7], a3);
+                    }
+                    for (; a < t; ++a) acc = __builtin_fma(Msrc[(size_t)idx[a] * KP + e], zs[a], acc);
+                    acc = (acc + a1) + (a2 + a3);
+                }
+                const bool pe = pas[e] != 0;
+                xs[e] = comp ? (pe ? acc : 0.0) : 0.0;          // the block's own entries are scattered below
+                ys[e] = comp ? 0.0 : (pe ? 0.0 : acc);
+            }
+            WAVE_SYNC();
+            if (!bad)
+                for (int a = lane; a < t; a += 64) {
+                    if (comp) ys[idx[a]] = zs[a];
+                    else xs[idx[a]] = zs[a];
+                }
+            WAVE_SYNC();
+            ng = 0;
+            last = -1;
+            for (int e0 = 0; e0 < kq; e0 += 64) {
+                const int e = e0 + lane;
+                double x = xs[e], y = ys[e];
+                if (zeroize) {                                  // ZeroizeSmallValues, nnls.hpp:213,224-225
+                    if (fabs(x) < 1.0e-12) x = 0.0;
+                    if (fabs(y) < 1.0e-12) y = 0.0;
+                    xs[e] = x;
+                    ys[e] = y;
+                }
+                const bool pe = pas[e] != 0, in = e < k;
+                const bool viol = in && ((!pe && y < 0.0) || (pe && x < 0.0));
+                const unsigned long long m = __ballot(viol);
+                if (m) { ng += __popcll(m); last = e0 + 63 - __clzll(m); }
+                // remember the violation in bit 1 of the mask byte for the exchange below
+                pas[e] = (unsigned char)((pe ? 1 : 0) | (viol ? 2 : 0));
+            }
+            WAVE_SYNC();
+            return bad;
+        };
+        // NOTE: after solve_and_classify pas[e] carries bit 0 = passive, bit 1 = violates; the (pas[e] != 0) tests above see
+        // only clean bytes because every exchange below rewrites them to 0 / 1 first.
+        auto clean = [&]() {
+            for (int e = lane; e < kq; e += 64) pas[e] &= 1;
+            WAVE_SYNC();
+        };
+
+        bool failed = solve_and_classify(false);
+        int Pc = 3, Ninf = k + 1, iter = 0;                     // PBAR = 3, nnls.hpp:152,170
+        const int max_iter = 5 * k;
+        while (ng > 0 && !failed) {
+            if (iter >= max_iter) { failed = true; break; }
+            // UpdatePassiveSet, src/nnls.cpp:18-74
+            const bool full = (ng < Ninf) || (Pc >= 1);
+            if (ng < Ninf) { Pc = 3; Ninf = ng; }
+            else if (Pc >= 1) { Pc -= 1; }
+            if (full) {
+                for (int e = lane; e < kq; e += 64) {
+                    const unsigned char b = pas[e];
+                    pas[e] = (b & 2) ? (unsigned char)((b & 1) ^ 1) : (unsigned char)(b & 1);   // violators change side
+                }
+            } else {
+                for (int e = lane; e < kq; e += 64) {
+                    const unsigned char b = pas[e];
+                    pas[e] = (e == last) ? (unsigned char)((b & 1) ^ 1) : (unsigned char)(b & 1);   // backup rule: the largest violator
+                }
+            }
+            WAVE_SYNC();
+            failed = solve_and_classify(true);
+            ++iter;
+        }
+        clean();
+        for (int e = lane; e < k; e += 64) {
+            X[col * KP + e] = xs[e];
+            if (Y) Y[col * KP + e] = ys[e];
+        }
+        failed_any |= failed ? 1 : 0;
+        WAVE_SYNC();
+    }
+    if (failed_any && lane == 0) atomicMin(fail_flag, iter_tag);
+}
+
+// workgroups per CU: the LDS panel only has to hold the smaller of a passive set and its complement, <= k / 2 rows
+static inline int nnls_wide_tl(int k) { const int h = (k + 1) / 2; return h < WIDE_TL ? h : WIDE_TL; }
+static inline int nnls_wide_wgs_per_cu(int k)
+{
+    const int lds = nnls_wide_tl(k) * nnls_wide_tl(k) * 8 + 26 * 1024;       // panel + the static vectors
+    const int w = (160 * 1024) / lds;
+    return w < 1 ? 1 : (w > 2 ? 2 : w);
+}
+// scratch: [panels: wgs x KP x KP][L: KP x KP][Ginv: KP x KP][status: 8]
 size_t nnls_wide_scratch_elems(int k, int num_cus)
 {
     const size_t KP = (size_t)kp_of(k);
-    return (size_t)(2 * num_cus) * KP * KP;
+    return ((size_t)num_cus * nnls_wide_wgs_per_cu(k) + 2) * KP * KP + 8;
 }
 
 int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G, int* fail_flag,
@@ -545,9 +930,51 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
     const i64 ncols = col_end - col_begin;
     if (ncols <= 0) return 0;
     if (!scratch) { set_error("nnls: k > 128 needs the scratch panels"); return -100; }
-    i64 grid = 2 * (i64)num_cus;
+    const int KP = kp_of(k);
+    const int wgs = num_cus * nnls_wide_wgs_per_cu(k), tl = nnls_wide_tl(k);
+    double* L = scratch + (size_t)wgs * KP * KP;
+    double* Ginv = L + (size_t)KP * KP;
+    int* status = (int*)(Ginv + (size_t)KP * KP);
+    static const bool use_inv = [] { const char* e = getenv("SMK_NNLS_INV"); return !(e && e[0] == '0'); }();
+    if (use_inv) {
+        chol_wide_kernel<<<1, 1024, 0, st>>>(G, k, KP, L, status);
+        SMK_HIP(hipGetLastError());
+        inv_cols_wide_kernel<<<k, 256, 0, st>>>(L, k, KP, Ginv, status);
+        SMK_HIP(hipGetLastError());
+    }
+    const int lds = tl * tl * (int)sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    WIDE_TL * WIDE_TL * (int)sizeof(double)));
+        attr_set = true;
+    }
+    // k <= 256 and G invertible: one wave per column, no workgroup barriers; otherwise (and as the fallback that
+    // reproduces a "not SPD" failure) one workgroup per column
+    int took_wave = 0;
+    if (use_inv && k <= 256) {
+        const size_t slice = (wave_slice_bytes(k) + 15) / 16 * 16;
+        int waves = (int)((150 * 1024) / slice);
+        if (waves > 4) waves = 4;
+        if (waves >= 1) {
+            const int wlds = (int)(slice * waves);
+            static int attr_wave = 0;
+            if (attr_wave < wlds) {
+                SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+                attr_wave = 152 * 1024;
+            }
+            i64 g2 = (ncols + waves - 1) / waves;
+            if (g2 > (i64)num_cus * 2) g2 = (i64)num_cus * 2;
+            nnls_wide_wave_kernel<<<(unsigned)g2, 64 * waves, wlds, st>>>(X, Y, k, KP, col_end, R, G, Ginv, status, fail_flag, iter_tag,
+                                                                     col_begin, (int)slice);
+            SMK_HIP(hipGetLastError());
+            took_wave = 1;
+        }
+    }
+    i64 grid = wgs;                                              // as many workgroups as their LDS panels let be resident
     if (grid > ncols) grid = ncols;
-    nnls_wide_kernel<<<(unsigned)grid, 256, 0, st>>>(X, Y, k, kp_of(k), col_end, R, G, fail_flag, iter_tag, col_begin, scratch);
+    nnls_wide_kernel<<<(unsigned)grid, 256, lds, st>>>(X, Y, k, KP, col_end, R, G, use_inv ? Ginv : nullptr, status, fail_flag,
+                                                       iter_tag, col_begin, scratch, tl, took_wave);
     SMK_HIP(hipGetLastError());
     return 0;
 }
