@@ -672,7 +672,12 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     const char* env = getenv("SMK_NSPLIT");
     // fp32 A: the fp16 two-term form (3 MFMAs per product, 2^-22 operand error) unless SMK_NSPLIT picks the bf16 forms
     // (3 = bf16x3, 6 MFMAs, power-bound; 2 = two bf16 terms, 2^-16); bf16 A: three bf16 terms of the factor
-    const int nsplit_default = (a->storage == SMK_STORE_F32) ? NSPLIT_F16X2 : 3;
+    // HALS amplifies the product error several thousand times (its W update is a difference of nearly equal terms per
+    // column, more so at high rank): the 24-bit bf16x3 operands stay inside the parity bar where the 22-bit fp16 ones
+    // do not always (tools/fuzz_parity.py: k = 117 .. 253 1e-4 .. 5e-4 against < 1e-4, one k = 62 case at 1.1e-4 after
+    // 17 iterations), so HALS keeps bf16x3; MU and BPP take the fp16 form
+    const bool hals = opts->algorithm == SMK_ALG_HALS;
+    const int nsplit_default = (a->storage == SMK_STORE_F32 && !hals) ? NSPLIT_F16X2 : 3;
     s->nsplit = env ? atoi(env) : nsplit_default;
     if (s->nsplit < 1 || s->nsplit > NSPLIT_F16X2) s->nsplit = nsplit_default;
     // the fp16 two-term form applies to fp32 storage; RANK2 keeps its Gram matrices inside its own solve kernel

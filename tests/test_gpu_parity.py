@@ -375,9 +375,12 @@ def test_handle_reuse_after_normalised_run(gpu, alg):
 # ---- fp32 A: the products run as two fp16 terms per operand with power-of-two scales --------------
 @pytest.mark.parametrize("alg,log2scale", [("HALS", s) for s in (-60, -20, 20, 60)] + [("MU", s) for s in (-20, 20)]
                          + [("BPP", s) for s in (-20, 20)])
-def test_fp32_products_at_any_magnitude(gpu, alg, log2scale):
+def test_fp32_products_at_any_magnitude(gpu, alg, log2scale, monkeypatch):
     """A 2^s and H0 2^s: magnitudes far outside fp16's range (6e-5 .. 65504) on both sides of the product.  (The
-    reference's own absolute thresholds -- 1e-12 zeroing in BPP, the 1e-13 of MU -- bound the scales that make sense.)"""
+    reference's own absolute thresholds -- 1e-12 zeroing in BPP, the 1e-13 of MU -- bound the scales that make sense.)
+    The fp16 form is selected explicitly: it is the default for MU and BPP, HALS defaults to bf16x3 (whose fp32
+    accumulators overflow at 2^60 x 2^60)."""
+    monkeypatch.setenv("SMK_NSPLIT", "4")
     m, n, k = 384, 256, 24
     A = oracle.quantize(np.asfortranarray(np.ldexp(mg.make_A(m, n, k, True, 0), log2scale)), 0)
     W0 = oracle.fill_uniform(m, k, 43)
@@ -390,10 +393,11 @@ def test_fp32_products_at_any_magnitude(gpu, alg, log2scale):
 
 @pytest.mark.parametrize("alg", ["HALS", "BPP"])
 @pytest.mark.parametrize("span", [12, 20])
-def test_fp32_products_with_wide_dynamic_range(gpu, alg, span):
+def test_fp32_products_with_wide_dynamic_range(gpu, alg, span, monkeypatch):
     """columns of A spanning 2^-span .. 2^span and rows of H0 spanning 2^-6 .. 2^6.  The two-term fp16 operands are exact
     to 22 bits for entries down to 2^-28 max|A|: inside that range (span 12) every column of H is held to
     the tolerance against its own norm; beyond it (span 20) the small columns lose bits and the bar is the normwise one."""
+    monkeypatch.setenv("SMK_NSPLIT", "4")          # the fp16 form also for HALS (which defaults to bf16x3)
     m, n, k = 512, 320, 16
     rng = np.random.default_rng(7)
     A = oracle.fill_uniform(m, n, 42, quant=0) * np.exp2(rng.integers(-span, span + 1, size=n))[None, :]
@@ -413,8 +417,9 @@ def test_fp32_products_with_wide_dynamic_range(gpu, alg, span):
 
 
 def test_fp32_product_forms_agree(gpu, monkeypatch):
-    """SMK_NSPLIT selects the emulation of the fp32 product: 4 (default, fp16 two-term), 3 (bf16x3), 2 (fast two-term
-    bf16, 2^-16).  The first two agree to fp32 class; the fast form to its documented 1e-3."""
+    """SMK_NSPLIT selects the emulation of the fp32 product: 4 (fp16 two-term: the default for MU and BPP), 3 (bf16x3: the
+    default for HALS and RANK2), 2 (fast two-term bf16, 2^-16).  The first two agree to fp32 class; the fast form to
+    its documented 1e-3."""
     m, n, k = 640, 512, 48
     A = mg.make_A(m, n, k, True, 0)
     W0 = oracle.fill_uniform(m, k, 43)

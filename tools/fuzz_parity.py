@@ -1,5 +1,6 @@
 """Randomised parity sweep: many small random problems (shape, rank, algorithm, storage, dense/sparse,
-stopping rule) through the C ABI against the oracle.  usage: python tools/fuzz_parity.py [cases] [seed] [max_dim]"""
+stopping rule; ranks up to 260: every kernel family incl. the general path above 128) through the C ABI against the
+oracle.  usage: python tools/fuzz_parity.py [cases] [seed] [max_dim]"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, scipy.sparse as sp
@@ -18,7 +19,7 @@ for case in range(cases):
     alg = rng.choice(["MU", "HALS", "BPP", "RANK2"])
     sparse = rng.random() < 0.3
     storage = "f32" if sparse else rng.choice(["f32", "bf16"])
-    kmax = 2 if alg == "RANK2" else int(rng.choice([3, 8, 9, 16, 17, 32, 33, 48, 64]))
+    kmax = 2 if alg == "RANK2" else int(rng.choice([3, 8, 9, 16, 17, 32, 33, 48, 64, 64, 64, 100, 128, 160, 260]))
     m = int(rng.integers(max(kmax, 2) * (4 if alg in ("HALS", "BPP") else 1), maxdim))
     n = int(rng.integers(max(kmax, 2) * (4 if alg in ("HALS", "BPP") else 1), maxdim))
     k = 2 if alg == "RANK2" else int(rng.integers(1, kmax + 1))
@@ -40,6 +41,10 @@ for case in range(cases):
         min_iter = int(rng.integers(1, 6))
     tolcount = int(rng.integers(1, 3))
     prog = int(rng.integers(0, 2))
+    if alg == "HALS" and k > 64:
+        # HALS at high rank amplifies ANY product-level difference (2e-8 here) by ~2x per five iterations: k = 225, bf16 A,
+        # 34 iterations lands at 1.5e-4 with the most accurate product form there is.  Keep those runs short.
+        iters = min(iters, 8)
     W0 = oracle.fill_uniform(m, k, 100 + case)
     H0 = oracle.fill_uniform(k, n, 200 + case) * (2.0 * A.mean() / (0.5 * k))
     quant = 1 if storage == "bf16" else 0
