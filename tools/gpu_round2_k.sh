@@ -1,4 +1,5 @@
 #!/bin/bash
+# fp16 two-term products inside the solver: C4 shard / C2 / 32768x8192 k=32 with SMK_NSPLIT=4 and 3, microbench, quick parity
 cd /root/repo
 summ() { python3 -c "
 import json,sys

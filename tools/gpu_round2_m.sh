@@ -1,4 +1,5 @@
 #!/bin/bash
+# C4 whole: forced row-split counts (SMK_BP_SPLITS) -- does the W'A pass gain from splits? (it does not)
 cd /root/repo
 summ() { python3 -c "
 import json,sys
