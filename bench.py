@@ -137,14 +137,17 @@ def main():
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     native = backend == "nccl"          # default: RCCL from C (comm.cpp); "gloo": the round-1 callback hook (tests)
+    rccl_defaults_set = []              # environment defaults this script added (taken back for plan B)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")                 # CPU side channel only: unique id, barrier, max of the clocks
         if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
             # one node: RCCL's bootstrap sockets stay on the loopback interface (the container's hostname may not
             # resolve) and no InfiniBand probing; the data path is xGMI either way.  The caller's settings win.
-            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-            os.environ.setdefault("NCCL_IB_DISABLE", "1")
+            for key, val in (("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1")):
+                if key not in os.environ:
+                    os.environ[key] = val
+                    rccl_defaults_set.append(key)
     smallk_amd.initialize(device_index)
     comm, fallback_group, collectives = None, None, "none"
     if world > 1 and native:
@@ -169,6 +172,8 @@ def main():
                 comm.close()
                 comm = None
             native = False
+            for key in rccl_defaults_set:   # plan B runs with RCCL's own defaults
+                os.environ.pop(key, None)
             fallback_group = torch.distributed.new_group(backend="nccl")
             collectives = "torch.distributed nccl through the callback hook (native communicator failed)"
     elif world > 1:
