@@ -241,6 +241,7 @@ def main():
 
     ms0, c0 = solver.kernel_time(0)
     ms1, c1 = solver.kernel_time(1)
+    msc, cc = solver.kernel_time(2) if world > 1 else (0.0, 0)        # (AH')' sum + W all-gather, HIP events on this rank
     bytes_per_launch, flops_per_launch = solver.kernel_work(0)
     avg_ms = (ms0 + ms1) / max(c0 + c1, 1)
     achieved_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
@@ -270,6 +271,7 @@ def main():
             "useful_tflops_big_products": mfma_tf,
             "useful_tflops_vs_native_mfma_peak": mfma_tf / MFMA_PEAK_TF[storage],
             "whole_iteration_tflops": 4.0 * m * n * k / (elapsed / args.steps) / 1e12,
+            "collectives_ms_per_step_rank0": (msc / max((c0 + c1) // 2, 1)) if world > 1 else None,
             "windows": len(windows), "windows_ms": [round(w * 1e3, 4) for w in windows],
             "timed_region_s": sum(windows),
             "roofline": {

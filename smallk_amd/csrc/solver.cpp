@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 #include <algorithm>
 #include <thread>
@@ -140,9 +141,9 @@ struct smk_solver {
     double* snap[2] = {nullptr, nullptr};
     // timing
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
-    double acc_ms[2] = {0, 0};
-    int launches[2] = {0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];    // 0: W'A passes, 1: H*At passes, 2: the big collectives of a sharded run
+    double acc_ms[3] = {0, 0, 0};
+    int launches[3] = {0, 0, 0};
 };
 
 static const int GRAM_BLOCKS = 256;
@@ -767,7 +768,7 @@ void smk_solver_destroy(smk_solver* s)
                     s->xscale[0], s->xscale[1], s->oscale[0], s->oscale[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < 3; ++w)
         for (auto& e : s->ev[w]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (int b = 0; b < 2; ++b) {
         if (s->snap[b]) (void)hipFree(s->snap[b]);
@@ -988,6 +989,21 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
     return rc;
 }
 
+// a collective of the iteration bracketed by events when timing is on (slot 2 of smk_solver_kernel_time)
+static int timed_collective(smk_solver* s, const std::function<int()>& issue)
+{
+    if (!s->timing) return issue();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    SMK_HIP(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
+    (void)hipEventRecord(e0, s->st);
+    const int rc = issue();
+    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    (void)hipEventRecord(e1, s->st);
+    s->ev[2].push_back({e0, e1});
+    return 0;
+}
+
 static int prod1(smk_solver* s)
 {
     if (s->a->sparse) return timed_spmm(s, 0, s->a->colptr, s->a->rowidx, s->a->val, s->n, s->Wt, s->P1);
@@ -1022,8 +1038,10 @@ static int prod2(smk_solver* s)
         PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
         rc = launch_reduce_partials(pv, s->k, s->pl2.ncols_pad, s->R2red, s->st);
         if (rc) return rc;
-        if (w_rows_sharded(s)) rc = comm_reduce_scatter(s->comm, s->R2red, s->w_chunk * s->kpp, 0, s->st);   // own rows only
-        else rc = dist_allreduce(s, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, 0, s->st);
+        rc = timed_collective(s, [&] {
+            if (w_rows_sharded(s)) return comm_reduce_scatter(s->comm, s->R2red, s->w_chunk * s->kpp, 0, s->st);   // own rows only
+            return dist_allreduce(s, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, 0, s->st);
+        });
         if (rc) return rc;
     }
     return 0;
@@ -1118,7 +1136,8 @@ static int solver_iteration(smk_solver* s)
                     // sum-all-reduce of the whole matrix would move)
                     const i64 i0 = std::min<i64>(s->m, s->rank * s->w_chunk), i1 = std::min<i64>(s->m, i0 + s->w_chunk);
                     rc = nnls_side(s, 1, s->Wt, i0, i1, view2(s), s->Gh); if (rc) return rc;
-                    rc = comm_allgather(s->comm, s->Wt, s->w_chunk * s->KP, 1, s->st); if (rc) return rc;
+                    rc = timed_collective(s, [&] { return comm_allgather(s->comm, s->Wt, s->w_chunk * s->KP, 1, s->st); });
+                    if (rc) return rc;
                 } else {
                     // callback hook (one primitive only): zero the other rows and sum-all-reduce
                     const i64 base = s->m / s->world, extra = s->m % s->world;
@@ -1155,7 +1174,7 @@ static int solver_iteration(smk_solver* s)
 
 static int resolve_events(smk_solver* s)
 {
-    for (int w = 0; w < 2; ++w) {
+    for (int w = 0; w < 3; ++w) {
         for (auto& e : s->ev[w]) {
             float ms = 0.f;
             SMK_HIP(hipEventElapsedTime(&ms, e.first, e.second));
@@ -1622,14 +1641,14 @@ int smk_solver_enable_timing(smk_solver* s, int on)
 {
     if (!s) return SMK_BAD_PARAM;
     s->timing = on != 0;
-    s->acc_ms[0] = s->acc_ms[1] = 0.0;
-    s->launches[0] = s->launches[1] = 0;
+    s->acc_ms[0] = s->acc_ms[1] = s->acc_ms[2] = 0.0;
+    s->launches[0] = s->launches[1] = s->launches[2] = 0;
     return SMK_OK;
 }
 
 int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* launches)
 {
-    if (!s || which < 0 || which > 1) return SMK_BAD_PARAM;
+    if (!s || which < 0 || which > 2) return SMK_BAD_PARAM;      // 2: the (AH')' sum and the W all-gather of a sharded run
     if (total_ms) *total_ms = s->acc_ms[which];
     if (launches) *launches = s->launches[which];
     return SMK_OK;
