@@ -9,6 +9,12 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 
+# single-node RCCL in the tests: bootstrap over the loopback interface (the container's hostname may not resolve and
+# interface probing has been seen to stall for minutes on some boxes), no InfiniBand probing.  The caller's settings win.
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # a fresh checkout has no built artefacts: build them once (hipcc cross-compiles without a GPU)
