@@ -677,8 +677,10 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     // column, more so at high rank): the 24-bit bf16x3 operands stay inside the parity bar where the 22-bit fp16 ones
     // do not always (tools/fuzz_parity.py: k = 117 .. 253 1e-4 .. 5e-4 against < 1e-4, one k = 62 case at 1.1e-4 after
     // 17 iterations), so HALS keeps bf16x3; MU and BPP take the fp16 form
+    // The amplification grows with the rank for every algorithm (BPP k = 191 after 34 iterations: 1.26e-4 with the
+    // fp16 form), so above k = 64 the 24-bit operands are kept as well; C2 (k = 16) and C4 (k = 64) take the fp16 form.
     const bool hals = opts->algorithm == SMK_ALG_HALS;
-    const int nsplit_default = (a->storage == SMK_STORE_F32 && !hals) ? NSPLIT_F16X2 : 3;
+    const int nsplit_default = (a->storage == SMK_STORE_F32 && !hals && opts->k <= 64) ? NSPLIT_F16X2 : 3;
     s->nsplit = env ? atoi(env) : nsplit_default;
     if (s->nsplit < 1 || s->nsplit > NSPLIT_F16X2) s->nsplit = nsplit_default;
     // the fp16 two-term form applies to fp32 storage; RANK2 keeps its Gram matrices inside its own solve kernel

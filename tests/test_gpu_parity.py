@@ -378,7 +378,7 @@ def test_handle_reuse_after_normalised_run(gpu, alg):
 def test_fp32_products_at_any_magnitude(gpu, alg, log2scale, monkeypatch):
     """A 2^s and H0 2^s: magnitudes far outside fp16's range (6e-5 .. 65504) on both sides of the product.  (The
     reference's own absolute thresholds -- 1e-12 zeroing in BPP, the 1e-13 of MU -- bound the scales that make sense.)
-    The fp16 form is selected explicitly: it is the default for MU and BPP, HALS defaults to bf16x3 (whose fp32
+    The fp16 form is selected explicitly: it is the default for MU and BPP at k <= 64, HALS defaults to bf16x3 (whose fp32
     accumulators overflow at 2^60 x 2^60)."""
     monkeypatch.setenv("SMK_NSPLIT", "4")
     m, n, k = 384, 256, 24
@@ -417,8 +417,8 @@ def test_fp32_products_with_wide_dynamic_range(gpu, alg, span, monkeypatch):
 
 
 def test_fp32_product_forms_agree(gpu, monkeypatch):
-    """SMK_NSPLIT selects the emulation of the fp32 product: 4 (fp16 two-term: the default for MU and BPP), 3 (bf16x3: the
-    default for HALS and RANK2), 2 (fast two-term bf16, 2^-16).  The first two agree to fp32 class; the fast form to
+    """SMK_NSPLIT selects the emulation of the fp32 product: 4 (fp16 two-term: the default for MU and BPP at k <= 64), 3 (bf16x3: the
+    default for HALS, RANK2 and higher ranks), 2 (fast two-term bf16, 2^-16).  The first two agree to fp32 class; the fast form to
     its documented 1e-3."""
     m, n, k = 640, 512, 48
     A = mg.make_A(m, n, k, True, 0)
