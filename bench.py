@@ -150,6 +150,12 @@ def main():
                     rccl_defaults_set.append(key)
     smallk_amd.initialize(device_index)
     comm, fallback_group, collectives = None, None, "none"
+    # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the one JSON line
+    saved_stdout = None
+    if world > 1:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
     if world > 1 and native:
         # RCCL communicator created by libsmallk_amd.so itself; every collective of the iteration is issued from C
         ok = 1
@@ -181,6 +187,10 @@ def main():
     if world > 1 and not native:
         # callback hook: the solver launches on torch's current stream so that the all-reduces order against it
         smallk_amd.set_stream(torch.cuda.current_stream().cuda_stream)
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     m, n, k, alg, storage, desc = WORKLOADS[args.workload]
     col0, ncols = sdist.shard_columns(n, world, rank)
