@@ -85,7 +85,7 @@ template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK, in
 __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                          const unsigned char* __restrict__ Xp,
                                                          double* __restrict__ P, i64 stages, i64 nst,
-                                                         i64 tiles, i64 ncols_pad, int S, int logS, int pstride)
+                                                         i64 tiles, i64 ncols_pad, int S, int logS, int pstride, int accum)
 {
     using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
     constexpr int KTW = C::KTW;
@@ -376,6 +376,7 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
                         }
                         v[u] = tsum;
                     }
+                    if (accum) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);   // a later row chunk of the same product
                     *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
                 }
             }
@@ -508,6 +509,15 @@ size_t packed_bytes(int storage, int k, i64 N, int nsplit)
     return total;
 }
 
+// bytes from the start of a group's packed block to the fragments of row r0 (a multiple of 16): the layout is
+// chunk-pair major, so a row range of the operand is a contiguous byte range
+size_t packed_row_offset(int storage, int kg, int nsplit, i64 r0)
+{
+    const i64 E = pack_is_bf16(storage, nsplit) ? 8 : 4;
+    if (!pack_is_bf16(storage, nsplit)) nsplit = 1;
+    return (size_t)(r0 / (2 * E)) * pack_terms(nsplit) * kt_of(kg) * 1024;
+}
+
 int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st,
                      const double* xscale)
 {
@@ -586,7 +596,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
                                                                         const unsigned char* __restrict__ Xp,
                                                                         double* __restrict__ P, i64 stages, i64 nst,
                                                                         i64 tiles, i64 ncols_pad, int S, int logS, int pstride,
-                                                                        const double* __restrict__ oscale, float ascale)
+                                                                        const double* __restrict__ oscale, float ascale, int accum)
 {
     using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -826,6 +836,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
                     v[0] *= os[0];
                     v[1] *= os[1];
                 }
+                if (accum) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);
                 *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
             }
 }
@@ -853,7 +864,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
                                                                         const unsigned char* __restrict__ Xp,
                                                                         double* __restrict__ P, i64 stages, i64 nst,
                                                                         i64 tiles, i64 ncols_pad, int S, int logS, int pstride,
-                                                                        const double* __restrict__ oscale, float ascale)
+                                                                        const double* __restrict__ oscale, float ascale, int accum)
 {
     using C = F3Cfg<KT, 32, NSTAGE, NWL, NS>;
     constexpr int PDN = NSTAGE - 2;                 // stages in flight ahead of the published one
@@ -1075,6 +1086,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
                     v[0] *= os[0];
                     v[1] *= os[1];
                 }
+                if (accum) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);
                 *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
             }
 }
@@ -1104,7 +1116,7 @@ static int launch_f3p_t(const BigProdPlan& pl, const void* B, i64 ldb, const voi
             grid = pl.tiles * pl.S;
         }
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
-                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale);
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale, pl.accum);
         SMK_HIP(hipGetLastError());
         return 0;
     }
@@ -1168,7 +1180,7 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
             grid = pl.tiles * pl.S;
         }
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
-                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale);
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale, pl.accum);
         SMK_HIP(hipGetLastError());
         return 0;
     }
@@ -1318,6 +1330,7 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
         if (!f3_fits(v)) v = 110;
         pl.variant = v;
         const int MB = kF3Variants[v - 100].mb;
+        pl.mb = MB; pl.nb = 128;
         pl.stages = (len + MB - 1) / MB;
         pl.tiles = (ncols + 127) / 128;
         pl.ncols_pad = round_up(ncols, COL_PAD);
@@ -1343,6 +1356,7 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     pl.variant = v;
     const int MB = kVariants[v].mb;
     const int NB = 128 * kVariants[v].cw;
+    pl.mb = MB; pl.nb = NB;
     pl.stages = (len + MB - 1) / MB;
     pl.tiles = (ncols + NB - 1) / NB;
     pl.ncols_pad = round_up(ncols, COL_PAD);
@@ -1378,7 +1392,7 @@ static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const
         grid = pl.tiles * pl.S;
     }
     kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * EBYTES, (const unsigned char*)Xp, P,
-                                           pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride);
+                                           pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.accum);
     SMK_HIP(hipGetLastError());
     return 0;
 }

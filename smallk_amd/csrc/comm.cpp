@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -62,9 +63,16 @@ static int local_collective(smk_comm* c, void* ptr, i64 count, int f64, hipStrea
     return rc;
 }
 
+bool comm_forced()
+{
+    const char* e = getenv("SMK_COMM_FORCE");       // read per call: tests switch it inside one process
+    return e && atoi(e) != 0;
+}
+static inline bool skip_collective(const smk_comm* c) { return !c || (c->world == 1 && !comm_forced()); }
+
 int comm_allreduce(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st)
 {
-    if (!c || c->world == 1) return 0;
+    if (skip_collective(c) || count <= 0) return 0;
     if (c->local) return local_collective(c, ptr, count, f64, st, LOCAL_ALLREDUCE);
     const ncclResult_t r = ncclAllReduce(ptr, ptr, (size_t)count, f64 ? ncclDouble : ncclFloat, ncclSum, (ncclComm_t)c->nccl, st);
     if (r != ncclSuccess) { set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return SMK_DEVICE_ERROR; }
@@ -74,7 +82,7 @@ int comm_allreduce(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st)
 // every rank contributes `count_per_rank` elements at buf + rank * count_per_rank (in place)
 int comm_allgather(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st)
 {
-    if (!c || c->world == 1) return 0;
+    if (skip_collective(c) || count_per_rank <= 0) return 0;
     if (c->local) return local_collective(c, buf, count_per_rank, f64, st, LOCAL_ALLGATHER);
     const size_t es = f64 ? 8 : 4;
     const ncclResult_t r = ncclAllGather((const char*)buf + (size_t)c->rank * count_per_rank * es, buf, (size_t)count_per_rank,
@@ -87,7 +95,7 @@ int comm_allgather(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStrea
 // over ranks of their slice `rank` (the other slices keep this rank's own contribution)
 int comm_reduce_scatter(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st)
 {
-    if (!c || c->world == 1) return 0;
+    if (skip_collective(c) || count_per_rank <= 0) return 0;
     if (c->local) return local_collective(c, buf, count_per_rank, f64, st, LOCAL_REDUCE_SCATTER);
     const size_t es = f64 ? 8 : 4;
     const ncclResult_t r = ncclReduceScatter(buf, (char*)buf + (size_t)c->rank * count_per_rank * es, (size_t)count_per_rank,

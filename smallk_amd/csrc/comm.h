@@ -12,6 +12,8 @@ struct smk_comm {
 };
 
 namespace smk {
+// SMK_COMM_FORCE=1: a world of one rank issues its collectives too (tests: the real nccl* calls on the solver's streams)
+bool comm_forced();
 // in-place sum over ranks of `count` elements (f64 != 0: doubles, else floats), ordered on stream `st`
 int comm_allreduce(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st);
 // in place: rank r contributes buf[r * count_per_rank ...]; afterwards every rank holds all slices

@@ -71,6 +71,7 @@ int launch_transpose_f64(const double* src, i64 ld_src, double* dst, i64 ld_dst,
 // nsplit: 1..3 = bf16 terms of the skinny operand; NSPLIT_F16X2 = two fp16 terms with per-row power-of-two scales
 constexpr int NSPLIT_F16X2 = 4;
 size_t packed_bytes(int storage, int k, i64 N, int nsplit);
+size_t packed_row_offset(int storage, int kg, int nsplit, i64 r0);
 int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st, const double* xscale = nullptr);
 // rows [k0, k0 + kg) of a factor stored with leading dimension ldx
 int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st,
@@ -86,6 +87,8 @@ struct BigProdPlan {
     // packed operand carries per-row scales, and row r of the result is multiplied by oscale[r] = 1 / (xscale[r] ascale)
     const double* oscale = nullptr;   // device, indexed by the factor row (0 .. k-1 of the WHOLE factor)
     float ascale = 1.0f;
+    int accum = 0;  // != 0: the launch adds to P instead of overwriting it (a later row chunk of the same product)
+    int mb = 0, nb = 0;   // rows per stage / columns per workgroup tile of the chosen kernel variant
     int S;          // row splits
     i64 stages;     // total stages = ceil(len / MB)
     i64 nst;        // stages per split
@@ -99,13 +102,19 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
 int plan_bigprod_groups(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out /* 2 */);
 int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st);
 
-int launch_reduce_partials(PartialView pv, int k, i64 N, float* out /* [N][kpp] */, hipStream_t st);
+int launch_reduce_partials(PartialView pv, int k, i64 c0, i64 N, void* out /* [.][kpp] */, int out_f64, hipStream_t st);
 
 // xscale / oscale (KP doubles each, optional): per-row scales of the fp16 two-term operand, derived from the diagonal
 // in the same reduce launch: xscale[r] = 2^e with sqrt(G_rr) 2^e in [2^13, 2^14], oscale[r] = 1 / (xscale[r] * ascale)
 int launch_gram(const double* X, int k, i64 N, double* G /* KP x KP */, double* scratch, int max_blocks, hipStream_t st,
                 double* xscale = nullptr, double* oscale = nullptr, double ascale = 1.0);
 size_t gram_scratch_elems(int k, int max_blocks);
+// the two halves of launch_gram, for a factor given as several row segments (one partials call per segment with a
+// scratch offset of nblk * KP * KP doubles, then one reduce); launch_gram_scales: the fp16 row scales from a finished G
+int launch_gram_partials(const double* X, int k, i64 N, double* scratch, int max_blocks, int* nblk_out, hipStream_t st);
+int launch_gram_reduce(const double* scratch, int nblk, int k, double* G, hipStream_t st, double* xscale = nullptr,
+                       double* oscale = nullptr, double ascale = 1.0);
+int launch_gram_scales(const double* G, int k, double* xscale, double* oscale, double ascale, hipStream_t st);
 // *out = bits of max |A[i]| (NaN entries are ignored by fmaxf)
 int launch_absmax_f32(const float* A, i64 elems, unsigned* out, hipStream_t st);
 // G = X X' and the packed streaming operand of X in one launch (k <= 64, bf16 fragments); returns 1 if this shape has
@@ -134,6 +143,9 @@ int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, h
 // gradient G*X - R, optional store, projected-gradient partial sums -> pg_accum[slot] += sum
 int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
                    double* pg_partials, double* pg_accum, int slot, hipStream_t st);
+int launch_grad_pg_partials(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
+                            double* pg_partials, int* grid_out, hipStream_t st);
+int launch_sum_partials(const double* partials, int n, double* out, hipStream_t st);
 // both factors in two launches; also mirrors *flag into pg_accum[flag_slot] (as a double)
 int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,
                     PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,

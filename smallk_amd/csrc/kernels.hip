@@ -313,23 +313,28 @@ int launch_local_allgather(void* const* ptrs, int world, i64 count_per_rank, int
     return 0;
 }
 
-// sum the S slabs into one fp32 slab (used before a cross-GPU all-reduce)
+// sum the S slabs into one slab (fp32 or fp64) ahead of a cross-GPU sum
+template <typename T>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ p, int S, i64 slab, i64 count,
-                                                              float* __restrict__ out)
+                                                              T* __restrict__ out)
 {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (i64)gridDim.x * blockDim.x) {
         double s = 0.0;
         for (int t = 0; t < S; ++t) s += p[t * slab + i];
-        out[i] = (float)s;
+        out[i] = (T)s;
     }
 }
 
-int launch_reduce_partials(PartialView pv, int k, i64 N, float* out, hipStream_t st)
+// columns [c0, c0 + N) of the partial products (every slab holds ncols_pad columns of kpp doubles)
+int launch_reduce_partials(PartialView pv, int k, i64 c0, i64 N, void* out /* [.][kpp], same column index */, int out_f64,
+                           hipStream_t st)
 {
     i64 count = N * pv.kpp;
-    if (count == 0) return 0;
+    if (count <= 0) return 0;
     int grid = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
-    reduce_partials_kernel<<<grid, 256, 0, st>>>((const double*)pv.p, pv.S, pv.slab, count, out);
+    const double* src = (const double*)pv.p + c0 * pv.kpp;
+    if (out_f64) reduce_partials_kernel<double><<<grid, 256, 0, st>>>(src, pv.S, pv.slab, count, (double*)out + c0 * pv.kpp);
+    else reduce_partials_kernel<float><<<grid, 256, 0, st>>>(src, pv.S, pv.slab, count, (float*)out + c0 * pv.kpp);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -730,11 +735,11 @@ size_t gram_scratch_elems(int k, int max_blocks)
     return (size_t)max_blocks * KP * KP + 8;             // + the ticket word of the fused Gram/pack kernel
 }
 
-int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, hipStream_t st, double* xscale,
-                double* oscale, double ascale)
+// partial Gram matrices of the columns [0, N) of X into scratch ([*nblk_out][KP * KP]); several calls with scratch
+// offsets (row segments of a factor) followed by ONE launch_gram_reduce give the Gram matrix of the union
+int launch_gram_partials(const double* X, int k, i64 N, double* scratch, int max_blocks, int* nblk_out, hipStream_t st)
 {
     const int KP = kp_of(k);
-    const int elems = KP * KP;
     int nblk;
     if (is_wide(k)) {
         const int rc = launch_gram_wide_partials(X, KP, N, scratch, max_blocks, &nblk, st);
@@ -758,9 +763,53 @@ int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int m
         gram_stream8_kernel<<<nblk, 256, 0, st>>>(X, N, scratch);
     }
     SMK_HIP(hipGetLastError());
+    *nblk_out = nblk;
+    return 0;
+}
+
+int launch_gram_reduce(const double* scratch, int nblk, int k, double* G, hipStream_t st, double* xscale, double* oscale,
+                       double ascale)
+{
+    const int KP = kp_of(k), elems = KP * KP;
     gram_reduce_kernel<<<(elems + 15) / 16, 256, 0, st>>>(scratch, nblk, elems, G, KP, xscale, oscale, ascale);
     SMK_HIP(hipGetLastError());
     return 0;
+}
+
+// the row scales of the fp16 two-term operand from a FINISHED Gram matrix (sharded runs: after its all-reduce);
+// the same rule as gram_reduce_kernel
+__global__ void gram_scales_kernel(const double* __restrict__ G, int KP, int k, double* __restrict__ xscale,
+                                   double* __restrict__ oscale, double ascale)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= KP) return;
+    const double t = G[(i64)r * KP + r];
+    int ex = 0;
+    double xs = 1.0;
+    if (t > 0.0 && t < 1.0e300) {
+        (void)frexp(t, &ex);
+        const int half = (ex >= 0) ? (ex + 1) / 2 : -((-ex) / 2);
+        xs = ldexp(1.0, 14 - half);
+    }
+    xscale[r] = xs;
+    if (oscale) oscale[r] = 1.0 / (xs * ascale);
+}
+
+int launch_gram_scales(const double* G, int k, double* xscale, double* oscale, double ascale, hipStream_t st)
+{
+    const int KP = kp_of(k);
+    gram_scales_kernel<<<(KP + 63) / 64, 64, 0, st>>>(G, KP, k, xscale, oscale, ascale);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gram(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, hipStream_t st, double* xscale,
+                double* oscale, double ascale)
+{
+    int nblk = 0;
+    const int rc = launch_gram_partials(X, k, N, scratch, max_blocks, &nblk, st);
+    if (rc) return rc;
+    return launch_gram_reduce(scratch, nblk, k, G, st, xscale, oscale, ascale);
 }
 
 // gram scratch: [max_blocks][KP*KP] partials followed by one ticket word.  Returns 1 when this shape has no fused
@@ -979,23 +1028,33 @@ int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, h
     return 0;
 }
 
-int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
-                   double* pg_partials, double* pg_accum, int slot, hipStream_t st)
+// the per-workgroup partial sums only (*grid_out of them); several calls with partials offsets (row segments of a
+// factor) followed by ONE launch_sum_partials give the sum over the union
+int launch_grad_pg_partials(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
+                            double* pg_partials, int* grid_out, hipStream_t st)
 {
-    if (is_wide(k)) {
-        int g = 0;
-        const int rc = launch_grad_pg_wide(X, k, N, R, G, grad_out, pg_partials, &g, st);
-        if (rc) return rc;
-        sum_partials_kernel<<<1, 256, 0, st>>>(pg_partials, g, pg_accum + slot);
-        SMK_HIP(hipGetLastError());
-        return 0;
-    }
+    if (is_wide(k)) return launch_grad_pg_wide(X, k, N, R, G, grad_out, pg_partials, grid_out, st);
     const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
     COLTILE_LAUNCH(grad_pg_kernel, grid, X, k, N, R, G, grad_out, pg_partials);
     SMK_HIP(hipGetLastError());
-    sum_partials_kernel<<<1, 256, 0, st>>>(pg_partials, grid, pg_accum + slot);
+    *grid_out = grid;
+    return 0;
+}
+
+int launch_sum_partials(const double* partials, int n, double* out, hipStream_t st)
+{
+    sum_partials_kernel<<<1, 256, 0, st>>>(partials, n, out);
     SMK_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
+                   double* pg_partials, double* pg_accum, int slot, hipStream_t st)
+{
+    int g = 0;
+    const int rc = launch_grad_pg_partials(X, k, N, R, G, grad_out, pg_partials, &g, st);
+    if (rc) return rc;
+    return launch_sum_partials(pg_partials, g, pg_accum + slot, st);
 }
 
 // projected-gradient sums of both factors: pg_accum[0] (side 1), pg_accum[1] (side 2), and the failure flag

@@ -91,6 +91,8 @@ struct smk_matrix {
     std::vector<double> h_val;
 };
 
+static const int MAX_CHUNKS = 8;
+
 struct smk_solver {
     smk_options o;
     const smk_matrix* a = nullptr;
@@ -129,10 +131,22 @@ struct smk_solver {
     void* ar_user = nullptr;
     smk_comm* comm = nullptr;
     void* comm_ws = nullptr;              // owned workspace when a native communicator is attached
-    i64 w_chunk = 0;                      // rows of W per rank in the BPP all-gather (ceil(m / world))
-    hipStream_t st2 = nullptr;            // the small HH' all-reduce runs here, beside the H*At pass
-    hipEvent_t ev_gram = nullptr, ev_gh = nullptr;
+    // Native communicator: EVERY collective is issued on st2 (one stream per communicator), tied to the main stream by
+    // events.  The rows of A (= columns of A', rows of W) are cut into `nchunk` chunks of world * blk rows; block r of a
+    // chunk belongs to rank r (block-cyclic), so a chunk is at once a contiguous range of the H*At pass, the send buffer
+    // of one reduce-scatter / all-reduce and the receive buffer of one all-gather: the exchange of chunk j runs on st2
+    // while the streaming product works on chunk j + 1.
+    int nchunk = 1;
+    i64 blk = 0, rows_cap = 0;            // rows per (chunk, rank) block (multiple of 256); world * nchunk * blk >= m_pad
+    bool red_f64 = false;                 // element type of the summed (AH')' (fp32 unless SMK_COMM_F64=1)
+    bool w_sharded = false;               // BPP: every rank solves (and holds current) only its own blocks of W
+    bool w_full = true;                   // all rows of the fp64 W on this rank are current
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_gram = nullptr, ev_gh = nullptr, ev_x = nullptr, ev_y = nullptr;
+    hipEvent_t ev_c[MAX_CHUNKS] = {}, ev_r[MAX_CHUNKS] = {}, ev_a[MAX_CHUNKS] = {};
     bool gh_pending = false;
+    bool r2_pending = false;              // the chunk exchanges of the last H*At pass have not been joined by the main stream yet
+    bool inv_done[2] = {false, false};    // the inverse of this side's current Gram matrix is in place (ordered before the main stream)
     // stopping rule evaluated one iteration late (smk_solver_run): pinned result slots, events, and a
     // snapshot of (W, H, W'W) per checked iteration so that a speculative iteration can be undone
     struct ProgSlot { double h[8]; int flag; int fused; };     // fused: the flag travels in h[5]
@@ -141,12 +155,14 @@ struct smk_solver {
     double* snap[2] = {nullptr, nullptr};
     // timing
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];    // 0: W'A passes, 1: H*At passes, 2: the big collectives of a sharded run
+    struct TimedSpan { hipEvent_t e0, e1; int counts; };     // counts: this span completes one launch (a pass cut into chunks is ONE launch)
+    std::vector<TimedSpan> ev[3];         // 0: W'A passes, 1: H*At passes, 2: the big collectives of a sharded run (on st2)
     double acc_ms[3] = {0, 0, 0};
     int launches[3] = {0, 0, 0};
 };
 
 static const int GRAM_BLOCKS = 256;
+
 
 extern "C" {
 
@@ -593,33 +609,43 @@ static PartialView view1(const smk_solver* s)
     return PartialView{s->P1, s->pl1.S, (i64)s->pl1.ncols_pad * s->kpp, s->kpp, 1};
 }
 static inline bool is_dist(const smk_solver* s) { return s->ar != nullptr || s->comm != nullptr; }
-// BPP with a native communicator: every rank solves only its own rows of W, so it needs only those rows of the summed
-// (AH')' -- a reduce-scatter instead of an all-reduce (half the bytes on the wire) -- and W comes back by all-gather
-static inline bool w_rows_sharded(const smk_solver* s)
-{
-    return s->comm != nullptr && s->world > 1 && s->o.algorithm == SMK_ALG_BPP;
-}
+// BPP with a native communicator: every rank solves only its own blocks of W, so it needs only those rows of the summed
+// (AH')' -- a reduce-scatter instead of an all-reduce (half the bytes on the wire) -- and the other ranks receive the
+// packed streaming operand of those rows (4 B per entry in the fp16 form) instead of the fp64 values
+static inline bool w_rows_sharded(const smk_solver* s) { return s->w_sharded; }
 
 static PartialView view2(const smk_solver* s)
 {
-    if (is_dist(s)) return PartialView{s->R2red, 1, 0, s->kpp, 0};
+    if (is_dist(s)) return PartialView{s->R2red, 1, 0, s->kpp, s->red_f64 ? 1 : 0};
     return PartialView{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
 }
 
+// rows [r0, r1) of chunk j (clipped to the padded row count of the H*At pass) and this rank's block [a, b) of it
+// (valid rows only: b <= m; empty when b <= a)
+static inline void chunk_rows(const smk_solver* s, int j, i64* r0, i64* r1)
+{
+    *r0 = (i64)j * s->world * s->blk;
+    *r1 = std::min<i64>(*r0 + (i64)s->world * s->blk, s->pl2.ncols_pad);
+}
+static inline void own_block(const smk_solver* s, int j, i64* a, i64* b)
+{
+    *a = ((i64)j * s->world + s->rank) * s->blk;
+    *b = std::min<i64>(*a + s->blk, s->m);
+}
+
+// workspace layout: [R2red: rows x kpp f32|f64][Gh: KP*KP f64][scal: 8 f64][Wt: KP x rows f64].  rows = the padded
+// row count (callback hook: one all-reduce per buffer, any world) or world * nchunk * blk with a native communicator
+// (equal blocks for the reduce-scatter / all-gather)
+static inline i64 comm_rows(const smk_solver* s) { return s->comm ? std::max<i64>(s->rows_cap, s->pl2.ncols_pad) : s->pl2.ncols_pad; }
 static size_t comm_bytes(const smk_solver* s)
 {
-    // [R2red: rows * kpp f32][Gh: KP*KP f64][scal: 8 f64]; rows = m_pad, or world equal chunks of ceil(m / world) rows
-    // when that is more (the reduce-scatter / all-gather of the row-sharded W solve work on equal chunks)
-    const i64 world = s->comm ? s->comm->world : (s->world > 0 ? s->world : 1);
-    const i64 chunk = (s->m + world - 1) / world;
-    size_t b = (size_t)std::max<i64>(s->pl2.ncols_pad, chunk * world) * s->kpp * sizeof(float);
+    size_t b = (size_t)comm_rows(s) * s->kpp * (s->red_f64 ? sizeof(double) : sizeof(float));
     b = (b + 255) / 256 * 256;
     b += (size_t)s->KP * s->KP * sizeof(double);
     b = (b + 255) / 256 * 256;
     b += 8 * sizeof(double);
     b = (b + 255) / 256 * 256;
-    // Wt: the row-sharded W-side NNLS gathers equal chunks of ceil(m / world) rows (the last one is padded)
-    b += (size_t)s->KP * (size_t)std::max<i64>(chunk * world, s->m) * sizeof(double);
+    b += (size_t)s->KP * (size_t)comm_rows(s) * sizeof(double);
     return b;
 }
 
@@ -765,13 +791,15 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
 void smk_solver_destroy(smk_solver* s)
 {
     if (!s) return;
+    if (s->st2) (void)hipStreamSynchronize(s->st2);
+    if (s->st_inv) (void)hipStreamSynchronize(s->st_inv);
     void* ptrs[] = {s->H, s->Wt_own, s->Gw, s->Gh_own, s->gram_scratch, s->tmpW, s->pg_partials, s->scal_own,
                     s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH, s->nnls_scratch, s->W0c, s->H0c,
                     s->xscale[0], s->xscale[1], s->oscale[0], s->oscale[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int w = 0; w < 3; ++w)
-        for (auto& e : s->ev[w]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto& e : s->ev[w]) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     for (int b = 0; b < 2; ++b) {
         if (s->snap[b]) (void)hipFree(s->snap[b]);
         if (s->pev[b]) (void)hipEventDestroy(s->pev[b]);
@@ -784,8 +812,13 @@ void smk_solver_destroy(smk_solver* s)
         if (s->ev_g[i]) (void)hipEventDestroy(s->ev_g[i]);
         if (s->ev_inv[i]) (void)hipEventDestroy(s->ev_inv[i]);
     }
-    if (s->ev_gram) (void)hipEventDestroy(s->ev_gram);
-    if (s->ev_gh) (void)hipEventDestroy(s->ev_gh);
+    hipEvent_t single[] = {s->ev_gram, s->ev_gh, s->ev_x, s->ev_y};
+    for (hipEvent_t e : single) if (e) (void)hipEventDestroy(e);
+    for (int j = 0; j < MAX_CHUNKS; ++j) {
+        if (s->ev_c[j]) (void)hipEventDestroy(s->ev_c[j]);
+        if (s->ev_r[j]) (void)hipEventDestroy(s->ev_r[j]);
+        if (s->ev_a[j]) (void)hipEventDestroy(s->ev_a[j]);
+    }
     --g_live_solvers;
     delete s;
 }
@@ -801,9 +834,7 @@ static void carve_workspace(smk_solver* s, void* workspace)
 {
     unsigned char* p = (unsigned char*)workspace;
     s->R2red = (float*)p;
-    const i64 world = s->comm ? s->comm->world : (s->world > 0 ? s->world : 1);      // same layout as comm_bytes()
-    const i64 chunk = (s->m + world - 1) / world;
-    size_t b = (size_t)std::max<i64>(s->pl2.ncols_pad, chunk * world) * s->kpp * sizeof(float);
+    size_t b = (size_t)comm_rows(s) * s->kpp * (s->red_f64 ? sizeof(double) : sizeof(float));      // same layout as comm_bytes()
     b = (b + 255) / 256 * 256;
     s->Gh = (double*)(p + b);
     b += (size_t)s->KP * s->KP * sizeof(double);
@@ -833,7 +864,9 @@ int smk_solver_set_comm(smk_solver* s, int rank, int world, smk_allreduce_fn fn,
     return SMK_OK;
 }
 
-// Native path: every collective is issued from C on the solver's streams (RCCL over xGMI, or the in-process
+static int progress_prealloc(smk_solver* s);
+
+// Native path: every collective is issued from C on the solver's second stream (RCCL over xGMI, or the in-process
 // stand-in).  Call before set_factors().  The communicator must outlive the solver.
 int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
 {
@@ -841,15 +874,50 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
     if (s->ar || s->comm) { set_error("solver already has a communicator"); return SMK_BAD_PARAM; }
     s->comm = comm;
     s->rank = comm->rank; s->world = comm->world;
-    s->w_chunk = (s->m + comm->world - 1) / comm->world;
+    // chunk geometry: blocks of >= 4096 rows, at most 4 chunks (SMK_COMM_CHUNKS overrides: 1 .. 8), block a multiple of
+    // 256 rows (the column tile of the streaming kernels and a whole number of packed chunk pairs)
+    {
+        const i64 mpad = s->pl2.ncols_pad;
+        i64 c = mpad / ((i64)s->world * 4096);
+        c = std::max<i64>(1, std::min<i64>(c, 4));
+        if (const char* e = getenv("SMK_COMM_CHUNKS")) c = std::max(1, std::min(atoi(e), MAX_CHUNKS));
+        s->blk = round_up((mpad + (i64)s->world * c - 1) / ((i64)s->world * c), 256);
+        s->nchunk = (int)((mpad + (i64)s->world * s->blk - 1) / ((i64)s->world * s->blk));      // chunks that hold rows
+        s->rows_cap = (i64)s->nchunk * s->world * s->blk;
+    }
+    {
+        const char* e = getenv("SMK_COMM_F64");
+        s->red_f64 = e && atoi(e) != 0;
+    }
+    s->w_sharded = s->o.algorithm == SMK_ALG_BPP && !s->a->sparse && (s->world > 1 || comm_forced());
     const size_t bytes = comm_bytes(s);
-    if (hipMalloc(&s->comm_ws, bytes) != hipSuccess) { s->comm = nullptr; set_error("hipMalloc(comm workspace)"); return SMK_DEVICE_ERROR; }
+    if (hipMalloc(&s->comm_ws, bytes) != hipSuccess) { s->comm = nullptr; s->w_sharded = false; set_error("hipMalloc(comm workspace)"); return SMK_DEVICE_ERROR; }
     SMK_HIP(hipMemsetAsync(s->comm_ws, 0, bytes, s->st));
     carve_workspace(s, s->comm_ws);
+    if (s->w_sharded) {
+        // the packed operand of W is gathered in equal blocks: room for rows_cap rows, groups laid out for that length
+        if (s->packW) (void)hipFree(s->packW);
+        s->packW = nullptr;
+        const size_t pb = packed_bytes(s->a->storage, s->k, s->rows_cap, s->nsplit);
+        if (dev_alloc((unsigned char**)&s->packW, pb)) return SMK_DEVICE_ERROR;
+        SMK_HIP(hipMemsetAsync(s->packW, 0, pb, s->st));
+        size_t off = 0;
+        for (int g = 0; g < s->ng; ++g) {
+            s->pg1[g].pack_offset = off;
+            off += packed_bytes(s->a->storage, s->pg1[g].kg, s->rows_cap, s->nsplit);
+        }
+        s->pl1.pack_offset = s->pg1[0].pack_offset;
+    }
     SMK_HIP(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
-    SMK_HIP(hipEventCreateWithFlags(&s->ev_gram, hipEventDisableTiming));
-    SMK_HIP(hipEventCreateWithFlags(&s->ev_gh, hipEventDisableTiming));
-    return SMK_OK;
+    hipEvent_t* evs[] = {&s->ev_gram, &s->ev_gh, &s->ev_x, &s->ev_y};
+    for (hipEvent_t* e : evs) SMK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (int j = 0; j < MAX_CHUNKS; ++j) {
+        SMK_HIP(hipEventCreateWithFlags(&s->ev_c[j], hipEventDisableTiming));
+        SMK_HIP(hipEventCreateWithFlags(&s->ev_r[j], hipEventDisableTiming));
+        SMK_HIP(hipEventCreateWithFlags(&s->ev_a[j], hipEventDisableTiming));
+    }
+    // nothing is allocated once the collectives are in flight (several ranks may live in one process)
+    return progress_prealloc(s);
 }
 
 int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const double* H0, int64_t ldH)
@@ -889,24 +957,63 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
 }
 
 // ---- collectives -------------------------------------------------------------------------------
-static int dist_allreduce(smk_solver* s, void* ptr, i64 count, int f64, hipStream_t st)
+// callback hook: one host call per buffer, in stream order on the main stream
+static int dist_allreduce_cb(smk_solver* s, void* ptr, i64 count, int f64)
 {
-    if (s->comm) return comm_allreduce(s->comm, ptr, count, f64, st);
-    if (s->ar) {
-        if (s->ar(s->ar_user, ptr, (int64_t)count, f64)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
-    }
+    if (s->ar && s->ar(s->ar_user, ptr, (int64_t)count, f64)) { set_error("all-reduce callback failed"); return SMK_DEVICE_ERROR; }
     return 0;
 }
 
-// HH' is needed only after the H*At pass: with a native communicator its all-reduce runs on a second stream
+// native communicator: st2 picks up after everything enqueued on the main stream so far
+static int comm_fork(smk_solver* s, hipEvent_t ev)
+{
+    SMK_HIP(hipEventRecord(ev, s->st));
+    SMK_HIP(hipStreamWaitEvent(s->st2, ev, 0));
+    return 0;
+}
+// ... and the main stream waits for what st2 has been given so far
+static int comm_join(smk_solver* s, hipEvent_t ev)
+{
+    SMK_HIP(hipEventRecord(ev, s->st2));
+    SMK_HIP(hipStreamWaitEvent(s->st, ev, 0));
+    return 0;
+}
+
+// a collective on st2 bracketed by events when timing is on (slot 2 of smk_solver_kernel_time)
+static int timed_collective(smk_solver* s, const std::function<int()>& issue)
+{
+    if (!s->timing) return issue();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    SMK_HIP(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
+    (void)hipEventRecord(e0, s->st2);
+    const int rc = issue();
+    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    (void)hipEventRecord(e1, s->st2);
+    s->ev[2].push_back({e0, e1, 1});
+    return 0;
+}
+
+// a small in-place sum that the main stream needs right away (scalars of the stopping rule, W'W of a row-sharded W)
+static int dist_allreduce_now(smk_solver* s, void* ptr, i64 count, int f64)
+{
+    if (!s->comm) return dist_allreduce_cb(s, ptr, count, f64);
+    int rc = comm_fork(s, s->ev_x);
+    if (rc) return rc;
+    rc = comm_allreduce(s->comm, ptr, count, f64, s->st2);
+    if (rc) return rc;
+    return comm_join(s, s->ev_y);
+}
+
+// HH' is needed only after the H*At pass: with a native communicator its all-reduce runs on the second stream
 // beside that pass; wait_gh() joins it back.
 static int allreduce_gh(smk_solver* s)
 {
     if (!is_dist(s)) return 0;
-    if (!s->comm) return dist_allreduce(s, s->Gh, (i64)s->KP * s->KP, 1, s->st);
-    SMK_HIP(hipEventRecord(s->ev_gram, s->st));
-    SMK_HIP(hipStreamWaitEvent(s->st2, s->ev_gram, 0));
-    int rc = comm_allreduce(s->comm, s->Gh, (i64)s->KP * s->KP, 1, s->st2);
+    if (!s->comm) return dist_allreduce_cb(s, s->Gh, (i64)s->KP * s->KP, 1);
+    int rc = comm_fork(s, s->ev_gram);
+    if (rc) return rc;
+    rc = comm_allreduce(s->comm, s->Gh, (i64)s->KP * s->KP, 1, s->st2);
     if (rc) return rc;
     SMK_HIP(hipEventRecord(s->ev_gh, s->st2));
     s->gh_pending = true;
@@ -917,6 +1024,14 @@ static int wait_gh(smk_solver* s)
     if (!s->gh_pending) return 0;
     SMK_HIP(hipStreamWaitEvent(s->st, s->ev_gh, 0));
     s->gh_pending = false;
+    return 0;
+}
+// the main stream joins the chunk exchanges of the last H*At pass (every consumer of the summed (AH')' calls this)
+static int wait_r2(smk_solver* s)
+{
+    if (!s->r2_pending) return 0;
+    for (int j = 0; j < s->nchunk; ++j) SMK_HIP(hipStreamWaitEvent(s->st, s->ev_r[j], 0));
+    s->r2_pending = false;
     return 0;
 }
 
@@ -930,6 +1045,7 @@ static inline double* inv_scratch(smk_solver* s, int side)
 // sharded run finishes on the second stream)
 static int start_inverse(smk_solver* s, int side, const double* G, hipEvent_t after = nullptr)
 {
+    s->inv_done[side] = false;
     if (!s->st_inv || s->o.algorithm != SMK_ALG_BPP) return 0;
     if (after) {
         SMK_HIP(hipStreamWaitEvent(s->st_inv, after, 0));
@@ -945,24 +1061,27 @@ static int start_inverse(smk_solver* s, int side, const double* G, hipEvent_t af
 }
 static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, PartialView R, const double* G)
 {
-    int ready = 0;
     if (s->inv_pending[side]) {
         SMK_HIP(hipStreamWaitEvent(s->st, s->ev_inv[side], 0));
         s->inv_pending[side] = false;
-        ready = 1;
+        s->inv_done[side] = true;
     }
-    return launch_nnls_bpp(X, nullptr, s->k, c0, c1, R, G, s->fail_flag, s->iter, inv_scratch(s, side), ready, g_cus, s->st);
+    const int rc = launch_nnls_bpp(X, nullptr, s->k, c0, c1, R, G, s->fail_flag, s->iter, inv_scratch(s, side), s->inv_done[side] ? 1 : 0, g_cus, s->st);
+    // without the side stream (k <= 32, wide ranks) a first launch at k in (32, 128] computes the inverse itself, in stream order
+    if (!rc && c1 > c0 && s->KP >= 64 && !is_wide(s->k)) s->inv_done[side] = true;
+    return rc;
 }
 
 // ---- building blocks -----------------------------------------------------------------------
+// one launch of the streaming product, bracketed by events when timing is on; `counts`: this launch completes a pass
 static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp,
-                         double* P)
+                         double* P, int counts = 1)
 {
     if (s->timing) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         SMK_HIP(hipEventCreate(&e0));
         if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
-        s->ev[which].push_back({e0, e1});          // owned by the solver from here on (destroyed with it)
+        s->ev[which].push_back({e0, e1, counts});   // owned by the solver from here on (destroyed with it)
         SMK_HIP(hipEventRecord(e0, s->st));
         int rc = launch_bigprod(pl, B, ldb, Xp, P, s->st);
         if (rc) { s->ev[which].pop_back(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
@@ -986,29 +1105,72 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
     if (s->timing) {
         if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         (void)hipEventRecord(e1, s->st);
-        s->ev[which].push_back({e0, e1});
+        s->ev[which].push_back({e0, e1, 1});
     }
     return rc;
 }
 
-// a collective of the iteration bracketed by events when timing is on (slot 2 of smk_solver_kernel_time)
-static int timed_collective(smk_solver* s, const std::function<int()>& issue)
+// W'A with a row-sharded W (BPP, native communicator): every rank packs its own blocks, the blocks of chunk j are
+// all-gathered on st2 (packed operand: 4 B per entry in the fp16 form, half of the fp64 values) and the product is
+// taken chunk by chunk down the contraction, each launch adding to P1, as soon as its chunk of the operand has landed.
+static int prod1_sharded(smk_solver* s)
 {
-    if (!s->timing) return issue();
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    SMK_HIP(hipEventCreate(&e0));
-    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
-    (void)hipEventRecord(e0, s->st);
-    const int rc = issue();
-    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
-    (void)hipEventRecord(e1, s->st);
-    s->ev[2].push_back({e0, e1});
+    const int storage = s->a->storage;
+    const size_t es = (size_t)elem_size(storage);
+    int rc = 0;
+    for (int j = 0; j < s->nchunk && !rc; ++j) {
+        i64 a, b;
+        own_block(s, j, &a, &b);
+        for (int g = 0; g < s->ng && !rc; ++g) {
+            unsigned char* out = (unsigned char*)s->packW + s->pg1[g].pack_offset + packed_row_offset(storage, s->pg1[g].kg, s->nsplit, a);
+            if (b > a) rc = launch_pack_rows(s->Wt + a * s->KP, s->KP, s->pg1[g].k0, s->pg1[g].kg, b - a, storage, s->nsplit, out, s->st, s->xscale[0]);
+            // rows [b, a + blk) of the block stay zero (set at attach; a block never shrinks)
+        }
+    }
+    if (rc) return rc;
+    rc = comm_fork(s, s->ev_x);
+    if (rc) return rc;
+    for (int j = 0; j < s->nchunk; ++j) {
+        i64 r0, r1;
+        chunk_rows(s, j, &r0, &r1);
+        rc = timed_collective(s, [&] {
+            for (int g = 0; g < s->ng; ++g) {
+                const size_t per = packed_row_offset(storage, s->pg1[g].kg, s->nsplit, s->blk);          // bytes per block
+                unsigned char* base = (unsigned char*)s->packW + s->pg1[g].pack_offset + packed_row_offset(storage, s->pg1[g].kg, s->nsplit, r0);
+                const int grc = comm_allgather(s->comm, base, (i64)(per / 4), 0, s->st2);
+                if (grc) return grc;
+            }
+            return 0;
+        });
+        if (rc) return rc;
+        SMK_HIP(hipEventRecord(s->ev_a[j], s->st2));
+    }
+    bool first = true;
+    for (int j = 0; j < s->nchunk; ++j) {
+        i64 r0, r1;
+        chunk_rows(s, j, &r0, &r1);
+        SMK_HIP(hipStreamWaitEvent(s->st, s->ev_a[j], 0));
+        const i64 rows = std::min<i64>(r1, s->m) - r0;
+        if (rows <= 0) continue;
+        const bool last = (j == s->nchunk - 1) || (std::min<i64>(r1, s->m) >= s->m);
+        for (int g = 0; g < s->ng; ++g) {
+            BigProdPlan pl = s->pg1[g];
+            pl.stages = (rows + pl.mb - 1) / pl.mb;
+            pl.nst = (pl.stages + pl.S - 1) / pl.S;
+            pl.accum = first ? 0 : 1;
+            const unsigned char* Xp = (const unsigned char*)s->packW + pl.pack_offset + packed_row_offset(storage, pl.kg, s->nsplit, r0);
+            rc = timed_bigprod(s, 0, pl, (const unsigned char*)s->a->A + (size_t)r0 * es, s->a->ldA, Xp, s->P1 + pl.k0, last ? 1 : 0);
+            if (rc) return rc;
+        }
+        first = false;
+    }
     return 0;
 }
 
 static int prod1(smk_solver* s)
 {
     if (s->a->sparse) return timed_spmm(s, 0, s->a->colptr, s->a->rowidx, s->a->val, s->n, s->Wt, s->P1);
+    if (s->w_sharded) return prod1_sharded(s);
     int rc = 0;
     if (!s->packed_fresh[0]) rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st, s->xscale[0]);
     s->packed_fresh[0] = false;
@@ -1020,33 +1182,65 @@ static int prod1(smk_solver* s)
     return 0;
 }
 
-// R2 = H At = (A H')'  (k x m), summed over ranks when sharded
+// R2 = H At = (A H')'  (k x m), summed over ranks when sharded.  With a native communicator the pass runs chunk by
+// chunk over the rows of A and the sum of chunk j (reduce-scatter for the row-sharded BPP solve, all-reduce otherwise)
+// travels on st2 while the product streams chunk j + 1; consumers call wait_r2().
 static int prod2(smk_solver* s)
 {
     int rc = 0;
+    const PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
     if (s->a->sparse) {
         rc = timed_spmm(s, 1, s->a->colptr_t, s->a->rowidx_t, s->a->val_t, s->m, s->H, s->P2);
-    } else {
-        if (!s->packed_fresh[1]) rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st, s->xscale[1]);
-        s->packed_fresh[1] = false;
         if (rc) return rc;
+        rc = wait_gh(s);
+        if (rc || !is_dist(s)) return rc;
+        rc = launch_reduce_partials(pv, s->k, 0, s->pl2.ncols_pad, s->R2red, s->red_f64 ? 1 : 0, s->st);
+        if (rc) return rc;
+        if (!s->comm) return dist_allreduce_cb(s, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, 0);
+        rc = comm_fork(s, s->ev_c[0]);
+        if (rc) return rc;
+        rc = timed_collective(s, [&] { return comm_allreduce(s->comm, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, s->red_f64 ? 1 : 0, s->st2); });
+        if (rc) return rc;
+        return comm_join(s, s->ev_r[0]);
+    }
+    if (!s->packed_fresh[1]) rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st, s->xscale[1]);
+    s->packed_fresh[1] = false;
+    if (rc) return rc;
+    if (!s->comm) {
         for (int g = 0; g < s->ng && !rc; ++g)
             rc = timed_bigprod(s, 1, s->pg2[g], s->a->At, s->a->ldAt, (const unsigned char*)s->packH + s->pg2[g].pack_offset, s->P2 + s->pg2[g].k0);
-    }
-    if (rc) return rc;
-    rc = wait_gh(s);
-    if (rc) return rc;
-    if (is_dist(s)) {
-        PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
-        rc = launch_reduce_partials(pv, s->k, s->pl2.ncols_pad, s->R2red, s->st);
         if (rc) return rc;
+        rc = wait_gh(s);
+        if (rc || !is_dist(s)) return rc;
+        rc = launch_reduce_partials(pv, s->k, 0, s->pl2.ncols_pad, s->R2red, 0, s->st);
+        if (rc) return rc;
+        return dist_allreduce_cb(s, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, 0);
+    }
+    const size_t es = (size_t)elem_size(s->a->storage), rb = s->red_f64 ? sizeof(double) : sizeof(float);
+    for (int j = 0; j < s->nchunk; ++j) {
+        i64 r0, r1;
+        chunk_rows(s, j, &r0, &r1);
+        for (int g = 0; g < s->ng; ++g) {
+            BigProdPlan pl = s->pg2[g];
+            pl.tiles = (r1 - r0 + pl.nb - 1) / pl.nb;
+            rc = timed_bigprod(s, 1, pl, (const unsigned char*)s->a->At + (size_t)r0 * s->a->ldAt * es, s->a->ldAt,
+                               (const unsigned char*)s->packH + pl.pack_offset, s->P2 + pl.k0 + r0 * pl.pstride, j == s->nchunk - 1 ? 1 : 0);
+            if (rc) return rc;
+        }
+        rc = launch_reduce_partials(pv, s->k, r0, r1 - r0, s->R2red, s->red_f64 ? 1 : 0, s->st);
+        if (rc) return rc;
+        rc = comm_fork(s, s->ev_c[j]);
+        if (rc) return rc;
+        unsigned char* base = (unsigned char*)s->R2red + (size_t)r0 * s->kpp * rb;
         rc = timed_collective(s, [&] {
-            if (w_rows_sharded(s)) return comm_reduce_scatter(s->comm, s->R2red, s->w_chunk * s->kpp, 0, s->st);   // own rows only
-            return dist_allreduce(s, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, 0, s->st);
+            if (s->w_sharded) return comm_reduce_scatter(s->comm, base, s->blk * s->kpp, s->red_f64 ? 1 : 0, s->st2);   // own block only
+            return comm_allreduce(s->comm, base, (r1 - r0) * s->kpp, s->red_f64 ? 1 : 0, s->st2);
         });
         if (rc) return rc;
+        SMK_HIP(hipEventRecord(s->ev_r[j], s->st2));
     }
-    return 0;
+    s->r2_pending = true;
+    return wait_gh(s);
 }
 
 // Gram matrix of a factor; for dense A the same launch also writes the packed operand of the product that follows
@@ -1057,6 +1251,26 @@ static int gram_factor(smk_solver* s, int side)
     const i64 N = side == 0 ? s->m : s->n;
     double* G = side == 0 ? s->Gw : s->Gh;
     s->packed_fresh[side] = false;
+    if (side == 0 && s->w_sharded) {
+        // W'W from this rank's own blocks, summed over the ranks; the fp16 row scales follow the finished matrix
+        int nb_tot = 0;
+        const int per = std::max(1, GRAM_BLOCKS / s->nchunk);
+        for (int j = 0; j < s->nchunk; ++j) {
+            i64 a, b;
+            own_block(s, j, &a, &b);
+            if (b <= a) continue;
+            int nb = 0;
+            const int rc = launch_gram_partials(s->Wt + a * s->KP, s->k, b - a, s->gram_scratch + (size_t)nb_tot * s->KP * s->KP, per, &nb, s->st);
+            if (rc) return rc;
+            nb_tot += nb;
+        }
+        int rc = nb_tot ? launch_gram_reduce(s->gram_scratch, nb_tot, s->k, G, s->st) : launch_zero_f64(G, (i64)s->KP * s->KP, s->st);
+        if (rc) return rc;
+        rc = dist_allreduce_now(s, G, (i64)s->KP * s->KP, 1);
+        if (rc) return rc;
+        if (s->nsplit == NSPLIT_F16X2) return launch_gram_scales(G, s->k, s->xscale[0], s->oscale[0], (double)s->a->ascale, s->st);
+        return 0;
+    }
     if (s->nsplit == NSPLIT_F16X2)       // the reduce launch also derives the row scales of the operand packed next
         return launch_gram(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->st, s->xscale[side], s->oscale[side], (double)s->a->ascale);
     if (!s->a->sparse && s->o.algorithm != SMK_ALG_RANK2) {
@@ -1086,6 +1300,19 @@ static int gram_h(smk_solver* s)
     return start_inverse(s, 1, s->Gh, (is_dist(s) && s->gh_pending) ? s->ev_gh : nullptr);
 }
 
+// row-sharded W: bring every row of the fp64 W to every rank (results, DELTA_FNORM); one in-place all-gather per chunk
+static int gather_w(smk_solver* s)
+{
+    if (!s->w_sharded || s->w_full) return 0;
+    int rc = comm_fork(s, s->ev_x);
+    if (rc) return rc;
+    for (int j = 0; j < s->nchunk && !rc; ++j)
+        rc = comm_allgather(s->comm, s->Wt + (i64)j * s->world * s->blk * s->KP, s->blk * s->KP, 1, s->st2);
+    if (rc) return rc;
+    s->w_full = true;
+    return comm_join(s, s->ev_y);
+}
+
 // solver.Init (mu :98-114, hals :142-159, bpp :310-335) + progress_est->Init
 static int solver_init(smk_solver* s)
 {
@@ -1097,8 +1324,10 @@ static int solver_init(smk_solver* s)
         rc = gram_w(s);  if (rc) return rc;
         rc = prod1(s);   if (rc) return rc;
     }
-    if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM)
+    if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM) {
+        rc = gather_w(s); if (rc) return rc;
         SMK_HIP(hipMemcpyAsync(s->Wprev, s->Wt, (size_t)s->KP * s->m * sizeof(double), hipMemcpyDeviceToDevice, s->st));
+    }
     s->inited = true;
     return 0;
 }
@@ -1115,11 +1344,13 @@ static int solver_iteration(smk_solver* s)
             rc = launch_mu_update(s->H, s->k, s->n, r1, s->Gw, s->st);  if (rc) return rc;
             rc = gram_h(s);   if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
+            rc = wait_r2(s);  if (rc) return rc;
             rc = launch_mu_update(s->Wt, s->k, s->m, r2, s->Gh, s->st); if (rc) return rc;
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
             break;
         case SMK_ALG_HALS: // nmf_solver_hals.hpp:166-199
+            rc = wait_r2(s);  if (rc) return rc;
             rc = launch_hals_w_update(s->Wt, s->k, s->m, r2, s->Gh, s->hals_scratch, g_cus, s->fail_flag, s->hals_calls++, s->hals_multi ? 1 : 0, s->st); if (rc) return rc;
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
@@ -1131,27 +1362,29 @@ static int solver_iteration(smk_solver* s)
             rc = nnls_side(s, 0, s->H, 0, s->n, r1, s->Gw); if (rc) return rc;
             rc = gram_h(s);   if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
-            if (is_dist(s) && s->world > 1) {
-                // W is replicated but its rows are independent NNLS problems: every rank solves its own rows only.
-                if (s->comm) {
-                    // equal chunks of ceil(m / world) rows, gathered in place (ncclAllGather: 1/world of the bytes a
-                    // sum-all-reduce of the whole matrix would move)
-                    const i64 i0 = std::min<i64>(s->m, s->rank * s->w_chunk), i1 = std::min<i64>(s->m, i0 + s->w_chunk);
-                    rc = nnls_side(s, 1, s->Wt, i0, i1, view2(s), s->Gh); if (rc) return rc;
-                    rc = timed_collective(s, [&] { return comm_allgather(s->comm, s->Wt, s->w_chunk * s->KP, 1, s->st); });
-                    if (rc) return rc;
-                } else {
-                    // callback hook (one primitive only): zero the other rows and sum-all-reduce
-                    const i64 base = s->m / s->world, extra = s->m % s->world;
-                    const i64 i0 = s->rank * base + (s->rank < extra ? s->rank : extra);
-                    const i64 i1 = i0 + base + (s->rank < extra ? 1 : 0);
-                    rc = nnls_side(s, 1, s->Wt, i0, i1, view2(s), s->Gh); if (rc) return rc;
-                    if (i0 > 0) SMK_HIP(hipMemsetAsync(s->Wt, 0, (size_t)i0 * s->KP * sizeof(double), s->st));
-                    if (i1 < s->m) SMK_HIP(hipMemsetAsync(s->Wt + i1 * s->KP, 0, (size_t)(s->m - i1) * s->KP * sizeof(double), s->st));
-                    rc = dist_allreduce(s, s->Wt, (i64)s->KP * s->m, 1, s->st); if (rc) return rc;
+            if (s->w_sharded) {
+                // W is replicated in the algorithm but its rows are independent NNLS problems: every rank solves its own
+                // blocks, each as soon as its slice of the reduce-scatter has landed
+                for (int j = 0; j < s->nchunk; ++j) {
+                    i64 a, b;
+                    own_block(s, j, &a, &b);
+                    SMK_HIP(hipStreamWaitEvent(s->st, s->ev_r[j], 0));
+                    if (b > a) { rc = nnls_side(s, 1, s->Wt, a, b, r2, s->Gh); if (rc) return rc; }
                 }
+                s->r2_pending = false;
+                s->w_full = false;
+            } else if (s->ar && s->world > 1) {
+                // callback hook (one primitive only): every rank solves a row range, zeroes the rest and sum-all-reduces
+                const i64 base = s->m / s->world, extra = s->m % s->world;
+                const i64 i0 = s->rank * base + (s->rank < extra ? s->rank : extra);
+                const i64 i1 = i0 + base + (s->rank < extra ? 1 : 0);
+                rc = nnls_side(s, 1, s->Wt, i0, i1, r2, s->Gh); if (rc) return rc;
+                if (i0 > 0) SMK_HIP(hipMemsetAsync(s->Wt, 0, (size_t)i0 * s->KP * sizeof(double), s->st));
+                if (i1 < s->m) SMK_HIP(hipMemsetAsync(s->Wt + i1 * s->KP, 0, (size_t)(s->m - i1) * s->KP * sizeof(double), s->st));
+                rc = dist_allreduce_cb(s, s->Wt, (i64)s->KP * s->m, 1); if (rc) return rc;
             } else {
-                rc = nnls_side(s, 1, s->Wt, 0, s->m, view2(s), s->Gh); if (rc) return rc;
+                rc = wait_r2(s);  if (rc) return rc;
+                rc = nnls_side(s, 1, s->Wt, 0, s->m, r2, s->Gh); if (rc) return rc;
             }
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
@@ -1161,10 +1394,11 @@ static int solver_iteration(smk_solver* s)
             rc = launch_rank2_solve(s->H, s->n, r1, s->Gw, 0, s->fail_flag, s->iter, s->Gh, s->gram_scratch, s->st); if (rc) return rc;
             rc = allreduce_gh(s); if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
-            rc = launch_rank2_solve(s->Wt, s->m, view2(s), s->Gh, 1, s->fail_flag, s->iter, s->Gw, s->gram_scratch, s->st); if (rc) return rc;
+            rc = wait_r2(s);  if (rc) return rc;
+            rc = launch_rank2_solve(s->Wt, s->m, r2, s->Gh, 1, s->fail_flag, s->iter, s->Gw, s->gram_scratch, s->st); if (rc) return rc;
             // NormalizeAndScale(W, H, ScaleFactors) every iteration, norms from the Gram matrix of the new W;
             // also rescales HH' and AH' and leaves Gw = W'W of the normalised W (D^-1 Gw D^-1)
-            rc = launch_rank2_normalize(s->H, s->n, s->Wt, s->m, view2(s), s->Gh, s->Gw, s->fail_flag, s->st); if (rc) return rc;
+            rc = launch_rank2_normalize(s->H, s->n, s->Wt, s->m, r2, s->Gh, s->Gw, s->fail_flag, s->st); if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
             break;
         default:
@@ -1179,11 +1413,11 @@ static int resolve_events(smk_solver* s)
     for (int w = 0; w < 3; ++w) {
         for (auto& e : s->ev[w]) {
             float ms = 0.f;
-            SMK_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+            SMK_HIP(hipEventElapsedTime(&ms, e.e0, e.e1));
             s->acc_ms[w] += ms;
-            s->launches[w] += 1;
-            (void)hipEventDestroy(e.first);
-            (void)hipEventDestroy(e.second);
+            s->launches[w] += e.counts;
+            (void)hipEventDestroy(e.e0);
+            (void)hipEventDestroy(e.e1);
         }
         s->ev[w].clear();
     }
@@ -1194,9 +1428,11 @@ static int resolve_events(smk_solver* s)
 static int sync_and_check(smk_solver* s, int* fail_iter)
 {
     int flag = INT_MAX;
+    int rc = wait_r2(s);                 // chunk exchanges still on the second stream
+    if (rc) return rc;
     SMK_HIP(hipMemcpyAsync(&flag, s->fail_flag, sizeof(int), hipMemcpyDeviceToHost, s->st));
     SMK_HIP(hipStreamSynchronize(s->st));
-    int rc = resolve_events(s);
+    rc = resolve_events(s);
     if (rc) return rc;
     if (fail_iter) *fail_iter = flag;
     if (flag != INT_MAX) return SMK_FAILURE;
@@ -1210,7 +1446,7 @@ static int dist_agree(smk_solver* s)
     const int wpart = w_rows_sharded(s) ? 1 : 0;      // the W-side sum covers this rank's rows only
     int rc = launch_dist_scalars(s->scal, s->fail_flag, s->iter > 0 ? s->iter - 1 : 0, 0, wpart, s->st);
     if (rc) return rc;
-    rc = dist_allreduce(s, s->scal + 5, 3, 1, s->st);
+    rc = dist_allreduce_now(s, s->scal + 5, 3, 1);
     if (rc) return rc;
     return launch_dist_scalars(s->scal, s->fail_flag, s->iter > 0 ? s->iter - 1 : 0, 1, wpart, s->st);
 }
@@ -1219,18 +1455,29 @@ static int dist_agree(smk_solver* s)
 // the kernels (and, sharded, the scalar all-reduce) of one progress evaluation; results land in s->scal
 static int enqueue_progress_kernels(smk_solver* s)
 {
-    int rc = 0;
+    int rc = wait_r2(s);
+    if (rc) return rc;
     if (s->o.prog_est_algorithm == SMK_PROG_DELTA_FNORM) {
+        rc = gather_w(s);             // a row-sharded W: the norm runs over all of it (BPP's default rule is PG_RATIO)
+        if (rc) return rc;
         rc = launch_delta_fnorm(s->Wt, s->Wprev, (i64)s->KP * s->m, s->pg_partials, s->scal + 2, s->st);
         if (rc) return rc;
     } else {
         // gradW = W*HHt - AHt  (slot 0, replicated), gradH = WtW*H - WtA (slot 1, local shard)
-        if (w_rows_sharded(s)) {      // only this rank's rows of the summed (AH')' exist here: partial sum, joined in dist_agree
-            const i64 i0 = std::min<i64>(s->m, s->rank * s->w_chunk), i1 = std::min<i64>(s->m, i0 + s->w_chunk);
-            PartialView own = view2(s);
-            own.p = (const float*)own.p + i0 * s->kpp;
-            if (i1 > i0) rc = launch_grad_pg(s->Wt + i0 * s->KP, s->k, i1 - i0, own, s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st);
-            else rc = launch_zero_f64(s->scal, 1, s->st);
+        if (w_rows_sharded(s)) {      // only this rank's blocks of the summed (AH')' exist here: partial sum, joined in dist_agree
+            int total = 0;
+            for (int j = 0; j < s->nchunk; ++j) {
+                i64 a, b;
+                own_block(s, j, &a, &b);
+                if (b <= a) continue;
+                PartialView own = view2(s);
+                own.p = (const unsigned char*)own.p + (size_t)a * s->kpp * (s->red_f64 ? sizeof(double) : sizeof(float));
+                int g = 0;
+                rc = launch_grad_pg_partials(s->Wt + a * s->KP, s->k, b - a, own, s->Gh, nullptr, s->pg_partials + total, &g, s->st);
+                if (rc) return rc;
+                total += g;
+            }
+            rc = total ? launch_sum_partials(s->pg_partials, total, s->scal, s->st) : launch_zero_f64(s->scal, 1, s->st);
         } else {
             rc = launch_grad_pg(s->Wt, s->k, s->m, view2(s), s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st);
         }
@@ -1274,13 +1521,25 @@ static int update_progress(smk_solver* s, int iter_index, double* metric)
 // Enqueue the progress kernels of the iteration that has just been enqueued, copy their scalars and
 // the failure flag into pinned slot `b` and record an event; when `snapshot` is set also keep
 // (W, H, W'W) of this iteration so that the NEXT, speculatively enqueued iteration can be undone.
+static int progress_prealloc(smk_solver* s)
+{
+    if (!s->pin) {
+        SMK_HIP(hipHostMalloc((void**)&s->pin, 2 * sizeof(smk_solver::ProgSlot)));
+        for (int i = 0; i < 2; ++i) SMK_HIP(hipEventCreateWithFlags(&s->pev[i], hipEventDisableTiming));
+    }
+    for (int b = 0; b < 2; ++b)
+        if (!s->snap[b]) { const int rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
+    return 0;
+}
+
 static int progress_begin(smk_solver* s, int b, bool snapshot)
 {
     if (!s->pin) {
         SMK_HIP(hipHostMalloc((void**)&s->pin, 2 * sizeof(smk_solver::ProgSlot)));
         for (int i = 0; i < 2; ++i) SMK_HIP(hipEventCreateWithFlags(&s->pev[i], hipEventDisableTiming));
     }
-    int rc = 0;
+    int rc = wait_r2(s);
+    if (rc) return rc;
     if (s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s) && !is_wide(s->k)) {
         // both gradients in one launch, both sums + the failure flag in a second, one 64-byte read-back
         rc = launch_grad_pg2(s->Wt, s->m, view2(s), s->Gh, s->pg_partials, s->H, s->n, view1(s), s->Gw,
@@ -1322,12 +1581,14 @@ static int progress_restore(smk_solver* s, int b)
     SMK_HIP(hipMemcpyAsync(s->fail_flag, &big, sizeof(int), hipMemcpyHostToDevice, s->st));
     SMK_HIP(hipStreamSynchronize(s->st));
     s->inited = false;
+    if (s->w_sharded) s->w_full = false;    // the snapshot holds this rank's own blocks (the others as stale as they were)
     return 0;
 }
 
 static int normalize_device(smk_solver* s)
 {
     if (s->normalized) return 0;
+    { const int grc = gather_w(s); if (grc) return grc; }
     // nu_c^2 = (W'W)[c][c]; Gw is current in all three schedules after the last W update
     int rc = launch_scale_rows(s->H, s->k, s->n, s->Gw, 0, s->fail_flag, s->st);
     if (rc) return rc;
@@ -1380,7 +1641,9 @@ int smk_solver_sync(smk_solver* s)
 {
     if (!s) return SMK_BAD_PARAM;
     const int target = s->iter;
-    int rc = sync_and_check(s, nullptr);
+    int rc = gather_w(s);                 // every rank calls sync: the fp64 W is whole again afterwards
+    if (rc) return rc;
+    rc = sync_and_check(s, nullptr);
     if (rc == SMK_FAILURE && !is_dist(s) && hals_fail_soft(s)) {
         rc = smk_solver_iterate(s, target);
         if (rc == SMK_OK) rc = sync_and_check(s, nullptr);
@@ -1479,6 +1742,8 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
         }
     }
 
+    rc = gather_w(s);
+    if (rc) { result = rc; goto done; }
     if (o.normalize) { rc = normalize_device(s); if (rc) { result = rc; goto done; } }
     if (is_dist(s)) { rc = dist_agree(s); if (rc) { result = rc; goto done; } }
     rc = sync_and_check(s, &fail_iter);
@@ -1607,7 +1872,8 @@ int smk_solver_get_factors(smk_solver* s, int normalize, double* W, int64_t ldW,
 {
     if (!s || !W || !H) return SMK_BAD_PARAM;
     if (ldW < s->m || ldH < s->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
-    int rc = 0;
+    int rc = gather_w(s);                 // a collective when W is row-sharded and stale: every rank must be here
+    if (rc) return rc;
     if (normalize) { rc = normalize_device(s); if (rc) return rc; }
     rc = launch_transpose_f64(s->Wt, s->KP, s->tmpW, s->m, s->k, s->m, s->st);
     if (rc) return rc;

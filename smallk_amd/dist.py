@@ -19,6 +19,30 @@ def shard_columns(n: int, world: int, rank: int):
     return col0, ncols
 
 
+def chunk_geometry(m: int, world: int, chunks: int | None = None):
+    """The block-cyclic row layout of the native exchange (solver.cpp: smk_solver_attach_comm).
+
+    The rows of A (= rows of W) are cut into ``nchunk`` chunks of ``world * blk`` rows; block r of a chunk belongs to
+    rank r.  A chunk is one contiguous range of the H*At pass, the send buffer of one reduce-scatter and the receive
+    buffer of one all-gather.  Returns (blk, nchunk, rows_cap); blk is a multiple of 256."""
+    mpad = -(-m // 256) * 256
+    c = max(1, min(mpad // (world * 4096), 4)) if chunks is None else max(1, min(int(chunks), 8))
+    blk = -(-(-(-mpad // (world * c))) // 256) * 256
+    nchunk = -(-mpad // (world * blk))
+    return blk, nchunk, nchunk * world * blk
+
+
+def own_blocks(m: int, world: int, rank: int, blk: int, nchunk: int):
+    """Row ranges [a, b) of W that ``rank`` solves (valid rows only)."""
+    out = []
+    for j in range(nchunk):
+        a = (j * world + rank) * blk
+        b = min(a + blk, m)
+        if b > a:
+            out.append((a, b))
+    return out
+
+
 class TorchAllReduce:
     """Owns the comm workspace (a torch uint8 tensor on the GPU) and all-reduces views of it."""
 

@@ -231,6 +231,143 @@ def test_rccl_world_of_one_native(gpu):
         assert rc == 0 and it == iters and rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
 
 
+@pytest.mark.parametrize("alg,storage,quant,k,chunks", [("BPP", "f32", 0, 16, 3), ("BPP", "f32", 0, 64, 2), ("BPP", "bf16", 1, 40, 4),
+                                                         ("BPP", "f32", 0, 140, 2), ("HALS", "bf16", 1, 32, 3), ("MU", "f32", 0, 12, 2),
+                                                         ("BPP", "f32", 0, 16, 1)])
+def test_rccl_collectives_forced_at_world_one(gpu, monkeypatch, alg, storage, quant, k, chunks):
+    """SMK_COMM_FORCE=1: a world of ONE rank runs the whole multi-GPU schedule with the real nccl* calls -- the H*At
+    pass in row chunks with ncclReduceScatter (BPP) / ncclAllReduce (MU, HALS) of chunk j on the second stream beside
+    the product of chunk j + 1, block-cyclic NNLS of W, W'W from the own blocks + ncclAllReduce, the packed operand
+    by ncclAllGather per chunk, W'A accumulated chunk by chunk, the fp64 W gathered at the end.  With one rank every
+    collective is the identity, so the result must be the unsharded one; what the test pins is that the RCCL calls,
+    the event choreography and the chunk arithmetic are executed and leave the bits alone."""
+    from smallk_amd import Comm, NmfSolver, DenseMatrix, make_options
+    monkeypatch.setenv("SMK_COMM_FORCE", "1")
+    monkeypatch.setenv("SMK_COMM_CHUNKS", str(chunks))
+    m, n, iters = 2000, 901, 6
+    A = oracle.fill_uniform(m, n, 42, quant=quant)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters)
+    one = gpu.nmf(A, W0, H0, alg, storage=storage, min_iter=iters, max_iter=iters)
+    comm = Comm.init_all(1)[0]
+    D = DenseMatrix.from_host(A, storage=storage)
+    s = NmfSolver(D, make_options(m, n, k, alg, min_iter=iters, max_iter=iters))
+    s.attach_comm(comm)
+    s.set_factors(W0, H0)
+    s.enable_timing(True)
+    rc, it, _ = s.run()
+    W, H = s.factors()
+    ms_c, n_c = s.kernel_time(2)
+    _, n_p = s.kernel_time(1)
+    s.close()
+    D.close()
+    comm.close()
+    assert rc == 0 and it == iters
+    assert n_c > 0 and ms_c >= 0.0                      # collectives were issued (and timed on the second stream)
+    assert n_p == (iters + (1 if alg == "HALS" else 0)) * ((k + 63) // 64)       # a pass cut into chunks counts once per group
+    assert rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
+    assert rel(W, one.W) < (1e-5 if storage == "f32" else 1e-5) and rel(H, one.H) < 1e-5
+
+
+@pytest.mark.parametrize("chunks,f64", [(1, 0), (3, 0), (2, 1)])
+def test_sharded_bpp_chunk_pipeline_on_the_stand_in(gpu, monkeypatch, chunks, f64):
+    """3 shards on one device, BPP k = 64 (fp16 two-term products): the chunk count of the exchange and the element type
+    of the summed (AH')' (fp32 default, SMK_COMM_F64=1 for fp64) do not change the result beyond summation order.
+    (Measured: 3.8e-6 between sharded and unsharded with EITHER element type -- the difference is the fp32 accumulation
+    order inside the streaming products of differently shaped shards, not the wire format.)"""
+    monkeypatch.setenv("SMK_COMM_CHUNKS", str(chunks))
+    monkeypatch.setenv("SMK_COMM_F64", str(f64))
+    m, n, k, iters = 3000, 640, 64, 5
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    kw = dict(min_iter=iters, max_iter=iters, tol=1e-9)
+    ref = oracle.nmf(A, W0, H0, "BPP", **kw)
+    one = gpu.nmf(A, W0, H0, "BPP", **kw)
+    many = gpu.nmf_sharded(A, W0, H0, "BPP", 3, local_stub=True, **kw)
+    assert many.result == 0 and many.iteration_count == iters
+    assert rel(many.W, ref.W) < TOL and rel(many.H, ref.H) < TOL
+    assert rel(many.W, one.W) < 1e-5 and rel(many.H, one.H) < 1e-5
+
+
+def test_sharded_delta_fnorm_rule_with_row_sharded_w(gpu):
+    """BPP with the DELTA_FNORM rule on 2 shards: the rule needs all of W, so the fp64 rows are gathered for every check."""
+    from smallk_amd import _lib as L
+    import make_golden as mg
+    m, n, k = 1100, 480, 6
+    A = mg.make_A(m, n, k, True, 0)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    kw = dict(min_iter=2, max_iter=300, tol=0.01, prog_est=L.PROG_DELTA_FNORM)
+    ref = oracle.nmf(A, W0, H0, "BPP", **kw)
+    many = gpu.nmf_sharded(A, W0, H0, "BPP", 2, local_stub=True, **kw)
+    assert many.result == ref.result == 0 and many.iteration_count == ref.iteration_count
+    assert rel(many.W, ref.W) < TOL and rel(many.H, ref.H) < TOL
+
+
+@pytest.mark.parametrize("alg,m", [("BPP", 1501), ("HALS", 1001)])
+def test_callback_hook_with_rows_not_divisible_by_world(gpu, alg, m):
+    """the callback path (smk_solver_set_comm) with m % world != 0: its workspace layout does not depend on the world"""
+    import torch
+    from smallk_amd import dist as sdist
+    n, k, iters, world = 300, 10, 4, 3
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda", 0)
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, tol=1e-9)
+    barrier = threading.Barrier(world)
+    views, out, errors = [None] * world, [None] * world, []
+
+    def make_cb(rank, ar):
+        def cb(ptr, count, dtype):
+            esz = 4 if dtype == 0 else 8
+            off = ptr - ar.base
+            views[rank] = ar.ws[off:off + count * esz].view(torch.float32 if dtype == 0 else torch.float64)
+            barrier.wait(timeout=60)
+            if rank == 0:
+                total = views[0] + views[1] + views[2]
+                for v in views:
+                    v.copy_(total)
+                torch.cuda.synchronize()
+            barrier.wait(timeout=60)
+            return 0
+        return cb
+
+    def run(rank):
+        try:
+            c0, nc = sdist.shard_columns(n, world, rank)
+            D = gpu.DenseMatrix(m, n, col0=c0, ncols=nc)
+            D.upload(A[:, c0:c0 + nc])
+            s = gpu.NmfSolver(D, gpu.make_options(m, n, k, alg, min_iter=iters, max_iter=iters, tol=1e-9))
+            ar = sdist.TorchAllReduce(s.comm_workspace_bytes(), dev)       # sized BEFORE the world is known to the solver
+            s.set_comm(rank, world, make_cb(rank, ar), ar.ptr, ar.nbytes)
+            s._keep = ar
+            s.set_factors(W0, H0[:, c0:c0 + nc])
+            rc, it, _ = s.run()
+            W, H = s.factors()
+            out[rank] = (rc, it, W, H)
+        except Exception as e:     # pragma: no cover
+            errors.append(e)
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errors, errors
+    H = np.concatenate([o[3] for o in out], axis=1)
+    for o in out:
+        assert o[0] == 0 and o[1] == iters and rel(o[2], ref.W) < TOL
+    assert rel(H, ref.H) < TOL
+
+
 def test_comm_selftest_on_the_stand_in(gpu):
     """smk_comm_selftest through the in-process communicator: 3 ranks = 3 host threads on this device"""
     import threading
