@@ -51,10 +51,16 @@ MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
 
 def cpu_baseline(m, n, k, alg, quant, budget_s=20.0):
     """The CPU oracle on a bounded sample (same k, algorithm, dtype rounding; fewer rows/cols), timed on this
-    host's cores.  The oracle's own GEMM is a plain OpenMP loop; the reference links an optimized BLAS
-    (sphinx/source/pages_installation.rst:355), so the two big products W'A and AH' of the same sample are also
-    timed through torch's CPU matmul (MKL/OpenBLAS, fp64) and `value` prices an iteration as
-    (oracle iteration - oracle's two big products + BLAS's two big products).  Both raw figures are reported."""
+    host's cores, priced so that the parts add up:
+
+      t_iter  = t_big + t_other     per iteration of the sample, both measured INSIDE the oracle's iterations
+                                    (t_big: its products with A, exported by orc_big_product_time; t_other: the rest --
+                                    NNLS / element-wise updates / Gram matrices / gradients)
+      t_blas  = the same products the selected algorithm runs (BPP: W'A and H*At against the stored transpose;
+                MU / HALS: W'A and A*H') through torch's CPU matmul (MKL, fp64) on warm buffers: the reference links
+                an optimized BLAS (sphinx/source/pages_installation.rst:355), the oracle's GEMM is a plain OpenMP loop
+      value   = 1 / ( min(t_big, t_blas) * (m n)/(ms ns)  +  t_other * (m + n)/(ms + ns) )
+                the products scale with the matrix, the rest with the number of factor rows and columns."""
     import numpy as np
     import oracle
     ms, ns = min(m, 8192), min(n, 4096)
@@ -70,43 +76,56 @@ def cpu_baseline(m, n, k, alg, quant, budget_s=20.0):
         if t > budget_s / 2 or iters >= 128:
             break
         iters *= 2
+    t_big_total, big_calls = oracle.big_product_time()
     t_iter = t / r.iteration_count
-    # the oracle's own big products, alone
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        oracle.gemm_tn(W0, A)
-        oracle.gemm_nt(A, H0)
-    t_big_own = (time.perf_counter() - t0) / reps
-    kind, blas, t_big_blas = "port", "none (oracle's OpenMP loops)", t_big_own
+    t_big = 2.0 * t_big_total / max(big_calls, 1)             # two products per iteration (+ one in Init)
+    t_other = max(t_iter - t_big, 0.0)
+    kind, blas, t_blas = "port", "none (oracle's OpenMP loops)", t_big
     try:
         import torch
         torch.set_num_threads(oracle.num_threads())
-        # column-major views (no copies: BLAS takes the transposes); let the oracle's OpenMP team go to sleep first
-        At, Wt_, Ht = torch.from_numpy(A.T).T, torch.from_numpy(W0.T).T, torch.from_numpy(H0.T).T
-        time.sleep(0.2)
-        (Wt_.T @ At), (At @ Ht.T)
+        At = torch.from_numpy(A.T).T                          # column-major views, no copies
+        Wt_, Ht = torch.from_numpy(W0.T).T, torch.from_numpy(H0.T).T
+        if alg == "BPP":
+            Att = torch.from_numpy(np.asfortranarray(A.T).T).T          # the stored transpose (nmf_solver_bpp.hpp:319)
+            run = lambda: ((Wt_.T @ At), (Ht @ Att))
+        else:
+            run = lambda: ((Wt_.T @ At), (At @ Ht.T))
+        time.sleep(0.2)                                       # let the oracle's OpenMP team go to sleep
+        run()
         best = float("inf")
-        for _ in range(reps + 2):
+        for _ in range(5):
             t0 = time.perf_counter()
-            (Wt_.T @ At), (At @ Ht.T)
+            run()
             best = min(best, time.perf_counter() - t0)
-        t_big_blas = best
+        t_blas = best
         blas = "torch CPU matmul fp64 (" + str(torch.__config__.show().split("BLAS_INFO=")[-1].split(",")[0]).strip() + ")"
         kind = "port+blas"
     except Exception:
         pass
-    t_big_blas = min(t_big_blas, t_big_own)                 # BLAS only where it is the faster of the two
-    t_iter_blas = max(t_iter - t_big_own + t_big_blas, t_big_blas)
-    scale = (ms * ns) / float(m * n)
+    t_prod = min(t_big, t_blas)
+    s_prod = (m * n) / float(ms * ns)
+    s_other = (m + n) / float(ms + ns)
+    t_full = t_prod * s_prod + t_other * s_other
     return {
-        "value": scale / t_iter_blas, "unit": "iterations/s", "cores": oracle.num_threads(), "kind": kind,
-        "sample_it_s": 1.0 / t_iter_blas, "sample_it_s_plain_oracle": 1.0 / t_iter, "scale": scale, "blas": blas,
+        "value": 1.0 / t_full, "unit": "iterations/s", "cores": oracle.num_threads(), "kind": kind, "blas": blas,
+        "sample_it_s": 1.0 / (t_prod + t_other), "sample_it_s_plain_oracle": 1.0 / t_iter,
+        "sample_ms": {"iteration": t_iter * 1e3, "big_products_inside": t_big * 1e3, "other": t_other * 1e3,
+                      "big_products_blas": t_blas * 1e3, "priced_products": t_prod * 1e3},
+        "scale": {"products_mn": s_prod, "other_m_plus_n": s_other},
         "sample": f"oracle (C/OpenMP fp64 restatement) on a {ms}x{ns} k={k} {alg} sub-problem: {r.iteration_count} iterations in "
-                  f"{t:.2f} s = {1.0 / t_iter:.3f} it/s with its own GEMM loops; its two big products take {t_big_own * 1e3:.1f} ms, "
-                  f"the same two through {blas} {t_big_blas * 1e3:.1f} ms -> {1.0 / t_iter_blas:.3f} it/s on the sample; "
-                  f"value = that x (sample m*n)/(full m*n) = {scale:.4g} (UNSCALED sample figure: sample_it_s)",
+                  f"{t:.2f} s = {t_iter * 1e3:.1f} ms each = {t_big * 1e3:.1f} ms in its two products with A + {t_other * 1e3:.1f} ms "
+                  f"elsewhere (NNLS / updates / Gram); the same two products through {blas}: {t_blas * 1e3:.1f} ms; priced "
+                  f"{t_prod * 1e3:.1f} ms x {s_prod:.4g} (m n ratio) + {t_other * 1e3:.1f} ms x {s_other:.4g} ((m + n) ratio) "
+                  f"= {t_full:.3f} s per full-size iteration",
     }
+
+
+def kernel_source_sha16():
+    """first 16 hex digits of sha256(smallk_amd/csrc/bigprod.hip): ties a PMC traffic figure to the kernel it was taken on"""
+    import hashlib
+    with open(os.path.join(ROOT, "smallk_amd", "csrc", "bigprod.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def main():
@@ -116,6 +135,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="MEASUREMENT HOOK, one GPU: run as rank 0 of a world of this many ranks -- its column shard, the chunk "
+                         "geometry and the row blocks of that world, every collective issued through RCCL with ONE rank "
+                         "(device-local).  Times the per-rank work of an N-GPU run without the xGMI transfers; the factors "
+                         "it produces are meaningless (the other ranks' blocks never arrive)")
     args = ap.parse_args()
 
     import numpy as np
@@ -123,6 +147,9 @@ def main():
     import smallk_amd
     from smallk_amd import dist as sdist
 
+    if args.emulate_world > 1:
+        os.environ["SMK_COMM_FORCE"] = "1"
+        os.environ["SMK_COMM_EMULATE_WORLD"] = str(args.emulate_world)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,6 +168,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")                 # CPU side channel only: unique id, barrier, max of the clocks
+        # RCCL's own description of what it built (rings / trees / transport per channel) goes to a file per rank; rank 0
+        # prints an excerpt to stderr after the run so that a scaling run explains itself.  The caller's settings win.
+        if "NCCL_DEBUG" not in os.environ:
+            os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH" + (",TUNING" if os.environ.get("SMK_BENCH_RCCL_TUNING") else ""))
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/smk_rccl_%h_%p.log")
         if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
             # one node: RCCL's bootstrap sockets stay on the loopback interface (the container's hostname may not
             # resolve) and no InfiniBand probing; the data path is xGMI either way.  The caller's settings win.
@@ -152,7 +185,7 @@ def main():
     comm, fallback_group, collectives = None, None, "none"
     # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the one JSON line
     saved_stdout = None
-    if world > 1:
+    if world > 1 or args.emulate_world > 1:
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
@@ -187,13 +220,22 @@ def main():
     if world > 1 and not native:
         # callback hook: the solver launches on torch's current stream so that the all-reduces order against it
         smallk_amd.set_stream(torch.cuda.current_stream().cuda_stream)
-    if saved_stdout is not None:
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
-
     m, n, k, alg, storage, desc = WORKLOADS[args.workload]
     col0, ncols = sdist.shard_columns(n, world, rank)
+    if args.emulate_world > 1:
+        assert world == 1, "--emulate-world is a one-GPU hook"
+        col0, ncols = sdist.shard_columns(n, args.emulate_world, 0)
+        comm = smallk_amd.Comm.init_all(1)[0]
+        collectives = f"EMULATED rank 0 of {args.emulate_world}: RCCL calls with one rank (device-local)"
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        try:                                # the banner sits in the C library's stdio buffer: push it out while fd 1 is still stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     total_iters = args.warmup + args.steps
 
     A = smallk_amd.DenseMatrix(m, n, col0=col0, ncols=ncols, storage=storage)
@@ -251,11 +293,27 @@ def main():
 
     ms0, c0 = solver.kernel_time(0)
     ms1, c1 = solver.kernel_time(1)
-    msc, cc = solver.kernel_time(2) if world > 1 else (0.0, 0)        # (AH')' sum + W all-gather, HIP events on this rank
+    sharded = world > 1 or args.emulate_world > 1
+    msc, cc = solver.kernel_time(2) if sharded else (0.0, 0)    # spans of the collectives on the second stream, this rank
     bytes_per_launch, flops_per_launch = solver.kernel_work(0)
     avg_ms = (ms0 + ms1) / max(c0 + c1, 1)
     achieved_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     mfma_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12
+    # per rank and per step: both streaming passes, the collectives' own spans, and what the step spends outside the
+    # passes.  If the collectives take longer than that remainder, the difference was hidden behind the products:
+    # overlap_lower_bound = max(0, 1 - outside / collectives).
+    timed_steps = max(len(windows) * args.steps, 1)
+    ngroups = max((k + 63) // 64, 1)
+    per_rank = {"rank": rank, "ms_per_step": sum(windows) / timed_steps * 1e3,
+                "products_ms_per_step": (ms0 + ms1) / timed_steps, "collectives_ms_per_step": msc / timed_steps,
+                "collective_calls_per_step": cc / timed_steps, "passes_per_step": (c0 + c1) / ngroups / timed_steps}
+    per_rank["outside_products_ms_per_step"] = per_rank["ms_per_step"] - per_rank["products_ms_per_step"]
+    per_rank["overlap_lower_bound"] = (max(0.0, 1.0 - per_rank["outside_products_ms_per_step"] / per_rank["collectives_ms_per_step"])
+                                       if per_rank["collectives_ms_per_step"] > 0 else None)
+    ranks_report = [per_rank]
+    if world > 1:
+        ranks_report = [None] * world
+        torch.distributed.all_gather_object(ranks_report, per_rank)
 
     if rank == 0:
         out = {
@@ -273,7 +331,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "m": m, "n": n, "k": k, "algorithm": alg, "A_storage": storage,
                        "state": "W,H,Gram fp64; big products: MFMA with fp32 accumulation folded into fp64",
-                       "parallelism": f"column-shard x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"column-shard x{world}" if world > 1 else
+                                       f"EMULATED rank 0 of {args.emulate_world} on one GPU (not a benchmark line)" if args.emulate_world > 1
+                                       else "single GPU"),
                        "collectives": collectives},
             # useful flops (2 k per matrix entry) of the streaming products.  fp32 storage computes them as three fp16
             # MFMAs per product, so its ratio is against the NATIVE fp32 matrix peak that this replaces
@@ -281,7 +341,8 @@ def main():
             "useful_tflops_big_products": mfma_tf,
             "useful_tflops_vs_native_mfma_peak": mfma_tf / MFMA_PEAK_TF[storage],
             "whole_iteration_tflops": 4.0 * m * n * k / (elapsed / args.steps) / 1e12,
-            "collectives_ms_per_step_rank0": (msc / max((c0 + c1) // 2, 1)) if world > 1 else None,
+            "collectives_ms_per_step_rank0": per_rank["collectives_ms_per_step"] if sharded else None,
+            "per_rank": ranks_report if sharded else None,
             "windows": len(windows), "windows_ms": [round(w * 1e3, 4) for w in windows],
             "timed_region_s": sum(windows),
             "roofline": {
@@ -295,19 +356,37 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_launch,
             },
         }
+        # HBM traffic comes from separate rocprofv3 --pmc passes (tools/profile_r03.sh -> profiles/hbm_traffic.json).  The
+        # entry records the hash of the kernel source it was measured on: a figure from an older kernel is not printed.
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(prof):
+        if os.path.exists(prof) and args.emulate_world <= 1:
             try:
                 pj = json.load(open(prof))
                 key = f"{args.workload}_n{world}"
                 if key in pj:
-                    out["roofline"]["traffic"] = pj[key]["bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = pj[key].get("source", "profiles/")
+                    if pj[key].get("kernel_source_sha16") == kernel_source_sha16():
+                        out["roofline"]["traffic"] = pj[key]["bytes_per_launch"]
+                        out["roofline"]["traffic_source"] = pj[key].get("source", "profiles/")
+                    else:
+                        out["roofline"]["traffic_stale"] = ("profiles/hbm_traffic.json was measured on another version of "
+                                                            "smallk_amd/csrc/bigprod.hip; rerun tools/profile_r03.sh")
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, n, k, alg, 1 if storage == "bf16" else 0)
         print(json.dumps(out), flush=True)
+    if rank == 0 and world > 1:
+        import glob
+        import re
+        pat = re.compile(r"Channel|Ring|Tree|Trees|XGMI|xgmi|P2P|SHM|NET|algo|Algo|proto|Connected|nChannels|comm 0x", re.I)
+        for fn in sorted(glob.glob("/tmp/smk_rccl_*.log"))[:1]:
+            try:
+                lines = [l.rstrip() for l in open(fn, errors="replace") if pat.search(l)]
+                print(f"[bench] RCCL log excerpt ({fn}, {len(lines)} matching lines, first 60):", file=sys.stderr)
+                for l in lines[:60]:
+                    print("[rccl] " + l[:220], file=sys.stderr)
+            except Exception as e:      # pragma: no cover
+                print(f"[bench] no RCCL log: {e}", file=sys.stderr)
     barrier()
     if comm is not None:
         solver.close()

@@ -81,6 +81,8 @@ def lib():
         _lib.orc_gemm.restype = None
         _lib.orc_gemm.argtypes = [C.c_int, C.c_int, i64, i64, i64, C.c_double, dp, i64, dp, i64, C.c_double, dp, i64]
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_big_product_time.restype = None
+        _lib.orc_big_product_time.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
         _lib.orc_set_num_threads.restype = None
         _lib.orc_set_num_threads.argtypes = [C.c_int]
         # hosts with hundreds of cores: an OpenMP team per tiny loop is pathological
@@ -204,6 +206,13 @@ def gemm_nt(A, H) -> np.ndarray:
     out = np.zeros((m, k), order="F")
     lib().orc_gemm(0, 1, m, k, n, 1.0, _p(A), m, _p(H), k, 0.0, _p(out), m)
     return out
+
+
+def big_product_time():
+    """(seconds, calls) spent in the products with A during the last nmf() / nmf_sparse() call."""
+    t, c = C.c_double(0), C.c_int(0)
+    lib().orc_big_product_time(C.byref(t), C.byref(c))
+    return t.value, c.value
 
 
 def num_threads() -> int:

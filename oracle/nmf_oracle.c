@@ -636,10 +636,22 @@ static double* dalloc(size_t n) { return (double*)calloc(n ? n : 1, sizeof(doubl
 /* ---- the three products that touch A.  Dense: Gemm -> BLAS.  Sparse: the reference's own loops,     */
 /* sparse_gemm_ba_impl.hpp (B'A and BA: one dot / axpy per stored entry, column by column of A) and    */
 /* sparse_gemm_ab_impl.hpp (AB': scatter of every stored entry into row i of the result).              */
+/* wall time spent in the big products of the last orc_nmf / orc_nmf_sparse call (bench.py prices the CPU baseline  */
+/* from it: the rest of an iteration is NNLS / element-wise work that scales with m + n, the products with m n)     */
+static double g_big_us = 0.0;
+static int g_big_calls = 0;
+void orc_big_product_time(double* seconds, int* calls)
+{
+    if (seconds) *seconds = g_big_us * 1e-6;
+    if (calls) *calls = g_big_calls;
+}
+#define BIG_T0 const double big_t0_ = now_us()
+#define BIG_T1 do { g_big_us += now_us() - big_t0_; g_big_calls += 1; } while (0)
+
 static void prod_WtA(const solver_ws* s, const double* W, i64 ldw, double* out)      /* k x n, ld k */
 {
     const int k = s->k;
-    if (s->A) { orc_gemm(1, 0, k, s->n, s->m, 1.0, W, ldw, s->A, s->lda, 0.0, out, k); return; }
+    if (s->A) { BIG_T0; orc_gemm(1, 0, k, s->n, s->m, 1.0, W, ldw, s->A, s->lda, 0.0, out, k); BIG_T1; return; }
 #pragma omp parallel for schedule(dynamic, 64)
     for (i64 j = 0; j < s->n; ++j) {
         double* o = out + j * k;
@@ -655,7 +667,7 @@ static void prod_WtA(const solver_ws* s, const double* W, i64 ldw, double* out) 
 static void prod_AHt(const solver_ws* s, const double* H, i64 ldh, double* out)      /* m x k, ld m */
 {
     const int k = s->k;
-    if (s->A) { orc_gemm(0, 1, s->m, k, s->n, 1.0, s->A, s->lda, H, ldh, 0.0, out, s->m); return; }
+    if (s->A) { BIG_T0; orc_gemm(0, 1, s->m, k, s->n, 1.0, s->A, s->lda, H, ldh, 0.0, out, s->m); BIG_T1; return; }
     for (i64 e = 0; e < s->m * k; ++e) out[e] = 0.0;
     for (i64 j = 0; j < s->n; ++j)
         for (unsigned p = s->cp[j]; p < s->cp[j + 1]; ++p) {
@@ -668,7 +680,7 @@ static void prod_AHt(const solver_ws* s, const double* H, i64 ldh, double* out) 
 static void prod_HAt(const solver_ws* s, const double* H, i64 ldh, double* out)      /* k x m, ld k */
 {
     const int k = s->k;
-    if (s->A) { orc_gemm(0, 0, k, s->m, s->n, 1.0, H, ldh, s->At, s->n, 0.0, out, k); return; }
+    if (s->A) { BIG_T0; orc_gemm(0, 0, k, s->m, s->n, 1.0, H, ldh, s->At, s->n, 0.0, out, k); BIG_T1; return; }
 #pragma omp parallel for schedule(dynamic, 64)
     for (i64 i = 0; i < s->m; ++i) {
         double* o = out + i * k;
@@ -1009,6 +1021,7 @@ static int nmf_driver(const orc_options* o, const double* A, i64 lda, const unsi
     if (metrics) for (int i = 0; i < o->max_iter; ++i) metrics[i] = NAN;
 
     double t0 = now_us();
+    g_big_us = 0.0; g_big_calls = 0;
 
     /* solver.Init, progress_est->Init */
     if (o->algorithm == ORC_MU) mu_init(&s, W, ldw);

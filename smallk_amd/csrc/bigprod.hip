@@ -385,21 +385,30 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
 }
 
 // ---- packing of the skinny operand -------------------------------------------------
+// Destination of chunk pair q.  Identity, or -- a row-sharded W (solver.cpp) -- the source holds this rank's blocks back
+// to back (block j = rows [j blk, (j+1) blk) of the source) and block j belongs at rows ((j world + rank) blk ...) of the
+// operand: bq = chunk pairs per block.
+struct PackMap {
+    i64 bq = 0;
+    int world = 1, rank = 0;
+    __host__ __device__ i64 dest(i64 q) const { return bq > 0 ? ((q / bq) * world + rank) * bq + q % bq : q; }
+};
 // out layout: [q][s][kt][lane = (r, h)][16 B], chunk = 2q + h covers rows chunk*E .. +E-1,
 // r = k index inside tile kt.  bf16: hi = bf16(x), mid = bf16(x-hi), lo = bf16(x-hi-mid).
 template <int EBYTES, int NSPLIT>
 __global__ __launch_bounds__(256) void pack_kernel(const double* __restrict__ X, int k, int ldx, i64 N, int KT, i64 nq,
-                                                   unsigned char* __restrict__ out)
+                                                   unsigned char* __restrict__ out, PackMap pm)
 {
     constexpr int E = 16 / EBYTES;
     const i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(gid & 63);
     const i64 rest = gid >> 6;
     const int kt = (int)(rest % KT);
-    const i64 q = rest / KT;
+    i64 q = rest / KT;
     if (q >= nq) return;
     const int r = kt * 32 + (lane & 31);
     const i64 row0 = (2 * q + (lane >> 5)) * E;
+    q = pm.dest(q);
     double v[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -458,16 +467,18 @@ static __device__ __forceinline__ void f16x2_residual(unsigned hi_pair, float xl
 // multiplied by xscale[k0 + r] (a power of two from the Gram diagonal, gram_reduce_kernel) before the split so that its
 // entries sit in fp16's range with full 11-bit precision: hi = fp16(x), lo = fp16(x - hi)  (22 significant bits).
 __global__ __launch_bounds__(256) void pack_f16x2_kernel(const double* __restrict__ X, int k, int ldx, i64 N, int KT, i64 nq,
-                                                         const double* __restrict__ xscale, unsigned char* __restrict__ out)
+                                                         const double* __restrict__ xscale, unsigned char* __restrict__ out,
+                                                         PackMap pm)
 {
     const i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(gid & 63);
     const i64 rest = gid >> 6;
     const int kt = (int)(rest % KT);
-    const i64 q = rest / KT;
+    i64 q = rest / KT;
     if (q >= nq) return;
     const int r = kt * 32 + (lane & 31);
     const i64 row0 = (2 * q + (lane >> 5)) * 8;
+    q = pm.dest(q);
     const double sc = (r < k) ? xscale[r] : 0.0;
     double res[8];
 #pragma unroll
@@ -518,27 +529,43 @@ size_t packed_row_offset(int storage, int kg, int nsplit, i64 r0)
     return (size_t)(r0 / (2 * E)) * pack_terms(nsplit) * kt_of(kg) * 1024;
 }
 
-int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st,
-                     const double* xscale)
+static int launch_pack_rows_mapped(const double* X, int ldx, int k0, int kg, i64 N, i64 nq, int storage, int nsplit, void* out,
+                                   hipStream_t st, const double* xscale, PackMap pm)
 {
     const int KT = kt_of(kg);
-    const i64 nq = pack_nq(storage, nsplit, N);
     const i64 threads = nq * KT * 64;
     const int grid = (int)((threads + 255) / 256);
     if (grid == 0) return 0;
     const double* Xg = X + k0;                   // the kernel sees rows [k0, k0 + kg) as rows [0, kg)
     if (nsplit == NSPLIT_F16X2) {
         if (!xscale) { set_error("pack: the fp16 two-term form needs the row scales"); return -100; }
-        pack_f16x2_kernel<<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, xscale + k0, (unsigned char*)out);
+        pack_f16x2_kernel<<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, xscale + k0, (unsigned char*)out, pm);
     } else if (pack_is_bf16(storage, nsplit)) {
-        if (nsplit == 3) pack_kernel<2, 3><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
-        else if (nsplit == 2) pack_kernel<2, 2><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
-        else pack_kernel<2, 1><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
+        if (nsplit == 3) pack_kernel<2, 3><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out, pm);
+        else if (nsplit == 2) pack_kernel<2, 2><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out, pm);
+        else pack_kernel<2, 1><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out, pm);
     } else {
-        pack_kernel<4, 1><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out);
+        pack_kernel<4, 1><<<grid, 256, 0, st>>>(Xg, kg, ldx, N, KT, nq, (unsigned char*)out, pm);
     }
     SMK_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st,
+                     const double* xscale)
+{
+    return launch_pack_rows_mapped(X, ldx, k0, kg, N, pack_nq(storage, nsplit, N), storage, nsplit, out, st, xscale, PackMap{});
+}
+
+// rows [0, N) of X are this rank's blocks of `blk` rows back to back (nblocks of them; rows >= N are padding and pack
+// as zeros); block j goes to rows ((j world + rank) blk ...) of the operand that starts at `out`
+int launch_pack_own_blocks(const double* X, int ldx, int k0, int kg, i64 N, i64 blk, int nblocks, int world, int rank,
+                           int storage, int nsplit, void* out, hipStream_t st, const double* xscale)
+{
+    const i64 E2 = pack_is_bf16(storage, nsplit) ? 16 : 8;       // rows per chunk pair
+    PackMap pm;
+    pm.bq = blk / E2; pm.world = world; pm.rank = rank;
+    return launch_pack_rows_mapped(X, ldx, k0, kg, N, (i64)nblocks * pm.bq, storage, nsplit, out, st, xscale, pm);
 }
 
 int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st, const double* xscale)

@@ -28,7 +28,7 @@ struct LocalGroup {
     std::condition_variable cv;
     int arrived = 0;
     long generation = 0;
-    std::vector<void*> ptr;
+    std::vector<void*> ptr, ptr2;          // send / receive buffer of every rank for the collective in flight
     std::vector<hipStream_t> stream;
     int refs = 0;
     void barrier()
@@ -41,22 +41,23 @@ struct LocalGroup {
 };
 
 int launch_local_allreduce(void* const* ptrs, int world, i64 count, int f64, hipStream_t st);               // kernels.hip
-int launch_local_allgather(void* const* ptrs, int world, i64 count_per_rank, int f64, hipStream_t st);
-int launch_local_reduce_scatter(void* const* ptrs, int world, i64 count_per_rank, int f64, hipStream_t st);
+int launch_local_allgather(void* const* sends, void* const* recvs, int world, i64 count_per_rank, int f64, hipStream_t st);
+int launch_local_reduce_scatter(void* const* sends, void* const* recvs, int world, i64 count_per_rank, int f64, hipStream_t st);
 
 enum { LOCAL_ALLREDUCE = 0, LOCAL_ALLGATHER = 1, LOCAL_REDUCE_SCATTER = 2 };
-static int local_collective(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st, int op)
+static int local_collective(smk_comm* c, const void* send, void* recv, i64 count, int f64, hipStream_t st, int op)
 {
     LocalGroup* g = c->local;
     SMK_HIP(hipStreamSynchronize(st));          // this rank's contribution is complete
-    g->ptr[c->rank] = ptr;
+    g->ptr[c->rank] = const_cast<void*>(send);
+    g->ptr2[c->rank] = recv;
     g->stream[c->rank] = st;
     g->barrier();
     int rc = 0;
     if (c->rank == 0) {
-        rc = op == LOCAL_ALLGATHER        ? launch_local_allgather(g->ptr.data(), g->world, count, f64, st)
-             : op == LOCAL_REDUCE_SCATTER ? launch_local_reduce_scatter(g->ptr.data(), g->world, count, f64, st)
-                                          : launch_local_allreduce(g->ptr.data(), g->world, count, f64, st);
+        rc = op == LOCAL_ALLGATHER        ? launch_local_allgather(g->ptr.data(), g->ptr2.data(), g->world, count, f64, st)
+             : op == LOCAL_REDUCE_SCATTER ? launch_local_reduce_scatter(g->ptr.data(), g->ptr2.data(), g->world, count, f64, st)
+                                          : launch_local_allreduce(g->ptr2.data(), g->world, count, f64, st);
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = SMK_DEVICE_ERROR;
     }
     g->barrier();                               // results are in every rank's buffer
@@ -73,35 +74,52 @@ static inline bool skip_collective(const smk_comm* c) { return !c || (c->world =
 int comm_allreduce(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st)
 {
     if (skip_collective(c) || count <= 0) return 0;
-    if (c->local) return local_collective(c, ptr, count, f64, st, LOCAL_ALLREDUCE);
+    if (c->local) return local_collective(c, ptr, ptr, count, f64, st, LOCAL_ALLREDUCE);
     const ncclResult_t r = ncclAllReduce(ptr, ptr, (size_t)count, f64 ? ncclDouble : ncclFloat, ncclSum, (ncclComm_t)c->nccl, st);
     if (r != ncclSuccess) { set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); return SMK_DEVICE_ERROR; }
     return 0;
 }
 
-// every rank contributes `count_per_rank` elements at buf + rank * count_per_rank (in place)
-int comm_allgather(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st)
+// every rank contributes `count_per_rank` elements at `send`; afterwards recv holds all contributions in rank order
+// (send == recv + rank * count_per_rank: in place)
+int comm_allgather_to(smk_comm* c, const void* send, void* recv, i64 count_per_rank, int f64, hipStream_t st)
 {
-    if (skip_collective(c) || count_per_rank <= 0) return 0;
-    if (c->local) return local_collective(c, buf, count_per_rank, f64, st, LOCAL_ALLGATHER);
     const size_t es = f64 ? 8 : 4;
-    const ncclResult_t r = ncclAllGather((const char*)buf + (size_t)c->rank * count_per_rank * es, buf, (size_t)count_per_rank,
-                                         f64 ? ncclDouble : ncclFloat, (ncclComm_t)c->nccl, st);
+    if (count_per_rank <= 0 || !c) return 0;
+    if (skip_collective(c)) {        // one rank: the gather is a copy (or nothing, in place)
+        if (send != recv) SMK_HIP(hipMemcpyAsync(recv, send, (size_t)count_per_rank * es, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    if (c->local) return local_collective(c, send, recv, count_per_rank, f64, st, LOCAL_ALLGATHER);
+    const ncclResult_t r = ncclAllGather(send, recv, (size_t)count_per_rank, f64 ? ncclDouble : ncclFloat, (ncclComm_t)c->nccl, st);
     if (r != ncclSuccess) { set_error(std::string("ncclAllGather: ") + ncclGetErrorString(r)); return SMK_DEVICE_ERROR; }
     return 0;
 }
-
-// in place: every rank holds world * count_per_rank elements; afterwards slice `rank` of this rank's buffer is the sum
-// over ranks of their slice `rank` (the other slices keep this rank's own contribution)
-int comm_reduce_scatter(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st)
+int comm_allgather(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st)
 {
-    if (skip_collective(c) || count_per_rank <= 0) return 0;
-    if (c->local) return local_collective(c, buf, count_per_rank, f64, st, LOCAL_REDUCE_SCATTER);
+    if (!c) return 0;
+    return comm_allgather_to(c, (const char*)buf + (size_t)c->rank * count_per_rank * (f64 ? 8 : 4), buf, count_per_rank, f64, st);
+}
+
+// every rank holds world * count_per_rank elements at `send`; afterwards recv (count_per_rank elements) is the sum over
+// ranks of their slice `rank` (recv == send + rank * count_per_rank: in place)
+int comm_reduce_scatter_to(smk_comm* c, const void* send, void* recv, i64 count_per_rank, int f64, hipStream_t st)
+{
     const size_t es = f64 ? 8 : 4;
-    const ncclResult_t r = ncclReduceScatter(buf, (char*)buf + (size_t)c->rank * count_per_rank * es, (size_t)count_per_rank,
-                                             f64 ? ncclDouble : ncclFloat, ncclSum, (ncclComm_t)c->nccl, st);
+    if (count_per_rank <= 0 || !c) return 0;
+    if (skip_collective(c)) {
+        if (send != recv) SMK_HIP(hipMemcpyAsync(recv, send, (size_t)count_per_rank * es, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    if (c->local) return local_collective(c, send, recv, count_per_rank, f64, st, LOCAL_REDUCE_SCATTER);
+    const ncclResult_t r = ncclReduceScatter(send, recv, (size_t)count_per_rank, f64 ? ncclDouble : ncclFloat, ncclSum, (ncclComm_t)c->nccl, st);
     if (r != ncclSuccess) { set_error(std::string("ncclReduceScatter: ") + ncclGetErrorString(r)); return SMK_DEVICE_ERROR; }
     return 0;
+}
+int comm_reduce_scatter(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st)
+{
+    if (!c) return 0;
+    return comm_reduce_scatter_to(c, buf, (char*)buf + (size_t)c->rank * count_per_rank * (f64 ? 8 : 4), count_per_rank, f64, st);
 }
 
 }  // namespace smk
@@ -158,6 +176,7 @@ int smk_comm_init_local(smk_comm** out, int nranks)
     LocalGroup* g = new LocalGroup;
     g->world = nranks;
     g->ptr.assign((size_t)nranks, nullptr);
+    g->ptr2.assign((size_t)nranks, nullptr);
     g->stream.assign((size_t)nranks, nullptr);
     g->refs = nranks;
     for (int i = 0; i < nranks; ++i) {

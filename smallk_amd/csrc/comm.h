@@ -20,4 +20,7 @@ int comm_allreduce(smk_comm* c, void* ptr, i64 count, int f64, hipStream_t st);
 int comm_allgather(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st);
 // in place: afterwards slice `rank` (count_per_rank elements) of this rank's buffer holds the sum over ranks of that slice
 int comm_reduce_scatter(smk_comm* c, void* buf, i64 count_per_rank, int f64, hipStream_t st);
+// the same two with separate send and receive buffers (send: count_per_rank / world * count_per_rank elements)
+int comm_allgather_to(smk_comm* c, const void* send, void* recv, i64 count_per_rank, int f64, hipStream_t st);
+int comm_reduce_scatter_to(smk_comm* c, const void* send, void* recv, i64 count_per_rank, int f64, hipStream_t st);
 }  // namespace smk

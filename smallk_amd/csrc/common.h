@@ -72,6 +72,10 @@ int launch_transpose_f64(const double* src, i64 ld_src, double* dst, i64 ld_dst,
 constexpr int NSPLIT_F16X2 = 4;
 size_t packed_bytes(int storage, int k, i64 N, int nsplit);
 size_t packed_row_offset(int storage, int kg, int nsplit, i64 r0);
+// a row-sharded factor: X holds this rank's `nblocks` blocks of `blk` rows back to back (N valid rows, the rest packs as
+// zeros); block j lands at rows ((j world + rank) blk ...) of the operand starting at `out`
+int launch_pack_own_blocks(const double* X, int ldx, int k0, int kg, i64 N, i64 blk, int nblocks, int world, int rank,
+                           int storage, int nsplit, void* out, hipStream_t st, const double* xscale = nullptr);
 int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st, const double* xscale = nullptr);
 // rows [k0, k0 + kg) of a factor stored with leading dimension ldx
 int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st,

@@ -251,39 +251,39 @@ __global__ __launch_bounds__(256) void local_allreduce_kernel(RankPtrs rp, int w
         for (int r = 0; r < world; ++r) ((T*)rp.p[r])[i] = s;
     }
 }
+// every rank's `per` elements at send[r] land at recv[q] + r * per on every rank q
 template <typename T>
-__global__ __launch_bounds__(256) void local_allgather_kernel(RankPtrs rp, int world, i64 per)
+__global__ __launch_bounds__(256) void local_allgather_kernel(RankPtrs send, RankPtrs recv, int world, i64 per)
 {
     const i64 total = per * world;
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
         const int src = (int)(i / per);
-        const T v = ((const T*)rp.p[src])[i];
-        for (int r = 0; r < world; ++r)
-            if (r != src) ((T*)rp.p[r])[i] = v;
+        const T v = ((const T*)send.p[src])[i - (i64)src * per];
+        for (int r = 0; r < world; ++r) ((T*)recv.p[r])[i] = v;
     }
 }
-// slice r (per elements) of rank r's buffer <- sum over ranks of their slice r, fixed rank order; other slices untouched
+// recv[r] (per elements) <- sum over ranks q of send[q][r * per ...], fixed rank order
 template <typename T>
-__global__ __launch_bounds__(256) void local_reduce_scatter_kernel(RankPtrs rp, int world, i64 per)
+__global__ __launch_bounds__(256) void local_reduce_scatter_kernel(RankPtrs send, RankPtrs recv, int world, i64 per)
 {
     const i64 total = per * world;
     for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < total; i += (i64)gridDim.x * 256) {
         const int dst = (int)(i / per);
-        T s = ((const T*)rp.p[0])[i];
-        for (int r = 1; r < world; ++r) s += ((const T*)rp.p[r])[i];
-        ((T*)rp.p[dst])[i] = s;
+        T s = ((const T*)send.p[0])[i];
+        for (int r = 1; r < world; ++r) s += ((const T*)send.p[r])[i];
+        ((T*)recv.p[dst])[i - (i64)dst * per] = s;
     }
 }
-int launch_local_reduce_scatter(void* const* ptrs, int world, i64 per, int f64, hipStream_t st)
+int launch_local_reduce_scatter(void* const* sends, void* const* recvs, int world, i64 per, int f64, hipStream_t st)
 {
     if (world > 16) { set_error("local communicator: at most 16 ranks"); return -100; }
-    RankPtrs rp;
-    for (int r = 0; r < world; ++r) rp.p[r] = ptrs[r];
+    RankPtrs rp, rq;
+    for (int r = 0; r < 16; ++r) { rp.p[r] = r < world ? sends[r] : nullptr; rq.p[r] = r < world ? recvs[r] : nullptr; }
     i64 grid = (per * world + 255) / 256;
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
-    if (f64) local_reduce_scatter_kernel<double><<<(unsigned)grid, 256, 0, st>>>(rp, world, per);
-    else local_reduce_scatter_kernel<float><<<(unsigned)grid, 256, 0, st>>>(rp, world, per);
+    if (f64) local_reduce_scatter_kernel<double><<<(unsigned)grid, 256, 0, st>>>(rp, rq, world, per);
+    else local_reduce_scatter_kernel<float><<<(unsigned)grid, 256, 0, st>>>(rp, rq, world, per);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -299,16 +299,16 @@ int launch_local_allreduce(void* const* ptrs, int world, i64 count, int f64, hip
     SMK_HIP(hipGetLastError());
     return 0;
 }
-int launch_local_allgather(void* const* ptrs, int world, i64 count_per_rank, int f64, hipStream_t st)
+int launch_local_allgather(void* const* sends, void* const* recvs, int world, i64 count_per_rank, int f64, hipStream_t st)
 {
     if (world > 16) { set_error("local communicator: at most 16 ranks"); return -100; }
-    RankPtrs rp;
-    for (int r = 0; r < 16; ++r) rp.p[r] = r < world ? ptrs[r] : nullptr;
+    RankPtrs rp, rq;
+    for (int r = 0; r < 16; ++r) { rp.p[r] = r < world ? sends[r] : nullptr; rq.p[r] = r < world ? recvs[r] : nullptr; }
     const i64 total = count_per_rank * world;
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     if (grid < 1) return 0;
-    if (f64) local_allgather_kernel<double><<<grid, 256, 0, st>>>(rp, world, count_per_rank);
-    else local_allgather_kernel<float><<<grid, 256, 0, st>>>(rp, world, count_per_rank);
+    if (f64) local_allgather_kernel<double><<<grid, 256, 0, st>>>(rp, rq, world, count_per_rank);
+    else local_allgather_kernel<float><<<grid, 256, 0, st>>>(rp, rq, world, count_per_rank);
     SMK_HIP(hipGetLastError());
     return 0;
 }

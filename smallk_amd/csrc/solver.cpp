@@ -141,6 +141,11 @@ struct smk_solver {
     bool red_f64 = false;                 // element type of the summed (AH')' (fp32 unless SMK_COMM_F64=1)
     bool w_sharded = false;               // BPP: every rank solves (and holds current) only its own blocks of W
     bool w_full = true;                   // all rows of the fp64 W on this rank are current
+    // a row-sharded W: this rank's blocks back to back (KP x nchunk*blk; the n_own valid rows are a prefix because only the
+    // last non-empty block of a rank can be short) and, in the same order, its rows of the summed (AH')'
+    double* Wown = nullptr;
+    void* R2own = nullptr;
+    i64 n_own = 0;
     hipStream_t st2 = nullptr;
     hipEvent_t ev_gram = nullptr, ev_gh = nullptr, ev_x = nullptr, ev_y = nullptr;
     hipEvent_t ev_c[MAX_CHUNKS] = {}, ev_r[MAX_CHUNKS] = {}, ev_a[MAX_CHUNKS] = {};
@@ -620,6 +625,8 @@ static PartialView view2(const smk_solver* s)
     return PartialView{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
 }
 
+static PartialView view_own(const smk_solver* s) { return PartialView{s->R2own, 1, 0, s->kpp, s->red_f64 ? 1 : 0}; }
+
 // rows [r0, r1) of chunk j (clipped to the padded row count of the H*At pass) and this rank's block [a, b) of it
 // (valid rows only: b <= m; empty when b <= a)
 static inline void chunk_rows(const smk_solver* s, int j, i64* r0, i64* r1)
@@ -806,6 +813,8 @@ void smk_solver_destroy(smk_solver* s)
     }
     if (s->pin) (void)hipHostFree(s->pin);
     if (s->comm_ws) (void)hipFree(s->comm_ws);
+    if (s->Wown) (void)hipFree(s->Wown);
+    if (s->R2own) (void)hipFree(s->R2own);
     if (s->st2) (void)hipStreamDestroy(s->st2);
     if (s->st_inv) (void)hipStreamDestroy(s->st_inv);
     for (int i = 0; i < 2; ++i) {
@@ -874,6 +883,11 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
     if (s->ar || s->comm) { set_error("solver already has a communicator"); return SMK_BAD_PARAM; }
     s->comm = comm;
     s->rank = comm->rank; s->world = comm->world;
+    // MEASUREMENT HOOK (bench.py --emulate-world N, one GPU): the geometry of rank 0 of N ranks -- row blocks, chunk
+    // sizes, per-rank NNLS / Gram / packing work -- while the collectives run through the real one-rank communicator.
+    // Times a rank's work without the transfers; the blocks of the other ranks never arrive, so the factors mean nothing.
+    if (const char* e = getenv("SMK_COMM_EMULATE_WORLD"))
+        if (comm->world == 1 && atoi(e) > 1 && atoi(e) <= 64) { s->world = atoi(e); s->rank = 0; }
     // chunk geometry: blocks of >= 4096 rows, at most 4 chunks (SMK_COMM_CHUNKS overrides: 1 .. 8), block a multiple of
     // 256 rows (the column tile of the streaming kernels and a whole number of packed chunk pairs)
     {
@@ -907,6 +921,18 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
             off += packed_bytes(s->a->storage, s->pg1[g].kg, s->rows_cap, s->nsplit);
         }
         s->pl1.pack_offset = s->pg1[0].pack_offset;
+        const size_t own_rows = (size_t)s->nchunk * s->blk;
+        const size_t rb = s->red_f64 ? sizeof(double) : sizeof(float);
+        if (dev_alloc(&s->Wown, own_rows * s->KP)) return SMK_DEVICE_ERROR;
+        if (dev_alloc((unsigned char**)&s->R2own, own_rows * s->kpp * rb)) return SMK_DEVICE_ERROR;
+        SMK_HIP(hipMemsetAsync(s->Wown, 0, own_rows * s->KP * sizeof(double), s->st));
+        SMK_HIP(hipMemsetAsync(s->R2own, 0, own_rows * s->kpp * rb, s->st));
+        s->n_own = 0;
+        for (int j = 0; j < s->nchunk; ++j) {
+            i64 a, b;
+            own_block(s, j, &a, &b);
+            if (b > a) s->n_own += b - a;
+        }
     }
     SMK_HIP(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
     hipEvent_t* evs[] = {&s->ev_gram, &s->ev_gh, &s->ev_x, &s->ev_y};
@@ -918,6 +944,19 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
     }
     // nothing is allocated once the collectives are in flight (several ranks may live in one process)
     return progress_prealloc(s);
+}
+
+// this rank's blocks of the full W (every rank holds all of it after set_factors / a gather / the final scaling) -> Wown
+static int scatter_own(smk_solver* s)
+{
+    for (int j = 0; j < s->nchunk; ++j) {
+        i64 a, b;
+        own_block(s, j, &a, &b);
+        if (b > a)
+            SMK_HIP(hipMemcpyAsync(s->Wown + (i64)j * s->blk * s->KP, s->Wt + a * s->KP, (size_t)(b - a) * s->KP * sizeof(double),
+                                   hipMemcpyDeviceToDevice, s->st));
+    }
+    return 0;
 }
 
 int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const double* H0, int64_t ldH)
@@ -946,7 +985,9 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
         SMK_HIP(hipMemcpyAsync(s->W0c, s->Wt, (size_t)s->KP * s->m * sizeof(double), hipMemcpyDeviceToDevice, s->st));
         SMK_HIP(hipMemcpyAsync(s->H0c, s->H, (size_t)s->KP * s->n * sizeof(double), hipMemcpyDeviceToDevice, s->st));
     }
+    if (s->w_sharded) { rc = scatter_own(s); if (rc) return rc; }
     SMK_HIP(hipStreamSynchronize(s->st));
+    s->w_full = true;
     s->have_factors = true;
     s->inited = false;
     s->normalized = false;
@@ -1118,15 +1159,10 @@ static int prod1_sharded(smk_solver* s)
     const int storage = s->a->storage;
     const size_t es = (size_t)elem_size(storage);
     int rc = 0;
-    for (int j = 0; j < s->nchunk && !rc; ++j) {
-        i64 a, b;
-        own_block(s, j, &a, &b);
-        for (int g = 0; g < s->ng && !rc; ++g) {
-            unsigned char* out = (unsigned char*)s->packW + s->pg1[g].pack_offset + packed_row_offset(storage, s->pg1[g].kg, s->nsplit, a);
-            if (b > a) rc = launch_pack_rows(s->Wt + a * s->KP, s->KP, s->pg1[g].k0, s->pg1[g].kg, b - a, storage, s->nsplit, out, s->st, s->xscale[0]);
-            // rows [b, a + blk) of the block stay zero (set at attach; a block never shrinks)
-        }
-    }
+    // one launch per group of 64 factor rows: this rank's blocks into their places in the operand (padding rows as zeros)
+    for (int g = 0; g < s->ng && !rc; ++g)
+        rc = launch_pack_own_blocks(s->Wown, s->KP, s->pg1[g].k0, s->pg1[g].kg, s->n_own, s->blk, s->nchunk, s->world, s->rank, storage,
+                                    s->nsplit, (unsigned char*)s->packW + s->pg1[g].pack_offset, s->st, s->xscale[0]);
     if (rc) return rc;
     rc = comm_fork(s, s->ev_x);
     if (rc) return rc;
@@ -1227,13 +1263,16 @@ static int prod2(smk_solver* s)
                                (const unsigned char*)s->packH + pl.pack_offset, s->P2 + pl.k0 + r0 * pl.pstride, j == s->nchunk - 1 ? 1 : 0);
             if (rc) return rc;
         }
-        rc = launch_reduce_partials(pv, s->k, r0, r1 - r0, s->R2red, s->red_f64 ? 1 : 0, s->st);
-        if (rc) return rc;
         rc = comm_fork(s, s->ev_c[j]);
+        if (rc) return rc;
+        // off the main stream: the row splits of the chunk summed (and rounded to the wire type), then its exchange
+        rc = launch_reduce_partials(pv, s->k, r0, r1 - r0, s->R2red, s->red_f64 ? 1 : 0, s->st2);
         if (rc) return rc;
         unsigned char* base = (unsigned char*)s->R2red + (size_t)r0 * s->kpp * rb;
         rc = timed_collective(s, [&] {
-            if (s->w_sharded) return comm_reduce_scatter(s->comm, base, s->blk * s->kpp, s->red_f64 ? 1 : 0, s->st2);   // own block only
+            if (s->w_sharded)       // every rank receives the sum of ITS block, next to its other blocks
+                return comm_reduce_scatter_to(s->comm, base, (unsigned char*)s->R2own + (size_t)j * s->blk * s->kpp * rb, s->blk * s->kpp,
+                                              s->red_f64 ? 1 : 0, s->st2);
             return comm_allreduce(s->comm, base, (r1 - r0) * s->kpp, s->red_f64 ? 1 : 0, s->st2);
         });
         if (rc) return rc;
@@ -1252,19 +1291,9 @@ static int gram_factor(smk_solver* s, int side)
     double* G = side == 0 ? s->Gw : s->Gh;
     s->packed_fresh[side] = false;
     if (side == 0 && s->w_sharded) {
-        // W'W from this rank's own blocks, summed over the ranks; the fp16 row scales follow the finished matrix
-        int nb_tot = 0;
-        const int per = std::max(1, GRAM_BLOCKS / s->nchunk);
-        for (int j = 0; j < s->nchunk; ++j) {
-            i64 a, b;
-            own_block(s, j, &a, &b);
-            if (b <= a) continue;
-            int nb = 0;
-            const int rc = launch_gram_partials(s->Wt + a * s->KP, s->k, b - a, s->gram_scratch + (size_t)nb_tot * s->KP * s->KP, per, &nb, s->st);
-            if (rc) return rc;
-            nb_tot += nb;
-        }
-        int rc = nb_tot ? launch_gram_reduce(s->gram_scratch, nb_tot, s->k, G, s->st) : launch_zero_f64(G, (i64)s->KP * s->KP, s->st);
+        // W'W from this rank's own rows, summed over the ranks; the fp16 row scales follow the finished matrix
+        int rc = s->n_own > 0 ? launch_gram(s->Wown, s->k, s->n_own, G, s->gram_scratch, GRAM_BLOCKS, s->st)
+                              : launch_zero_f64(G, (i64)s->KP * s->KP, s->st);
         if (rc) return rc;
         rc = dist_allreduce_now(s, G, (i64)s->KP * s->KP, 1);
         if (rc) return rc;
@@ -1307,7 +1336,7 @@ static int gather_w(smk_solver* s)
     int rc = comm_fork(s, s->ev_x);
     if (rc) return rc;
     for (int j = 0; j < s->nchunk && !rc; ++j)
-        rc = comm_allgather(s->comm, s->Wt + (i64)j * s->world * s->blk * s->KP, s->blk * s->KP, 1, s->st2);
+        rc = comm_allgather_to(s->comm, s->Wown + (i64)j * s->blk * s->KP, s->Wt + (i64)j * s->world * s->blk * s->KP, s->blk * s->KP, 1, s->st2);
     if (rc) return rc;
     s->w_full = true;
     return comm_join(s, s->ev_y);
@@ -1364,14 +1393,9 @@ static int solver_iteration(smk_solver* s)
             rc = prod2(s);    if (rc) return rc;
             if (s->w_sharded) {
                 // W is replicated in the algorithm but its rows are independent NNLS problems: every rank solves its own
-                // blocks, each as soon as its slice of the reduce-scatter has landed
-                for (int j = 0; j < s->nchunk; ++j) {
-                    i64 a, b;
-                    own_block(s, j, &a, &b);
-                    SMK_HIP(hipStreamWaitEvent(s->st, s->ev_r[j], 0));
-                    if (b > a) { rc = nnls_side(s, 1, s->Wt, a, b, r2, s->Gh); if (rc) return rc; }
-                }
-                s->r2_pending = false;
+                // blocks (held back to back, one launch) once the last slice of the reduce-scatter has landed
+                rc = wait_r2(s);  if (rc) return rc;
+                rc = nnls_side(s, 1, s->Wown, 0, s->n_own, view_own(s), s->Gh); if (rc) return rc;
                 s->w_full = false;
             } else if (s->ar && s->world > 1) {
                 // callback hook (one primitive only): every rank solves a row range, zeroes the rest and sum-all-reduces
@@ -1464,20 +1488,9 @@ static int enqueue_progress_kernels(smk_solver* s)
         if (rc) return rc;
     } else {
         // gradW = W*HHt - AHt  (slot 0, replicated), gradH = WtW*H - WtA (slot 1, local shard)
-        if (w_rows_sharded(s)) {      // only this rank's blocks of the summed (AH')' exist here: partial sum, joined in dist_agree
-            int total = 0;
-            for (int j = 0; j < s->nchunk; ++j) {
-                i64 a, b;
-                own_block(s, j, &a, &b);
-                if (b <= a) continue;
-                PartialView own = view2(s);
-                own.p = (const unsigned char*)own.p + (size_t)a * s->kpp * (s->red_f64 ? sizeof(double) : sizeof(float));
-                int g = 0;
-                rc = launch_grad_pg_partials(s->Wt + a * s->KP, s->k, b - a, own, s->Gh, nullptr, s->pg_partials + total, &g, s->st);
-                if (rc) return rc;
-                total += g;
-            }
-            rc = total ? launch_sum_partials(s->pg_partials, total, s->scal, s->st) : launch_zero_f64(s->scal, 1, s->st);
+        if (w_rows_sharded(s)) {      // only this rank's rows of the summed (AH')' exist here: partial sum, joined in dist_agree
+            rc = s->n_own > 0 ? launch_grad_pg(s->Wown, s->k, s->n_own, view_own(s), s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st)
+                              : launch_zero_f64(s->scal, 1, s->st);
         } else {
             rc = launch_grad_pg(s->Wt, s->k, s->m, view2(s), s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st);
         }
@@ -1556,7 +1569,8 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
     }
     if (snapshot) {
         if (!s->snap[b]) { rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
-        rc = launch_snapshot(s->Wt, s->m, s->H, s->n, s->Gw, s->snap[b], s->k, 1, s->st);
+        rc = s->w_sharded ? launch_snapshot(s->Wown, s->n_own, s->H, s->n, s->Gw, s->snap[b], s->k, 1, s->st)
+                          : launch_snapshot(s->Wt, s->m, s->H, s->n, s->Gw, s->snap[b], s->k, 1, s->st);
         if (rc) return rc;
     }
     SMK_HIP(hipEventRecord(s->pev[b], s->st));
@@ -1574,14 +1588,15 @@ static int progress_end(smk_solver* s, int b, int iter_index, double* metric)
 
 static int progress_restore(smk_solver* s, int b)
 {
-    int rc = launch_snapshot(s->Wt, s->m, s->H, s->n, s->Gw, s->snap[b], s->k, 0, s->st);
+    int rc = s->w_sharded ? launch_snapshot(s->Wown, s->n_own, s->H, s->n, s->Gw, s->snap[b], s->k, 0, s->st)
+                          : launch_snapshot(s->Wt, s->m, s->H, s->n, s->Gw, s->snap[b], s->k, 0, s->st);
     if (rc) return rc;
     // whatever the undone iteration did to the failure flag is void; products / HH' are stale
     const int big = INT_MAX;
     SMK_HIP(hipMemcpyAsync(s->fail_flag, &big, sizeof(int), hipMemcpyHostToDevice, s->st));
     SMK_HIP(hipStreamSynchronize(s->st));
     s->inited = false;
-    if (s->w_sharded) s->w_full = false;    // the snapshot holds this rank's own blocks (the others as stale as they were)
+    if (s->w_sharded) s->w_full = false;    // the snapshot holds this rank's own rows; the full copy is stale
     return 0;
 }
 
@@ -1594,6 +1609,7 @@ static int normalize_device(smk_solver* s)
     if (rc) return rc;
     rc = launch_scale_rows(s->Wt, s->k, s->m, s->Gw, 1, s->fail_flag, s->st);
     if (rc) return rc;
+    if (s->w_sharded) { rc = scatter_own(s); if (rc) return rc; }      // the own rows follow the scaled full copy
     s->normalized = true;
     // Gw/Gh and the stored products describe the un-normalised factors: a later iterate()/run() on this
     // handle starts from solver.Init on the scaled (W, H), exactly like a fresh solver given them

@@ -3,7 +3,9 @@
 SEPARATE runs, as MI355X_MICROARCH.md prescribes).  Units: both counters are KiB; on gfx950 FETCH_SIZE
 reports exactly half of the bytes of a wide coalesced streaming read, so it is doubled.
 Usage: pmc_traffic.py <fetch.db> <write.db> <kernel-substring> [key] [hbm_traffic.json]"""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
 
@@ -24,6 +26,9 @@ def main():
     out = {"bytes_per_launch": total, "fetch_size_kib_raw": f, "write_size_kib_raw": w, "launches_sampled": [nf, nw],
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); "
                      "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of a wide streaming read)"}
+    # bench.py prints the figure only while the streaming kernels' source is the one it was measured on
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "smallk_amd", "csrc", "bigprod.hip")
+    out["kernel_source_sha16"] = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 5:
         key, path = sys.argv[4], sys.argv[5]
