@@ -168,15 +168,25 @@ int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* laun
 /* algorithmic bytes / flops one launch of pass `which` moves (len*ncols*sizeof(elt), 2*k*len*ncols) */
 int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double* flops);
 
-/* ---- multi-GPU: A and H column sharded, W replicated.  The exchange steps are sum-all-reduces of
- * HH' (k x k, fp64) and H*At (k x m, fp32) per iteration, one 2-element all-reduce when the stopping rule is
- * evaluated, and for BPP an all-gather of the row slices of W each rank solved.  They are issued from C on the
- * solver's own HIP streams through a communicator object:
+/* ---- multi-GPU: A and H column sharded, W replicated in the algorithm.  Exchange steps per iteration:
+ *   - sum-all-reduce of HH' (k x k, fp64), beside the H*At pass;
+ *   - the sum of H*At = (AH')' (k x m; fp32 on the wire, SMK_COMM_F64=1: fp64): the pass runs in row chunks and the
+ *     sum of chunk j travels while the product streams chunk j + 1 -- an all-reduce for MU / HALS (replicated W
+ *     update), a reduce-scatter for BPP, whose W rows are independent NNLS problems: block r of every chunk belongs
+ *     to rank r (block-cyclic), every rank solves its own blocks;
+ *   - BPP: sum-all-reduce of W'W (k x k) built from the own blocks, and an all-gather per chunk of the PACKED
+ *     streaming operand of those blocks (4 B per entry in the fp16 form; the fp64 rows are gathered only when results
+ *     or the DELTA_FNORM rule need them); the W'A pass then runs chunk by chunk down the rows as the operand lands;
+ *   - one 3-element all-reduce when the stopping rule is evaluated.
+ * All of them are issued from C on ONE second HIP stream per solver (a communicator is never driven from two streams)
+ * and tied to the main stream by events.  Communicators:
  *   - RCCL over xGMI: one process per GPU (smk_comm_unique_id on rank 0, broadcast the 128 bytes by any means,
  *     smk_comm_init_rank everywhere) or one process driving several GPUs (smk_comm_init_all, one host thread per
  *     device -- what smk_nmf_dense_sharded does);
  *   - an in-process stand-in with the same semantics for several shards on ONE device (smk_comm_init_local: RCCL
  *     refuses two ranks on a device), used by the tests and by boxes with fewer GPUs than shards.
+ * Environment: SMK_COMM_CHUNKS=1..8 (row chunks of the exchange; default: blocks of >= 4096 rows, at most 4 chunks),
+ * SMK_COMM_F64=1, SMK_COMM_FORCE=1 (a world of ONE rank issues every collective too: tests of the real nccl* calls).
  * The reference has no distributed mode (sphinx/source/pages_installation.rst:38). */
 typedef struct smk_comm smk_comm;
 int smk_comm_unique_id(void* id128 /* 128 bytes out */);
@@ -188,6 +198,9 @@ int smk_comm_selftest(smk_comm* c);
 int smk_comm_rank(const smk_comm* c);
 int smk_comm_world(const smk_comm* c);
 void smk_comm_destroy(smk_comm* c);
+/* a rank that gives up calls this so that peers blocked in a collective are released (ncclCommAbort / the stand-in's
+ * failure flag); the handle is still destroyed with smk_comm_destroy */
+void smk_comm_abort(smk_comm* c);
 /* attach before smk_solver_set_factors(); the communicator must outlive the solver */
 int smk_solver_attach_comm(smk_solver* s, smk_comm* comm);
 /* Result Nmf(...) (common/src/nmf.cpp:173-229) on `nshards` column shards, one host thread and one device per shard;

@@ -110,6 +110,7 @@ SYMBOLS = {
     "smk_comm_rank": (C.c_int, [_vp]),
     "smk_comm_world": (C.c_int, [_vp]),
     "smk_comm_destroy": (None, [_vp]),
+    "smk_comm_abort": (None, [_vp]),
     "smk_solver_attach_comm": (C.c_int, [_vp, _vp]),
     "smk_nmf_dense_sharded": (C.c_int, [C.POINTER(Options), _dp, _i64, _dp, _i64, _dp, _i64, C.POINTER(Stats), C.c_int,
                                         C.c_int, C.POINTER(C.c_int), C.c_int]),

@@ -11,6 +11,7 @@
 
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -28,15 +29,23 @@ struct LocalGroup {
     std::condition_variable cv;
     int arrived = 0;
     long generation = 0;
+    int err = 0;                          // sticky: a rank that failed (or a wait that timed out) fails every later collective of the group
     std::vector<void*> ptr, ptr2;          // send / receive buffer of every rank for the collective in flight
     std::vector<hipStream_t> stream;
     int refs = 0;
-    void barrier()
+    // all ranks meet here; `my_err` is published before the meeting so that every rank leaves with the same verdict.
+    // A rank that never arrives (it returned early on an error of its own) does not strand the others for ever.
+    int barrier(int my_err)
     {
         std::unique_lock<std::mutex> lk(mu);
+        if (my_err && !err) err = my_err;
         const long gen = generation;
         if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen; });
+        else if (!cv.wait_for(lk, std::chrono::seconds(300), [&] { return generation != gen; })) {
+            if (!err) err = SMK_DEVICE_ERROR;
+            arrived = 0; ++generation; cv.notify_all();       // release whoever else is waiting
+        }
+        return err;
     }
 };
 
@@ -48,19 +57,20 @@ enum { LOCAL_ALLREDUCE = 0, LOCAL_ALLGATHER = 1, LOCAL_REDUCE_SCATTER = 2 };
 static int local_collective(smk_comm* c, const void* send, void* recv, i64 count, int f64, hipStream_t st, int op)
 {
     LocalGroup* g = c->local;
-    SMK_HIP(hipStreamSynchronize(st));          // this rank's contribution is complete
+    int mine = 0;
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("local communicator: hipStreamSynchronize failed"); mine = SMK_DEVICE_ERROR; }   // this rank's contribution is complete
     g->ptr[c->rank] = const_cast<void*>(send);
     g->ptr2[c->rank] = recv;
     g->stream[c->rank] = st;
-    g->barrier();
-    int rc = 0;
-    if (c->rank == 0) {
+    int rc = g->barrier(mine);
+    if (c->rank == 0 && !rc) {
         rc = op == LOCAL_ALLGATHER        ? launch_local_allgather(g->ptr.data(), g->ptr2.data(), g->world, count, f64, st)
              : op == LOCAL_REDUCE_SCATTER ? launch_local_reduce_scatter(g->ptr.data(), g->ptr2.data(), g->world, count, f64, st)
                                           : launch_local_allreduce(g->ptr2.data(), g->world, count, f64, st);
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = SMK_DEVICE_ERROR;
     }
-    g->barrier();                               // results are in every rank's buffer
+    rc = g->barrier(rc);                        // results are in every rank's buffer -- or every rank learns that they are not
+    if (rc) set_error("local communicator: a rank failed inside a collective");
     return rc;
 }
 
@@ -235,6 +245,20 @@ int smk_comm_selftest(smk_comm* c)
     (void)hipFree(d);
     (void)hipStreamDestroy(st);
     return rc;
+}
+
+// A rank that leaves its iteration loop with an error calls this so that peers blocked in a collective are released
+// (ncclCommAbort for RCCL; the stand-in marks the group failed and wakes every waiter).
+void smk_comm_abort(smk_comm* c)
+{
+    if (!c) return;
+    if (c->nccl) { (void)ncclCommAbort((ncclComm_t)c->nccl); c->nccl = nullptr; }
+    if (c->local) {
+        std::lock_guard<std::mutex> lk(c->local->mu);
+        if (!c->local->err) c->local->err = SMK_DEVICE_ERROR;
+        c->local->arrived = 0; ++c->local->generation;
+        c->local->cv.notify_all();
+    }
 }
 
 int smk_comm_rank(const smk_comm* c) { return c ? c->rank : 0; }

@@ -27,6 +27,8 @@
 #include <algorithm>
 #include <thread>
 
+struct smk_matrix;
+
 namespace smk {
 
 // One device context per process by default; the single-process multi-GPU driver (smk_nmf_dense_sharded) runs
@@ -37,6 +39,7 @@ struct DeviceCtx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int live_solvers = 0;               // solver handles cache the stream: it cannot change under them
+    std::vector<struct ::smk_matrix*> mats;   // live matrices: they follow the context's stream when it is replaced
 };
 static DeviceCtx g_ctx;
 static thread_local DeviceCtx* t_ctx = nullptr;
@@ -92,6 +95,18 @@ struct smk_matrix {
 };
 
 static const int MAX_CHUNKS = 8;
+static void repoint_matrices(hipStream_t st);
+
+static void repoint_matrices(hipStream_t st)
+{
+    for (smk_matrix* a : ctx().mats) a->st = st;
+}
+static void register_matrix(smk_matrix* a) { ctx().mats.push_back(a); }
+static void unregister_matrix(smk_matrix* a)
+{
+    auto& v = ctx().mats;
+    v.erase(std::remove(v.begin(), v.end(), a), v.end());
+}
 
 struct smk_solver {
     smk_options o;
@@ -191,7 +206,9 @@ int smk_is_initialized(void) { return g_init ? SMK_INITIALIZED : SMK_NOTINITIALI
 
 void smk_finalize(void)
 {
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
     if (g_own_stream && g_stream) (void)hipStreamDestroy(g_stream);
+    repoint_matrices(nullptr);            // a matrix that outlives the context takes the next context's stream
     g_stream = nullptr;
     g_own_stream = false;
     g_init = false;
@@ -207,6 +224,7 @@ int smk_set_stream(void* hip_stream)
     if (g_own_stream && g_stream) (void)hipStreamDestroy(g_stream);
     g_stream = (hipStream_t)hip_stream;
     g_own_stream = false;
+    repoint_matrices(g_stream);           // resident matrices were created under the old stream
     return SMK_OK;
 }
 
@@ -279,6 +297,7 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
     smk_matrix* a = new smk_matrix;
     a->m = height; a->n_global = width_global; a->c0 = col0; a->n = ncols_local; a->storage = storage;
     a->st = g_stream;
+    register_matrix(a);
     a->ldA = round_up(height, ROW_PAD);      a->colsA = round_up(ncols_local, COL_PAD);
     a->ldAt = round_up(ncols_local, ROW_PAD); a->colsAt = round_up(height, COL_PAD);
     const size_t es = (size_t)elem_size(storage);
@@ -375,6 +394,7 @@ int smk_matrix_download_f64(const smk_matrix* a, double* host, int64_t ld)
 void smk_matrix_destroy(smk_matrix* a)
 {
     if (!a) return;
+    unregister_matrix(a);
     void* ptrs[] = {a->A, a->At, a->colptr, a->colptr_t, a->rowidx, a->rowidx_t, a->val, a->val_t};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -504,6 +524,7 @@ int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_glo
     a->m = height; a->n_global = width_global; a->c0 = col0; a->n = ncols_local; a->storage = SMK_STORE_F32;
     a->sparse = true; a->nnz = nnz;
     a->st = g_stream;
+    register_matrix(a);
     a->h_colptr.resize((size_t)ncols_local + 1);
     for (int64_t c = 0; c <= ncols_local; ++c) a->h_colptr[(size_t)c] = col_offsets[c] - base;
     a->h_rowidx.assign(row_indices + base, row_indices + base + nnz);
@@ -587,6 +608,7 @@ int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t 
         a->m = od.m; a->n_global = ncols; a->c0 = 0; a->n = ncols; a->storage = SMK_STORE_F32;
         a->sparse = true; a->nnz = od.nnz;
         a->st = g_stream;
+        register_matrix(a);
         a->colptr = od.colptr; a->rowidx = od.rowidx; a->val = od.val;
         a->colptr_t = od.colptr_t; a->rowidx_t = od.rowidx_t; a->val_t = od.val_t;
         if (new_height) *new_height = od.m;
@@ -2046,6 +2068,9 @@ int smk_nmf_dense_sharded(const smk_options* opts, const double* A, int64_t ldA,
         }
         if (wrc == SMK_OK) {
             wrc = smk_solver_run(s, &sts[(size_t)r]);
+            // anything but an agreed result (OK / FAILURE are all-reduced) means this rank left the loop alone: release the
+            // peers that wait for it in a collective
+            if (wrc != SMK_OK && wrc != SMK_FAILURE) smk_comm_abort(comms[(size_t)r]);
             if (wrc == SMK_OK || wrc == SMK_FAILURE) {
                 // W is replicated: rank 0 returns it; every rank returns its own columns of H
                 std::vector<double> Wl(r == 0 ? 0 : (size_t)m * opts->k);

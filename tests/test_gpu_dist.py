@@ -436,3 +436,83 @@ np.save(%r, api.get_W())
         assert r.returncode == 0, r.stderr[-2000:]
         Ws[tag] = np.load(out / "W.npy")
     assert rel(Ws["two"], Ws["one"]) < 1e-5
+
+
+# ---- two or more real GPUs (skipped on the one-GPU test boxes; the driver's 8-GPU node runs them) -------------------
+def _device_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:      # pragma: no cover
+        return 0
+
+
+needs_two_gpus = pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs")
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("alg,k", [("BPP", 16), ("BPP", 64), ("HALS", 32), ("MU", 12)])
+def test_rccl_two_devices_match_one(gpu, alg, k):
+    """smk_nmf_dense_sharded over real devices: ncclCommInitAll, one host thread per device, every collective of the chunk
+    pipeline over xGMI.  Against the single-GPU run (<= 1e-5) and the oracle (<= 1e-4)."""
+    shards = min(_device_count(), 4)
+    m, n, iters = 3000, 1201, 6
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    kw = dict(min_iter=iters, max_iter=iters, tol=1e-9)
+    ref = oracle.nmf(A, W0, H0, alg, **kw)
+    one = gpu.nmf(A, W0, H0, alg, **kw)
+    many = gpu.nmf_sharded(A, W0, H0, alg, shards, local_stub=False, **kw)
+    assert many.result == 0 and many.iteration_count == iters
+    assert rel(many.W, one.W) < 1e-5 and rel(many.H, one.H) < 1e-5
+    assert rel(many.W, ref.W) < TOL and rel(many.H, ref.H) < TOL
+
+
+@needs_two_gpus
+def test_bench_two_ranks_over_rccl(tmp_path):
+    """bench.py exactly as the driver launches it for N = 2: one process per GPU, the native RCCL communicator."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--workload", "c2", "--no-cpu-baseline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=root, capture_output=True, text=True,
+                        timeout=600, env=dict(env, SMK_BENCH_DUMP_W=str(tmp_path / "w1.npy")))
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2"] + common,
+                        cwd=root, capture_output=True, text=True, timeout=900,
+                        env=dict(env, SMK_BENCH_DUMP_W=str(tmp_path / "w2.npy")))
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    line = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and "RCCL from C" in out["config"]["collectives"] and len(out["per_rank"]) == 2
+    W1, W2 = np.load(tmp_path / "w1.npy"), np.load(tmp_path / "w2.npy")
+    assert np.linalg.norm(W1 - W2) / np.linalg.norm(W1) < 1e-5
+
+
+def test_matrix_follows_a_stream_set_after_its_creation(gpu):
+    """initialize(), DenseMatrix(...), set_stream(torch's stream), NmfSolver(D): the matrix was created under the
+    library's own stream, which set_stream destroys -- the solver must run on the new one."""
+    import torch
+    m, n, k, iters = 700, 300, 8, 4
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    ref = oracle.nmf(A, W0, H0, "BPP", min_iter=iters, max_iter=iters)
+    gpu.finalize()
+    gpu.initialize(0)                       # fresh context with its own stream
+    D = gpu.DenseMatrix.from_host(A)
+    side = torch.cuda.Stream()
+    gpu.set_stream(side.cuda_stream)        # destroys the stream D was created under
+    s = gpu.NmfSolver(D, gpu.make_options(m, n, k, "BPP", min_iter=iters, max_iter=iters))
+    s.set_factors(W0, H0)
+    rc, it, _ = s.run()
+    W, H = s.factors()
+    s.close()
+    D.close()
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert rc == 0 and it == iters and rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
