@@ -182,17 +182,28 @@ int launch_compact_rows(const double* src, int KP, double* dst, int k, i64 N, hi
 // live rows of W' and H + the Gram matrix <-> one compact buffer (pack != 0: factors -> buffer)
 size_t snapshot_elems(int k, i64 m, i64 n);
 int launch_snapshot(double* Wt, i64 m, double* H, i64 n, double* G, double* buf, int k, int pack, hipStream_t st);
-// RANK2: closed-form 2x2 solve + optimal active set (side 0: H, side 1: W'); with Gout the Gram matrix
-// X X' of the result comes out of the same pass (scratch: rank2_gram_scratch_elems(N) doubles)
-int launch_rank2_solve(double* X, i64 N, PartialView R, const double* G, int side, int* fail_flag, int iter_tag,
-                       double* Gout, double* scratch, hipStream_t st);
+// ---- RANK2 (rank2.hip): the iteration as few fused launches
+// X <- closed-form 2x2 solve + optimal active set of G X = R (side 0: H, side 1: W'); Xc (optional): compact N x 2 copy.
+// The left-hand side: finished in Gin (gin_nb == 0) or gin_nb partial sums in Gin_p, which the kernel sums itself (its
+// workgroup 0 then stores the finished matrix in Gin).  Gp_out (optional): partial sums of X X' of the result for the next
+// consumer (*nb_out of them), or -- finish != 0 / too many -- summed into Gout by a second launch (*nb_out = 0).
+int launch_rank2_solve(double* X, double* Xc, i64 N, PartialView R, double* Gin, const double* Gin_p, int gin_nb, int side,
+                       int* fail_flag, int iter_tag, double* Gp_out, int* nb_out, double* Gout, int finish, hipStream_t st);
 size_t rank2_gram_scratch_elems(i64 N);
-// per-iteration NormalizeAndScale in one launch (H, W, the stored AH', HH'); leaves Gw = W'W of the
-// normalised W (Gw_ij / (nu_i nu_j))
-int launch_rank2_normalize(double* H, i64 n, double* Wt, i64 m, PartialView R, double* Gh, double* Gw, int* fail_flag,
-                           hipStream_t st);
+// per-iteration NormalizeAndScale in one launch (H, W, the stored AH', HH'); Graw = W'W of the W just solved, finished
+// or as partial sums; writes Gw = W'W of the normalised W (Graw_ij / (nu_i nu_j)) and, optionally, the compact copy of W
+int launch_rank2_normalize(double* H, i64 n, double* Wt, double* Wc, i64 m, PartialView R, double* Gh, const double* Graw,
+                           const double* Graw_p, int graw_nb, double* Gw, int* fail_flag, hipStream_t st);
+int launch_rank2_compact(const double* X, double* Xc, i64 N, hipStream_t st);
+// both projected-gradient sums as per-workgroup partials [blocks][2] (W, H) with the failure flag behind them, optional
+// snapshot of (W, H, Gw) in launch_snapshot's layout
+int launch_rank2_progress(const double* Wt, i64 m, PartialView R2, const double* Gh, const double* H, i64 n, PartialView R1,
+                          const double* Gw, double* partials, const int* flag, double* snap, hipStream_t st);
+int rank2_progress_blocks(i64 m, i64 n);
+size_t rank2_progress_scratch_elems(i64 m, i64 n);
 // sparse A (CSC): out[:, j] = sum_p val[p] * X[:, row[p]] over the nonzeros of column j
-int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X,
+// X: the gathered factor, row pitch ldx doubles (KP, or 2 for the compact copy of a rank-2 factor)
+int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X, int ldx,
                        int k, double* P, int kpp, hipStream_t st);
 
 // sparse_subset.hip: CSC(A[:, cols]) and CSC(A[:, cols]') with unused rows dropped, assembled on the device

@@ -118,6 +118,12 @@ __device__ __forceinline__ void load_rhs4(const PartialView& R, i64 j, int e0, d
 {
     b[0] = b[1] = b[2] = b[3] = 0.0;
     if (e0 >= R.kpp) return;
+    if (R.kpp - e0 < 4) {                 // compact rank-2 products (kpp = 2): only the entries that exist
+        for (int e = 0; e0 + e < R.kpp; ++e)
+            for (int s = 0; s < R.S; ++s)
+                b[e] += R.f64 ? ((const double*)R.p)[s * R.slab + j * R.kpp + e0 + e] : (double)((const float*)R.p)[s * R.slab + j * R.kpp + e0 + e];
+        return;
+    }
     if (R.f64) {
         for (int s = 0; s < R.S; ++s) {
             double t[4];

@@ -345,6 +345,13 @@ int factor_node(Run& r, const smk_matrix* a, i64 h, i64 w, const unsigned* rows,
         }
         smk_solver_destroy(s);
         r.iterations += st.iteration_count;
+        {
+            static const bool timing = [] { const char* e = getenv("SMK_CLUST_TIMING"); return e && atoi(e) != 0; }();
+            if (timing)
+                fprintf(stderr, "[smk_clust] %s %ld x %ld nnz %ld: %d iterations in %.1f ms (%.1f us each)\n", what, (long)h, (long)w,
+                        (long)smk_matrix_nnz(a), st.iteration_count, st.elapsed_us * 1e-3,
+                        st.iteration_count ? (double)st.elapsed_us / st.iteration_count : 0.0);
+        }
         if (rc == SMK_OK) {
             r.stats.nmf_count += 1;
             if (st.iteration_count == so.max_iter) r.stats.max_count += 1;

@@ -1486,181 +1486,22 @@ __global__ __launch_bounds__(256) void spmm_gather2_kernel(const i64* __restrict
     for (int e = 2; e < kpp && e < 8; e += 2) { f64x2_t z; z[0] = 0.0; z[1] = 0.0; *(f64x2_t*)(out + e) = z; }
 }
 
-int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X,
+int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X, int ldx,
                        int k, double* P, int kpp, hipStream_t st)
 {
     if (is_wide(k)) return launch_spmm_gather_wide(colptr, rowidx, val, ncols, X, k, P, kpp, st);
     const int KPv = kp_of(k);
-    static const bool rank2_path = [] { const char* e = getenv("SMK_SPMM2"); return !(e && e[0] == '0'); }();
-    if (k <= 2 && rank2_path) {
+    if (k <= 2 && (ldx == 2 || ldx == KPv)) {
         const int grid2 = (int)((ncols + 255) / 256);
         if (grid2 == 0) return 0;
-        spmm_gather2_kernel<<<grid2, 256, 0, st>>>(colptr, rowidx, val, ncols, X, KPv, P, kpp);
+        spmm_gather2_kernel<<<grid2, 256, 0, st>>>(colptr, rowidx, val, ncols, X, ldx, P, kpp);
         SMK_HIP(hipGetLastError());
         return 0;
     }
+    if (ldx != KPv) { set_error("spmm: unsupported row pitch of the gathered factor"); return -100; }
     const int grid = (int)((ncols * (KPv / 4) + 255) / 256);
     if (grid == 0) return 0;
     KP_DISPATCH128(KPv, (spmm_gather_kernel<KP><<<grid, 256, 0, st>>>(colptr, rowidx, val, ncols, X, P, kpp)));
-    SMK_HIP(hipGetLastError());
-    return 0;
-}
-
-// ==========================================================================
-// RANK2 (nmf_solver_rank2.hpp): closed-form 2x2 solves by one fast Givens rotation
-// (SystemSolveH :25-135 / SystemSolveW :139-212) followed by the optimal active set
-// (:216-318).  One thread per column of X (KP = 8 layout, rows 0 and 1 live).
-// ==========================================================================
-// Gp != nullptr: the kernel also leaves per-workgroup partial sums of X X' (the Gram matrix every
-// RANK2 step needs right after the solve) in Gp[block][64], so the solved factor is not re-read.
-__global__ __launch_bounds__(256) void rank2_solve_kernel(double* __restrict__ X, i64 N, PartialView R,
-                                                          const double* __restrict__ G, int side,
-                                                          int* __restrict__ fail_flag, int iter_tag,
-                                                          double* __restrict__ Gp)
-{
-    constexpr int KP = 8;
-    __shared__ double shg[4][3];
-    const double eps = DBL_EPSILON;
-    const double a00 = G[0], a10 = G[1], a01 = G[KP], a11 = G[KP + 1];
-    bool bad = (fabs(a00) < eps) && (fabs(a01) < eps);          // "singular matrix"
-    const bool cosine = fabs(a00) >= fabs(a01);
-    double t, a2, b2, d2;
-    if (side == 0) {
-        if (cosine) { t = -a10 / a00; a2 = a00 - t * a10; b2 = a01 - t * a11; d2 = a11 + t * a01; }
-        else        { t = -a00 / a10; a2 = -a10 + t * a00; b2 = -a11 + t * a01; d2 = a01 + t * a11; }
-    } else {
-        if (cosine) { t = a01 / a00; a2 = a00 + t * a01; b2 = a10 + t * a11; d2 = a11 - t * a10; }
-        else        { t = a00 / a01; a2 = -a01 - t * a00; b2 = -a11 - t * a10; d2 = a10 - t * a11; }
-    }
-    const double inv_a2 = 1.0 / a2, inv_d2 = 1.0 / d2;
-    if (fabs(d2 / a2) < eps) bad = true;
-    if (bad) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMin(fail_flag, iter_tag);
-        return;
-    }
-    const double inv0 = 1.0 / a00, inv1 = 1.0 / a11, sq0 = sqrt(a00), sq1 = sqrt(a11);
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = j < N;
-    if (!valid && !Gp) return;
-    double x0 = 0.0, x1 = 0.0;
-    if (valid) {
-        const double b0 = rhs_elem(R, j, 0), b1 = rhs_elem(R, j, 1);
-        double e2, f2;
-        if (side == 0) {
-            if (cosine) { e2 = b0 - t * b1; f2 = b1 + t * b0; }
-            else        { e2 = -b1 + t * b0; f2 = b0 + t * b1; }
-        } else {
-            if (cosine) { e2 = b0 + t * b1; f2 = b1 - t * b0; }
-            else        { e2 = -b1 - t * b0; f2 = b0 - t * b1; }
-        }
-        x1 = f2 * inv_d2;
-        x0 = (e2 - b2 * x1) * inv_a2;
-        if (x0 <= 0.0 || x1 <= 0.0) {               // OptimalActiveSet
-            double v1 = b0 * inv0, v2 = b1 * inv1;
-            if (v1 * sq0 >= v2 * sq1) v2 = 0.0; else v1 = 0.0;
-            x0 = v1;
-            x1 = v2;
-        }
-        f64x2_t v;
-        v[0] = x0;
-        v[1] = x1;
-        *(f64x2_t*)(X + j * KP) = v;
-    }
-    if (!Gp) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double s00 = wave_sum(x0 * x0), s01 = wave_sum(x0 * x1), s11 = wave_sum(x1 * x1);
-    if (lane == 0) { shg[wave][0] = s00; shg[wave][1] = s01; shg[wave][2] = s11; }
-    __syncthreads();
-    if (threadIdx.x < KP * KP) {
-        const int e = threadIdx.x;
-        const int q = (e == 0) ? 0 : (e == 1 || e == KP) ? 1 : (e == KP + 1) ? 2 : -1;
-        Gp[(i64)blockIdx.x * KP * KP + e] = (q < 0) ? 0.0 : (shg[0][q] + shg[1][q]) + (shg[2][q] + shg[3][q]);
-    }
-}
-
-// Gout != nullptr: also Gout = X X' (KP x KP), through `scratch` (rank2_gram_scratch_elems(N) doubles)
-int launch_rank2_solve(double* X, i64 N, PartialView R, const double* G, int side, int* fail_flag, int iter_tag,
-                       double* Gout, double* scratch, hipStream_t st)
-{
-    const int grid = (int)((N + 255) / 256);
-    rank2_solve_kernel<<<grid, 256, 0, st>>>(X, N, R, G, side, fail_flag, iter_tag, Gout ? scratch : nullptr);
-    SMK_HIP(hipGetLastError());
-    if (Gout) {
-        gram_reduce_kernel<<<4, 256, 0, st>>>(scratch, grid, 64, Gout);
-        SMK_HIP(hipGetLastError());
-    }
-    return 0;
-}
-size_t rank2_gram_scratch_elems(i64 N) { return (size_t)((N + 255) / 256) * 64; }
-
-// Per-iteration NormalizeAndScale of RANK2 (nmf_solver_rank2.hpp:418-437) in one launch: H rows *= nu,
-// W columns /= nu, the stored AH' *= nu per column, HH'_ij *= nu_i nu_j; nu_c = sqrt(Gw[c][c]).
-// A zero norm reports -2 through fail_flag and leaves that component unscaled (the reference throws).
-__global__ __launch_bounds__(256) void rank2_normalize_kernel(double* __restrict__ H, i64 n, double* __restrict__ Wt, i64 m,
-                                                              void* __restrict__ P, int S, i64 slab, int kpp, int f64,
-                                                              double* __restrict__ Gh, const double* __restrict__ Gw,
-                                                              int* __restrict__ fail_flag)
-{
-    constexpr int KP = 8;
-    const double nu0 = sqrt(Gw[0]), nu1 = sqrt(Gw[KP + 1]);
-    const bool ok0 = !(fabs(nu0) < DBL_EPSILON), ok1 = !(fabs(nu1) < DBL_EPSILON);
-    const double h0 = ok0 ? nu0 : 1.0, h1 = ok1 ? nu1 : 1.0;
-    const double w0 = ok0 ? 1.0 / nu0 : 1.0, w1 = ok1 ? 1.0 / nu1 : 1.0;
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0) {
-        if (!ok0 || !ok1) atomicMin(fail_flag, -2);
-        Gh[0] *= nu0 * nu0;
-        Gh[1] *= nu0 * nu1;
-        Gh[KP] *= nu0 * nu1;
-        Gh[KP + 1] *= nu1 * nu1;
-    }
-    if (j < n) {
-        f64x2_t v = *(f64x2_t*)(H + j * KP);
-        v[0] *= h0;
-        v[1] *= h1;
-        *(f64x2_t*)(H + j * KP) = v;
-    }
-    if (j < m) {
-        f64x2_t v = *(f64x2_t*)(Wt + j * KP);
-        v[0] *= w0;
-        v[1] *= w1;
-        *(f64x2_t*)(Wt + j * KP) = v;
-        for (int s = 0; s < S; ++s) {
-            if (f64) {
-                double* p = (double*)P + s * slab + j * kpp;
-                p[0] *= nu0;
-                p[1] *= nu1;
-            } else {
-                float* p = (float*)P + s * slab + j * kpp;
-                p[0] = (float)((double)p[0] * nu0);
-                p[1] = (float)((double)p[1] * nu1);
-            }
-        }
-    }
-}
-
-// W'W of the NORMALISED W without another pass over W: (D^-1 W'W D^-1)_ij = Gw_ij / (nu_i nu_j).
-// Runs after the consumer of the un-normalised Gram matrix (rank2_normalize_kernel) on the stream.
-__global__ void rank2_gw_normalize_kernel(double* __restrict__ Gw)
-{
-    constexpr int KP = 8;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double nu0 = sqrt(Gw[0]), nu1 = sqrt(Gw[KP + 1]);
-    Gw[0] = Gw[0] / (nu0 * nu0);
-    Gw[1] = Gw[1] / (nu0 * nu1);
-    Gw[KP] = Gw[KP] / (nu0 * nu1);
-    Gw[KP + 1] = Gw[KP + 1] / (nu1 * nu1);
-}
-
-int launch_rank2_normalize(double* H, i64 n, double* Wt, i64 m, PartialView R, double* Gh, double* Gw, int* fail_flag,
-                           hipStream_t st)
-{
-    const i64 cnt = n > m ? n : m;
-    const int grid = (int)((cnt + 255) / 256);
-    rank2_normalize_kernel<<<grid, 256, 0, st>>>(H, n, Wt, m, const_cast<void*>(R.p), R.S, R.slab, R.kpp, R.f64, Gh, Gw,
-                                                 fail_flag);
-    SMK_HIP(hipGetLastError());
-    rank2_gw_normalize_kernel<<<1, 64, 0, st>>>(Gw);
     SMK_HIP(hipGetLastError());
     return 0;
 }

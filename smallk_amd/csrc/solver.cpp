@@ -117,6 +117,11 @@ struct smk_solver {
     double *H = nullptr, *Wt = nullptr, *Gw = nullptr, *Gh = nullptr, *gram_scratch = nullptr;
     double *Wprev = nullptr, *hals_scratch = nullptr, *pg_partials = nullptr, *scal = nullptr, *tmpW = nullptr;
     double* tmpH = nullptr;               // k x n compact copy of H for the host (get_factors)
+    // RANK2 (rank2.hip): scratch of the fused solve / progress kernels (ticket + partial sums), W'W of the W just solved
+    // (before its normalisation), and -- sparse A -- compact N x 2 copies of the factors for the gather products
+    double *r2_scratch = nullptr, *r2_prog = nullptr, *Graw = nullptr, *Hc = nullptr, *Wc = nullptr;
+    double* pin_r2[2] = {nullptr, nullptr};      // pinned copies of the progress partials (the host sums them)
+    bool wc_valid = false;
     double* nnls_scratch = nullptr;       // BPP: inverses of W'W and HH' + path selectors (k > 32), two halves
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
@@ -760,8 +765,8 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
             s->pg2[g].oscale = s->oscale[1] + s->pg2[g].k0;  s->pg2[g].ascale = a->ascale;
         }
     }
-    if (a->sparse) {   // gather products write one slab, as dense as the factor layout (KP values per column)
-        s->kpp = s->KP;
+    if (a->sparse) {   // gather products write one slab, as dense as the factor layout (KP values per column; RANK2: the 2 live ones)
+        s->kpp = (opts->algorithm == SMK_ALG_RANK2) ? 2 : s->KP;
         s->pl1.S = 1; s->pl1.p_elems = (size_t)s->pl1.ncols_pad * s->kpp;
         s->pl2.S = 1; s->pl2.p_elems = (size_t)s->pl2.ncols_pad * s->kpp;
     }
@@ -773,8 +778,15 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     rc |= dev_alloc(&s->Gh_own, kk);
     {
         size_t gs = gram_scratch_elems(s->k, GRAM_BLOCKS);
-        if (s->o.algorithm == SMK_ALG_RANK2) gs = std::max(gs, rank2_gram_scratch_elems(std::max(s->m, s->n)));
         rc |= dev_alloc(&s->gram_scratch, gs);
+        if (s->o.algorithm == SMK_ALG_RANK2) {
+            const size_t e1 = rank2_gram_scratch_elems(std::max(s->m, s->n)), e2 = rank2_progress_scratch_elems(s->m, s->n);
+            rc |= dev_alloc(&s->r2_scratch, e1);
+            rc |= dev_alloc(&s->r2_prog, e2);
+            rc |= dev_alloc(&s->Graw, (size_t)s->KP * s->KP);
+            if (a->sparse) { rc |= dev_alloc(&s->Hc, (size_t)2 * s->n); rc |= dev_alloc(&s->Wc, (size_t)2 * s->m); }
+
+        }
         if (!rc && hipMemsetAsync(s->gram_scratch, 0, gs * sizeof(double), s->st) != hipSuccess) rc |= 1;   // incl. the ticket word
     }
     rc |= dev_alloc(&s->tmpW, (size_t)s->KP * s->m);
@@ -824,7 +836,7 @@ void smk_solver_destroy(smk_solver* s)
     if (s->st_inv) (void)hipStreamSynchronize(s->st_inv);
     void* ptrs[] = {s->H, s->Wt_own, s->Gw, s->Gh_own, s->gram_scratch, s->tmpW, s->pg_partials, s->scal_own,
                     s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH, s->nnls_scratch, s->W0c, s->H0c,
-                    s->xscale[0], s->xscale[1], s->oscale[0], s->oscale[1]};
+                    s->xscale[0], s->xscale[1], s->oscale[0], s->oscale[1], s->r2_scratch, s->r2_prog, s->Graw, s->Hc, s->Wc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int w = 0; w < 3; ++w)
@@ -834,6 +846,7 @@ void smk_solver_destroy(smk_solver* s)
         if (s->pev[b]) (void)hipEventDestroy(s->pev[b]);
     }
     if (s->pin) (void)hipHostFree(s->pin);
+    for (int b = 0; b < 2; ++b) if (s->pin_r2[b]) (void)hipHostFree(s->pin_r2[b]);
     if (s->comm_ws) (void)hipFree(s->comm_ws);
     if (s->Wown) (void)hipFree(s->Wown);
     if (s->R2own) (void)hipFree(s->R2own);
@@ -1010,6 +1023,7 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
     if (s->w_sharded) { rc = scatter_own(s); if (rc) return rc; }
     SMK_HIP(hipStreamSynchronize(s->st));
     s->w_full = true;
+    s->wc_valid = false;
     s->have_factors = true;
     s->inited = false;
     s->normalized = false;
@@ -1156,7 +1170,7 @@ static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl, const 
 
 // R1 = W'A  (k x n, local columns)
 static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols,
-                      const double* X, double* P)
+                      const double* X, int ldx, double* P)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing) {
@@ -1164,7 +1178,7 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
         if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
         (void)hipEventRecord(e0, s->st);
     }
-    int rc = launch_spmm_gather(colptr, rowidx, val, ncols, X, s->k, P, s->kpp, s->st);
+    int rc = launch_spmm_gather(colptr, rowidx, val, ncols, X, ldx, s->k, P, s->kpp, s->st);
     if (s->timing) {
         if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         (void)hipEventRecord(e1, s->st);
@@ -1227,7 +1241,13 @@ static int prod1_sharded(smk_solver* s)
 
 static int prod1(smk_solver* s)
 {
-    if (s->a->sparse) return timed_spmm(s, 0, s->a->colptr, s->a->rowidx, s->a->val, s->n, s->Wt, s->P1);
+    if (s->a->sparse) {
+        if (s->Wc) {        // RANK2: gather from the compact copy of W (16 B per row)
+            if (!s->wc_valid) { const int crc = launch_rank2_compact(s->Wt, s->Wc, s->m, s->st); if (crc) return crc; s->wc_valid = true; }
+            return timed_spmm(s, 0, s->a->colptr, s->a->rowidx, s->a->val, s->n, s->Wc, 2, s->P1);
+        }
+        return timed_spmm(s, 0, s->a->colptr, s->a->rowidx, s->a->val, s->n, s->Wt, s->KP, s->P1);
+    }
     if (s->w_sharded) return prod1_sharded(s);
     int rc = 0;
     if (!s->packed_fresh[0]) rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st, s->xscale[0]);
@@ -1248,7 +1268,8 @@ static int prod2(smk_solver* s)
     int rc = 0;
     const PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
     if (s->a->sparse) {
-        rc = timed_spmm(s, 1, s->a->colptr_t, s->a->rowidx_t, s->a->val_t, s->m, s->H, s->P2);
+        rc = s->Hc ? timed_spmm(s, 1, s->a->colptr_t, s->a->rowidx_t, s->a->val_t, s->m, s->Hc, 2, s->P2)
+                   : timed_spmm(s, 1, s->a->colptr_t, s->a->rowidx_t, s->a->val_t, s->m, s->H, s->KP, s->P2);
         if (rc) return rc;
         rc = wait_gh(s);
         if (rc || !is_dist(s)) return rc;
@@ -1436,15 +1457,22 @@ static int solver_iteration(smk_solver* s)
             rc = prod1(s);    if (rc) return rc;
             break;
         case SMK_ALG_RANK2:  // nmf_solver_rank2.hpp:353-455
-            // each closed-form solve also emits the Gram matrix of its result (no second pass over H / W)
-            rc = launch_rank2_solve(s->H, s->n, r1, s->Gw, 0, s->fail_flag, s->iter, s->Gh, s->gram_scratch, s->st); if (rc) return rc;
-            rc = allreduce_gh(s); if (rc) return rc;
-            rc = prod2(s);    if (rc) return rc;
-            rc = wait_r2(s);  if (rc) return rc;
-            rc = launch_rank2_solve(s->Wt, s->m, r2, s->Gh, 1, s->fail_flag, s->iter, s->Gw, s->gram_scratch, s->st); if (rc) return rc;
-            // NormalizeAndScale(W, H, ScaleFactors) every iteration, norms from the Gram matrix of the new W;
-            // also rescales HH' and AH' and leaves Gw = W'W of the normalised W (D^-1 Gw D^-1)
-            rc = launch_rank2_normalize(s->H, s->n, s->Wt, s->m, r2, s->Gh, s->Gw, s->fail_flag, s->st); if (rc) return rc;
+            // each closed-form solve also emits partial sums of the Gram matrix of its result (no second pass over H / W),
+            // which the kernel that needs the matrix adds up itself (rank2.hip)
+            {
+                double *GpH = s->r2_scratch, *GpW = s->r2_scratch + rank2_gram_scratch_elems(std::max(s->m, s->n)) / 2;
+                int nbh = 0, nbw = 0;
+                rc = launch_rank2_solve(s->H, s->Hc, s->n, r1, s->Gw, nullptr, 0, 0, s->fail_flag, s->iter, GpH, &nbh, s->Gh,
+                                        is_dist(s) ? 1 : 0, s->st); if (rc) return rc;       // sharded: HH' is finished here and summed over the ranks
+                rc = allreduce_gh(s); if (rc) return rc;
+                rc = prod2(s);    if (rc) return rc;
+                rc = wait_r2(s);  if (rc) return rc;
+                rc = launch_rank2_solve(s->Wt, nullptr, s->m, r2, s->Gh, GpH, nbh, 1, s->fail_flag, s->iter, GpW, &nbw, s->Graw, 0, s->st); if (rc) return rc;
+                // NormalizeAndScale(W, H, ScaleFactors) every iteration, norms from the Gram matrix of the new W;
+                // also rescales HH' and AH', leaves Gw = W'W of the normalised W (D^-1 Graw D^-1) and the compact copy of W
+                rc = launch_rank2_normalize(s->H, s->n, s->Wt, s->Wc, s->m, r2, s->Gh, s->Graw, GpW, nbw, s->Gw, s->fail_flag, s->st); if (rc) return rc;
+                s->wc_valid = s->Wc != nullptr;
+            }
             rc = prod1(s);    if (rc) return rc;
             break;
         default:
@@ -1575,6 +1603,19 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
     }
     int rc = wait_r2(s);
     if (rc) return rc;
+    if (s->o.algorithm == SMK_ALG_RANK2 && s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s)) {
+        // one launch: both gradient sums, the failure flag and the snapshot (rank2.hip)
+        if (snapshot && !s->snap[b]) { rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
+        const size_t pe = rank2_progress_scratch_elems(s->m, s->n);
+        if (!s->pin_r2[b]) SMK_HIP(hipHostMalloc((void**)&s->pin_r2[b], pe * sizeof(double)));
+        rc = launch_rank2_progress(s->Wt, s->m, view2(s), s->Gh, s->H, s->n, view1(s), s->Gw, s->r2_prog, s->fail_flag,
+                                   snapshot ? s->snap[b] : nullptr, s->st);
+        if (rc) return rc;
+        s->pin[b].fused = 2;             // per-workgroup partials: progress_end adds them up in index order
+        SMK_HIP(hipMemcpyAsync(s->pin_r2[b], s->r2_prog, pe * sizeof(double), hipMemcpyDeviceToHost, s->st));
+        SMK_HIP(hipEventRecord(s->pev[b], s->st));
+        return 0;
+    }
     if (s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s) && !is_wide(s->k)) {
         // both gradients in one launch, both sums + the failure flag in a second, one 64-byte read-back
         rc = launch_grad_pg2(s->Wt, s->m, view2(s), s->Gh, s->pg_partials, s->H, s->n, view1(s), s->Gw,
@@ -1603,7 +1644,15 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
 static int progress_end(smk_solver* s, int b, int iter_index, double* metric)
 {
     SMK_HIP(hipEventSynchronize(s->pev[b]));
-    if (s->pin[b].fused) s->pin[b].flag = (int)s->pin[b].h[5];
+    if (s->pin[b].fused == 2) {
+        const int nb = rank2_progress_blocks(s->m, s->n);
+        const double* p = s->pin_r2[b];
+        double sw = 0.0, sh = 0.0;
+        for (int i = 0; i < nb; ++i) { sw += p[2 * i]; sh += p[2 * i + 1]; }
+        s->pin[b].h[0] = sw;
+        s->pin[b].h[1] = sh;
+        s->pin[b].flag = (int)p[2 * (size_t)nb];
+    } else if (s->pin[b].fused) s->pin[b].flag = (int)s->pin[b].h[5];
     if (s->pin[b].flag != INT_MAX) return SMK_FAILURE;
     return evaluate_progress(s, s->pin[b].h, iter_index, metric);
 }
@@ -1618,6 +1667,7 @@ static int progress_restore(smk_solver* s, int b)
     SMK_HIP(hipMemcpyAsync(s->fail_flag, &big, sizeof(int), hipMemcpyHostToDevice, s->st));
     SMK_HIP(hipStreamSynchronize(s->st));
     s->inited = false;
+    s->wc_valid = false;
     if (s->w_sharded) s->w_full = false;    // the snapshot holds this rank's own rows; the full copy is stale
     return 0;
 }
@@ -1632,6 +1682,7 @@ static int normalize_device(smk_solver* s)
     rc = launch_scale_rows(s->Wt, s->k, s->m, s->Gw, 1, s->fail_flag, s->st);
     if (rc) return rc;
     if (s->w_sharded) { rc = scatter_own(s); if (rc) return rc; }      // the own rows follow the scaled full copy
+    s->wc_valid = false;
     s->normalized = true;
     // Gw/Gh and the stored products describe the un-normalised factors: a later iterate()/run() on this
     // handle starts from solver.Init on the scaled (W, H), exactly like a fresh solver given them
@@ -1964,7 +2015,7 @@ int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double
 {
     if (!s || which < 0 || which > 1) return SMK_BAD_PARAM;
     if (s->a->sparse) {   // per nonzero: 12 bytes of A (value + row index) + one KP-row of X gathered
-        if (bytes) *bytes = (double)s->a->nnz * (12.0 + 8.0 * s->KP);
+        if (bytes) *bytes = (double)s->a->nnz * (12.0 + 8.0 * (s->Wc ? 2 : s->KP));      // RANK2 gathers 16 B rows of the compact copy
         if (flops) *flops = 2.0 * (double)s->a->nnz * s->k;
         return SMK_OK;
     }
