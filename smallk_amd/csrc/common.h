@@ -203,8 +203,9 @@ int rank2_progress_blocks(i64 m, i64 n);
 size_t rank2_progress_scratch_elems(i64 m, i64 n);
 // sparse A (CSC): out[:, j] = sum_p val[p] * X[:, row[p]] over the nonzeros of column j
 // X: the gathered factor, row pitch ldx doubles (KP, or 2 for the compact copy of a rank-2 factor)
-int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X, int ldx,
-                       int k, double* P, int kpp, hipStream_t st);
+// nnz_hint: number of stored entries (picks the lanes per column of the rank-2 kernel; <= 0: unknown)
+int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, i64 nnz_hint, const double* X,
+                       int ldx, int k, double* P, int kpp, hipStream_t st);
 
 // sparse_subset.hip: CSC(A[:, cols]) and CSC(A[:, cols]') with unused rows dropped, assembled on the device
 // from the resident CSC(A) / CSC(A').  `cols` must be strictly increasing.  The six output arrays are
@@ -222,5 +223,10 @@ int device_sparse_subset(const SparseDev& src, const unsigned* cols_host, i64 nc
 // keys-only into sorted_host[v] otherwise)
 int device_sort_desc(const double* const* keys_host, int* const* idx_host, double* const* sorted_host, int count, i64 n,
                      hipStream_t st);
+// compute_priority (clust_hier_util.hpp:105-173) on the device: wp, wc[0..n), wc[n..2n) host vectors in, the score out;
+// n_part = number of nonzeros of wp.  0 on success (negative: not available, take the host path).  The workspace is kept
+// per host thread between calls; device_priority_release() frees it.
+int device_priority_score(const double* wp, const double* wc, i64 n, i64 n_part, double* score, hipStream_t st);
+void device_priority_release();
 
 }  // namespace smk

@@ -196,6 +196,11 @@ double ndcg_cum(const std::vector<int>& seq, const std::vector<int>& test, const
 
 double priority_score(const double* wp, const double* wc, i64 n)
 {
+    static const bool timing = [] { const char* e = getenv("SMK_CLUST_TIMING"); return e && atoi(e) > 1; }();
+    const auto T0 = std::chrono::high_resolution_clock::now();
+    auto lap = [&](const char* what) {
+        if (timing) fprintf(stderr, "[priority] %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - T0).count());
+    };
     i64 n_part = 0;
     for (i64 i = 0; i < n; ++i) n_part += (wp[i] != 0.0);
     if (n_part <= 1) return -3.0;
@@ -204,6 +209,13 @@ double priority_score(const double* wp, const double* wc, i64 n)
     // initialised device (host-only callers of smk_clust_priority) or for small n: host sorts, the
     // three independent ones side by side.
     const bool on_device = n >= DEVICE_SORT_MIN && smk_is_initialized() == SMK_INITIALIZED;
+    // the whole score on the device (sort.hip): three doubles come back.  SMK_PRIORITY_HOST=1 keeps the host arithmetic
+    // around the device sorts (bit-identical to the reference's sequential sums; the device sums differ by rounding).
+    static const bool host_arith = [] { const char* e = getenv("SMK_PRIORITY_HOST"); return e && atoi(e) != 0; }();
+    if (on_device && !host_arith) {
+        double sc = 0.0;
+        if (smk::device_priority_score(wp, wc, n, n_part, &sc, nullptr) == 0) { lap("device score done"); return sc; }
+    }
     std::vector<int> idx_parent, idx_c1, idx_c2;
     bool sorted = false;
     if (on_device) {
@@ -224,6 +236,7 @@ double priority_score(const double* wp, const double* wc, i64 n)
         idx_c1 = desc_ordered(wc, (size_t)n);
         idx_c2 = desc_ordered(wc + n, (size_t)n);
     }
+    lap("argsorts done");
     std::vector<double> weight((size_t)n), weight_part((size_t)n, 0.0);
     for (i64 j = 0; j < n; ++j) weight[(size_t)j] = std::log((double)(n - j));
     for (i64 i = 0; i < n; ++i)
@@ -241,8 +254,10 @@ double priority_score(const double* wp, const double* wc, i64 n)
         weight[(size_t)i] /= discount;
         weight_part[(size_t)i] /= discount;
     }
+    lap("weights done");
     const std::vector<int> seq = inverse_permutation(idx_parent);
     const double c1 = ndcg_cum(seq, idx_c1, weight_part), c2 = ndcg_cum(seq, idx_c2, weight_part);
+    lap("ndcg done");
     bool weight_sorted = false;
     if (on_device) {
         const double* keys[1] = {weight.data()};
@@ -251,8 +266,10 @@ double priority_score(const double* wp, const double* wc, i64 n)
         weight_sorted = smk::device_sort_desc(keys, idx, out, 1, n, nullptr) == 0;
     }
     if (!weight_sorted) std::sort(weight.begin(), weight.end(), std::greater<double>());
+    lap("weight sort done");
     double ideal_cum = 0.0;
     for (i64 i = 0; i < n; ++i) ideal_cum += (i > 0) ? weight[(size_t)i] / std::log2((double)(i + 1)) : weight[(size_t)i];
+    lap("ideal done");
     return (c1 / ideal_cum) * (c2 / ideal_cum);
 }
 
@@ -569,6 +586,7 @@ int run_clust(const smk_clust_options* opts, smk_matrix* full, uint64_t seed, ui
     if (rc == SMK_OK && opts->flat) rc = clust_flat(r, *t);
     if (draws) *draws = r.draws;
     if (stats) *stats = r.stats;
+    smk::device_priority_release();        // workspace of the device-side priority score (kept between the calls of a run)
     if (const char* e = getenv("SMK_CLUST_TIMING"))
         if (atoi(e))
             fprintf(stderr, "[smk_clust] subset %.3fs  factor %.3fs (%ld RANK2 iterations)  priority %.3fs  init %.3fs\n",

@@ -1452,49 +1452,70 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const i64* __restrict_
     if (4 * s < kpp) store4(P + j * kpp + 4 * s, acc);
 }
 
-// k <= 2 (the RANK2 / HierNMF2 hot loop): one lane per output column, 16 bytes of the X row per stored
-// entry instead of two lanes x 32 bytes, two independent accumulation chains per lane so that two
-// gathers are in flight.  `ldx` = row pitch of X in doubles (KP, or 2 for a compact copy).
+// k <= 2 (the RANK2 / HierNMF2 hot loop): LPC lanes per output column.  Lane l takes the stored entries p0 + l,
+// p0 + l + LPC, ... of its column, so the LPC lanes read consecutive values / row indices (and consecutive columns are
+// consecutive in memory: the wave streams them in full lines), every lane has all of its gathers in flight at once, and
+// the 2 x LPC partial sums are joined by DPP moves.  One lane per column (round 2) serialised ~16 dependent
+// gathers per lane and touched a different line of val / rowidx in every lane.
+// `ldx` = row pitch of X in doubles (KP, or 2 for the compact copy the RANK2 kernels keep).
+template <int LPC>
 __global__ __launch_bounds__(256) void spmm_gather2_kernel(const i64* __restrict__ colptr,
                                                            const unsigned* __restrict__ rowidx,
                                                            const double* __restrict__ val, i64 ncols,
                                                            const double* __restrict__ X, int ldx,
                                                            double* __restrict__ P, int kpp)
 {
-    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ncols) return;
+    const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 j = gtid / LPC;
+    const int l = (int)(gtid % LPC);
+    const bool valid = j < ncols;
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-    const i64 p0 = colptr[j], p1 = colptr[j + 1];
-    i64 p = p0;
-    for (; p + 1 < p1; p += 2) {
-        const double v0 = val[p], v1 = val[p + 1];
-        const f64x2_t x0 = *(const f64x2_t*)(X + (i64)rowidx[p] * ldx);
-        const f64x2_t x1 = *(const f64x2_t*)(X + (i64)rowidx[p + 1] * ldx);
-        a0 += v0 * x0[0]; a1 += v0 * x0[1];
-        b0 += v1 * x1[0]; b1 += v1 * x1[1];
+    if (valid) {
+        const i64 p0 = colptr[j], p1 = colptr[j + 1];
+        i64 p = p0 + l;
+        for (; p + LPC < p1; p += 2 * LPC) {
+            const double v0 = val[p], v1 = val[p + LPC];
+            const f64x2_t x0 = *(const f64x2_t*)(X + (i64)rowidx[p] * ldx);
+            const f64x2_t x1 = *(const f64x2_t*)(X + (i64)rowidx[p + LPC] * ldx);
+            a0 += v0 * x0[0]; a1 += v0 * x0[1];
+            b0 += v1 * x1[0]; b1 += v1 * x1[1];
+        }
+        if (p < p1) {
+            const double v0 = val[p];
+            const f64x2_t x0 = *(const f64x2_t*)(X + (i64)rowidx[p] * ldx);
+            a0 += v0 * x0[0]; a1 += v0 * x0[1];
+        }
     }
-    if (p < p1) {
-        const double v0 = val[p];
-        const f64x2_t x0 = *(const f64x2_t*)(X + (i64)rowidx[p] * ldx);
-        a0 += v0 * x0[0]; a1 += v0 * x0[1];
-    }
+    const double r0 = group_sum<LPC>(a0 + b0), r1 = group_sum<LPC>(a1 + b1);      // whole waves take part in the DPP moves
+    if (!valid || l != 0) return;
     double* out = P + j * kpp;
     f64x2_t r;
-    r[0] = a0 + b0;
-    r[1] = a1 + b1;
+    r[0] = r0;
+    r[1] = r1;
     *(f64x2_t*)out = r;
     for (int e = 2; e < kpp && e < 8; e += 2) { f64x2_t z; z[0] = 0.0; z[1] = 0.0; *(f64x2_t*)(out + e) = z; }
 }
 
-int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X, int ldx,
-                       int k, double* P, int kpp, hipStream_t st)
+int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, i64 nnz_hint, const double* X,
+                       int ldx, int k, double* P, int kpp, hipStream_t st)
 {
     if (is_wide(k)) return launch_spmm_gather_wide(colptr, rowidx, val, ncols, X, k, P, kpp, st);
     const int KPv = kp_of(k);
     if (k <= 2 && (ldx == 2 || ldx == KPv)) {
-        const int grid2 = (int)((ncols + 255) / 256);
-        if (grid2 == 0) return 0;
-        spmm_gather2_kernel<<<grid2, 256, 0, st>>>(colptr, rowidx, val, ncols, X, ldx, P, kpp);
+        if (ncols <= 0) return 0;
+        // lanes per column by the average column length (nnz_hint <= 0: unknown -> 8)
+        static const int forced = [] { const char* e = getenv("SMK_SPMM2_LPC"); return e ? atoi(e) : 0; }();
+        const double avg = nnz_hint > 0 ? (double)nnz_hint / (double)ncols : 12.0;
+        int lpc = forced ? forced : (avg <= 3.0 ? 2 : avg <= 6.0 ? 4 : avg <= 12.0 ? 8 : 16);
+        const i64 threads = ncols * lpc;
+        const unsigned grid2 = (unsigned)((threads + 255) / 256);
+        switch (lpc) {
+            case 1: spmm_gather2_kernel<1><<<grid2, 256, 0, st>>>(colptr, rowidx, val, ncols, X, ldx, P, kpp); break;
+            case 2: spmm_gather2_kernel<2><<<grid2, 256, 0, st>>>(colptr, rowidx, val, ncols, X, ldx, P, kpp); break;
+            case 4: spmm_gather2_kernel<4><<<grid2, 256, 0, st>>>(colptr, rowidx, val, ncols, X, ldx, P, kpp); break;
+            case 16: spmm_gather2_kernel<16><<<grid2, 256, 0, st>>>(colptr, rowidx, val, ncols, X, ldx, P, kpp); break;
+            default: spmm_gather2_kernel<8><<<grid2, 256, 0, st>>>(colptr, rowidx, val, ncols, X, ldx, P, kpp); break;
+        }
         SMK_HIP(hipGetLastError());
         return 0;
     }

@@ -1178,7 +1178,7 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
         if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
         (void)hipEventRecord(e0, s->st);
     }
-    int rc = launch_spmm_gather(colptr, rowidx, val, ncols, X, ldx, s->k, P, s->kpp, s->st);
+    int rc = launch_spmm_gather(colptr, rowidx, val, ncols, s->a->nnz, X, ldx, s->k, P, s->kpp, s->st);
     if (s->timing) {
         if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         (void)hipEventRecord(e1, s->st);

@@ -29,6 +29,8 @@ static bool g_init = false;
 namespace smk {
 void set_error(const std::string& m) { g_err = m; }
 int device_sort_desc(const double* const*, int* const*, double* const*, int, i64, hipStream_t) { return -1; }   // host sorts
+int device_priority_score(const double*, const double*, i64, i64, double*, hipStream_t) { return -1; }          // host arithmetic
+void device_priority_release() {}
 }
 
 struct smk_matrix {
@@ -112,6 +114,7 @@ int smk_matrix_create_sparse(smk_matrix** out, int64_t h, int64_t wg, int64_t c0
     return SMK_OK;
 }
 void smk_matrix_destroy(smk_matrix* a) { delete a; }
+int64_t smk_matrix_nnz(const smk_matrix* a) { return a ? (int64_t)a->va.size() : 0; }
 
 int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t ncols, smk_matrix** out, unsigned* n2o, int64_t* nh)
 {
