@@ -228,5 +228,9 @@ int device_sort_desc(const double* const* keys_host, int* const* idx_host, doubl
 // per host thread between calls; device_priority_release() frees it.
 int device_priority_score(const double* wp, const double* wc, i64 n, i64 n_part, double* score, hipStream_t st);
 void device_priority_release();
+// CSC(A') from CSC(A), all device arrays (colptr_t: height + 1 offsets); entry order = the host counting sort's.
+// Returns 0, or non-zero when the caller should take the host path.
+int device_csc_transpose(i64 height, i64 ncols, i64 nnz, const i64* colptr, const unsigned* rowidx, const double* val,
+                         i64* colptr_t, unsigned* rowidx_t, double* val_t, hipStream_t st);
 
 }  // namespace smk

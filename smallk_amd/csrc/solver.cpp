@@ -90,8 +90,8 @@ struct smk_matrix {
     unsigned *rowidx = nullptr, *rowidx_t = nullptr;
     double *val = nullptr, *val_t = nullptr;
     // host copy of the CSC (column subsets for HierNMF2 nodes are cut on the host)
-    std::vector<unsigned> h_colptr, h_rowidx;
-    std::vector<double> h_val;
+    mutable std::vector<unsigned> h_colptr, h_rowidx;     // fetched on first use (ensure_host_csc)
+    mutable std::vector<double> h_val;
 };
 
 static const int MAX_CHUNKS = 8;
@@ -512,28 +512,18 @@ int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_glo
         return SMK_BAD_PARAM;
     if ((int64_t)col_offsets[ncols_local] - (int64_t)col_offsets[0] != nnz) { set_error("col_offsets do not span nnz"); return SMK_BAD_PARAM; }
     const unsigned base = col_offsets[0];
-    std::vector<i64> cp((size_t)ncols_local + 1), cpt((size_t)height + 1, 0);
+    std::vector<i64> cp((size_t)ncols_local + 1);
     for (int64_t c = 0; c <= ncols_local; ++c) {
         if (c > 0 && col_offsets[c] < col_offsets[c - 1]) { set_error("col_offsets not monotone"); return SMK_BAD_PARAM; }
         cp[(size_t)c] = (i64)col_offsets[c] - base;
     }
-    std::vector<unsigned> rit((size_t)(nnz > 0 ? nnz : 1));
-    std::vector<double> vt((size_t)(nnz > 0 ? nnz : 1));
-    {
-        std::vector<unsigned> cpt32((size_t)height + 1);
-        const int trc = smk_csc_transpose(height, ncols_local, col_offsets, row_indices, data, cpt32.data(), rit.data(), vt.data());
-        if (trc != SMK_OK) return trc;
-        for (int64_t r = 0; r <= height; ++r) cpt[(size_t)r] = cpt32[(size_t)r];
-    }
+    for (int64_t p = 0; p < nnz; ++p)
+        if ((int64_t)row_indices[base + p] >= height) { set_error("row index out of range"); return SMK_BAD_PARAM; }
     smk_matrix* a = new smk_matrix;
     a->m = height; a->n_global = width_global; a->c0 = col0; a->n = ncols_local; a->storage = SMK_STORE_F32;
     a->sparse = true; a->nnz = nnz;
     a->st = g_stream;
     register_matrix(a);
-    a->h_colptr.resize((size_t)ncols_local + 1);
-    for (int64_t c = 0; c <= ncols_local; ++c) a->h_colptr[(size_t)c] = col_offsets[c] - base;
-    a->h_rowidx.assign(row_indices + base, row_indices + base + nnz);
-    a->h_val.assign(data + base, data + base + nnz);
     int rc = 0;
     rc |= dev_alloc(&a->colptr, (size_t)ncols_local + 1);
     rc |= dev_alloc(&a->colptr_t, (size_t)height + 1);
@@ -542,20 +532,45 @@ int smk_matrix_create_sparse(smk_matrix** out, int64_t height, int64_t width_glo
     rc |= dev_alloc(&a->val, (size_t)nnz);
     rc |= dev_alloc(&a->val_t, (size_t)nnz);
     if (rc) { smk_matrix_destroy(a); return SMK_DEVICE_ERROR; }
-    {
-        hipError_t e = hipMemcpy(a->colptr, cp.data(), cp.size() * sizeof(i64), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(a->colptr_t, cpt.data(), cpt.size() * sizeof(i64), hipMemcpyHostToDevice);
-        if (e == hipSuccess && nnz > 0) e = hipMemcpy(a->rowidx, row_indices + base, (size_t)nnz * sizeof(unsigned), hipMemcpyHostToDevice);
-        if (e == hipSuccess && nnz > 0) e = hipMemcpy(a->val, data + base, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(a->colptr, cp.data(), cp.size() * sizeof(i64), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpy(a->rowidx, row_indices + base, (size_t)nnz * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpy(a->val, data + base, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice);
+    // the transpose: a stable radix sort by row on the device (sort.hip) -- the entry order of the host counting sort --
+    // or, if that is not available (SMK_TRANSPOSE=host forces it), the host routine and a second upload
+    static const bool host_tr = [] { const char* ev = getenv("SMK_TRANSPOSE"); return ev && ev[0] == 'h'; }();
+    bool done = false;
+    if (e == hipSuccess && !host_tr)
+        done = device_csc_transpose(height, ncols_local, nnz, a->colptr, a->rowidx, a->val, a->colptr_t, a->rowidx_t, a->val_t, g_stream) == 0;
+    if (e == hipSuccess && !done) {
+        std::vector<unsigned> rit((size_t)(nnz > 0 ? nnz : 1)), cpt32((size_t)height + 1);
+        std::vector<double> vt((size_t)(nnz > 0 ? nnz : 1));
+        const int trc = smk_csc_transpose(height, ncols_local, col_offsets, row_indices, data, cpt32.data(), rit.data(), vt.data());
+        if (trc != SMK_OK) { smk_matrix_destroy(a); return trc; }
+        std::vector<i64> cpt((size_t)height + 1);
+        for (int64_t r = 0; r <= height; ++r) cpt[(size_t)r] = cpt32[(size_t)r];
+        e = hipMemcpy(a->colptr_t, cpt.data(), cpt.size() * sizeof(i64), hipMemcpyHostToDevice);
         if (e == hipSuccess && nnz > 0) e = hipMemcpy(a->rowidx_t, rit.data(), (size_t)nnz * sizeof(unsigned), hipMemcpyHostToDevice);
         if (e == hipSuccess && nnz > 0) e = hipMemcpy(a->val_t, vt.data(), (size_t)nnz * sizeof(double), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            set_error(std::string("hipMemcpy(CSC): ") + hipGetErrorString(e));
-            smk_matrix_destroy(a);
-            return SMK_DEVICE_ERROR;
-        }
+    }
+    if (e != hipSuccess) {
+        set_error(std::string("hipMemcpy(CSC): ") + hipGetErrorString(e));
+        smk_matrix_destroy(a);
+        return SMK_DEVICE_ERROR;
     }
     *out = a;
+    return SMK_OK;
+}
+
+// host copy of a resident CSC (32-bit offsets), fetched on first use: only column subsets whose list is not strictly
+// increasing are cut on the host
+static int ensure_host_csc(const smk_matrix* a)
+{
+    if (!a->h_colptr.empty()) return SMK_OK;
+    a->h_colptr.resize((size_t)a->n + 1);
+    a->h_rowidx.resize((size_t)(a->nnz > 0 ? a->nnz : 1));
+    a->h_val.resize((size_t)(a->nnz > 0 ? a->nnz : 1));
+    const int rc = smk_matrix_download_csc(a, 0, a->h_colptr.data(), a->h_rowidx.data(), a->h_val.data());
+    if (rc != SMK_OK) { a->h_colptr.clear(); return rc; }
     return SMK_OK;
 }
 
@@ -598,8 +613,7 @@ int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t 
     bool increasing = true;
     for (int64_t j = 1; j < ncols && increasing; ++j) increasing = cols[j] > cols[j - 1];
     static const bool force_host = [] { const char* e = getenv("SMK_SPARSE_SUBSET"); return e && e[0] == 'h'; }();
-    if ((increasing && !force_host) || src->h_colptr.empty()) {
-        if (!increasing) { set_error("SubMatrixColsCompact: this matrix needs an increasing column list"); return SMK_UNSUPPORTED; }
+    if (increasing && !force_host) {
         SparseDev sd, od;
         sd.m = src->m; sd.n = src->n; sd.nnz = src->nnz;
         sd.colptr = src->colptr; sd.rowidx = src->rowidx; sd.val = src->val;
@@ -621,7 +635,9 @@ int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t 
         return SMK_OK;
     }
     int64_t nh = 0, nz = 0;
-    int rc = smk_csc_subset_cols_compact(src->m, src->n, src->h_colptr.data(), src->h_rowidx.data(), src->h_val.data(), cols,
+    int rc = ensure_host_csc(src);
+    if (rc != SMK_OK) return rc;
+    rc = smk_csc_subset_cols_compact(src->m, src->n, src->h_colptr.data(), src->h_rowidx.data(), src->h_val.data(), cols,
                                          ncols, nullptr, nullptr, nullptr, nullptr, nullptr, &nh, &nz);
     if (rc != SMK_OK) return rc;
     std::vector<unsigned> cp((size_t)ncols + 1), ri((size_t)nz);
