@@ -513,6 +513,7 @@ static inline i64 pack_nq(int storage, int nsplit, i64 N)
 
 size_t packed_bytes(int storage, int k, i64 N, int nsplit)
 {
+    if (nsplit == NSPLIT_F64) return 16;         // the accurate form reads the factor itself
     if (!pack_is_bf16(storage, nsplit)) nsplit = 1;
     size_t total = 0;
     for (int k0 = 0; k0 < k; k0 += 64)          // groups of 64 factor rows, each packed with its own k-tile count
@@ -1267,6 +1268,96 @@ static int launch_f3_f16(const BigProdPlan& pl, const void* B, i64 ldb, const vo
     return -100;
 }
 
+// ==========================================================================
+// The accurate form (NSPLIT_F64): P = X B with B's entries (bf16 / fp32, exact in fp64) against the fp64 factor itself on
+// the fp64 matrix cores, fp64 accumulation from the first product on.  About 3x the time of the 16-bit forms (78 TFLOP/s
+// of fp64 MFMA against an HBM-bound stream), but the result is the fp64 product of the stored data to rounding (1e-16),
+// where the 16-bit forms sit at 1e-8 .. 4e-8 -- which HALS at high rank amplifies past the 1e-4 parity bar in long runs.
+// Workgroup = 4 waves, tile = 64 columns (16 per wave) x 64 rows per stage, both operands staged through LDS
+// (B: coalesced along the contraction, X: 64 x kg slab); one group of <= 64 factor rows per launch, as the other forms.
+// ==========================================================================
+template <int EBYTES>
+__global__ __launch_bounds__(256) void bigprod_f64_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
+                                                          const double* __restrict__ X, int ldx, int kvalid, i64 len,
+                                                          double* __restrict__ P, i64 stages, i64 nst, i64 tiles, i64 ncols_pad,
+                                                          int S, int pstride, int ktw, int accum)
+{
+    constexpr int MB = 64, NB = 64, KG = 64;
+    __shared__ float Bs[NB][MB + 1];
+    __shared__ double Xs[MB][KG + 2];
+    const i64 tile = blockIdx.x / S;
+    const int split = (int)(blockIdx.x % S);
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    i64 st0 = (i64)split * nst, st1 = st0 + nst;
+    if (st1 > stages) st1 = stages;
+    const i64 col0 = tile * NB;
+    const int kt16 = (kvalid + 15) / 16;                     // live 16-row tiles of this group (<= 4)
+    typedef __attribute__((ext_vector_type(4))) double f64x4;
+    f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int l15 = lane & 15, l4 = lane >> 4;
+    for (i64 st = st0; st < st1; ++st) {
+        const i64 r0 = st * MB;
+        // B tile: consecutive threads take consecutive rows of a column (contiguous in memory; padding rows / columns are zero)
+#pragma unroll
+        for (int i = 0; i < (NB * MB) / 256; ++i) {
+            const int idx = i * 256 + tid, c = idx / MB, r = idx % MB;
+            const unsigned char* src = B + (col0 + c) * ldb_bytes + (r0 + r) * EBYTES;
+            float v;
+            if constexpr (EBYTES == 2) v = bf16_bits_to_f32(*(const unsigned short*)src);
+            else v = *(const float*)src;
+            Bs[c][r] = v;
+        }
+        // X slab: 64 contraction rows x the group's factor rows (zero beyond the factor / the contraction length)
+#pragma unroll
+        for (int i = 0; i < (MB * KG) / 256; ++i) {
+            const int idx = i * 256 + tid, r = idx / KG, kk = idx % KG;
+            Xs[r][kk] = (r0 + r < len && kk < kvalid) ? X[(r0 + r) * ldx + kk] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int q = 0; q < MB / 4; ++q) {
+            const double b = (double)Bs[16 * wave + l15][4 * q + l4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < kt16) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[4 * q + l4][16 * t + l15], b, acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D: column = lane & 15 (column of B), row = (lane >> 4) + 4 reg (factor row inside the 16-row tile)
+    double* pout = P + ((i64)split * ncols_pad + col0 + 16 * wave + l15) * pstride;
+    // ktw 16-row tiles are written: the group's 32-row k tiles in full (rows past the live ones as zeros, like the other forms)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (t < ktw)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + l4 + 4 * r;
+                double v = acc[t][r];
+                if (accum) v += pout[row];
+                pout[row] = v;
+            }
+}
+
+static int launch_bigprod_f64(const BigProdPlan& pl, const void* B, i64 ldb, const void* X, double* P, i64 len, hipStream_t st)
+{
+    const i64 grid = pl.tiles * pl.S;
+    if (grid <= 0) return 0;
+    // the factor's live rows of this group: kg of them, never past the padded rank
+    const int kvalid = pl.kg < pl.ldx - pl.k0 ? pl.kg : pl.ldx - pl.k0;
+    const int ktw = 2 * kt_of(pl.kg);                      // 16-row tiles covering the group's 32-row k tiles
+    if (pl.storage == STORE_BF16)
+        bigprod_f64_kernel<2><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * 2, (const double*)X, pl.ldx, kvalid, len, P,
+                                                              pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum);
+    else
+        bigprod_f64_kernel<4><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * 4, (const double*)X, pl.ldx, kvalid, len, P,
+                                                              pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw, int wk, int nwl);
 // ---- kernel variants (tile shape / pipeline depth); chosen per plan, SMK_BP_VARIANT overrides ----
 struct BPVariant { int mb, nstage, cw, wk, nwl; };
@@ -1327,6 +1418,21 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     pl.k0 = 0; pl.kg = k; pl.pstride = kt_of(k) * 32; pl.pack_offset = 0;
     // fp32 storage: nsplit 3 selects the bf16x3 emulation (default), 1 the native fp32 MFMA
     pl.nsplit = storage == STORE_BF16 ? nsplit : (nsplit >= 2 ? nsplit : 1);
+    if (nsplit == NSPLIT_F64) {            // the accurate form: fp64 matrix cores, 64 x 64 tiles
+        pl.nsplit = NSPLIT_F64;
+        pl.variant = 200;
+        pl.mb = 64; pl.nb = 64;
+        pl.stages = (len + 63) / 64;
+        pl.tiles = (ncols + 63) / 64;
+        pl.ncols_pad = round_up(ncols, COL_PAD);
+        int S = 1;
+        while (pl.tiles * S < 4 * (i64)num_cus && S < 64 && pl.stages / (2 * S) >= 4) S *= 2;
+        pl.S = S;
+        pl.nst = (pl.stages + S - 1) / S;
+        pl.len = len;
+        pl.p_elems = (size_t)S * pl.ncols_pad * pl.kt * 32;
+        return pl;
+    }
     // measured best on MI355X: bf16 -> 64-row stages, 2-deep ring, 2 workgroups per CU (C3: 5.98 TB/s)
     int v = (storage == STORE_BF16) ? 6 : 7;
     // k in (32,64]: 8 compute waves (one k tile each) + 4 loader waves
@@ -1481,6 +1587,7 @@ static int launch_bigprod_v(const BigProdPlan& pl, const void* B, i64 ldb, const
 
 int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
+    if (pl.nsplit == NSPLIT_F64) return launch_bigprod_f64(pl, B, ldb, Xp, P, pl.len, st);
     if (pl.storage == STORE_BF16) {
         if (pl.kt == 1) {
             if (pl.nsplit == 3) return launch_bigprod_v<2, 1, 3>(pl, B, ldb, Xp, P, st);

@@ -70,6 +70,10 @@ int launch_transpose_f64(const double* src, i64 ld_src, double* dst, i64 ld_dst,
 // packed MFMA operand of X (k x N): bytes needed
 // nsplit: 1..3 = bf16 terms of the skinny operand; NSPLIT_F16X2 = two fp16 terms with per-row power-of-two scales
 constexpr int NSPLIT_F16X2 = 4;
+// the accurate form: A's entries (exact in fp64) times the fp64 factor itself on the fp64 matrix cores (v_mfma_f64_16x16x4),
+// fp64 accumulation throughout -- no packed operand; Xp of launch_bigprod is then the factor (KP doubles per column, rows
+// from the plan's k0 on)
+constexpr int NSPLIT_F64 = 8;
 size_t packed_bytes(int storage, int k, i64 N, int nsplit);
 size_t packed_row_offset(int storage, int kg, int nsplit, i64 r0);
 // a row-sharded factor: X holds this rank's `nblocks` blocks of `blk` rows back to back (N valid rows, the rest packs as
@@ -91,9 +95,11 @@ struct BigProdPlan {
     // packed operand carries per-row scales, and row r of the result is multiplied by oscale[r] = 1 / (xscale[r] ascale)
     const double* oscale = nullptr;   // device, indexed by the factor row (0 .. k-1 of the WHOLE factor)
     float ascale = 1.0f;
+    int ldx = 0;    // NSPLIT_F64: doubles per column of the factor (its padded rank KP)
     int accum = 0;  // != 0: the launch adds to P instead of overwriting it (a later row chunk of the same product)
     int mb = 0, nb = 0;   // rows per stage / columns per workgroup tile of the chosen kernel variant
     int S;          // row splits
+    i64 len = 0;    // NSPLIT_F64: contraction length (rows past it read as zero from the factor)
     i64 stages;     // total stages = ceil(len / MB)
     i64 nst;        // stages per split
     i64 tiles;      // column tiles of 128
@@ -121,6 +127,8 @@ int launch_gram_reduce(const double* scratch, int nblk, int k, double* G, hipStr
 int launch_gram_scales(const double* G, int k, double* xscale, double* oscale, double ascale, hipStream_t st);
 // *out = bits of max |A[i]| (NaN entries are ignored by fmaxf)
 int launch_absmax_f32(const float* A, i64 elems, unsigned* out, hipStream_t st);
+// out2[0] = bits of the largest column maximum of |A|, out2[1] = bits of the smallest non-zero one (0xFFFFFFFF: none)
+int launch_colrange(const void* A, int storage, i64 ld, i64 rows, i64 cols, unsigned* out2, hipStream_t st);
 // G = X X' and the packed streaming operand of X in one launch (k <= 64, bf16 fragments); returns 1 if this shape has
 // no fused kernel.  The ticket word at scratch[max_blocks * KP * KP] must be zero before the first call.
 int launch_gram_pack(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, int storage, int nsplit,

@@ -717,6 +717,45 @@ __global__ __launch_bounds__(256) void absmax_f32_kernel(const float* __restrict
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bits
 }
 
+// per-column max |A| folded into two words: out[0] = bits of the largest column maximum, out[1] = bits of the smallest
+// NON-ZERO column maximum (0xFFFFFFFF if every column is zero).  Their ratio is the spread of the column scales: fp32-class
+// products lose the small columns of an iteration once that spread passes ~2^28 (tests: columns spanning 2^+-20).
+template <typename T>
+__global__ __launch_bounds__(256) void colrange_kernel(const T* __restrict__ A, i64 ld, i64 rows, i64 cols, unsigned* __restrict__ out)
+{
+    const i64 wave = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const i64 nw = ((i64)gridDim.x * 256) >> 6;
+    for (i64 j = wave; j < cols; j += nw) {
+        float m = 0.f;
+        for (i64 r = lane; r < rows; r += 64) {
+            float v;
+            if constexpr (sizeof(T) == 2) v = bf16_bits_to_f32(A[j * ld + r]);
+            else v = A[j * ld + r];
+            m = fmaxf(m, fabsf(v));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0 && m > 0.f && m < 3.0e38f) {
+            atomicMax(out, __float_as_uint(m));
+            atomicMin(out + 1, __float_as_uint(m));
+        }
+    }
+}
+
+int launch_colrange(const void* A, int storage, i64 ld, i64 rows, i64 cols, unsigned* out2, hipStream_t st)
+{
+    const unsigned init[2] = {0u, 0xFFFFFFFFu};
+    SMK_HIP(hipMemcpyAsync(out2, init, sizeof(init), hipMemcpyHostToDevice, st));
+    i64 grid = (cols * 64 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    if (storage == STORE_BF16) colrange_kernel<unsigned short><<<(unsigned)grid, 256, 0, st>>>((const unsigned short*)A, ld, rows, cols, out2);
+    else colrange_kernel<float><<<(unsigned)grid, 256, 0, st>>>((const float*)A, ld, rows, cols, out2);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_absmax_f32(const float* A, i64 elems, unsigned* out, hipStream_t st)
 {
     SMK_HIP(hipMemsetAsync(out, 0, sizeof(unsigned), st));

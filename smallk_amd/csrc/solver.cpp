@@ -81,6 +81,7 @@ struct smk_matrix {
     int storage = SMK_STORE_F32;
     hipStream_t st = nullptr;                        // stream of the context that created it
     mutable float ascale = 0.f;                      // fp16 two-term products: power of two with max|A| ascale in [2^13, 2^14); 0 = not yet measured
+    mutable int col_spread_log2 = -1;                // log2(largest / smallest non-zero column maximum of |A|); -1 = not yet measured
     void* A = nullptr;  i64 ldA = 0, colsA = 0;      // m_pad x n_pad
     void* At = nullptr; i64 ldAt = 0, colsAt = 0;    // n_pad x m_pad
     // sparse A: CSC of the local columns and CSC of its transpose (fp64 values, 64-bit offsets)
@@ -332,7 +333,7 @@ static int matrix_make_transpose(smk_matrix* a)
 
 int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
 {
-    if (a) a->ascale = 0.f;                 // new contents: the fp16 product scale is measured again on first use
+    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; }     // new contents: scale and column spread are measured again on first use
     if (!a || !host || ld < a->m || a->sparse) return SMK_BAD_PARAM;
     const size_t budget = (size_t)64 << 20;   // staging bytes
     i64 chunk = (i64)(budget / ((size_t)a->m * sizeof(double)));
@@ -360,7 +361,7 @@ int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
 
 int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed)
 {
-    if (a) a->ascale = 0.f;
+    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; }
     if (!a || a->sparse) return SMK_BAD_PARAM;
     int rc = launch_fill_uniform(a->A, a->storage, a->ldA, a->m, a->n, a->ldA, a->colsA, 0, a->c0, a->m, seed,
                                  a->storage == SMK_STORE_BF16 ? 1 : 0, g_stream);
@@ -699,27 +700,32 @@ static size_t comm_bytes(const smk_solver* s)
     return b;
 }
 
-// max |A| of a dense fp32 matrix -> ascale (power of two, max |A| ascale in [2^13, 2^14)); 1 for an all-zero or
-// non-finite matrix.  One pass over A at HBM rate, once per matrix.
+// One pass over a dense A at HBM rate, once per matrix contents: the column maxima of |A| give
+//   ascale          power of two with max |A| ascale in [2^13, 2^14) (fp16 two-term products; 1 for an all-zero matrix)
+//   col_spread_log2 log2 of (largest / smallest non-zero column maximum): how far apart the column scales are
 static int matrix_measure_scale(const smk_matrix* a, hipStream_t st)
 {
     unsigned* d = nullptr;
-    SMK_HIP(hipMalloc((void**)&d, sizeof(unsigned)));
-    unsigned bits = 0;
-    int rc = launch_absmax_f32((const float*)a->A, a->ldA * a->colsA, d, st);
-    if (!rc && hipMemcpyAsync(&bits, d, sizeof(bits), hipMemcpyDeviceToHost, st) != hipSuccess) rc = SMK_DEVICE_ERROR;
+    SMK_HIP(hipMalloc((void**)&d, 2 * sizeof(unsigned)));
+    unsigned bits[2] = {0, 0};
+    int rc = launch_colrange(a->A, a->storage, a->ldA, a->m, a->n, d, st);
+    if (!rc && hipMemcpyAsync(bits, d, sizeof(bits), hipMemcpyDeviceToHost, st) != hipSuccess) rc = SMK_DEVICE_ERROR;
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = SMK_DEVICE_ERROR;
     (void)hipFree(d);
     if (rc) { set_error("could not measure max |A|"); return rc; }
-    float mx;
-    memcpy(&mx, &bits, sizeof(mx));
+    float mx, mn;
+    memcpy(&mx, &bits[0], sizeof(mx));
+    memcpy(&mn, &bits[1], sizeof(mn));
     float sc = 1.f;
+    int spread = 0;
     if (mx > 0.f && std::isfinite(mx)) {
         int ex = 0;
         (void)frexpf(mx, &ex);                     // mx = f 2^ex, f in [0.5, 1)
         sc = ldexpf(1.f, 14 - ex);
+        if (bits[1] != 0xFFFFFFFFu && mn > 0.f) { int en = 0; (void)frexpf(mn, &en); spread = ex - en; }
     }
     a->ascale = sc;
+    a->col_spread_log2 = spread;
     return 0;
 }
 
@@ -756,9 +762,21 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     // The amplification grows with the rank for every algorithm (BPP k = 191 after 34 iterations: 1.26e-4 with the
     // fp16 form), so above k = 64 the 24-bit operands are kept as well; C2 (k = 16) and C4 (k = 64) take the fp16 form.
     const bool hals = opts->algorithm == SMK_ALG_HALS;
-    const int nsplit_default = (a->storage == SMK_STORE_F32 && !hals && opts->k <= 64) ? NSPLIT_F16X2 : 3;
+    // HALS above k = 64: the 1e-8-class products of the 16-bit forms, amplified ~2x per five iterations at these ranks, leave
+    // the 1e-4 parity bar in runs of 30+ iterations (1.4e-4 .. 1.6e-4 at k = 100 .. 150 after 30) -- with either 16-bit form
+    // and with bf16 A alike, so it is the accumulation, not the operands.  Those runs take the ACCURATE form (NSPLIT_F64:
+    // the stored A against the fp64 factor on the fp64 matrix cores), ~3x the product time.  SMK_NSPLIT=8 selects it anywhere.
+    int nsplit_default = (a->storage == SMK_STORE_F32 && !hals && opts->k <= 64) ? NSPLIT_F16X2 : 3;
+    if (hals && opts->k > 64 && !a->sparse) nsplit_default = NSPLIT_F64;
+    // Column scales of A more than 2^28 apart: the small columns fall below what fp32-class products resolve next to the
+    // large ones (HALS / BPP leave the bar at 2^+-20, tests/test_gpu_parity.py) -- the accurate form as well.
+    if (!env && !a->sparse && opts->algorithm != SMK_ALG_RANK2) {
+        if (a->col_spread_log2 < 0) { const int rc0 = matrix_measure_scale(a, a->st ? a->st : g_stream); if (rc0) { --g_live_solvers; delete s; return rc0; } }
+        if (a->col_spread_log2 > 28) nsplit_default = NSPLIT_F64;
+    }
     s->nsplit = env ? atoi(env) : nsplit_default;
-    if (s->nsplit < 1 || s->nsplit > NSPLIT_F16X2) s->nsplit = nsplit_default;
+    if (s->nsplit != NSPLIT_F64 && (s->nsplit < 1 || s->nsplit > NSPLIT_F16X2)) s->nsplit = nsplit_default;
+    if (s->nsplit == NSPLIT_F64 && (a->sparse || opts->algorithm == SMK_ALG_RANK2)) s->nsplit = 3;      // those paths form their products elsewhere
     // the fp16 two-term form applies to fp32 storage; RANK2 keeps its Gram matrices inside its own solve kernel
     if (s->nsplit == NSPLIT_F16X2 && (a->storage != SMK_STORE_F32 || a->sparse || opts->algorithm == SMK_ALG_RANK2)) s->nsplit = 3;
     if (s->nsplit == NSPLIT_F16X2 && a->ascale == 0.f) {
@@ -767,6 +785,8 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     }
     s->ng = plan_bigprod_groups(a->storage, s->k, s->m, s->n, s->nsplit, g_cus, s->pg1);
     (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
+    if (s->nsplit == NSPLIT_F64)
+        for (int g = 0; g < s->ng; ++g) { s->pg1[g].ldx = s->KP; s->pg2[g].ldx = s->KP; }
     s->pl1 = s->pg1[0];
     s->pl2 = s->pg2[0];
     int rc = 0;
@@ -954,7 +974,7 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
         const char* e = getenv("SMK_COMM_F64");
         s->red_f64 = e && atoi(e) != 0;
     }
-    s->w_sharded = s->o.algorithm == SMK_ALG_BPP && !s->a->sparse && (s->world > 1 || comm_forced());
+    s->w_sharded = s->o.algorithm == SMK_ALG_BPP && !s->a->sparse && s->nsplit != NSPLIT_F64 && (s->world > 1 || comm_forced());
     const size_t bytes = comm_bytes(s);
     if (hipMalloc(&s->comm_ws, bytes) != hipSuccess) { s->comm = nullptr; s->w_sharded = false; set_error("hipMalloc(comm workspace)"); return SMK_DEVICE_ERROR; }
     SMK_HIP(hipMemsetAsync(s->comm_ws, 0, bytes, s->st));
@@ -1266,11 +1286,13 @@ static int prod1(smk_solver* s)
     }
     if (s->w_sharded) return prod1_sharded(s);
     int rc = 0;
-    if (!s->packed_fresh[0]) rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st, s->xscale[0]);
+    const bool f64 = s->nsplit == NSPLIT_F64;                 // the accurate form reads the fp64 factor itself
+    if (!s->packed_fresh[0] && !f64) rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st, s->xscale[0]);
     s->packed_fresh[0] = false;
     if (rc) return rc;
     for (int g = 0; g < s->ng; ++g) {
-        rc = timed_bigprod(s, 0, s->pg1[g], s->a->A, s->a->ldA, (const unsigned char*)s->packW + s->pg1[g].pack_offset, s->P1 + s->pg1[g].k0);
+        const void* Xp = f64 ? (const void*)(s->Wt + s->pg1[g].k0) : (const void*)((const unsigned char*)s->packW + s->pg1[g].pack_offset);
+        rc = timed_bigprod(s, 0, s->pg1[g], s->a->A, s->a->ldA, Xp, s->P1 + s->pg1[g].k0);
         if (rc) return rc;
     }
     return 0;
@@ -1298,12 +1320,16 @@ static int prod2(smk_solver* s)
         if (rc) return rc;
         return comm_join(s, s->ev_r[0]);
     }
-    if (!s->packed_fresh[1]) rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st, s->xscale[1]);
+    const bool f64 = s->nsplit == NSPLIT_F64;
+    if (!s->packed_fresh[1] && !f64) rc = launch_pack(s->H, s->k, s->n, s->a->storage, s->nsplit, s->packH, s->st, s->xscale[1]);
     s->packed_fresh[1] = false;
     if (rc) return rc;
+    auto xh = [&](const BigProdPlan& pl) -> const void* {
+        return f64 ? (const void*)(s->H + pl.k0) : (const void*)((const unsigned char*)s->packH + pl.pack_offset);
+    };
     if (!s->comm) {
         for (int g = 0; g < s->ng && !rc; ++g)
-            rc = timed_bigprod(s, 1, s->pg2[g], s->a->At, s->a->ldAt, (const unsigned char*)s->packH + s->pg2[g].pack_offset, s->P2 + s->pg2[g].k0);
+            rc = timed_bigprod(s, 1, s->pg2[g], s->a->At, s->a->ldAt, xh(s->pg2[g]), s->P2 + s->pg2[g].k0);
         if (rc) return rc;
         rc = wait_gh(s);
         if (rc || !is_dist(s)) return rc;
@@ -1319,7 +1345,7 @@ static int prod2(smk_solver* s)
             BigProdPlan pl = s->pg2[g];
             pl.tiles = (r1 - r0 + pl.nb - 1) / pl.nb;
             rc = timed_bigprod(s, 1, pl, (const unsigned char*)s->a->At + (size_t)r0 * s->a->ldAt * es, s->a->ldAt,
-                               (const unsigned char*)s->packH + pl.pack_offset, s->P2 + pl.k0 + r0 * pl.pstride, j == s->nchunk - 1 ? 1 : 0);
+                               xh(pl), s->P2 + pl.k0 + r0 * pl.pstride, j == s->nchunk - 1 ? 1 : 0);
             if (rc) return rc;
         }
         rc = comm_fork(s, s->ev_c[j]);
@@ -1361,7 +1387,7 @@ static int gram_factor(smk_solver* s, int side)
     }
     if (s->nsplit == NSPLIT_F16X2)       // the reduce launch also derives the row scales of the operand packed next
         return launch_gram(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->st, s->xscale[side], s->oscale[side], (double)s->a->ascale);
-    if (!s->a->sparse && s->o.algorithm != SMK_ALG_RANK2) {
+    if (!s->a->sparse && s->o.algorithm != SMK_ALG_RANK2 && s->nsplit != NSPLIT_F64) {
         const int rc = launch_gram_pack(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->a->storage, s->nsplit,
                                         side == 0 ? s->packW : s->packH, s->st);
         if (rc == 0) { s->packed_fresh[side] = true; return 0; }

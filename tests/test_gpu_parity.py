@@ -392,12 +392,18 @@ def test_fp32_products_at_any_magnitude(gpu, alg, log2scale, monkeypatch):
 
 
 @pytest.mark.parametrize("alg", ["HALS", "BPP"])
-@pytest.mark.parametrize("span", [12, 20])
-def test_fp32_products_with_wide_dynamic_range(gpu, alg, span, monkeypatch):
-    """columns of A spanning 2^-span .. 2^span and rows of H0 spanning 2^-6 .. 2^6.  The two-term fp16 operands are exact
-    to 22 bits for entries down to 2^-28 max|A|: inside that range (span 12) every column of H is held to
-    the tolerance against its own norm; beyond it (span 20) the small columns lose bits and the bar is the normwise one."""
-    monkeypatch.setenv("SMK_NSPLIT", "4")          # the fp16 form also for HALS (which defaults to bf16x3)
+@pytest.mark.parametrize("span,form", [(12, "4"), (12, None), (20, None), (20, "8")])
+def test_fp32_products_with_wide_dynamic_range(gpu, alg, span, form, monkeypatch):
+    """columns of A spanning 2^-span .. 2^span and rows of H0 spanning 2^-6 .. 2^6, every case at the 1e-4 bar.
+    span 12 (column scales 2^24 apart): the two-term fp16 operands are exact to 22 bits for entries down to 2^-28 max|A|
+    (DESIGN 5.1), so the fast forms hold every column of H against its own norm -- forced fp16 form ("4") and the defaults.
+    span 20 (2^40 apart): fp32-class products cannot resolve the small columns next to the large ones (measured with the
+    fast forms forced: 1.6e-4 .. 1e-3); the solver measures the spread of the column maxima when it is created and takes
+    the accurate form (fp64 matrix cores) by itself -- form None -- which SMK_NSPLIT=8 also selects explicitly."""
+    if form is not None:
+        monkeypatch.setenv("SMK_NSPLIT", form)
+    else:
+        monkeypatch.delenv("SMK_NSPLIT", raising=False)
     m, n, k = 512, 320, 16
     rng = np.random.default_rng(7)
     A = oracle.fill_uniform(m, n, 42, quant=0) * np.exp2(rng.integers(-span, span + 1, size=n))[None, :]
@@ -407,13 +413,26 @@ def test_fp32_products_with_wide_dynamic_range(gpu, alg, span, monkeypatch):
     ref = oracle.nmf(A, W0, H0, alg, min_iter=6, max_iter=6)
     got = gpu.nmf(A, W0, H0, alg, min_iter=6, max_iter=6, storage="f32")
     assert ref.result == 0 and got.result == 0
-    # span 20: the iteration itself is this sensitive to fp32-class products (the bf16x3 form measures 1.6e-4 here)
-    bar = TOL if span <= 12 else 1e-3
-    assert rel(got.W, ref.W) < bar and rel(got.H, ref.H) < bar
-    if span <= 12:
-        cn = np.linalg.norm(ref.H, axis=0)
-        live = cn > 0
-        assert (np.linalg.norm(got.H - ref.H, axis=0)[live] / cn[live]).max() < 1e-3
+    assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL
+    cn = np.linalg.norm(ref.H, axis=0)
+    live = cn > 0
+    assert (np.linalg.norm(got.H - ref.H, axis=0)[live] / cn[live]).max() < 1e-3
+
+
+@pytest.mark.parametrize("alg,storage,quant,k", [("HALS", "f32", 0, 100), ("HALS", "bf16", 1, 128), ("BPP", "f32", 0, 40), ("MU", "bf16", 1, 150),
+                                                  ("BPP", "f32", 0, 200), ("HALS", "f32", 0, 8)])
+def test_accurate_product_form(gpu, monkeypatch, alg, storage, quant, k):
+    """SMK_NSPLIT=8: A's stored entries against the fp64 factor on the fp64 matrix cores.  Against the oracle the run then
+    differs by summation order only -- 1e-9 after 30 iterations where the 16-bit forms are at 1e-5 .. 1.6e-4."""
+    monkeypatch.setenv("SMK_NSPLIT", "8")
+    m, n, iters = 900, 700, 30
+    A = oracle.quantize(mg.make_A(m, n, k, True, 0), quant)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters)
+    got = gpu.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, storage=storage)
+    assert ref.result == 0 and got.result == 0 and got.iteration_count == iters
+    assert rel(got.W, ref.W) < 1e-8 and rel(got.H, ref.H) < 1e-8
 
 
 def test_fp32_product_forms_agree(gpu, monkeypatch):
@@ -496,9 +515,8 @@ def test_rank_above_128_stopping_rule_and_solver_object(gpu, alg):
         rc, it, _ = s.run()
         W, H = s.factors(normalize=True)
         assert rc == ref.result == 0 and it == ref.iteration_count
-        # HALS at this rank amplifies the 4e-8 of the streaming products by ~2x per five iterations on this input, at
-        # k = 100 and 128 (narrow kernels) just as at 150: 2e-5 after 5 iterations, 1.4e-4 .. 1.6e-4 after 30
-        bar = 5e-4 if alg == "HALS" else TOL
-        assert rel(W, ref.W) < bar and rel(H, ref.H) < bar
+        # HALS at this rank amplifies the 4e-8 of the 16-bit product forms by ~2x per five iterations on this input (2e-5
+        # after 5 iterations, 1.4e-4 .. 1.6e-4 after 30): above k = 64 it runs on the accurate form (fp64 matrix cores)
+        assert rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
     s.close()
     D.close()
