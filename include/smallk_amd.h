@@ -110,6 +110,14 @@ int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed);
 /* read the shard back as fp64 (tests) */
 int smk_matrix_download_f64(const smk_matrix* a, double* host, int64_t ld);
 void smk_matrix_destroy(smk_matrix* a);
+/* a copy of a resident matrix in the calling thread's context (current device): device-to-device, also across devices */
+int smk_matrix_clone(const smk_matrix* src, smk_matrix** out);
+/* a host thread with a device context of its own (stream, handles) on `device_ordinal`, separate from the process-wide
+ * one, until smk_thread_context_end(); smk_device_count / smk_current_device: the HIP runtime's answers */
+int smk_thread_context_begin(int device_ordinal);
+void smk_thread_context_end(void);
+int smk_device_count(void);
+int smk_current_device(void);
 /* sparse A in CSC (replaces SparseMatrix<double>, common/include/sparse_matrix_decl.hpp:21-132): the local
  * columns [col0, col0+ncols_local); 32-bit indices as in the reference, duplicates allowed (they add up).
  * The transpose is built here too (the reference does it in Solver_Generic_BPP::Init, nmf_solver_bpp.hpp:319). */

@@ -73,6 +73,11 @@ SYMBOLS = {
     "smk_matrix_fill_uniform": (C.c_int, [_vp, C.c_uint64]),
     "smk_matrix_download_f64": (C.c_int, [_vp, _dp, _i64]),
     "smk_matrix_destroy": (None, [_vp]),
+    "smk_matrix_clone": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "smk_thread_context_begin": (C.c_int, [C.c_int]),
+    "smk_thread_context_end": (None, []),
+    "smk_device_count": (C.c_int, []),
+    "smk_current_device": (C.c_int, []),
     "smk_matrix_create_sparse": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _i64, _i64, C.POINTER(C.c_uint),
                                            C.POINTER(C.c_uint), _dp]),
     "smk_nmf_sparse": (C.c_int, [C.POINTER(Options), C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint),

@@ -215,6 +215,23 @@ size_t rank2_progress_scratch_elems(i64 m, i64 n);
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, i64 nnz_hint, const double* X,
                        int ldx, int k, double* P, int kpp, hipStream_t st);
 
+// spmm_blocked.hip: the rank-2 gather product with the gathered factor cut into row blocks that stay in one XCD's L2.
+// A matrix regrouped by row block: block b is a CSC of its own (cp[b * (ncols + 1) + j] .. are absolute positions in ri / va)
+struct BlockedCsc {
+    int nb = 0;              // row blocks: 2, 4 or 8 (0: not built)
+    i64 rb = 0;              // rows per block (a power of two)
+    i64 ncols = 0, nnz = 0;
+    i64* cp = nullptr;
+    unsigned* ri = nullptr;
+    double* va = nullptr;
+};
+int blocked_csc_blocks(i64 rows);      // 1: the factor fits an L2, no blocking
+int build_blocked_csc(i64 rows, i64 ncols, i64 nnz, const i64* colptr, const unsigned* rowidx, const double* val, int nb,
+                      BlockedCsc* out, hipStream_t st);
+void free_blocked_csc(BlockedCsc* b);
+// P: [nb][ncols_pad][2] partial products (the consumers add the slabs), X: compact copy of the factor (16 B per row)
+int launch_spmm_blocked2(const BlockedCsc& b, const double* X, double* P, i64 ncols_pad, hipStream_t st);
+
 // sparse_subset.hip: CSC(A[:, cols]) and CSC(A[:, cols]') with unused rows dropped, assembled on the device
 // from the resident CSC(A) / CSC(A').  `cols` must be strictly increasing.  The six output arrays are
 // hipMalloc'ed for the caller; new_to_old_host (capacity src.m) receives the kept rows.

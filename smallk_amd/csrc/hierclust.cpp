@@ -27,6 +27,8 @@
 #include <numeric>
 #include <sstream>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -471,6 +473,111 @@ int trial_split(Run& r, std::vector<unsigned>& subset, double min_priority, cons
     return SMK_OK;
 }
 
+// ---- two devices (SMK_CLUST_DEVICES=2): the two TrialSplits of a step are independent (clust_hier_generic.hpp:383-517
+// runs them one after the other) -- the second one runs on a worker thread that owns a second device context and a copy
+// of A there.  The sequential run hands the second child the initialiser draws (or init-file counter) that follow the
+// first child's; the worker assumes the first child takes its nominal share (one factorisation, or none for a node of
+// <= 3 documents) and the step is repeated for the second child on the main device if that turns out wrong (a retry or
+// an outlier trial consumed more) -- so the tree is the one-device tree, draw for draw.
+struct SplitTask {
+    std::vector<unsigned>* docs = nullptr;
+    double min_priority = 0.0;
+    const std::vector<double>* w_parent = nullptr;
+    std::vector<double>*W = nullptr, *H = nullptr;
+    double priority = 0.0;
+    uint64_t draws0 = 0, draws1 = 0;
+    int counter0 = 0, counter1 = 0;
+    int rc = SMK_OK;
+    std::string err;
+    smk_clust_stats stats = {0, 0};
+    long iterations = 0;
+};
+
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    SplitTask* task = nullptr;
+    bool quit = false, done = false, ready = false;
+    int device = 0, setup_rc = SMK_OK;
+    const smk_matrix* src = nullptr;
+    Run run;                              // the worker's own scratch, timers and copy of A
+
+    void body()
+    {
+        setup_rc = smk_thread_context_begin(device);
+        const bool have_ctx = setup_rc == SMK_OK;
+        smk_matrix* copy = nullptr;
+        if (setup_rc == SMK_OK) setup_rc = smk_matrix_clone(src, &copy);
+        run.full = copy;
+        { std::lock_guard<std::mutex> lk(mu); ready = true; }
+        cv.notify_all();
+        for (;;) {
+            SplitTask* t = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return quit || task != nullptr; });
+                if (quit) break;
+                t = task;
+            }
+            run.draws = t->draws0;
+            run.init_counter = t->counter0;
+            run.stats = smk_clust_stats{0, 0};              // per task: only an ACCEPTED speculation counts in the run's totals
+            run.iterations = 0;
+            t->rc = (setup_rc == SMK_OK) ? trial_split(run, *t->docs, t->min_priority, *t->w_parent, *t->W, *t->H, &t->priority) : setup_rc;
+            if (t->rc != SMK_OK) t->err = smk_last_error();
+            t->draws1 = run.draws;
+            t->counter1 = run.init_counter;
+            t->stats = run.stats;
+            t->iterations = run.iterations;
+            { std::lock_guard<std::mutex> lk(mu); task = nullptr; done = true; }
+            cv.notify_all();
+        }
+        smk::device_priority_release();
+        smk_matrix_destroy(copy);
+        if (have_ctx) smk_thread_context_end();
+    }
+    void submit(SplitTask* t)
+    {
+        { std::lock_guard<std::mutex> lk(mu); done = false; task = t; }
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
+// a second worker for this run, or nullptr (one device, or it could not be set up)
+Worker* start_worker(const Run& r)
+{
+    const char* e = getenv("SMK_CLUST_DEVICES");
+    if (!e || atoi(e) < 2) return nullptr;
+    const int cur = smk_current_device(), ndev = smk_device_count();
+    if (cur < 0 || ndev < 1) return nullptr;
+    const char* one = getenv("SMK_SHARDS_ON_ONE_GPU");
+    const bool same = one && atoi(one) != 0;
+    if (!same && ndev < 2) return nullptr;
+    Worker* w = new Worker;
+    w->device = same ? cur : (cur + 1) % ndev;
+    w->src = r.full;
+    w->run.o = r.o; w->run.m = r.m; w->run.n = r.n; w->run.seed = r.seed; w->run.initdir = r.initdir;
+    w->th = std::thread([w] { w->body(); });
+    {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->ready; });
+    }
+    if (w->setup_rc != SMK_OK) { w->stop(); delete w; return nullptr; }
+    return w;
+}
+
 // ClustHier, clust_hier_generic.hpp:67-196
 int clust_hier(Run& r, smk_tree& tree)
 {
@@ -484,6 +591,18 @@ int clust_hier(Run& r, smk_tree& tree)
     int rc = factor_node(r, r.full, m, n, nullptr, nullptr, W0, H0, "Root node");
     if (rc != SMK_OK) return rc;
 
+    struct WorkerGuard {
+        Worker* w;
+        Run& r;
+        ~WorkerGuard()
+        {
+            if (!w) return;
+            w->stop();
+            r.t_subset += w->run.t_subset; r.t_factor += w->run.t_factor; r.t_priority += w->run.t_priority; r.t_init += w->run.t_init;
+            delete w;
+        }
+    } guard{start_worker(r), r};
+    Worker* worker = guard.w;
     std::vector<std::vector<double>> Wbuf(node_count), Hbuf(node_count);
     double min_priority = 0.0, max_priority = 0.0;
     unsigned split_index = 0;
@@ -503,13 +622,40 @@ int clust_hier(Run& r, smk_tree& tree)
             std::vector<double>().swap(Hbuf[split_index]);
         }
         const unsigned idx[2] = {tree.index0, tree.index1};
-        for (int s = 0; s < 2; ++s) {
-            double pr = 0.0;
-            // the parent's topic vector may not alias a buffer that trial_split resizes
-            const std::vector<double> w_parent(tree.nodes[idx[s]].topic);
-            rc = trial_split(r, tree.nodes[idx[s]].docs, min_priority, w_parent, Wbuf[idx[s]], Hbuf[idx[s]], &pr);
+        // the parent's topic vector may not alias a buffer that trial_split resizes
+        const std::vector<double> w_parent0(tree.nodes[idx[0]].topic), w_parent1(tree.nodes[idx[1]].topic);
+        SplitTask spec;
+        std::vector<unsigned> docs1_backup;
+        bool speculated = false;
+        if (worker) {
+            // second child on the other device, assuming the first one takes its nominal share of the initialisers
+            const bool first_factors = tree.nodes[idx[0]].docs.size() > 3;
+            docs1_backup = tree.nodes[idx[1]].docs;
+            spec.docs = &tree.nodes[idx[1]].docs; spec.min_priority = min_priority; spec.w_parent = &w_parent1;
+            spec.W = &Wbuf[idx[1]]; spec.H = &Hbuf[idx[1]];
+            spec.draws0 = r.draws + (first_factors && r.initdir.empty() ? 2 : 0);
+            spec.counter0 = r.init_counter + (first_factors && !r.initdir.empty() ? 1 : 0);
+            worker->submit(&spec);
+            speculated = true;
+        }
+        double pr0 = 0.0;
+        rc = trial_split(r, tree.nodes[idx[0]].docs, min_priority, w_parent0, Wbuf[idx[0]], Hbuf[idx[0]], &pr0);
+        if (speculated) worker->wait();
+        if (rc != SMK_OK) return rc;
+        tree.nodes[idx[0]].priority = pr0;
+        if (speculated && spec.draws0 == r.draws && spec.counter0 == r.init_counter) {
+            if (spec.rc != SMK_OK) { set_error(spec.err); return spec.rc; }
+            tree.nodes[idx[1]].priority = spec.priority;
+            r.draws = spec.draws1;
+            r.init_counter = spec.counter1;
+            r.stats.nmf_count += spec.stats.nmf_count; r.stats.max_count += spec.stats.max_count;
+            r.iterations += spec.iterations;
+        } else {
+            if (speculated) tree.nodes[idx[1]].docs = docs1_backup;      // the first child took more initialisers: this one again, in order
+            double pr1 = 0.0;
+            rc = trial_split(r, tree.nodes[idx[1]].docs, min_priority, w_parent1, Wbuf[idx[1]], Hbuf[idx[1]], &pr1);
             if (rc != SMK_OK) return rc;
-            tree.nodes[idx[s]].priority = pr;
+            tree.nodes[idx[1]].priority = pr1;
         }
         if (o.verbose) { printf("[%u] ", i + 1); fflush(stdout); }
     }

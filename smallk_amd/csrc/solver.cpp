@@ -91,6 +91,9 @@ struct smk_matrix {
     unsigned *rowidx = nullptr, *rowidx_t = nullptr;
     double *val = nullptr, *val_t = nullptr;
     // host copy of the CSC (column subsets for HierNMF2 nodes are cut on the host)
+    // RANK2 on a factor larger than an L2: the entries regrouped by row block (spmm_blocked.hip), built on first use
+    mutable BlockedCsc bA, bAt;
+    mutable bool blocked_tried = false;
     mutable std::vector<unsigned> h_colptr, h_rowidx;     // fetched on first use (ensure_host_csc)
     mutable std::vector<double> h_val;
 };
@@ -218,6 +221,34 @@ void smk_finalize(void)
     g_stream = nullptr;
     g_own_stream = false;
     g_init = false;
+}
+
+// A host thread that drives a device of its own (the second device of a two-device HierNMF2 run, hierclust.cpp): its
+// library state -- stream, CU count, live handles -- is separate from the process-wide context from here to _end().
+int smk_thread_context_begin(int device_ordinal)
+{
+    if (t_ctx) { set_error("this thread already has a context of its own"); return SMK_BAD_PARAM; }
+    t_ctx = new DeviceCtx;
+    const int rc = smk_initialize(device_ordinal);
+    if (rc != SMK_OK) { delete t_ctx; t_ctx = nullptr; }
+    return rc;
+}
+void smk_thread_context_end(void)
+{
+    if (!t_ctx) return;
+    smk_finalize();
+    delete t_ctx;
+    t_ctx = nullptr;
+}
+int smk_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+int smk_current_device(void)
+{
+    int d = 0;
+    return hipGetDevice(&d) == hipSuccess ? d : -1;
 }
 
 const char* smk_last_error(void) { return g_err.c_str(); }
@@ -401,10 +432,49 @@ void smk_matrix_destroy(smk_matrix* a)
 {
     if (!a) return;
     unregister_matrix(a);
+    free_blocked_csc(&a->bA);
+    free_blocked_csc(&a->bAt);
     void* ptrs[] = {a->A, a->At, a->colptr, a->colptr_t, a->rowidx, a->rowidx_t, a->val, a->val_t};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete a;
+}
+
+// A copy of a resident matrix in the CALLING thread's context (its current device and stream): the second device of a
+// two-device HierNMF2 run holds one (hierclust.cpp).  Device-to-device copies; works across devices and on one.
+int smk_matrix_clone(const smk_matrix* src, smk_matrix** out)
+{
+    if (!src || !out) return SMK_BAD_PARAM;
+    *out = nullptr;
+    if (!g_init) { set_error("smk_initialize() has not been called"); return SMK_NOTINITIALIZED; }
+    smk_matrix* a = new smk_matrix;
+    a->m = src->m; a->n_global = src->n_global; a->c0 = src->c0; a->n = src->n; a->storage = src->storage;
+    a->ascale = src->ascale; a->col_spread_log2 = src->col_spread_log2;
+    a->ldA = src->ldA; a->colsA = src->colsA; a->ldAt = src->ldAt; a->colsAt = src->colsAt;
+    a->sparse = src->sparse; a->nnz = src->nnz;
+    a->st = g_stream;
+    register_matrix(a);
+    bool ok = true;
+    auto dup = [&](void** dst, const void* from, size_t bytes) {
+        if (!ok || !from) return;
+        if (bytes == 0) bytes = 8;
+        if (hipMalloc(dst, bytes) != hipSuccess || hipMemcpy(*dst, from, bytes, hipMemcpyDefault) != hipSuccess) ok = false;
+    };
+    if (src->sparse) {
+        dup((void**)&a->colptr, src->colptr, (size_t)(src->n + 1) * sizeof(i64));
+        dup((void**)&a->colptr_t, src->colptr_t, (size_t)(src->m + 1) * sizeof(i64));
+        dup((void**)&a->rowidx, src->rowidx, (size_t)src->nnz * sizeof(unsigned));
+        dup((void**)&a->rowidx_t, src->rowidx_t, (size_t)src->nnz * sizeof(unsigned));
+        dup((void**)&a->val, src->val, (size_t)src->nnz * sizeof(double));
+        dup((void**)&a->val_t, src->val_t, (size_t)src->nnz * sizeof(double));
+    } else {
+        const size_t es = (size_t)elem_size(src->storage);
+        dup(&a->A, src->A, (size_t)src->ldA * src->colsA * es);
+        dup(&a->At, src->At, (size_t)src->ldAt * src->colsAt * es);
+    }
+    if (!ok) { set_error("smk_matrix_clone: device allocation or copy failed"); smk_matrix_destroy(a); return SMK_DEVICE_ERROR; }
+    *out = a;
+    return SMK_OK;
 }
 
 // ---- host-side CSC bookkeeping (no device involved; pinned against the reference's own SparseMatrix code
@@ -803,8 +873,21 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     }
     if (a->sparse) {   // gather products write one slab, as dense as the factor layout (KP values per column; RANK2: the 2 live ones)
         s->kpp = (opts->algorithm == SMK_ALG_RANK2) ? 2 : s->KP;
-        s->pl1.S = 1; s->pl1.p_elems = (size_t)s->pl1.ncols_pad * s->kpp;
-        s->pl2.S = 1; s->pl2.p_elems = (size_t)s->pl2.ncols_pad * s->kpp;
+        int nb1 = 1, nb2 = 1;
+        if (opts->algorithm == SMK_ALG_RANK2) {
+            // a factor that does not fit an XCD's L2 is gathered block by block (one partial slab per row block)
+            if (!a->blocked_tried) {
+                a->blocked_tried = true;
+                const int b1 = blocked_csc_blocks(a->m), b2 = blocked_csc_blocks(a->n);
+                hipStream_t bst = a->st ? a->st : g_stream;
+                if (b1 > 1) (void)build_blocked_csc(a->m, a->n, a->nnz, a->colptr, a->rowidx, a->val, b1, &a->bA, bst);
+                if (b2 > 1) (void)build_blocked_csc(a->n, a->m, a->nnz, a->colptr_t, a->rowidx_t, a->val_t, b2, &a->bAt, bst);
+            }
+            nb1 = a->bA.nb > 1 ? a->bA.nb : 1;
+            nb2 = a->bAt.nb > 1 ? a->bAt.nb : 1;
+        }
+        s->pl1.S = nb1; s->pl1.p_elems = (size_t)nb1 * s->pl1.ncols_pad * s->kpp;
+        s->pl2.S = nb2; s->pl2.p_elems = (size_t)nb2 * s->pl2.ncols_pad * s->kpp;
     }
 
     const size_t kk = (size_t)s->KP * s->KP;
@@ -1214,7 +1297,10 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
         if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
         (void)hipEventRecord(e0, s->st);
     }
-    int rc = launch_spmm_gather(colptr, rowidx, val, ncols, s->a->nnz, X, ldx, s->k, P, s->kpp, s->st);
+    int rc;
+    const BlockedCsc& blk = (which == 0) ? s->a->bA : s->a->bAt;
+    if (ldx == 2 && blk.nb > 1) rc = launch_spmm_blocked2(blk, X, P, which == 0 ? s->pl1.ncols_pad : s->pl2.ncols_pad, s->st);
+    else rc = launch_spmm_gather(colptr, rowidx, val, ncols, s->a->nnz, X, ldx, s->k, P, s->kpp, s->st);
     if (s->timing) {
         if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         (void)hipEventRecord(e1, s->st);

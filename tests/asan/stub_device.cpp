@@ -24,7 +24,7 @@ void orc_fill_uniform(double* buf, int64_t ld, int64_t rows, int64_t cols, int64
 int orc_normalize_and_scale(int64_t m, int64_t n, int k, double* W, int64_t ldw, double* H, int64_t ldh);
 }
 
-static std::string g_err;
+static thread_local std::string g_err;
 static bool g_init = false;
 namespace smk {
 void set_error(const std::string& m) { g_err = m; }
@@ -60,6 +60,17 @@ void smk_finalize(void) { g_init = false; }
 const char* smk_last_error(void) { return g_err.c_str(); }
 int smk_device_cu_count(void) { return 1; }
 int smk_set_stream(void*) { return SMK_OK; }
+// a second "device" is just a second host thread here: the two-device HierNMF2 step runs under the sanitizers too
+int smk_thread_context_begin(int) { return SMK_OK; }
+void smk_thread_context_end(void) {}
+int smk_device_count(void) { return 1; }
+int smk_current_device(void) { return 0; }
+int smk_matrix_clone(const smk_matrix* src, smk_matrix** out)
+{
+    if (!src || !out) return SMK_BAD_PARAM;
+    *out = new smk_matrix(*src);
+    return SMK_OK;
+}
 
 int smk_is_valid(const smk_options* o, int vm)
 {   // same checks and messages as solver.cpp / nmf_options.cpp:23-112

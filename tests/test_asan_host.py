@@ -99,3 +99,28 @@ def test_flatclust_tool_is_clean(built, data, alg):
     k = "2" if alg == "RANK2" else "3"
     run([fc, "--matrixfile", str(data / "a.mtx"), "--dictfile", str(data / "dictionary.txt"), "--clusters", k, "--algorithm", alg,
          "--maxiter", "6", "--verbose", "0", "--fuzzyfile", "fuzzy.csv"], cwd=str(data), ok_codes=tuple(range(0, 256)))
+
+
+@pytest.mark.parametrize("init", ["seeded", "initdir"])
+def test_hierclust_two_device_step_gives_the_one_device_tree(built, data, init):
+    """SMK_CLUST_DEVICES=2: the second TrialSplit of every step runs on a worker thread with its own context and copy of A
+    (here: a second host thread over the stub device), speculating on the first child's share of the initialisers.  The
+    tree and the assignment files must be byte-identical to the one-device run -- under ASAN + UBSan.  (One OpenMP
+    thread: the stub's factorisations come from the CPU oracle, whose reductions change their summation order with the
+    team size, and two concurrent callers do not always get the same team.)"""
+    hc = os.path.join(built, "hierclust")
+    common = [hc, "--matrixfile", str(data / "a.mtx"), "--dictfile", str(data / "dictionary.txt"), "--format", "JSON",
+              "--verbose", "0", "--clusters", "5", "--maxterms", "3", "--seed", "11"]
+    if init == "initdir":
+        common += ["--initdir", str(data) + "/"]
+    outs = {}
+    for tag, extra in (("one", {}), ("two", {"SMK_CLUST_DEVICES": "2", "SMK_SHARDS_ON_ONE_GPU": "1"})):
+        d = data / f"hier_{init}_{tag}"
+        d.mkdir()
+        r = subprocess.run(common + ["--assignfile", "asg.csv", "--treefile", "tree.json"], cwd=str(d), capture_output=True,
+                           text=True, timeout=600, env=dict(ENV, OMP_NUM_THREADS="1", **extra))
+        text = r.stdout + r.stderr
+        assert "AddressSanitizer" not in text and "runtime error:" not in text and "LeakSanitizer" not in text, text[-4000:]
+        assert r.returncode == 0, text[-3000:]
+        outs[tag] = ((d / "asg.csv").read_bytes(), (d / "tree.json").read_bytes())
+    assert outs["one"] == outs["two"]

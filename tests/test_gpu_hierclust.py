@@ -327,3 +327,30 @@ def test_resident_matrix_is_reused(gpu):
     W, H = s.factors()
     ref = oracle.nmf(oracle.quantize(D, 1), W0, H0, "BPP", min_iter=4, max_iter=4)
     assert np.linalg.norm(W - ref.W) / np.linalg.norm(ref.W) < 1e-4
+
+
+@pytest.mark.parametrize("sparse,case", [(True, (300, 400, 6, 2, 0, 6)), (True, (150, 260, 3, 4, 5, 5)), (False, (120, 240, 3, 3, 4, 4))])
+def test_two_device_step_gives_the_one_device_tree(gpu, monkeypatch, sparse, case):
+    """SMK_CLUST_DEVICES=2 (the two TrialSplits of a step on two devices, clust_hier_generic.hpp:383-517 runs them one after
+    the other): the second child is factored by a worker thread with a device context and a copy of A of its own -- on this
+    one-GPU box both contexts sit on device 0 (SMK_SHARDS_ON_ONE_GPU=1).  Same tree as the one-device run, node for node and
+    bit for bit (it is the same arithmetic on the same initialiser draws), also when outlier trials make the speculation on
+    the first child's share of the draws fail (case with tiny clusters)."""
+    m, n, topics, seed, tiny, clusters = case
+    A, _ = planted(m, n, topics, seed, sparse=sparse, tiny=tiny)
+    one = gpu.hier_nmf2(A, clusters, seed=seed + 7)
+    monkeypatch.setenv("SMK_CLUST_DEVICES", "2")
+    monkeypatch.setenv("SMK_SHARDS_ON_ONE_GPU", "1")
+    two = gpu.hier_nmf2(A, clusters, seed=seed + 7)
+    a, b = tree_arrays(one.nodes), tree_arrays(two.nodes)
+    assert len(a) == len(b)
+    for q, (x, y) in enumerate(zip(a, b)):
+        assert x["valid"] == y["valid"], q
+        if not x["valid"]:
+            continue
+        for key in ("parent", "left", "right", "is_left", "docs", "terms"):
+            assert x[key] == y[key], (q, key)
+        assert x["priority"] == y["priority"], q
+        assert np.array_equal(one.nodes[q].topic_vector, two.nodes[q].topic_vector), q
+    assert list(one.get_assignments()) == list(two.get_assignments())
+    assert (one.nmf_count, one.max_count, one.draws) == (two.nmf_count, two.max_count, two.draws)
