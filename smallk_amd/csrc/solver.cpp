@@ -1473,6 +1473,8 @@ static int gram_factor(smk_solver* s, int side)
     }
     if (s->nsplit == NSPLIT_F16X2)       // the reduce launch also derives the row scales of the operand packed next
         return launch_gram(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->st, s->xscale[side], s->oscale[side], (double)s->a->ascale);
+    // (round 3, again: leaving the partial sums to the pack launch -- every pack thread adding up its diagonal entry, workgroup 0
+    // finishing the matrix -- costs 12 us where reduce + pack cost 9.5: C2 went from 119 to 130 us per iteration.  Not kept.)
     if (!s->a->sparse && s->o.algorithm != SMK_ALG_RANK2 && s->nsplit != NSPLIT_F64) {
         const int rc = launch_gram_pack(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->a->storage, s->nsplit,
                                         side == 0 ? s->packW : s->packH, s->st);
@@ -2163,6 +2165,7 @@ int smk_nmf_dense(const smk_options* opts, const double* A, int64_t ldA, double*
     }
     if (!opts || !smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
     if (!A || !W || !H) return SMK_BAD_PARAM;
+    if (opts->k > MAX_K) { set_error("device path supports k <= 512"); return SMK_UNSUPPORTED; }     // before anything is uploaded
     const int64_t m = opts->height, n = opts->width;
     if (ldA < m || ldW < m || ldH < opts->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
     smk_matrix* a = nullptr;
@@ -2196,6 +2199,7 @@ int smk_nmf_dense_sharded(const smk_options* opts, const double* A, int64_t ldA,
     }
     if (!opts || !smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
     if (!A || !W || !H || nshards < 1 || nshards > 16) return SMK_BAD_PARAM;
+    if (opts->k > MAX_K) { set_error("device path supports k <= 512"); return SMK_UNSUPPORTED; }
     const int64_t m = opts->height, n = opts->width;
     if (ldA < m || ldW < m || ldH < opts->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
     if (nshards > n) nshards = (int)n;
@@ -2286,6 +2290,7 @@ int smk_nmf_sparse(const smk_options* opts, unsigned height, unsigned width, uns
     }
     if (!opts || !smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
     if (!col_offsets || !row_indices || !data || !W || !H) return SMK_BAD_PARAM;
+    if (opts->k > MAX_K) { set_error("device path supports k <= 512"); return SMK_UNSUPPORTED; }
     if ((int64_t)height != opts->height || (int64_t)width != opts->width) return SMK_BAD_PARAM;
     if (ldW < opts->height || ldH < opts->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
     smk_matrix* a = nullptr;

@@ -45,12 +45,12 @@ def test_flatclust_rejects_mu_and_bad_rank2(gpu):
 
 
 @pytest.mark.parametrize("sparse", [False, True])
-@pytest.mark.parametrize("k", [3, 6, 20])
+@pytest.mark.parametrize("k", [3, 6, 20, 150, 300])         # the flat step of HierNMF2 runs this with k = number of clusters (<= 512)
 def test_nnls_hals_matches_oracle(gpu, sparse, k):
     import oracle
     from oracle import flatclust as of
     from smallk_amd import _lib as L
-    m, n = 130, 210
+    m, n = (130, 210) if k <= 20 else (700, 900)
     rng = np.random.default_rng(k)
     A, _ = planted(m, n, min(k, 6), 17, sparse=sparse)
     W = np.asfortranarray(rng.random((m, k)) * (rng.random((m, k)) > 0.3))
