@@ -1180,6 +1180,7 @@ static const F3Variant kF3Variants[] = {
     {32, 5, 4, 4, 0},   // 124: EXPERIMENT no X fetch, no MFMA, no split
     {32, 2, 0, 8, 2},   // 125: as 108, folding into fp64 every 8 stages (256-row fp32 chains)
     {32, 3, 0, 4, 2},   // 126: as 108 with a 3-deep ring
+    {32, 2, 0, 16, 2},  // 127: as 125, folding every 16 stages (512-row fp32 chains)
 };
 static const int kNumF3 = (int)(sizeof(kF3Variants) / sizeof(kF3Variants[0]));
 
@@ -1245,6 +1246,7 @@ static int launch_f3(const BigProdPlan& pl, const void* B, i64 ldb, const void* 
         case 24: return launch_f3p_t<KT, NS, 5, 4, 4, 22>(pl, B, ldb, Xp, P, st);
         case 25: return launch_f3_t<KT, NS, 32, 2, 0, 8, 2>(pl, B, ldb, Xp, P, st);
         case 26: return launch_f3_t<KT, NS, 32, 3, 0, 4, 2>(pl, B, ldb, Xp, P, st);
+        case 27: return launch_f3_t<KT, NS, 32, 2, 0, 16, 2>(pl, B, ldb, Xp, P, st);
         default: break;
     }
     set_error("unknown bigprod f3 variant");
@@ -1262,6 +1264,7 @@ static int launch_f3_f16(const BigProdPlan& pl, const void* B, i64 ldb, const vo
         case 15: return launch_f3p_t<KT, 2, 3, 2, 4, 1, 1>(pl, B, ldb, Xp, P, st);
         case 25: return launch_f3_t<KT, 2, 32, 2, 0, 8, 2, 1>(pl, B, ldb, Xp, P, st);
         case 26: return launch_f3_t<KT, 2, 32, 3, 0, 4, 2, 1>(pl, B, ldb, Xp, P, st);
+        case 27: return launch_f3_t<KT, 2, 32, 2, 0, 16, 2, 1>(pl, B, ldb, Xp, P, st);
         default: break;
     }
     set_error("unknown bigprod f16 variant");
@@ -1449,7 +1452,7 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     const char* env2 = getenv("SMK_BP_VARIANT_K64");       // only for k in (32, 64]
     if (env2 && pl.kt == 2) v = atoi(env2);
     if (storage == STORE_F32 && pl.nsplit == 2 && v < 100) v = (pl.kt == 2) ? 108 : 115;   // the 2-term forms exist only there
-    if (pl.nsplit == NSPLIT_F16X2 && v != 108 && v != 110 && v != 111 && v != 115 && v != 125 && v != 126) v = 125;
+    if (pl.nsplit == NSPLIT_F16X2 && v != 108 && v != 110 && v != 111 && v != 115 && v != 125 && v != 126 && v != 127) v = 125;
     if (v >= 100 && storage == STORE_F32 && pl.nsplit >= 2) {
         auto f3_fits = [&](int vv) {
             if (vv < 100 || vv >= 100 + kNumF3) return false;
