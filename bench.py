@@ -227,17 +227,23 @@ def main():
         col0, ncols = sdist.shard_columns(n, args.emulate_world, 0)
         comm = smallk_amd.Comm.init_all(1)[0]
         collectives = f"EMULATED rank 0 of {args.emulate_world}: RCCL calls with one rank (device-local)"
-    if saved_stdout is not None:
+    def restore_stdout():
+        """fd 1 was pointed at stderr while RCCL could print (its banner at communicator creation, INFO lines at the first
+        collectives if NCCL_DEBUG_FILE is not honoured): stdout carries ONLY the JSON line, so it comes back right before it"""
+        nonlocal saved_stdout
+        if saved_stdout is None:
+            return
         sys.stdout.flush()
-        try:                                # the banner sits in the C library's stdio buffer: push it out while fd 1 is still stderr
+        try:                                # what sits in the C library's stdio buffer goes out while fd 1 is still stderr
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
-    total_iters = args.warmup + args.steps
+        saved_stdout = None
 
+    total_iters = args.warmup + args.steps
     A = smallk_amd.DenseMatrix(m, n, col0=col0, ncols=ncols, storage=storage)
     A.fill_uniform(42)
     W0 = smallk_amd.uniform_host(m, k, 43)
@@ -374,6 +380,7 @@ def main():
                 pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, n, k, alg, 1 if storage == "bf16" else 0)
+        restore_stdout()
         print(json.dumps(out), flush=True)
     if rank == 0 and world > 1:
         import glob
