@@ -178,7 +178,7 @@ int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double
 
 /* ---- multi-GPU: A and H column sharded, W replicated in the algorithm.  Exchange steps per iteration:
  *   - sum-all-reduce of HH' (k x k, fp64), beside the H*At pass;
- *   - the sum of H*At = (AH')' (k x m; fp32 on the wire, SMK_COMM_F64=1: fp64): the pass runs in row chunks and the
+ *   - the sum of H*At = (AH')' (k x m; fp64 on the wire, SMK_COMM_F64=0: fp32): the pass runs in row chunks and the
  *     sum of chunk j travels while the product streams chunk j + 1 -- an all-reduce for MU / HALS (replicated W
  *     update), a reduce-scatter for BPP, whose W rows are independent NNLS problems: block r of every chunk belongs
  *     to rank r (block-cyclic), every rank solves its own blocks;
@@ -194,7 +194,7 @@ int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double
  *   - an in-process stand-in with the same semantics for several shards on ONE device (smk_comm_init_local: RCCL
  *     refuses two ranks on a device), used by the tests and by boxes with fewer GPUs than shards.
  * Environment: SMK_COMM_CHUNKS=1..8 (row chunks of the exchange; default: blocks of >= 4096 rows, at most 4 chunks),
- * SMK_COMM_F64=1, SMK_COMM_FORCE=1 (a world of ONE rank issues every collective too: tests of the real nccl* calls).
+ * SMK_COMM_F64=0 (fp32 on the wire), SMK_COMM_FORCE=1 (a world of ONE rank issues every collective too: tests of the real nccl* calls).
  * The reference has no distributed mode (sphinx/source/pages_installation.rst:38). */
 typedef struct smk_comm smk_comm;
 int smk_comm_unique_id(void* id128 /* 128 bytes out */);

@@ -7,7 +7,7 @@ surface (pysmallk ``SmallkAPI``) plus thin object wrappers.  No CPU fallback exi
 from . import _lib
 from .solver import (DenseMatrix, SparseMatrix, NmfSolver, NmfResult, nmf, nmf_sparse, load_matrix_market,
                      initialize, finalize, is_initialized, make_options, uniform_host, set_stream,
-                     nnls_blockpivot, nmf_sharded, Comm)
+                     nnls_blockpivot, nmf_sharded, Comm, thread_context_begin, thread_context_end)
 from .api import SmallkAPI
 from . import hierclust
 from . import flatclust
@@ -15,4 +15,4 @@ from .hierclust import hier_nmf2, TreeResults
 from .pyclust import Flatclust, Hierclust
 
 __all__ = ["DenseMatrix", "SparseMatrix", "nmf_sparse", "load_matrix_market", "NmfSolver", "NmfResult", "nmf", "initialize", "finalize", "is_initialized",
-           "make_options", "uniform_host", "nnls_blockpivot", "nmf_sharded", "Comm", "set_stream", "SmallkAPI", "hierclust", "flatclust", "hier_nmf2", "TreeResults", "Flatclust", "Hierclust", "_lib"]
+           "make_options", "uniform_host", "nnls_blockpivot", "nmf_sharded", "Comm", "set_stream", "thread_context_begin", "thread_context_end", "SmallkAPI", "hierclust", "flatclust", "hier_nmf2", "TreeResults", "Flatclust", "Hierclust", "_lib"]

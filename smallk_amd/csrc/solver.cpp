@@ -162,7 +162,8 @@ struct smk_solver {
     // while the streaming product works on chunk j + 1.
     int nchunk = 1;
     i64 blk = 0, rows_cap = 0;            // rows per (chunk, rank) block (multiple of 256); world * nchunk * blk >= m_pad
-    bool red_f64 = false;                 // element type of the summed (AH')' (fp32 unless SMK_COMM_F64=1)
+    bool r2_alias = false;                // the H*At pass writes ONE slab of fp64 partial products: the collectives work on it directly (no copy)
+    bool red_f64 = false;                 // element type of the summed (AH')' on the wire (native communicator: fp64 unless SMK_COMM_F64=0)
     bool w_sharded = false;               // BPP: every rank solves (and holds current) only its own blocks of W
     bool w_full = true;                   // all rows of the fp64 W on this rank are current
     // a row-sharded W: this rank's blocks back to back (KP x nchunk*blk; the n_own valid rows are a prefix because only the
@@ -1054,14 +1055,30 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
         s->rows_cap = (i64)s->nchunk * s->world * s->blk;
     }
     {
+        // fp64 on the wire unless SMK_COMM_F64=0.  SURVEY 8e suggested fp32 (half the bytes); measured at the full C4 size on
+        // the bench's noise-like data (tools/shard8_fullsize.py: 8 shards against one GPU): fp32 costs 1.1e-4 in W after ONE
+        // iteration -- the sums over 65536 columns are ~500, their fp32 rounding 3e-5, and HH' of such data amplifies it a
+        // thousand times -- against 6e-7 with fp64.  With the exchange pipelined behind the pass the extra bytes are hidden
+        // except in the last chunk.
         const char* e = getenv("SMK_COMM_F64");
-        s->red_f64 = e && atoi(e) != 0;
+        s->red_f64 = !(e && atoi(e) == 0);
     }
     s->w_sharded = s->o.algorithm == SMK_ALG_BPP && !s->a->sparse && s->nsplit != NSPLIT_F64 && (s->world > 1 || comm_forced());
     const size_t bytes = comm_bytes(s);
     if (hipMalloc(&s->comm_ws, bytes) != hipSuccess) { s->comm = nullptr; s->w_sharded = false; set_error("hipMalloc(comm workspace)"); return SMK_DEVICE_ERROR; }
     SMK_HIP(hipMemsetAsync(s->comm_ws, 0, bytes, s->st));
     carve_workspace(s, s->comm_ws);
+    if (!s->a->sparse && s->pl2.S == 1 && s->red_f64) {
+        // one row split and fp64 on the wire: the partial products ARE the send buffer.  They get room for the equal
+        // blocks of the last chunk (rows past the padded row count are never written and stay zero).
+        if (s->P2) (void)hipFree(s->P2);
+        s->P2 = nullptr;
+        const size_t pe = (size_t)comm_rows(s) * s->kpp;
+        if (dev_alloc(&s->P2, pe)) return SMK_DEVICE_ERROR;
+        SMK_HIP(hipMemsetAsync(s->P2, 0, pe * sizeof(double), s->st));
+        s->R2red = (float*)s->P2;
+        s->r2_alias = true;
+    }
     if (s->w_sharded) {
         // the packed operand of W is gathered in equal blocks: room for rows_cap rows, groups laid out for that length
         if (s->packW) (void)hipFree(s->packW);
@@ -1437,8 +1454,7 @@ static int prod2(smk_solver* s)
         rc = comm_fork(s, s->ev_c[j]);
         if (rc) return rc;
         // off the main stream: the row splits of the chunk summed (and rounded to the wire type), then its exchange
-        rc = launch_reduce_partials(pv, s->k, r0, r1 - r0, s->R2red, s->red_f64 ? 1 : 0, s->st2);
-        if (rc) return rc;
+        if (!s->r2_alias) { rc = launch_reduce_partials(pv, s->k, r0, r1 - r0, s->R2red, s->red_f64 ? 1 : 0, s->st2); if (rc) return rc; }
         unsigned char* base = (unsigned char*)s->R2red + (size_t)r0 * s->kpp * rb;
         rc = timed_collective(s, [&] {
             if (s->w_sharded)       // every rank receives the sum of ITS block, next to its other blocks

@@ -38,6 +38,15 @@ def finalize():
     L.lib().smk_finalize()
 
 
+def thread_context_begin(device: int = -1):
+    """this host thread gets a device context of its own (stream, handles) until thread_context_end()"""
+    L.check(L.lib().smk_thread_context_begin(device), "smk_thread_context_begin")
+
+
+def thread_context_end():
+    L.lib().smk_thread_context_end()
+
+
 def set_stream(stream_ptr: int):
     L.check(L.lib().smk_set_stream(C.c_void_p(stream_ptr)), "smk_set_stream")
 

@@ -130,3 +130,69 @@ def test_c4_full_f32_bpp_sampled(gpu):
     ref = oracle.nmf(np.asfortranarray(Ar.T), np.asfortranarray(H1.T), np.asfortranarray(W0[rows, :].T), "BPP",
                      min_iter=1, max_iter=1, normalize=False)
     assert ref.result == 0 and relerr(W1[rows, :], ref.H.T) < 1e-4
+
+
+def test_c4_full_size_in_eight_shards_matches_one(gpu):
+    """configs[3] in the geometry of the 8-GPU run -- 8 column shards of 8192 columns, 4 row chunks of 8 blocks of 8192
+    rows, block-cyclic rows of W, reduce-scatter / all-reduce / all-gather of the packed operand per chunk -- with all 8
+    ranks on this box's ONE GPU (one host thread and one device context per rank, the in-process stand-in for RCCL;
+    the 137 GB of A and A' are the same bytes as in the one-GPU run, held as 8 shards).  Three BPP iterations; W and the
+    columns of H must agree with the unsharded run on the same data to summation order (1e-5), at every rank.  What this
+    pins at FULL size is the index arithmetic of the chunk pipeline (64-bit offsets into A', the packed operand and the
+    partial products, uneven last blocks are covered by the small tests) -- only the transport differs from 8 GPUs -- and
+    the wire type: with fp32 on the wire this comparison reads 1.1e-4 in W after one iteration (sums over 65536 columns
+    rounded to 24 bits, amplified by the Gram matrix of noise-like data), with fp64 (the default) 6e-7."""
+    import threading
+    from smallk_amd import DenseMatrix, NmfSolver, Comm, make_options, uniform_host, thread_context_begin, thread_context_end
+    from smallk_amd import dist as sdist
+    m, n, k, world, iters = 262144, 65536, 64, 8, 3
+    W0 = uniform_host(m, k, 312)
+    H0 = uniform_host(k, n, 313) * (2.0 / k)
+    opts = dict(min_iter=iters, max_iter=iters, normalize=False)
+    # one GPU, unsharded
+    A = DenseMatrix(m, n)
+    A.fill_uniform(311)
+    s = NmfSolver(A, make_options(m, n, k, "BPP", **opts))
+    s.set_factors(W0, H0)
+    s.iterate(iters)
+    assert s.sync() == 0
+    W1, H1 = s.factors(normalize=False)
+    s.close()
+    A.close()
+    # eight shards, eight threads
+    comms = Comm.init_local(world)
+    out, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            thread_context_begin(0)
+            c0, nc = sdist.shard_columns(n, world, rank)
+            D = DenseMatrix(m, n, col0=c0, ncols=nc)
+            D.fill_uniform(311)                      # the generator is keyed by the global element index
+            sv = NmfSolver(D, make_options(m, n, k, "BPP", **opts))
+            sv.attach_comm(comms[rank])
+            sv.set_factors(W0, H0[:, c0:c0 + nc])
+            sv.iterate(iters)
+            rc = sv.sync()
+            W, H = sv.factors(normalize=False)
+            out[rank] = (rc, c0, nc, W if rank in (0, world - 1) else None, H)
+            sv.close()
+            D.close()
+        except Exception as e:          # pragma: no cover
+            errors.append((rank, repr(e)))
+        finally:
+            thread_context_end()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=900)
+    for c in comms:
+        c.close()
+    assert not errors, errors
+    assert all(o is not None and o[0] == 0 for o in out)
+    H8 = np.concatenate([o[4] for o in out], axis=1)
+    fro = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert fro(H8, H1) < 1e-5
+    assert fro(out[0][3], W1) < 1e-5 and np.array_equal(out[0][3], out[world - 1][3])      # the gathered W: same bits on every rank
