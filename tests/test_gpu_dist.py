@@ -145,7 +145,8 @@ def test_bench_two_processes_match_one(tmp_path):
 # ---- native communicators (comm.cpp): collectives issued from C on the solver's streams ------------------------
 @pytest.mark.parametrize("alg,storage,quant,k,shards", [("HALS", "bf16", 1, 12, 2), ("MU", "f32", 0, 12, 3), ("BPP", "f32", 0, 12, 2),
                                                         ("BPP", "f32", 0, 40, 3), ("HALS", "f32", 0, 33, 4), ("BPP", "bf16", 1, 64, 2),
-                                                        ("BPP", "f32", 0, 140, 2), ("MU", "f32", 0, 200, 3)])
+                                                        ("BPP", "f32", 0, 140, 2), ("MU", "f32", 0, 200, 3),
+                                                        ("HALS", "f32", 0, 100, 2), ("HALS", "bf16", 1, 150, 3)])     # HALS above k = 64: the accurate product form, sharded
 def test_sharded_one_shot_matches_single_and_oracle(gpu, alg, storage, quant, k, shards):
     """smk_nmf_dense_sharded with the in-process stand-in for RCCL: `shards` host threads, each with its own
     device context, column shard (uneven: 701 columns), solver and streams, all on this box's one GPU.  The code
