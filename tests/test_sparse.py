@@ -127,3 +127,42 @@ def test_smallkapi_sparse_inputs(gpu, tmp_path):
                     col_offsets=list(A.indptr))
     api.nmf(k, "BPP", infile_W=fw, infile_H=fh, min_iter=1, max_iter=200, tol=0.01, outdir=str(tmp_path))
     assert rel(api.get_W(), ref.W) < 1e-8 and rel(api.get_H(), ref.H) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks,lpc", [("2", None), ("4", "1"), ("8", "4"), ("1", "16")])
+def test_rank2_gather_product_by_row_blocks_and_lanes(blocks, lpc, tmp_path):
+    """The rank-2 gather product in its other shapes -- the gathered factor cut into 2 / 4 / 8 row blocks (spmm_blocked.hip:
+    normally only above 6 MB of factor), 1 .. 16 lanes per column -- forced on a small matrix (the switches are read once per
+    process, hence the child process): RANK2 on an uneven 700 x 450 sparse matrix against the oracle at 1e-8, both stopping
+    rules, and the HierNMF2 tree of a planted matrix identical to the unblocked one."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, scipy.sparse as sp
+import oracle, smallk_amd
+from test_sparse import random_sparse, rel
+from hier_cases import planted
+smallk_amd.initialize(0)
+A = random_sparse(700, 450, 0.05, 5)
+W0 = oracle.fill_uniform(700, 2, 3); H0 = oracle.fill_uniform(2, 450, 4)
+for kw in (dict(min_iter=12, max_iter=12), dict(min_iter=2, max_iter=400, tol=1e-3)):
+    ref = oracle.nmf_sparse(A, W0, H0, "RANK2", **kw)
+    got = smallk_amd.nmf_sparse(A, W0, H0, "RANK2", **kw)
+    assert got.result == ref.result == 0 and got.iteration_count == ref.iteration_count, (got.result, got.iteration_count, ref.iteration_count)
+    assert rel(got.W, ref.W) < 1e-8 and rel(got.H, ref.H) < 1e-8, (rel(got.W, ref.W), rel(got.H, ref.H))
+P, _ = planted(300, 400, 6, 2, sparse=True)
+t = smallk_amd.hier_nmf2(P, 6, seed=2)
+print("ASSIGN", ",".join(str(int(x)) for x in t.get_assignments()))
+""" % (root, os.path.join(root, "tests"))
+    outs = []
+    for env in ({"SMK_SPMM_BLOCKS": blocks, **({"SMK_SPMM2_LPC": lpc, "SMK_SPMM_BLOCKED_LPC": lpc if lpc in ("1", "2", "4", "8") else "8"} if lpc else {})},
+                {"SMK_SPMM_BLOCKS": "1"}):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("ASSIGN")][0])
+    assert outs[0] == outs[1]
