@@ -170,8 +170,9 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
 
 /* measurement: HIP events around the streaming-product launches (stream of the solver) */
 int smk_solver_enable_timing(smk_solver* s, int on);
-/* which: 0 = W'A pass, 1 = H*At pass, 2 = the big collectives of a sharded run (the sum of (AH')' and, BPP, the
- * all-gather of W).  Returns total ms and launch count since enable. */
+/* which: 0 = W'A pass, 1 = H*At pass (a pass that the multi-GPU schedule cuts into chunks counts as ONE launch per group of
+ * 64 factor rows; its time is the sum of its chunk launches), 2 = the per-chunk collectives of a sharded run, timed on the
+ * collective stream (the sums of (AH')' and, BPP, the all-gathers of the packed W).  Total ms and count since enable. */
 int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* launches);
 /* algorithmic bytes / flops one launch of pass `which` moves (len*ncols*sizeof(elt), 2*k*len*ncols) */
 int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double* flops);
