@@ -65,45 +65,66 @@ __global__ __launch_bounds__(256) void bl_offsets_kernel(const unsigned* __restr
     }
 }
 
-// LPC lanes per (block, column) segment; workgroup w serves block (w mod 8) mod nb -- the XCD it is dispatched to
-template <int LPC>
+// LPC lanes per (block, column) segment, U segments per lane group in flight at once; workgroup w serves block
+// (w mod 8) mod nb -- the XCD it is dispatched to.  A segment is short (nnz / columns / blocks: 2 - 4 entries), so a lane
+// has ONE entry of it: offsets -> (value, row) -> gathered row are three dependent round trips, and with one segment per
+// lane group the wave spends them waiting (81 % of its cycles, SQ_WAIT_ANY / SQ_WAVE_CYCLES).  With U segments the three
+// trips are shared by U independent chains.  (Measured, tools/gpu_round3_j.sh: U = 2 / 4 are 2 - 5 % SLOWER than U = 1 at every
+// lane count, while more lanes per segment always help (753 / 564 / 514 us per root-sized iteration at 1 / 2 / 4 lanes): the
+// kernel is bound by how the value / index reads coalesce, not by the depth of a lane's dependency chain.  U = 1 is the default.)
+template <int LPC, int U>
 __global__ __launch_bounds__(256) void spmm_blocked2_kernel(const i64* __restrict__ cp, const unsigned* __restrict__ ri,
                                                             const double* __restrict__ va, i64 ncols, i64 ncols_pad, int nb,
                                                             const double* __restrict__ X, double* __restrict__ P)
 {
-    constexpr int CPW = 256 / LPC;                      // columns per workgroup
+    constexpr int CPW = 256 / LPC;                      // columns per workgroup and step
     const int xcd = blockIdx.x & 7;
     const int b = xcd % nb;
     const i64 tile = (i64)(blockIdx.x >> 3) * (8 / nb) + xcd / nb;
-    const i64 j = tile * CPW + threadIdx.x / LPC;
     const int l = threadIdx.x % LPC;
-    const bool valid = j < ncols;
-    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-    if (valid) {
-        const i64* c = cp + (i64)b * (ncols + 1) + j;
-        const i64 p0 = c[0], p1 = c[1];
-        i64 p = p0 + l;
-        for (; p + LPC < p1; p += 2 * LPC) {
-            const double v0 = __builtin_nontemporal_load(va + p), v1 = __builtin_nontemporal_load(va + p + LPC);
-            const unsigned r0 = __builtin_nontemporal_load(ri + p), r1 = __builtin_nontemporal_load(ri + p + LPC);
-            const f64x2_t x0 = *(const f64x2_t*)(X + (i64)r0 * 2);
-            const f64x2_t x1 = *(const f64x2_t*)(X + (i64)r1 * 2);
-            a0 += v0 * x0[0]; a1 += v0 * x0[1];
-            b0 += v1 * x1[0]; b1 += v1 * x1[1];
+    const i64* cpb = cp + (i64)b * (ncols + 1);
+    i64 j[U], p[U], p1[U];
+    double a0[U], a1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        j[u] = (tile * U + u) * CPW + threadIdx.x / LPC;
+        a0[u] = a1[u] = 0.0;
+        p[u] = p1[u] = 0;
+        if (j[u] < ncols) { p[u] = cpb[j[u]] + l; p1[u] = cpb[j[u] + 1]; }
+    }
+    bool more = true;
+    while (more) {
+        double v[U];
+        unsigned r[U];
+        bool have[U];
+        more = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            have[u] = p[u] < p1[u];
+            v[u] = have[u] ? __builtin_nontemporal_load(va + p[u]) : 0.0;
+            r[u] = have[u] ? __builtin_nontemporal_load(ri + p[u]) : 0u;
         }
-        if (p < p1) {
-            const double v0 = __builtin_nontemporal_load(va + p);
-            const unsigned r0 = __builtin_nontemporal_load(ri + p);
-            const f64x2_t x0 = *(const f64x2_t*)(X + (i64)r0 * 2);
-            a0 += v0 * x0[0]; a1 += v0 * x0[1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (have[u]) {
+                const f64x2_t x = *(const f64x2_t*)(X + (i64)r[u] * 2);
+                a0[u] += v[u] * x[0];
+                a1[u] += v[u] * x[1];
+            }
+            p[u] += LPC;
+            more |= p[u] < p1[u];
         }
     }
-    const double s0 = group_sum<LPC>(a0 + b0), s1 = group_sum<LPC>(a1 + b1);
-    if (!valid || l != 0) return;
-    f64x2_t r;
-    r[0] = s0;
-    r[1] = s1;
-    *(f64x2_t*)(P + ((i64)b * ncols_pad + j) * 2) = r;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const double s0 = group_sum<LPC>(a0[u]), s1 = group_sum<LPC>(a1[u]);      // whole waves take part in the DPP moves
+        if (l == 0 && j[u] < ncols) {
+            f64x2_t o;
+            o[0] = s0;
+            o[1] = s1;
+            *(f64x2_t*)(P + ((i64)b * ncols_pad + j[u]) * 2) = o;
+        }
+    }
 }
 
 }  // namespace
@@ -182,16 +203,22 @@ int launch_spmm_blocked2(const BlockedCsc& b, const double* X, double* P, i64 nc
     const double avg = (double)b.nnz / ((double)b.ncols * b.nb);
     static const int forced = [] { const char* e = getenv("SMK_SPMM_BLOCKED_LPC"); return e ? atoi(e) : 0; }();
     const int lpc = forced ? forced : (avg <= 1.5 ? 1 : avg <= 3.0 ? 2 : avg <= 6.0 ? 4 : 8);
-    const i64 cpw = 256 / lpc;
+    static const int unroll = [] { const char* e = getenv("SMK_SPMM_UNROLL"); return e ? atoi(e) : 1; }();
+    const int U = unroll >= 4 ? 4 : unroll >= 2 ? 2 : 1;
+    const i64 cpw = (256 / lpc) * U;                            // columns per workgroup
     const i64 tiles = (b.ncols + cpw - 1) / cpw;
     const i64 per = 8 / b.nb;                                   // column tiles per group of 8 workgroups
     const i64 grid = (tiles + per - 1) / per * 8;
+#define SMK_BL(LP, UU) spmm_blocked2_kernel<LP, UU><<<(unsigned)grid, 256, 0, st>>>(b.cp, b.ri, b.va, b.ncols, ncols_pad, b.nb, X, P)
+#define SMK_BLU(LP) do { if (U == 4) SMK_BL(LP, 4); else if (U == 2) SMK_BL(LP, 2); else SMK_BL(LP, 1); } while (0)
     switch (lpc) {
-        case 1: spmm_blocked2_kernel<1><<<(unsigned)grid, 256, 0, st>>>(b.cp, b.ri, b.va, b.ncols, ncols_pad, b.nb, X, P); break;
-        case 2: spmm_blocked2_kernel<2><<<(unsigned)grid, 256, 0, st>>>(b.cp, b.ri, b.va, b.ncols, ncols_pad, b.nb, X, P); break;
-        case 4: spmm_blocked2_kernel<4><<<(unsigned)grid, 256, 0, st>>>(b.cp, b.ri, b.va, b.ncols, ncols_pad, b.nb, X, P); break;
-        default: spmm_blocked2_kernel<8><<<(unsigned)grid, 256, 0, st>>>(b.cp, b.ri, b.va, b.ncols, ncols_pad, b.nb, X, P); break;
+        case 1: SMK_BLU(1); break;
+        case 2: SMK_BLU(2); break;
+        case 4: SMK_BLU(4); break;
+        default: SMK_BLU(8); break;
     }
+#undef SMK_BLU
+#undef SMK_BL
     SMK_HIP(hipGetLastError());
     return 0;
 }
