@@ -172,8 +172,12 @@ int hals_w_scratch_init(double* scratch, int k, i64 M, hipStream_t st);
 size_t hals_w_scratch_elems(int k, i64 M);
 // BPP / NNLS block principal pivoting over all columns
 // scratch: nnls_scratch_elems(k) doubles (k > 32: inverse of G + path selector), may be NULL (slow path only)
+// gram_partials / gram_nblk (optional): k in (8, 16], all columns from 0, at most NNLS_GRAM_MAX workgroups: the launch also
+// leaves partial Gram matrices X X' of the solved columns ([*gram_nblk][16 * 16], for launch_gram_reduce); *gram_nblk = 0 otherwise
+constexpr int NNLS_GRAM_MAX = 1024;
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
-                    int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st);
+                    int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st,
+                    double* gram_partials = nullptr, int* gram_nblk = nullptr);
 // k > 32: the inverse of G into scratch, ahead of launch_nnls_bpp(..., inverse_ready = 1, ...) (any stream)
 int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st);
 size_t nnls_scratch_elems(int k);

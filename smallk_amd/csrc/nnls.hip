@@ -68,7 +68,7 @@ template <int KP>
 __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N,
                                                        PartialView R, const double* __restrict__ G,
                                                        int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
-                                                       const int* __restrict__ skip_if)
+                                                       const int* __restrict__ skip_if, double* __restrict__ Gp)
 {
     constexpr int GS = KP;
     constexpr int GPB = 256 / GS;                   // column groups per block
@@ -79,6 +79,13 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
 
     const int lane = threadIdx.x & 63;
     const int i = threadIdx.x % GS;                 // component owned by this lane
+    // KP = 16, Gp != nullptr: the Gram matrix X X' of the SOLVED columns comes out of this launch too.  A wave holds 4 columns
+    // x 16 components with lane = component + 16 column -- exactly the A (and B) operand of v_mfma_f64_16x16x4 -- so one
+    // matrix instruction per trip accumulates the wave's 16 x 16 partial; the four waves are added through LDS and the
+    // workgroup leaves its partial in Gp[blockIdx] (the layout gram_reduce_kernel sums).  Saves the separate Gram launch over
+    // the factor on latency-bound problems (C2: 4.6 us + a launch gap per side).
+    typedef double f64x4_acc __attribute__((ext_vector_type(4)));
+    f64x4_acc gacc = {0.0, 0.0, 0.0, 0.0};
     // grid-stride over blocks of GPB columns: the k in (32, 64] fallback is launched with a small grid so that its
     // usual early exit costs 2 us, not one workgroup per 4 columns; every other launch covers its columns in one trip
     for (i64 vb = blockIdx.x; vb * GPB < N - col_begin; vb += gridDim.x) {
@@ -182,6 +189,30 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
         if (Y) Y[col * KP + i] = y;
     }
     if (failed && col_ok) atomicMin(fail_flag, iter_tag);
+    if constexpr (KP == 16) {
+        if (Gp) {
+            const double xg = (col_ok && comp_ok) ? x : 0.0;
+            gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(xg, xg, gacc, 0, 0, 0);
+        }
+    }
+    }
+    if constexpr (KP == 16) {
+        if (Gp) {
+            // D: column = lane & 15, row = (lane >> 4) + 4 reg; waves added in a fixed order through LDS (gs is free now)
+            const int wave = threadIdx.x >> 6, kc = lane >> 4, r16 = lane & 15;
+            __syncthreads();
+            for (int w = 0; w < 4; ++w) {
+                if (wave == w) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = r16 * KP + kc + 4 * r;
+                        gs[idx] = (w == 0) ? gacc[r] : gs[idx] + gacc[r];
+                    }
+                }
+                __syncthreads();
+            }
+            Gp[(i64)blockIdx.x * KP * KP + threadIdx.x] = gs[threadIdx.x];
+        }
     }
 }
 
@@ -629,8 +660,10 @@ int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st)
 // `scratch`: nnls_scratch_elems(k) doubles (the inverse of G and the path selector for k > 32);
 // inverse_ready != 0: launch_gram_inverse(G, ...) has already been ordered before this call.
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
-                    int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st)
+                    int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st,
+                    double* gram_partials, int* gram_nblk)
 {
+    if (gram_nblk) *gram_nblk = 0;
     if (is_wide(k)) return launch_nnls_bpp_wide(X, Y, k, col_begin, col_end, R, G, fail_flag, iter_tag, scratch, num_cus, st);
     const int KPv = kp_of(k);
     const int gpb = 256 / KPv;
@@ -678,7 +711,10 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
     }
     int grid1 = grid;
     if (skip_if && grid1 > num_cus * 12) grid1 = num_cus * 12;      // 3 resident workgroups per CU x 4 trips when it does run
-    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid1, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if)));
+    // KP = 16, all columns, at most NNLS_GRAM_MAX workgroups: the launch also leaves the Gram partials of the solved factor
+    double* gp = nullptr;
+    if (gram_partials && gram_nblk && KPv == 16 && col_begin == 0 && grid1 == grid && grid <= NNLS_GRAM_MAX) { gp = gram_partials; *gram_nblk = grid; }
+    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid1, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if, gp)));
     SMK_HIP(hipGetLastError());
     return 0;
 }

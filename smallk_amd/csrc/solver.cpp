@@ -132,6 +132,7 @@ struct smk_solver {
     bool inv_pending[2] = {false, false};
     double *xscale[2] = {nullptr, nullptr}, *oscale[2] = {nullptr, nullptr};   // fp16 two-term products: row scales of W / H (from the Gram diagonal) and their inverses
     bool packed_fresh[2] = {false, false};   // the fused Gram kernel has already written packW / packH for the next product
+    int nnls_gram_nblk[2] = {0, 0};          // > 0: the NNLS launch of this side left that many Gram partials in gram_scratch (k <= 16)
     // HALS: the fused W sweep needs every workgroup resident; if its bounded polls ever expire (flag -3) the run is
     // repeated from the initial factors on the one-launch-per-column path, latched for the life of the handle
     double *W0c = nullptr, *H0c = nullptr;
@@ -898,6 +899,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     rc |= dev_alloc(&s->Gh_own, kk);
     {
         size_t gs = gram_scratch_elems(s->k, GRAM_BLOCKS);
+        if (s->KP == 16 && opts->algorithm == SMK_ALG_BPP) gs = std::max(gs, (size_t)NNLS_GRAM_MAX * 256 + 8);   // partials from the NNLS launch
         rc |= dev_alloc(&s->gram_scratch, gs);
         if (s->o.algorithm == SMK_ALG_RANK2) {
             const size_t e1 = rank2_gram_scratch_elems(std::max(s->m, s->n)), e2 = rank2_progress_scratch_elems(s->m, s->n);
@@ -1279,7 +1281,14 @@ static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, Partial
         s->inv_pending[side] = false;
         s->inv_done[side] = true;
     }
-    const int rc = launch_nnls_bpp(X, nullptr, s->k, c0, c1, R, G, s->fail_flag, s->iter, inv_scratch(s, side), s->inv_done[side] ? 1 : 0, g_cus, s->st);
+    // k in (8, 16], fp16 form, one GPU: the launch that solves ALL columns of a factor also leaves its Gram partials (the
+    // gram_x that follows in every BPP schedule then only reduces them)
+    static const bool fuse = [] { const char* e = getenv("SMK_NNLS_GRAM"); return !(e && e[0] == '0'); }();
+    const i64 N = side == 0 ? s->n : s->m;
+    const bool want = fuse && s->KP == 16 && s->nsplit == NSPLIT_F16X2 && !is_dist(s) && c0 == 0 && c1 == N && (X == s->H || X == s->Wt);
+    s->nnls_gram_nblk[side] = 0;
+    const int rc = launch_nnls_bpp(X, nullptr, s->k, c0, c1, R, G, s->fail_flag, s->iter, inv_scratch(s, side), s->inv_done[side] ? 1 : 0, g_cus, s->st,
+                                   want ? s->gram_scratch : nullptr, want ? &s->nnls_gram_nblk[side] : nullptr);
     // without the side stream (k <= 32, wide ranks) a first launch at k in (32, 128] computes the inverse itself, in stream order
     if (!rc && c1 > c0 && s->KP >= 64 && !is_wide(s->k)) s->inv_done[side] = true;
     return rc;
@@ -1487,8 +1496,15 @@ static int gram_factor(smk_solver* s, int side)
         if (s->nsplit == NSPLIT_F16X2) return launch_gram_scales(G, s->k, s->xscale[0], s->oscale[0], (double)s->a->ascale, s->st);
         return 0;
     }
-    if (s->nsplit == NSPLIT_F16X2)       // the reduce launch also derives the row scales of the operand packed next
+    if (s->nsplit == NSPLIT_F16X2) {     // the reduce launch also derives the row scales of the operand packed next
+        const int ns = side == 0 ? 1 : 0;            // the NNLS launch that solved THIS factor (side 1 solves W, side 0 solves H)
+        if (s->nnls_gram_nblk[ns] > 0) {
+            const int nb = s->nnls_gram_nblk[ns];
+            s->nnls_gram_nblk[ns] = 0;
+            return launch_gram_reduce(s->gram_scratch, nb, s->k, G, s->st, s->xscale[side], s->oscale[side], (double)s->a->ascale);
+        }
         return launch_gram(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->st, s->xscale[side], s->oscale[side], (double)s->a->ascale);
+    }
     // (round 3, again: leaving the partial sums to the pack launch -- every pack thread adding up its diagonal entry, workgroup 0
     // finishing the matrix -- costs 12 us where reduce + pack cost 9.5: C2 went from 119 to 130 us per iteration.  Not kept.)
     if (!s->a->sparse && s->o.algorithm != SMK_ALG_RANK2 && s->nsplit != NSPLIT_F64) {
