@@ -168,7 +168,9 @@ int smk_solver_iteration_count(const smk_solver* s);
 int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, const double* RHS, int64_t ldR,
                         double* X, int64_t ldX, double* Y, int64_t ldY);
 
-/* measurement: HIP events around the streaming-product launches (stream of the solver) */
+/* measurement: HIP events around the streaming-product launches (stream of the solver).  A pair of event records costs
+ * ~11 us of idle time around the launch, so passes over less than 1 GB are timed one launch in 16 and the totals scaled
+ * back up (SMK_TIMING_STRIDE overrides) */
 int smk_solver_enable_timing(smk_solver* s, int on);
 /* which: 0 = W'A pass, 1 = H*At pass (a pass that the multi-GPU schedule cuts into chunks counts as ONE launch per group of
  * 64 factor rows; its time is the sum of its chunk launches), 2 = the per-chunk collectives of a sharded run, timed on the

@@ -186,6 +186,12 @@ struct smk_solver {
     double* snap[2] = {nullptr, nullptr};
     // timing
     bool timing = false;
+    // a pair of event records around a launch costs ~11 us of idle time (5.7 us in front of the kernel, 5.8 behind it: measured
+    // on C2, where that was 23 of 119 us per iteration): passes shorter than ~0.2 ms are timed one launch in `timing_stride`
+    // and the totals scaled back up, so that measuring does not change what is measured
+    int timing_stride = 1;
+    unsigned pass_counter[2] = {0, 0};
+    bool pass_timed[2] = {false, false};     // this W'A / H*At pass (all of its launches, and the collectives behind it) is a timed sample
     struct TimedSpan { hipEvent_t e0, e1; int counts; };     // counts: this span completes one launch (a pass cut into chunks is ONE launch)
     std::vector<TimedSpan> ev[3];         // 0: W'A passes, 1: H*At passes, 2: the big collectives of a sharded run (on st2)
     double acc_ms[3] = {0, 0, 0};
@@ -1195,9 +1201,9 @@ static int comm_join(smk_solver* s, hipEvent_t ev)
 }
 
 // a collective on st2 bracketed by events when timing is on (slot 2 of smk_solver_kernel_time)
-static int timed_collective(smk_solver* s, const std::function<int()>& issue)
+static int timed_collective(smk_solver* s, int pass, const std::function<int()>& issue)
 {
-    if (!s->timing) return issue();
+    if (!s->timing || !s->pass_timed[pass]) return issue();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     SMK_HIP(hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
@@ -1295,11 +1301,17 @@ static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, Partial
 }
 
 // ---- building blocks -----------------------------------------------------------------------
+// every pass starts here: is it one of the timed samples?
+static inline void begin_pass(smk_solver* s, int which)
+{
+    s->pass_timed[which] = s->timing && (s->timing_stride <= 1 || (s->pass_counter[which]++ % (unsigned)s->timing_stride) == 0);
+}
+
 // one launch of the streaming product, bracketed by events when timing is on; `counts`: this launch completes a pass
 static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp,
                          double* P, int counts = 1)
 {
-    if (s->timing) {
+    if (s->timing && s->pass_timed[which]) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         SMK_HIP(hipEventCreate(&e0));
         if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
@@ -1318,7 +1330,8 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
                       const double* X, int ldx, double* P)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (s->timing) {
+    const bool timed = s->timing && s->pass_timed[which];
+    if (timed) {
         SMK_HIP(hipEventCreate(&e0));
         if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
         (void)hipEventRecord(e0, s->st);
@@ -1327,7 +1340,7 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
     const BlockedCsc& blk = (which == 0) ? s->a->bA : s->a->bAt;
     if (ldx == 2 && blk.nb > 1) rc = launch_spmm_blocked2(blk, X, P, which == 0 ? s->pl1.ncols_pad : s->pl2.ncols_pad, s->st);
     else rc = launch_spmm_gather(colptr, rowidx, val, ncols, s->a->nnz, X, ldx, s->k, P, s->kpp, s->st);
-    if (s->timing) {
+    if (timed) {
         if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         (void)hipEventRecord(e1, s->st);
         s->ev[which].push_back({e0, e1, 1});
@@ -1340,6 +1353,7 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
 // taken chunk by chunk down the contraction, each launch adding to P1, as soon as its chunk of the operand has landed.
 static int prod1_sharded(smk_solver* s)
 {
+    begin_pass(s, 0);
     const int storage = s->a->storage;
     const size_t es = (size_t)elem_size(storage);
     int rc = 0;
@@ -1353,7 +1367,7 @@ static int prod1_sharded(smk_solver* s)
     for (int j = 0; j < s->nchunk; ++j) {
         i64 r0, r1;
         chunk_rows(s, j, &r0, &r1);
-        rc = timed_collective(s, [&] {
+        rc = timed_collective(s, 0, [&] {
             for (int g = 0; g < s->ng; ++g) {
                 const size_t per = packed_row_offset(storage, s->pg1[g].kg, s->nsplit, s->blk);          // bytes per block
                 unsigned char* base = (unsigned char*)s->packW + s->pg1[g].pack_offset + packed_row_offset(storage, s->pg1[g].kg, s->nsplit, r0);
@@ -1389,6 +1403,8 @@ static int prod1_sharded(smk_solver* s)
 
 static int prod1(smk_solver* s)
 {
+    if (s->w_sharded) return prod1_sharded(s);
+    begin_pass(s, 0);
     if (s->a->sparse) {
         if (s->Wc) {        // RANK2: gather from the compact copy of W (16 B per row)
             if (!s->wc_valid) { const int crc = launch_rank2_compact(s->Wt, s->Wc, s->m, s->st); if (crc) return crc; s->wc_valid = true; }
@@ -1396,7 +1412,6 @@ static int prod1(smk_solver* s)
         }
         return timed_spmm(s, 0, s->a->colptr, s->a->rowidx, s->a->val, s->n, s->Wt, s->KP, s->P1);
     }
-    if (s->w_sharded) return prod1_sharded(s);
     int rc = 0;
     const bool f64 = s->nsplit == NSPLIT_F64;                 // the accurate form reads the fp64 factor itself
     if (!s->packed_fresh[0] && !f64) rc = launch_pack(s->Wt, s->k, s->m, s->a->storage, s->nsplit, s->packW, s->st, s->xscale[0]);
@@ -1415,6 +1430,7 @@ static int prod1(smk_solver* s)
 // travels on st2 while the product streams chunk j + 1; consumers call wait_r2().
 static int prod2(smk_solver* s)
 {
+    begin_pass(s, 1);
     int rc = 0;
     const PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
     if (s->a->sparse) {
@@ -1428,7 +1444,7 @@ static int prod2(smk_solver* s)
         if (!s->comm) return dist_allreduce_cb(s, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, 0);
         rc = comm_fork(s, s->ev_c[0]);
         if (rc) return rc;
-        rc = timed_collective(s, [&] { return comm_allreduce(s->comm, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, s->red_f64 ? 1 : 0, s->st2); });
+        rc = timed_collective(s, 1, [&] { return comm_allreduce(s->comm, s->R2red, (i64)s->pl2.ncols_pad * s->kpp, s->red_f64 ? 1 : 0, s->st2); });
         if (rc) return rc;
         return comm_join(s, s->ev_r[0]);
     }
@@ -1465,7 +1481,7 @@ static int prod2(smk_solver* s)
         // off the main stream: the row splits of the chunk summed (and rounded to the wire type), then its exchange
         if (!s->r2_alias) { rc = launch_reduce_partials(pv, s->k, r0, r1 - r0, s->R2red, s->red_f64 ? 1 : 0, s->st2); if (rc) return rc; }
         unsigned char* base = (unsigned char*)s->R2red + (size_t)r0 * s->kpp * rb;
-        rc = timed_collective(s, [&] {
+        rc = timed_collective(s, 1, [&] {
             if (s->w_sharded)       // every rank receives the sum of ITS block, next to its other blocks
                 return comm_reduce_scatter_to(s->comm, base, (unsigned char*)s->R2own + (size_t)j * s->blk * s->kpp * rb, s->blk * s->kpp,
                                               s->red_f64 ? 1 : 0, s->st2);
@@ -1650,8 +1666,9 @@ static int resolve_events(smk_solver* s)
         for (auto& e : s->ev[w]) {
             float ms = 0.f;
             SMK_HIP(hipEventElapsedTime(&ms, e.e0, e.e1));
-            s->acc_ms[w] += ms;
-            s->launches[w] += e.counts;
+            const int scale = s->timing_stride;                        // a sampled pass stands for `stride` passes
+            s->acc_ms[w] += (double)ms * scale;
+            s->launches[w] += e.counts * scale;
             (void)hipEventDestroy(e.e0);
             (void)hipEventDestroy(e.e1);
         }
@@ -2160,6 +2177,14 @@ int smk_solver_enable_timing(smk_solver* s, int on)
 {
     if (!s) return SMK_BAD_PARAM;
     s->timing = on != 0;
+    // one pass in 16 under 1 GB of streamed matrix per pass, one in 8 under 32 GB (a C4 shard in chunks: 8 launches and 8
+    // collectives per iteration would carry ~0.1 ms of event gaps in 3.4 ms), every pass above
+    {
+        const double bytes = (double)s->m * (double)s->n * (s->a->sparse ? 12.0 : (double)elem_size(s->a->storage));
+        s->timing_stride = bytes < (double)((i64)1 << 30) ? 16 : bytes < 32.0 * (double)((i64)1 << 30) ? 8 : 1;
+    }
+    if (const char* e = getenv("SMK_TIMING_STRIDE")) s->timing_stride = std::max(1, atoi(e));
+    s->pass_counter[0] = s->pass_counter[1] = 0;
     s->acc_ms[0] = s->acc_ms[1] = s->acc_ms[2] = 0.0;
     s->launches[0] = s->launches[1] = s->launches[2] = 0;
     return SMK_OK;

@@ -245,6 +245,7 @@ def test_rccl_collectives_forced_at_world_one(gpu, monkeypatch, alg, storage, qu
     from smallk_amd import Comm, NmfSolver, DenseMatrix, make_options
     monkeypatch.setenv("SMK_COMM_FORCE", "1")
     monkeypatch.setenv("SMK_COMM_CHUNKS", str(chunks))
+    monkeypatch.setenv("SMK_TIMING_STRIDE", "1")        # count every pass (short passes are otherwise timed one in 16)
     m, n, iters = 2000, 901, 6
     A = oracle.fill_uniform(m, n, 42, quant=quant)
     W0 = oracle.fill_uniform(m, k, 43)

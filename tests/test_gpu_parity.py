@@ -136,7 +136,8 @@ def test_stopping_rule_matches_oracle(gpu, alg, tol):
     assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL
 
 
-def test_solver_object_iterate_progress(gpu):
+def test_solver_object_iterate_progress(gpu, monkeypatch):
+    monkeypatch.setenv("SMK_TIMING_STRIDE", "1")        # every pass is timed (short passes are otherwise sampled one in 16)
     m, n, k = 512, 256, 8
     A = oracle.fill_uniform(m, n, 42)
     W0 = oracle.fill_uniform(m, k, 43)
@@ -156,6 +157,13 @@ def test_solver_object_iterate_progress(gpu):
     assert c0 == 7 and c1 == 8 and ms0 > 0 and ms1 > 0       # pass 2 also runs once in Init
     b, f = s.kernel_work(0)
     assert b == m * n * 4 and f == 2.0 * m * n * k
+    # the default for passes this short: one in 16 carries events, the totals are scaled back up
+    monkeypatch.delenv("SMK_TIMING_STRIDE")
+    s.enable_timing(True)
+    s.iterate(32)
+    assert s.sync() == 0
+    ms0, c0 = s.kernel_time(0)
+    assert c0 == 32 and ms0 > 0
 
 
 def test_failure_and_bad_params(gpu):
