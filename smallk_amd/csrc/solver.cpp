@@ -1071,7 +1071,10 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
         const char* e = getenv("SMK_COMM_F64");
         s->red_f64 = !(e && atoi(e) == 0);
     }
-    s->w_sharded = s->o.algorithm == SMK_ALG_BPP && !s->a->sparse && s->nsplit != NSPLIT_F64 && (s->world > 1 || comm_forced());
+    // BPP and MU update the rows of W independently of each other: every rank takes its own blocks (HALS normalises column by
+    // column over ALL rows inside its sweep and keeps the replicated update)
+    s->w_sharded = (s->o.algorithm == SMK_ALG_BPP || s->o.algorithm == SMK_ALG_MU) && !s->a->sparse && s->nsplit != NSPLIT_F64 &&
+                   (s->world > 1 || comm_forced());
     const size_t bytes = comm_bytes(s);
     if (hipMalloc(&s->comm_ws, bytes) != hipSuccess) { s->comm = nullptr; s->w_sharded = false; set_error("hipMalloc(comm workspace)"); return SMK_DEVICE_ERROR; }
     SMK_HIP(hipMemsetAsync(s->comm_ws, 0, bytes, s->st));
@@ -1595,7 +1598,12 @@ static int solver_iteration(smk_solver* s)
             rc = gram_h(s);   if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
             rc = wait_r2(s);  if (rc) return rc;
-            rc = launch_mu_update(s->Wt, s->k, s->m, r2, s->Gh, s->st); if (rc) return rc;
+            if (s->w_sharded) {       // own blocks only (back to back in Wown, their rows of the summed (AH')' in R2own)
+                if (s->n_own > 0) { rc = launch_mu_update(s->Wown, s->k, s->n_own, view_own(s), s->Gh, s->st); if (rc) return rc; }
+                s->w_full = false;
+            } else {
+                rc = launch_mu_update(s->Wt, s->k, s->m, r2, s->Gh, s->st); if (rc) return rc;
+            }
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
             break;

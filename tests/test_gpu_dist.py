@@ -234,7 +234,7 @@ def test_rccl_world_of_one_native(gpu):
 
 @pytest.mark.parametrize("alg,storage,quant,k,chunks", [("BPP", "f32", 0, 16, 3), ("BPP", "f32", 0, 64, 2), ("BPP", "bf16", 1, 40, 4),
                                                          ("BPP", "f32", 0, 140, 2), ("HALS", "bf16", 1, 32, 3), ("MU", "f32", 0, 12, 2),
-                                                         ("BPP", "f32", 0, 16, 1)])
+                                                         ("MU", "bf16", 1, 70, 3), ("BPP", "f32", 0, 16, 1)])
 def test_rccl_collectives_forced_at_world_one(gpu, monkeypatch, alg, storage, quant, k, chunks):
     """SMK_COMM_FORCE=1: a world of ONE rank runs the whole multi-GPU schedule with the real nccl* calls -- the H*At
     pass in row chunks with ncclReduceScatter (BPP) / ncclAllReduce (MU, HALS) of chunk j on the second stream beside
