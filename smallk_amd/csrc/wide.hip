@@ -213,7 +213,15 @@ __global__ __launch_bounds__(256) void grad_pg_wide_kernel(const double* __restr
         case 6: { constexpr int V = 6; CALL; } break;              \
         case 7: { constexpr int V = 7; CALL; } break;              \
         case 8: { constexpr int V = 8; CALL; } break;              \
-        default: set_error("wide kernels: KP must be 192 .. 512"); return -100; \
+        case 9: { constexpr int V = 9; CALL; } break;              \
+        case 10: { constexpr int V = 10; CALL; } break;            \
+        case 11: { constexpr int V = 11; CALL; } break;            \
+        case 12: { constexpr int V = 12; CALL; } break;            \
+        case 13: { constexpr int V = 13; CALL; } break;            \
+        case 14: { constexpr int V = 14; CALL; } break;            \
+        case 15: { constexpr int V = 15; CALL; } break;            \
+        case 16: { constexpr int V = 16; CALL; } break;            \
+        default: set_error("wide kernels: KP must be 192 .. 1024"); return -100; \
     }
 
 int launch_mu_update_wide(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st)
@@ -399,7 +407,7 @@ int launch_spmm_gather_wide(const i64* colptr, const unsigned* rowidx, const dou
 // State machine as in nnls_bpp_kernel: PBAR = 3, backup rule on the largest index, 5 k pivots at most, 1e-12 zeroing
 // after every exchange.
 // --------------------------------------------------------------------------------------------------------------------
-constexpr int WIDE_MAX = 512;
+constexpr int WIDE_MAX = MAX_K;
 constexpr int WIDE_TL = 128;                       // largest block kept in LDS (128 KiB)
 
 // in-place Cholesky of the column-major lower triangle Mp (leading dimension t), then L z = b, L' x = z on zs (LDS).
@@ -515,11 +523,18 @@ __global__ __launch_bounds__(256) void nnls_wide_kernel(double* __restrict__ X, 
                                                         int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
                                                         double* __restrict__ panels, int tl_cap, int skip_if_invertible)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds_panel[];          // tl_cap * tl_cap doubles
+    extern __shared__ __attribute__((aligned(16))) double lds_panel[];          // tl_cap * tl_cap doubles, then the vectors
     if (skip_if_invertible && Ginv != nullptr && *status != 0) return;          // the wave kernel took this launch
-    __shared__ double xs[WIDE_MAX], ys[WIDE_MAX], rs[WIDE_MAX], zs[WIDE_MAX], vs[WIDE_MAX];
-    __shared__ int idx[WIDE_MAX];
-    __shared__ unsigned char pas[WIDE_MAX], nonopt[WIDE_MAX], infeas[WIDE_MAX];
+    // [panel][xs ys rs zs vs: 5 x KP doubles][idx: KP ints][pas nonopt infeas: 3 x KP bytes] (nnls_wide_lds_bytes)
+    double* const xs = lds_panel + (size_t)tl_cap * tl_cap;
+    double* const ys = xs + KP;
+    double* const rs = ys + KP;
+    double* const zs = rs + KP;
+    double* const vs = zs + KP;
+    int* const idx = (int*)(vs + KP);
+    unsigned char* const pas = (unsigned char*)(idx + KP);
+    unsigned char* const nonopt = pas + KP;
+    unsigned char* const infeas = nonopt + KP;
     __shared__ int s_t, s_ng, s_bad, s_last, s_comp;
     double* gpanel = panels + (size_t)blockIdx.x * KP * KP;
     const int tid = threadIdx.x;
@@ -910,10 +925,18 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
 }
 
 // workgroups per CU: the LDS panel only has to hold the smaller of a passive set and its complement, <= k / 2 rows
-static inline int nnls_wide_tl(int k) { const int h = (k + 1) / 2; return h < WIDE_TL ? h : WIDE_TL; }
+static inline int nnls_wide_vec_bytes(int k) { return kp_of(k) * (5 * 8 + 4 + 3); }
+static inline int nnls_wide_tl(int k)
+{
+    const int h = (k + 1) / 2;
+    int cap = WIDE_TL;                                                       // 128 rows = 128 KiB beside <= 24 KiB of vectors
+    while (cap * cap * 8 + nnls_wide_vec_bytes(k) > 156 * 1024) cap -= 8;    // k > 512: 112 rows
+    return h < cap ? h : cap;
+}
+static inline int nnls_wide_lds_bytes(int k) { return nnls_wide_tl(k) * nnls_wide_tl(k) * 8 + nnls_wide_vec_bytes(k); }
 static inline int nnls_wide_wgs_per_cu(int k)
 {
-    const int lds = nnls_wide_tl(k) * nnls_wide_tl(k) * 8 + 26 * 1024;       // panel + the static vectors
+    const int lds = nnls_wide_lds_bytes(k) + 1024;
     const int w = (160 * 1024) / lds;
     return w < 1 ? 1 : (w > 2 ? 2 : w);
 }
@@ -942,11 +965,10 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
         inv_cols_wide_kernel<<<k, 256, 0, st>>>(L, k, KP, Ginv, status);
         SMK_HIP(hipGetLastError());
     }
-    const int lds = tl * tl * (int)sizeof(double);
+    const int lds = nnls_wide_lds_bytes(k);
     static bool attr_set = false;
     if (!attr_set) {
-        SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    WIDE_TL * WIDE_TL * (int)sizeof(double)));
+        SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set = true;
     }
     // k <= 256 and G invertible: one wave per column, no workgroup barriers; otherwise (and as the fallback that

@@ -45,7 +45,7 @@ def test_flatclust_rejects_mu_and_bad_rank2(gpu):
 
 
 @pytest.mark.parametrize("sparse", [False, True])
-@pytest.mark.parametrize("k", [3, 6, 20, 150, 300])         # the flat step of HierNMF2 runs this with k = number of clusters (<= 512)
+@pytest.mark.parametrize("k", [3, 6, 20, 150, 300, 700])    # the flat step of HierNMF2 runs this with k = number of clusters (<= 1024)
 def test_nnls_hals_matches_oracle(gpu, sparse, k):
     import oracle
     from oracle import flatclust as of

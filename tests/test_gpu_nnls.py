@@ -114,7 +114,19 @@ def test_k_above_128_every_passive_density(gpu, k, fill):
     compare(gpu, G, B, np.asfortranarray(X0))
 
 
-@pytest.mark.parametrize("k", [4, 16, 40, 64, 100, 130, 260])
+@pytest.mark.parametrize("k,fill", [(513, 0.3), (600, 0.0), (600, 0.7), (800, 1.0), (1000, 0.4), (1024, 0.6)])
+def test_k_above_512(gpu, k, fill):
+    """k in (512, 1024]: the workgroup-per-column kernel with blocks of up to k / 2 rows (LDS up to 112 rows, else the
+    workgroup's panel of global scratch).  Few columns: the oracle's scalar Cholesky is what takes the time."""
+    rng = np.random.default_rng(int(k * 10 + fill * 100))
+    ncols = 12
+    G, B = problem(rng, 3 * k + 5, k, ncols, shift=False)
+    B -= np.quantile(B, 1.0 - fill) if 0.0 < fill < 1.0 else (np.abs(B).max() * 2 if fill == 0.0 else 0.0)
+    X0 = rng.random((k, ncols)) * (rng.random((k, ncols)) < fill)
+    compare(gpu, G, B, np.asfortranarray(X0))
+
+
+@pytest.mark.parametrize("k", [4, 16, 40, 64, 100, 130, 260, 700])
 def test_not_positive_definite_is_failure(gpu, k):
     """Rank-one Gram matrix: the passive block is not SPD -> false (normal_eq.hpp:35-50)."""
     G = np.ones((k, k), order="F")

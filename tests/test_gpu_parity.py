@@ -174,7 +174,7 @@ def test_failure_and_bad_params(gpu):
     assert gpu.nmf(A, np.ones((12, 3)), np.ones((3, 6)), "MU", tol=2.0).result == L.BAD_PARAM
     assert gpu.nmf(A[:, :2], np.ones((12, 3)), np.ones((3, 2)), "MU").result == L.BAD_PARAM   # k > n
     with pytest.raises(L.SmallkError):
-        gpu.nmf(np.ones((600, 520)), np.ones((600, 513)), np.ones((513, 520)), "MU")          # k > 512
+        gpu.nmf(np.ones((1100, 1030)), np.ones((1100, 1025)), np.ones((1025, 1030)), "MU")   # k > 1024
 
 
 @pytest.mark.parametrize("alg,storage,quant,m,n,k,iters", [
@@ -337,15 +337,33 @@ def test_rank_above_128(gpu, alg, m, n, k, storage, quant):
         assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
 
 
-def test_rank_above_512_is_refused_loudly(gpu):
-    """k > 512 is valid for the reference and not built on the device path: SMK_UNSUPPORTED with a message,
+@pytest.mark.parametrize("alg,m,n,k,iters", [("MU", 1100, 1030, 1000, 3), ("HALS", 1100, 1030, 1000, 2), ("MU", 700, 640, 577, 3),
+                                             ("HALS", 700, 640, 577, 3), ("BPP", 640, 580, 513, 2), ("BPP", 700, 660, 640, 1), ("BPP", 1040, 1030, 1024, 1)])
+def test_rank_above_512(gpu, alg, m, n, k, iters):
+    """k in (512, 1024]: the same general path with up to 16 values per lane and up to 16 passes over A per product.  The
+    block-pivoting cases are short (the oracle's scalar Cholesky is what takes the time); the isolated NNLS cases at these
+    ranks are in test_gpu_nnls.py."""
+    import oracle
+    import make_golden as mg
+    A = mg.make_A(m, n, k, True, 0)
+    W0, H0 = oracle.fill_uniform(m, k, 45), oracle.fill_uniform(k, n, 46)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters)
+    r = gpu.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters)
+    assert r.result == ref.result and r.iteration_count == ref.iteration_count
+    if ref.result == 0:
+        assert np.linalg.norm(r.W - ref.W) / np.linalg.norm(ref.W) < 1e-4
+        assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
+
+
+def test_rank_above_1024_is_refused_loudly(gpu):
+    """k > 1024 is valid for the reference and not built on the device path: SMK_UNSUPPORTED with a message,
     never a silent fallback."""
     import oracle
     from smallk_amd import _lib as L
-    A = oracle.fill_uniform(700, 600, 1)
+    A = oracle.fill_uniform(1100, 1030, 1)
     with pytest.raises(L.SmallkError) as e:
-        gpu.nmf(A, oracle.fill_uniform(700, 513, 2), oracle.fill_uniform(513, 600, 3), "MU", min_iter=1, max_iter=1)
-    assert e.value.code == L.UNSUPPORTED and "k <= 512" in str(e.value)
+        gpu.nmf(A, oracle.fill_uniform(1100, 1025, 2), oracle.fill_uniform(1025, 1030, 3), "MU", min_iter=1, max_iter=1)
+    assert e.value.code == L.UNSUPPORTED and "k <= 1024" in str(e.value)
 
 
 @pytest.mark.parametrize("alg", ["MU", "HALS", "BPP"])
