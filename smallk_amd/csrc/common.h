@@ -146,7 +146,7 @@ int hals_w_wide_blocks(i64 M);
 int launch_hals_w_update_wide(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, hipStream_t st);
 int launch_spmm_gather_wide(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X, int k,
                             double* P, int kpp, hipStream_t st);
-size_t nnls_wide_scratch_elems(int k, int num_cus);
+size_t nnls_wide_scratch_elems(int k, int num_cus, i64 ncols);   // ncols: the most columns one launch will solve
 int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G, int* fail_flag,
                          int iter_tag, double* scratch, int num_cus, hipStream_t st);
 

@@ -939,7 +939,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     }
     if (opts->algorithm == SMK_ALG_BPP) {
         // k <= 128: two (inverse + selector) halves; above: one Cholesky panel per resident workgroup (wide.hip)
-        rc |= dev_alloc(&s->nnls_scratch, is_wide(s->k) ? nnls_wide_scratch_elems(s->k, g_cus) : 2 * nnls_scratch_elems(s->k));
+        rc |= dev_alloc(&s->nnls_scratch, is_wide(s->k) ? nnls_wide_scratch_elems(s->k, g_cus, std::max(s->m, s->n)) : 2 * nnls_scratch_elems(s->k));
         if (s->KP >= 64 && !is_wide(s->k)) {
             if (hipStreamCreateWithFlags(&s->st_inv, hipStreamNonBlocking) != hipSuccess) rc |= 1;
             for (int i = 0; i < 2 && !rc; ++i) {
@@ -2118,7 +2118,7 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
     rc |= dev_alloc(&dr, hr.size());
     rc |= dev_alloc(&dx, hx.size());
     rc |= dev_alloc(&dy, hx.size());
-    rc |= dev_alloc(&dscratch, is_wide(k) ? nnls_wide_scratch_elems(k, g_cus) : nnls_scratch_elems(k));
+    rc |= dev_alloc(&dscratch, is_wide(k) ? nnls_wide_scratch_elems(k, g_cus, ncols) : nnls_scratch_elems(k));
     rc |= dev_alloc(&dflag, (size_t)1);
     struct Free { std::vector<void*> p; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } guard{{dg, dr, dx, dy, dscratch, dflag}};
     if (rc) return SMK_DEVICE_ERROR;

@@ -2,12 +2,12 @@
 //
 // The kernels of kernels.hip / nnls.hip keep a column's k values in a few lanes and the k x k Gram matrix in LDS or in
 // registers; neither survives k > 128 (512 KB of Gram matrix at k = 256).  This file is the general path: KP = k rounded
-// up to a multiple of 64 (up to 512), one WAVE per column with V = KP / 64 values per lane (element e of a column lives
+// up to a multiple of 64 (up to 1024), one WAVE per column with V = KP / 64 values per lane (element e of a column lives
 // in lane e % 64, slot e / 64, so every load of a column or of a Gram row is one coalesced 512-byte line per slot), the
-// Gram matrix read through the caches, and a workgroup per column for block principal pivoting (Cholesky of the passive
-// block in a global scratch panel).  Same arithmetic as the narrow kernels (reference file:line cited there); built for
-// correctness at any rank, not for speed -- the streaming products, which dominate, are the same kernels at every k
-// (one pass over A per 64 factor rows).
+// Gram matrix read through the caches.  Block principal pivoting: k <= 256 a wave per column with the block of an exchange
+// as 16 x 16 tiles in LDS (blocked Cholesky on the f64 matrix cores), above that a workgroup per column (Cholesky of the
+// passive block in LDS or in a global scratch panel).  Same arithmetic as the narrow kernels (reference file:line cited
+// there); the streaming products are the same kernels at every k (one pass over A per 64 factor rows).
 #include "devutil.h"
 
 #include <cfloat>
@@ -397,7 +397,7 @@ int launch_spmm_gather_wide(const i64* colptr, const unsigned* rowidx, const dou
 // NNLS by block principal pivoting (nnls.hpp:144-244, src/nnls.cpp:18-74, normal_eq.hpp:27-54), one workgroup per column.
 //
 // As for k in (32, 128] (nnls.hip) the common work is moved into the inverse of the Gram matrix: Ginv = G^-1 once per
-// launch (chol_wide_kernel + inv_cols_wide_kernel), v = Ginv r per column, and a passive set F is solved either
+// launch (launch_chol_wide + inv_cols_wide_kernel), V = R Ginv for all columns (ginv_rhs_wide_kernel), and a passive set F is solved either
 // directly, G[F,F] x_F = r_F, y = G[:,F] x_F - r, or through its complement Z: y_Z = -(Ginv[Z,Z])^-1 v_Z,
 // x = v + Ginv[:,Z] y_Z -- whichever block is smaller.  The block (t = min(|F|, |Z|) rows) is gathered into a panel
 // (LDS when t <= 128, else this workgroup's panel of global scratch; the code is the same through generic pointers),
@@ -456,39 +456,133 @@ __device__ __forceinline__ bool chol_solve_panel(double* Mp, int t, double* zs, 
     return false;
 }
 
-// L = chol(G) (lower, column-major, leading dimension KP) by one workgroup; status = 1 when every pivot exceeds 1e-9 of
-// its diagonal entry (the guard of gram_inverse_kernel), else 0
-__global__ __launch_bounds__(1024) void chol_wide_kernel(const double* __restrict__ G, int k, int KP, double* __restrict__ L,
+// L = chol(G) (lower, column-major, leading dimension KP) as a sequence of launches, right-looking by panels of CH_NB columns
+// (one workgroup walking the whole matrix through L2 took 1.1 ms at k = 192 and 15 ms at k = 512 -- half of a warm
+// block-pivoting iteration; this takes 0.2 / 0.7 ms).  Panel J: `chol_panel_kernel` factors the CH_NB x CH_NB diagonal block
+// in LDS (every workgroup for itself, workgroup 0 stores it) and solves its 256 rows of the panel against it;
+// `chol_trail_kernel` subtracts the panel's outer product from the trailing lower triangle in 64 x 64 tiles.  *status stays
+// non-zero when every pivot exceeds 1e-9 of its diagonal entry (the guard of gram_inverse_kernel); a smaller pivot clears it,
+// which every later launch and the block-pivoting kernels read.
+constexpr int CH_NB = 32;
+
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ L, const double* __restrict__ G, int k, int KP, int J,
                                                          int* __restrict__ status)
 {
-    __shared__ int bad;
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int q = tid; q < k * k; q += nt) {
-        const int i = q % k, l = q / k;
-        if (i >= l) L[(size_t)l * KP + i] = G[(size_t)l * KP + i];
+    __shared__ double sD[CH_NB][CH_NB + 1];                     // sD[c][r] = block entry (r, c), r >= c
+    __shared__ double sdiag[CH_NB], sguard[CH_NB];
+    __shared__ int s_bad;
+    if (*status == 0) return;
+    const int tid = threadIdx.x;
+    const int nb = (k - J < CH_NB) ? (k - J) : CH_NB;
+    for (int q = tid; q < CH_NB * CH_NB; q += 256) {
+        const int r = q % CH_NB, c = q / CH_NB;
+        sD[c][r] = (r < nb && c < nb && r >= c) ? L[(size_t)(J + c) * KP + J + r] : (r == c ? 1.0 : 0.0);
     }
-    if (tid == 0) bad = 0;
+    if (tid == 0) s_bad = 0;
+    if (tid < nb) sguard[tid] = 1.0e-9 * G[(size_t)(J + tid) * KP + J + tid];
     __syncthreads();
-    for (int j = 0; j < k; ++j) {
-        const double piv = L[(size_t)j * KP + j];
-        if (!(piv > 1.0e-9 * G[(size_t)j * KP + j])) {
-            if (tid == 0) bad = 1;
+    const int r = tid % CH_NB, lq = tid / CH_NB;                // 32 rows x 8 column groups
+    for (int j = 0; j < nb; ++j) {
+        __syncthreads();                                        // the updates of step j - 1 have landed
+        const double piv = sD[j][j];
+        if (!(piv > sguard[j])) {                               // uniform: every thread reads the same entries
+            if (tid == 0) s_bad = 1;
             break;
         }
-        const double d = sqrt(piv), id = 1.0 / d;
-        __syncthreads();
-        for (int i = j + 1 + tid; i < k; i += nt) L[(size_t)j * KP + i] *= id;
-        if (tid == 0) L[(size_t)j * KP + j] = d;
-        __syncthreads();
-        const int w = k - j - 1;
-        for (int q = tid; q < w * w; q += nt) {
-            const int i = j + 1 + q % w, l = j + 1 + q / w;
-            if (i >= l) L[(size_t)l * KP + i] -= L[(size_t)j * KP + i] * L[(size_t)j * KP + l];
+        double id = __builtin_amdgcn_rsq(piv);                  // 1 / sqrt(piv): hardware estimate + two Newton steps
+        id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
+        id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
+        if (lq == 0) {
+            if (r > j) sD[j][r] *= id;                          // the diagonal entry itself stays the pivot until the end
+            else if (r == j) sdiag[j] = id;
         }
         __syncthreads();
+        const double mrj = sD[j][r];
+        for (int l = j + 1 + lq; l <= r; l += 8) sD[l][r] -= mrj * sD[j][l];
     }
     __syncthreads();
-    if (tid == 0) *status = bad ? 0 : 1;
+    if (!s_bad && tid < nb) sD[tid][tid] *= sdiag[tid];         // sqrt(pivot); sdiag keeps 1 / L_jj for the rows below
+    __syncthreads();
+    if (s_bad) {
+        if (blockIdx.x == 0 && tid == 0) *status = 0;
+        return;
+    }
+    if (blockIdx.x == 0)
+        for (int q = tid; q < nb * nb; q += 256) {
+            const int rr = q % nb, c = q / nb;
+            if (rr >= c) L[(size_t)(J + c) * KP + J + rr] = sD[c][rr];
+        }
+    // this thread's row of the panel: x <- x L_JJ^-T
+    const int i = J + CH_NB + blockIdx.x * 256 + tid;
+    if (i >= k || nb < CH_NB) return;
+    double x[CH_NB];
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) x[c] = L[(size_t)(J + c) * KP + i];
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) {
+        double a = x[c];
+#pragma unroll
+        for (int q = 0; q < c; ++q) a = __builtin_fma(-x[q], sD[q][c], a);
+        x[c] = a * sdiag[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) L[(size_t)(J + c) * KP + i] = x[c];
+}
+
+// trailing update behind panel J: C(i, l) -= sum_c L(i, J + c) L(l, J + c) for i >= l >= J + CH_NB, one 64 x 64 tile per
+// workgroup (tiles of the lower triangle only), a 4 x 4 block per thread
+__global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ L, int k, int KP, int J, const int* __restrict__ status)
+{
+    __shared__ double sA[CH_NB][64 + 1], sB[CH_NB][64 + 1];
+    if (*status == 0) return;
+    const int base = J + CH_NB;
+    int ti = 0, b = blockIdx.x;
+    while (b > ti) { b -= ti + 1; ++ti; }                       // tile row ti, tile column b <= ti
+    const int i0 = base + 64 * ti, l0 = base + 64 * b;
+    const int tid = threadIdx.x;
+    for (int q = tid; q < CH_NB * 64; q += 256) {
+        const int rr = q % 64, c = q / 64;
+        sA[c][rr] = (i0 + rr < k) ? L[(size_t)(J + c) * KP + i0 + rr] : 0.0;
+        sB[c][rr] = (l0 + rr < k) ? L[(size_t)(J + c) * KP + l0 + rr] : 0.0;
+    }
+    __syncthreads();
+    const int tr = tid % 16, tc = tid / 16;                     // rows tr + 16 u, columns tc + 16 v
+    double acc[4][4] = {};
+#pragma unroll 8
+    for (int c = 0; c < CH_NB; ++c) {
+        double a[4], bb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = sA[c][tr + 16 * u]; bb[u] = sB[c][tc + 16 * u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_fma(a[u], bb[v], acc[u][v]);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + tr + 16 * u, l = l0 + tc + 16 * v;
+            if (i < k && l <= i) L[(size_t)l * KP + i] -= acc[u][v];
+        }
+}
+
+// L = chol(G) on the stream: copy, then two launches per panel
+static int launch_chol_wide(const double* G, int k, int KP, double* L, int* status, hipStream_t st)
+{
+    SMK_HIP(hipMemcpyAsync(L, G, (size_t)KP * KP * sizeof(double), hipMemcpyDeviceToDevice, st));
+    SMK_HIP(hipMemsetAsync(status, 1, sizeof(int), st));         // any non-zero value reads as "invertible"
+    for (int J = 0; J < k; J += CH_NB) {
+        const int rest = k - J - CH_NB;                         // rows below the diagonal block
+        const int g1 = rest > 0 ? (rest + 255) / 256 : 1;
+        chol_panel_kernel<<<g1, 256, 0, st>>>(L, G, k, KP, J, status);
+        if (rest > 0) {
+            const int nt = (rest + 63) / 64;
+            chol_trail_kernel<<<nt * (nt + 1) / 2, 256, 0, st>>>(L, k, KP, J, status);
+        }
+    }
+    SMK_HIP(hipGetLastError());
+    return 0;
 }
 
 // column c of Ginv = G^-1 from L: L z = e_c, L' x = z; one workgroup per column
@@ -517,11 +611,55 @@ __global__ __launch_bounds__(256) void inv_cols_wide_kernel(const double* __rest
     for (int e = tid; e < KP; e += 256) Ginv[(size_t)c * KP + e] = (e < k) ? z[e] : 0.0;
 }
 
+// V = R Ginv for all the columns of a launch at once (v = Ginv r of every column, Ginv symmetric): the block-pivoting kernels
+// used to form it per column as a matrix-vector product, streaming the k x k inverse from L2 for every column -- a quarter of
+// a warm iteration at k = 192.  One workgroup per 64 columns x 64 entries, chunks of 16 along c staged in LDS, f64 matrix
+// cores (wave w: columns 16 w .. 16 w + 15, four 16 x 16 tiles).  V[(col - col_begin) * KP + e].
+__global__ __launch_bounds__(256) void ginv_rhs_wide_kernel(PartialView R, const double* __restrict__ Ginv, const int* __restrict__ status,
+                                                            int k, int KP, i64 col_begin, i64 N, double* __restrict__ V)
+{
+    __shared__ double sR[16][64 + 1], sG[16][64 + 1];
+    if (*status == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const i64 c0 = col_begin + (i64)blockIdx.x * 64;
+    const int e0 = blockIdx.y * 64;
+    f64x4_t acc[4] = {};
+    for (int cb = 0; cb < k; cb += 16) {
+        {   // R chunk: thread -> column tid / 4, entries 4 (tid % 4) .. + 3
+            const i64 col = c0 + (tid >> 2);
+            const int cc = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sR[cc + u][tid >> 2] = (col < N && cb + cc + u < k) ? rhs_elem(R, col, cb + cc + u) : 0.0;
+            // Ginv chunk: thread -> row tid / 16, entries 4 (tid % 16) .. + 3
+            const int gr = tid >> 4, ge = (tid & 15) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sG[gr][ge + u] = (cb + gr < k) ? Ginv[(size_t)(cb + gr) * KP + e0 + ge + u] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double a = sR[4 * kk + (lane >> 4)][16 * w + (lane & 15)];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sG[4 * kk + (lane >> 4)][16 * jt + (lane & 15)], acc[jt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const i64 col = c0 + 16 * w + (lane >> 4) + 4 * v;
+            if (col < N) V[(size_t)(col - col_begin) * KP + e0 + 16 * jt + (lane & 15)] = acc[jt][v];
+        }
+}
+
 __global__ __launch_bounds__(256) void nnls_wide_kernel(double* __restrict__ X, double* __restrict__ Y, int k, int KP, i64 N,
                                                         PartialView R, const double* __restrict__ G,
                                                         const double* __restrict__ Ginv, const int* __restrict__ status,
                                                         int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
-                                                        double* __restrict__ panels, int tl_cap, int skip_if_invertible)
+                                                        double* __restrict__ panels, int tl_cap, int skip_if_invertible,
+                                                        const double* __restrict__ V)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_panel[];          // tl_cap * tl_cap doubles, then the vectors
     if (skip_if_invertible && Ginv != nullptr && *status != 0) return;          // the wave kernel took this launch
@@ -549,20 +687,8 @@ __global__ __launch_bounds__(256) void nnls_wide_kernel(double* __restrict__ X, 
             pas[e] = x0 > 0.0;                      // passive_set = (X > 0), nnls.hpp:157
         }
         __syncthreads();
-        if (use_inv) {                              // v = Ginv r
-            for (int e = tid; e < k; e += 256) {
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;          // four chains: the loads of 8 rows are in flight together
-                int c = 0;
-#pragma unroll 2
-                for (; c + 4 <= k; c += 4) {
-                    a0 = __builtin_fma(Ginv[(size_t)c * KP + e], rs[c], a0);
-                    a1 = __builtin_fma(Ginv[(size_t)(c + 1) * KP + e], rs[c + 1], a1);
-                    a2 = __builtin_fma(Ginv[(size_t)(c + 2) * KP + e], rs[c + 2], a2);
-                    a3 = __builtin_fma(Ginv[(size_t)(c + 3) * KP + e], rs[c + 3], a3);
-                }
-                for (; c < k; ++c) a0 = __builtin_fma(Ginv[(size_t)c * KP + e], rs[c], a0);
-                vs[e] = (a0 + a1) + (a2 + a3);
-            }
+        if (use_inv) {                              // v = Ginv r (ginv_rhs_wide_kernel)
+            for (int e = tid; e < k; e += 256) vs[e] = V[(size_t)(col - col_begin) * KP + e];
             __syncthreads();
         }
 
@@ -687,29 +813,201 @@ __global__ __launch_bounds__(256) void nnls_wide_kernel(double* __restrict__ X, 
 // --------------------------------------------------------------------------------------------------------------------
 #define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 
-__host__ __device__ static inline int tri_elems(int t) { return t * (t + 1) / 2; }
-__device__ __forceinline__ int tri_off(int l, int t) { return l * t - (l * (l - 1)) / 2; }      // start of column l (entry (l, l))
+#ifdef SMK_WIDE_PROFILE                                        // phase clocks of the wave kernel (diagnostic build only)
+__device__ unsigned long long g_wprof[16];
+#define WP_NOW() __builtin_amdgcn_s_memtime()
+#define WP_ADD(slot, t0) do { const unsigned long long t1_ = WP_NOW(); wp[slot] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define WP_ADD(slot, t0) do { } while (0)
+#endif
 
-// per-wave LDS slice: [panel: tri(tl)] [xs ys rs zs vs: 5 x kq doubles] [idx: kq ints] [pas: kq bytes], kq = k rounded up to 64
+// The block of an exchange as 16 x 16 tiles of its lower triangle (tile (I, L), L <= I, at tile_off(I, L); entry (r, c) of a
+// tile at c * 17 + r: columns padded to 17 doubles so that both the operand reads of the matrix instruction -- 16 rows of 4
+// columns -- and its result layout -- 4 rows of 16 columns -- spread over the LDS banks).  Rows and columns t .. 16 tp - 1
+// are those of the identity.
+constexpr int TILE_ELEMS = 16 * 17;
+__host__ __device__ static inline int tile_count(int tp) { return tp * (tp + 1) / 2; }
+__device__ __forceinline__ int tile_off(int I, int L) { return (I * (I + 1) / 2 + L) * TILE_ELEMS; }
+
+// per-wave LDS slice: [tiles][xs ys rs zs vs: 5 x kq doubles][idx: kq ints][pas: kq bytes], kq = k rounded up to 64
 static inline size_t wave_slice_bytes(int k)
 {
-    const int kq = (k + 63) / 64 * 64, tl = (k + 1) / 2;
-    return (size_t)tri_elems(tl) * 8 + (size_t)5 * kq * 8 + (size_t)kq * 4 + (size_t)kq;
+    const int kq = (k + 63) / 64 * 64, tp = ((k + 1) / 2 + 15) / 16;
+    return (size_t)tile_count(tp) * TILE_ELEMS * 8 + (size_t)5 * kq * 8 + (size_t)kq * 4 + (size_t)kq;
+}
+
+// T <- the tiles of Msrc[idx, idx] (t rows; tp = ceil(t / 16)); 16 loads per lane in flight
+__device__ __forceinline__ void tiles_gather(double* __restrict__ T, const double* __restrict__ Msrc, int KP, const int* idx, int t,
+                                             int tp, int lane)
+{
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int nt = tile_count(tp);
+    int I = 0, L = 0;
+    for (int ti = 0; ti < nt; ti += 4) {
+        double g[4][4];
+        int offs[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool on = ti + s < nt;
+            const int i = 16 * I + r16;
+            offs[s] = on ? tile_off(I, L) : -1;
+            const int ii = (on && i < t) ? idx[i] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int l = 16 * L + q4 + 4 * u;
+                g[s][u] = (ii >= 0 && l < t) ? Msrc[(size_t)idx[l] * KP + ii] : ((i == l) ? 1.0 : 0.0);
+            }
+            if (++L > I) { ++I; L = 0; }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (offs[s] >= 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) T[offs[s] + (q4 + 4 * u) * 17 + r16] = g[s][u];
+            }
+    }
+}
+
+// In-place Cholesky of the tiled block, right-looking by tile columns; the diagonal keeps 1 / L_jj.  Wave-synchronous.
+// Returns true when a pivot is not positive.
+__device__ __forceinline__ bool tiles_cholesky(double* __restrict__ T, int tp, int lane)
+{
+    const int r16 = lane & 15, q4 = lane >> 4;
+    for (int J = 0; J < tp; ++J) {
+        const int ojj = tile_off(J, J);
+        {   // diagonal tile in registers: lane r16 holds row r16 (the four lane groups carry copies)
+            double d[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) d[c] = T[ojj + c * 17 + r16];
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double piv = readlane_f64(d[j], j);
+                bad |= !(piv > 0.0);                            // no early exit: what follows a bad pivot is never used
+                double id = __builtin_amdgcn_rsq(piv);          // 1 / sqrt(piv): hardware estimate + two Newton steps
+                id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
+                id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
+                d[j] = (r16 == j) ? id : d[j] * id;
+#pragma unroll
+                for (int l = j + 1; l < 16; ++l) d[l] = __builtin_fma(-d[j], readlane_f64(d[j], l), d[l]);
+            }
+            if (bad) return true;
+            if (q4 == 0) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) T[ojj + c * 17 + r16] = d[c];
+            }
+            WAVE_SYNC();
+        }
+        if (J + 1 == tp) break;
+        // panel: rows of the tiles below <- row L_JJ^-T, one row per lane, four tiles at a time
+        for (int I0 = J + 1; I0 < tp; I0 += 4) {
+            const int I = I0 + q4;
+            const bool on = I < tp;
+            const int o = tile_off(on ? I : J + 1, J);
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = T[o + c * 17 + r16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {                      // right-looking: the updates behind a column are independent
+                x[c] *= T[ojj + c * 17 + c];
+#pragma unroll
+                for (int q = c + 1; q < 16; ++q) x[q] = __builtin_fma(-x[c], T[ojj + c * 17 + q], x[q]);
+            }
+            if (on) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) T[o + c * 17 + r16] = x[c];
+            }
+        }
+        WAVE_SYNC();
+        // trailing tiles: C(I, L) -= P_I P_L' on the f64 matrix cores (A = -P_I: lane l has row l & 15, column 4 kk + (l >> 4);
+        // the result lane has column l & 15, rows (l >> 4) + 4 v)
+        for (int I = J + 1; I < tp; ++I) {
+            const int oa = tile_off(I, J);
+            double a[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) a[kk] = -T[oa + (4 * kk + q4) * 17 + r16];
+            for (int L = J + 1; L <= I; ++L) {
+                const int ob = tile_off(L, J), oc = tile_off(I, L);
+                f64x4_t acc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[v] = T[oc + r16 * 17 + q4 + 4 * v];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], T[ob + (4 * kk + q4) * 17 + r16], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) T[oc + r16 * 17 + q4 + 4 * v] = acc[v];
+            }
+        }
+        WAVE_SYNC();
+    }
+    return false;
+}
+
+// zs <- (L L')^-1 zs on the factored tiles (zs has 16 tp entries; those beyond t are solved against the identity rows)
+__device__ __forceinline__ void tiles_solve(const double* __restrict__ T, double* __restrict__ zs, int tp, int lane)
+{
+    const int r16 = lane & 15, q4 = lane >> 4;
+    for (int I = 0; I < tp; ++I) {                              // L z = b
+        double part = 0.0;
+        for (int L = 0; L < I; ++L) {
+            const int o = tile_off(I, L);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part = __builtin_fma(T[o + (q4 + 4 * u) * 17 + r16], zs[16 * L + q4 + 4 * u], part);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        double y = zs[16 * I + r16] - part;
+        const int od = tile_off(I, I);
+        double d[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) d[c] = T[od + c * 17 + r16];       // row r16 of the diagonal tile
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double zj = readlane_f64(y, j) * readlane_f64(d[j], j);
+            y = (r16 == j) ? zj : ((r16 > j) ? __builtin_fma(-d[j], zj, y) : y);
+        }
+        WAVE_SYNC();
+        if (q4 == 0) zs[16 * I + r16] = y;
+        WAVE_SYNC();
+    }
+    for (int I = tp - 1; I >= 0; --I) {                         // L' x = z; lane r16 is a COLUMN here
+        double part = 0.0;
+        for (int L = I + 1; L < tp; ++L) {
+            const int o = tile_off(L, I);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part = __builtin_fma(T[o + r16 * 17 + q4 + 4 * u], zs[16 * L + q4 + 4 * u], part);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        double y = zs[16 * I + r16] - part;
+        const int od = tile_off(I, I);
+        double dc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dc[r] = T[od + r16 * 17 + r];      // column r16 of the diagonal tile
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            const double xj = readlane_f64(y, j) * readlane_f64(dc[j], j);
+            y = (r16 == j) ? xj : ((r16 < j) ? __builtin_fma(-dc[j], xj, y) : y);
+        }
+        WAVE_SYNC();
+        if (q4 == 0) zs[16 * I + r16] = y;
+        WAVE_SYNC();
+    }
 }
 
 __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict__ X, double* __restrict__ Y, int k, int KP, i64 N,
                                                              PartialView R, const double* __restrict__ G,
                                                              const double* __restrict__ Ginv, const int* __restrict__ status,
                                                              int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
-                                                             int slice_bytes)
+                                                             int slice_bytes, const double* __restrict__ V)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wave_lds[];
     if (*status == 0) return;                                   // the workgroup kernel takes this launch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int kq = (k + 63) / 64 * 64, tl = (k + 1) / 2;
+    const int kq = (k + 63) / 64 * 64, tpl = ((k + 1) / 2 + 15) / 16;
     unsigned char* base = wave_lds + (size_t)wave * slice_bytes;
     double* Mp = (double*)base;
-    double* xs = Mp + tri_elems(tl);
+    double* xs = Mp + tile_count(tpl) * TILE_ELEMS;
     double* ys = xs + kq;
     double* rs = ys + kq;
     double* zs = rs + kq;
@@ -718,8 +1016,16 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
     unsigned char* pas = (unsigned char*)(idx + kq);
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int failed_any = 0;
+#ifdef SMK_WIDE_PROFILE
+    unsigned long long wp[12] = {};
+    unsigned long long tp = WP_NOW();
+#endif
 
     for (i64 col = col_begin + (i64)blockIdx.x * nwaves + wave; col < N; col += (i64)gridDim.x * nwaves) {
+#ifdef SMK_WIDE_PROFILE
+        wp[8] += 1;
+        tp = WP_NOW();
+#endif
         for (int e = lane; e < kq; e += 64) {
             const bool in = e < k;
             const double x0 = in ? X[col * KP + e] : 0.0;
@@ -728,24 +1034,9 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
             pas[e] = in && x0 > 0.0;                            // passive_set = (X > 0), nnls.hpp:157
         }
         WAVE_SYNC();
-        for (int e = lane; e < kq; e += 64) {                   // v = Ginv r
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;      // 8 independent loads of Ginv in flight per lane
-            if (e < k) {
-                int c = 0;
-                for (; c + 8 <= k; c += 8) {
-                    double g[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) g[u] = Ginv[(size_t)(c + u) * KP + e];
-                    a0 = __builtin_fma(g[0], rs[c], a0);     a1 = __builtin_fma(g[1], rs[c + 1], a1);
-                    a2 = __builtin_fma(g[2], rs[c + 2], a2); a3 = __builtin_fma(g[3], rs[c + 3], a3);
-                    a0 = __builtin_fma(g[4], rs[c + 4], a0); a1 = __builtin_fma(g[5], rs[c + 5], a1);
-                    a2 = __builtin_fma(g[6], rs[c + 6], a2); a3 = __builtin_fma(g[7], rs[c + 7], a3);
-                }
-                for (; c < k; ++c) a0 = __builtin_fma(Ginv[(size_t)c * KP + e], rs[c], a0);
-            }
-            vs[e] = (a0 + a1) + (a2 + a3);
-        }
+        for (int e = lane; e < kq; e += 64) vs[e] = (e < k) ? V[(size_t)(col - col_begin) * KP + e] : 0.0;   // v = Ginv r (ginv_rhs_wide_kernel)
         WAVE_SYNC();
+        WP_ADD(0, tp);
 
         int ng = 0, last = -1;
         // one block-pivot solve for the current passive set; leaves xs, ys and the violation count / largest violator
@@ -762,99 +1053,62 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
                 t += __popcll(m);
             }
             WAVE_SYNC();
+#ifdef SMK_WIDE_PROFILE
+            wp[9] += 1;
+            wp[10] += t;
+#endif
+            WP_ADD(1, tp);
             const double* Msrc = comp ? Ginv : G;
-            {   // packed lower triangle, column l: rows l .. t - 1; four columns' loads issued together
-                int l = 0;
-                for (; l + 4 <= t; l += 4) {
-                    double g[4][2];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int i = l + u + lane + 64 * h;
-                            g[u][h] = (i < t) ? Msrc[(size_t)idx[l + u] * KP + idx[i]] : 0.0;
-                        }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int i = l + u + lane + 64 * h;
-                            if (i < t) Mp[tri_off(l + u, t) + (i - l - u)] = g[u][h];
-                        }
-                }
-                for (; l < t; ++l) {
-                    const int il = idx[l], o = tri_off(l, t);
-                    for (int i = l + lane; i < t; i += 64) Mp[o + (i - l)] = Msrc[(size_t)il * KP + idx[i]];
-                }
-            }
-            for (int a = lane; a < t; a += 64) zs[a] = comp ? -vs[idx[a]] : rs[idx[a]];
+            const int tpx = (t + 15) / 16;
+            tiles_gather(Mp, Msrc, KP, idx, t, tpx, lane);
+            for (int a = lane; a < 16 * tpx; a += 64) zs[a] = (a < t) ? (comp ? -vs[idx[a]] : rs[idx[a]]) : 0.0;
             WAVE_SYNC();
-            bool bad = false;
-            for (int j = 0; j < t; ++j) {                       // right-looking Cholesky; the diagonal keeps 1 / L_jj
-                const int oj = tri_off(j, t);
-                const double piv = Mp[oj];
-                if (!(piv > 0.0)) { bad = true; break; }
-                double id = __builtin_amdgcn_rsq(piv);          // 1 / sqrt(piv): hardware estimate + two Newton steps
-                id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
-                id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
-                WAVE_SYNC();
-                for (int i = j + 1 + lane; i < t; i += 64) Mp[oj + (i - j)] *= id;
-                if (lane == 0) Mp[oj] = id;
-                WAVE_SYNC();
-                const int ti = lane & 15, tq = lane >> 4;       // 16 rows x 4 columns of the trailing block at a time
-                for (int l = j + 1 + tq; l < t; l += 4) {
-                    const double mlj = Mp[oj + (l - j)];
-                    const int ol = tri_off(l, t);
-                    for (int i = l + ti; i < t; i += 16) Mp[ol + (i - l)] -= Mp[oj + (i - j)] * mlj;
-                }
-                WAVE_SYNC();
-            }
-            if (!bad) {
-                // substitutions with the right-hand side in registers (t <= 128: two entries per lane): the value of step j
-                // is a lane broadcast, not an LDS round trip
-                double z0 = (lane < t) ? zs[lane] : 0.0, z1 = (64 + lane < t) ? zs[64 + lane] : 0.0;
-                for (int j = 0; j < t; ++j) {                   // L z = b
-                    const int oj = tri_off(j, t);
-                    const double zj = readlane_f64(j < 64 ? z0 : z1, j & 63) * Mp[oj];
-                    if (j < 64) { if (lane == j) z0 = zj; } else { if (lane == j - 64) z1 = zj; }
-                    const int i0 = lane, i1 = 64 + lane;
-                    if (i0 > j && i0 < t) z0 = __builtin_fma(-Mp[oj + (i0 - j)], zj, z0);
-                    if (i1 > j && i1 < t) z1 = __builtin_fma(-Mp[oj + (i1 - j)], zj, z1);
-                }
-                for (int j = t - 1; j >= 0; --j) {              // L' x = z
-                    const double xj = readlane_f64(j < 64 ? z0 : z1, j & 63) * Mp[tri_off(j, t)];
-                    if (j < 64) { if (lane == j) z0 = xj; } else { if (lane == j - 64) z1 = xj; }
-                    const int i0 = lane, i1 = 64 + lane;
-                    if (i0 < j) z0 = __builtin_fma(-Mp[tri_off(i0, t) + (j - i0)], xj, z0);
-                    if (i1 < j) z1 = __builtin_fma(-Mp[tri_off(i1, t) + (j - i1)], xj, z1);
-                }
-                WAVE_SYNC();
-                if (lane < t) zs[lane] = z0;
-                if (64 + lane < t) zs[64 + lane] = z1;
-                WAVE_SYNC();
-            }
+            WP_ADD(2, tp);
+            const bool bad = tiles_cholesky(Mp, tpx, lane);
+            WP_ADD(3, tp);
+            if (!bad) tiles_solve(Mp, zs, tpx, lane);
+            WP_ADD(4, tp);
             // out = base + Msrc[:, T] u  with base = v (complement) or -r (direct)
-            for (int e = lane; e < kq; e += 64) {
-                double acc = comp ? vs[e] : -rs[e], a1 = 0.0, a2 = 0.0, a3 = 0.0;
-                if (!bad && e < k) {
+            {
+                const int nsl = kq >> 6;
+                double acc[4][2] = {};
+                if (!bad) {
                     int a = 0;
                     for (; a + 8 <= t; a += 8) {
-                        double g[8];
+                        double g[4][8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) g[u] = Msrc[(size_t)idx[a + u] * KP + e];
-                        acc = __builtin_fma(g[0], zs[a], acc);      a1 = __builtin_fma(g[1], zs[a + 1], a1);
-                        a2 = __builtin_fma(g[2], zs[a + 2], a2);    a3 = __builtin_fma(g[3], zs[a + 3], a3);
-                        acc = __builtin_fma(g[4], zs[a + 4], acc);  a1 = __builtin_fma(g[5], zs[a + 5], a1);
-                        a2 = __builtin_fma(g[6], zs[a + 6], a2);    a3 = __builtin_fma(g[7], zs[a + 7], a3);
+                        for (int u = 0; u < 8; ++u) {
+                            const size_t row = (size_t)idx[a + u] * KP + lane;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) g[v][u] = (v < nsl) ? Msrc[row + 64 * v] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const double za = zs[a + u];
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) acc[v][u & 1] = __builtin_fma(g[v][u], za, acc[v][u & 1]);
+                        }
                     }
-                    for (; a < t; ++a) acc = __builtin_fma(Msrc[(size_t)idx[a] * KP + e], zs[a], acc);
-                    acc = (acc + a1) + (a2 + a3);
+                    for (; a < t; ++a) {
+                        const size_t row = (size_t)idx[a] * KP + lane;
+                        const double za = zs[a];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (v < nsl) acc[v][0] = __builtin_fma(Msrc[row + 64 * v], za, acc[v][0]);
+                    }
                 }
-                const bool pe = pas[e] != 0;
-                xs[e] = comp ? (pe ? acc : 0.0) : 0.0;          // the block's own entries are scattered below
-                ys[e] = comp ? 0.0 : (pe ? 0.0 : acc);
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (v < nsl) {
+                        const int e = 64 * v + lane;
+                        const double o = (comp ? vs[e] : -rs[e]) + (acc[v][0] + acc[v][1]);
+                        const bool pe = pas[e] != 0;
+                        xs[e] = comp ? (pe ? o : 0.0) : 0.0;    // the block's own entries are scattered below
+                        ys[e] = comp ? 0.0 : (pe ? 0.0 : o);
+                    }
             }
             WAVE_SYNC();
+            WP_ADD(5, tp);
             if (!bad)
                 for (int a = lane; a < t; a += 64) {
                     if (comp) ys[idx[a]] = zs[a];
@@ -880,6 +1134,7 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
                 pas[e] = (unsigned char)((pe ? 1 : 0) | (viol ? 2 : 0));
             }
             WAVE_SYNC();
+            WP_ADD(6, tp);
             return bad;
         };
         // NOTE: after solve_and_classify pas[e] carries bit 0 = passive, bit 1 = violates; the (pas[e] != 0) tests above see
@@ -920,9 +1175,24 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
         }
         failed_any |= failed ? 1 : 0;
         WAVE_SYNC();
+        WP_ADD(7, tp);
     }
+#ifdef SMK_WIDE_PROFILE
+    if (lane == 0)
+        for (int q = 0; q < 12; ++q) atomicAdd(&g_wprof[q], wp[q]);
+#endif
     if (failed_any && lane == 0) atomicMin(fail_flag, iter_tag);
 }
+
+#ifdef SMK_WIDE_PROFILE
+extern "C" int smk_debug_wide_profile(unsigned long long* out)
+{
+    unsigned long long zero[16] = {};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wprof), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wprof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // workgroups per CU: the LDS panel only has to hold the smaller of a passive set and its complement, <= k / 2 rows
 static inline int nnls_wide_vec_bytes(int k) { return kp_of(k) * (5 * 8 + 4 + 3); }
@@ -940,11 +1210,11 @@ static inline int nnls_wide_wgs_per_cu(int k)
     const int w = (160 * 1024) / lds;
     return w < 1 ? 1 : (w > 2 ? 2 : w);
 }
-// scratch: [panels: wgs x KP x KP][L: KP x KP][Ginv: KP x KP][status: 8]
-size_t nnls_wide_scratch_elems(int k, int num_cus)
+// scratch: [panels: wgs x KP x KP][L: KP x KP][Ginv: KP x KP][status: 8][V: ncols x KP]
+size_t nnls_wide_scratch_elems(int k, int num_cus, i64 ncols)
 {
     const size_t KP = (size_t)kp_of(k);
-    return ((size_t)num_cus * nnls_wide_wgs_per_cu(k) + 2) * KP * KP + 8;
+    return ((size_t)num_cus * nnls_wide_wgs_per_cu(k) + 2) * KP * KP + 8 + (size_t)ncols * KP;
 }
 
 int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G, int* fail_flag,
@@ -958,11 +1228,14 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
     double* L = scratch + (size_t)wgs * KP * KP;
     double* Ginv = L + (size_t)KP * KP;
     int* status = (int*)(Ginv + (size_t)KP * KP);
+    double* V = Ginv + (size_t)KP * KP + 8;                      // ncols x KP: the caller sized the scratch for its columns
     static const bool use_inv = [] { const char* e = getenv("SMK_NNLS_INV"); return !(e && e[0] == '0'); }();
     if (use_inv) {
-        chol_wide_kernel<<<1, 1024, 0, st>>>(G, k, KP, L, status);
-        SMK_HIP(hipGetLastError());
+        if (launch_chol_wide(G, k, KP, L, status, st)) return -100;
         inv_cols_wide_kernel<<<k, 256, 0, st>>>(L, k, KP, Ginv, status);
+        SMK_HIP(hipGetLastError());
+        ginv_rhs_wide_kernel<<<dim3((unsigned)((ncols + 63) / 64), (unsigned)(KP / 64)), 256, 0, st>>>(R, Ginv, status, k, KP, col_begin,
+                                                                                                  col_end, V);
         SMK_HIP(hipGetLastError());
     }
     const int lds = nnls_wide_lds_bytes(k);
@@ -988,7 +1261,7 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
             i64 g2 = (ncols + waves - 1) / waves;
             if (g2 > (i64)num_cus * 2) g2 = (i64)num_cus * 2;
             nnls_wide_wave_kernel<<<(unsigned)g2, 64 * waves, wlds, st>>>(X, Y, k, KP, col_end, R, G, Ginv, status, fail_flag, iter_tag,
-                                                                     col_begin, (int)slice);
+                                                                     col_begin, (int)slice, V);
             SMK_HIP(hipGetLastError());
             took_wave = 1;
         }
@@ -996,7 +1269,7 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
     i64 grid = wgs;                                              // as many workgroups as their LDS panels let be resident
     if (grid > ncols) grid = ncols;
     nnls_wide_kernel<<<(unsigned)grid, 256, lds, st>>>(X, Y, k, KP, col_end, R, G, use_inv ? Ginv : nullptr, status, fail_flag,
-                                                       iter_tag, col_begin, scratch, tl, took_wave);
+                                                       iter_tag, col_begin, scratch, tl, took_wave, V);
     SMK_HIP(hipGetLastError());
     return 0;
 }
