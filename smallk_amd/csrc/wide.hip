@@ -829,21 +829,24 @@ constexpr int TILE_ELEMS = 16 * 17;
 __host__ __device__ static inline int tile_count(int tp) { return tp * (tp + 1) / 2; }
 __device__ __forceinline__ int tile_off(int I, int L) { return (I * (I + 1) / 2 + L) * TILE_ELEMS; }
 
-// per-wave LDS slice: [tiles][xs ys rs zs vs: 5 x kq doubles][idx: kq ints][pas: kq bytes], kq = k rounded up to 64
-static inline size_t wave_slice_bytes(int k)
+// A column is solved by a GROUP of NW waves: NW = 1, a wave per column (four columns per workgroup, no workgroup barrier),
+// or NW = 4, the whole workgroup on one column.  group_sync orders the group's LDS / scratch traffic.
+template <int NW> __device__ __forceinline__ void group_sync()
 {
-    const int kq = (k + 63) / 64 * 64, tp = ((k + 1) / 2 + 15) / 16;
-    return (size_t)tile_count(tp) * TILE_ELEMS * 8 + (size_t)5 * kq * 8 + (size_t)kq * 4 + (size_t)kq;
+    if constexpr (NW == 1) WAVE_SYNC();
+    else __syncthreads();
 }
 
-// T <- the tiles of Msrc[idx, idx] (t rows; tp = ceil(t / 16)); 16 loads per lane in flight
+// T <- the tiles of Msrc[idx, idx] (t rows; tp = ceil(t / 16)); 16 loads per lane in flight, four tiles per wave and round
+template <int NW>
 __device__ __forceinline__ void tiles_gather(double* __restrict__ T, const double* __restrict__ Msrc, int KP, const int* idx, int t,
-                                             int tp, int lane)
+                                             int tp, int lane, int wave)
 {
     const int r16 = lane & 15, q4 = lane >> 4;
     const int nt = tile_count(tp);
-    int I = 0, L = 0;
-    for (int ti = 0; ti < nt; ti += 4) {
+    for (int ti = 4 * wave; ti < nt; ti += 4 * NW) {
+        int I = 0, L = ti;
+        while (L > I) { L -= I + 1; ++I; }                      // tile ti = (I, L)
         double g[4][4];
         int offs[4];
 #pragma unroll
@@ -868,14 +871,15 @@ __device__ __forceinline__ void tiles_gather(double* __restrict__ T, const doubl
     }
 }
 
-// In-place Cholesky of the tiled block, right-looking by tile columns; the diagonal keeps 1 / L_jj.  Wave-synchronous.
-// Returns true when a pivot is not positive.
-__device__ __forceinline__ bool tiles_cholesky(double* __restrict__ T, int tp, int lane)
+// In-place Cholesky of the tiled block, right-looking by tile columns; the diagonal keeps 1 / L_jj.  Returns true when a
+// pivot is not positive (*s_bad, cleared by the caller before the group's last sync, carries that to the other waves).
+template <int NW>
+__device__ __forceinline__ bool tiles_cholesky(double* __restrict__ T, int tp, int lane, int wave, int* s_bad)
 {
     const int r16 = lane & 15, q4 = lane >> 4;
     for (int J = 0; J < tp; ++J) {
         const int ojj = tile_off(J, J);
-        {   // diagonal tile in registers: lane r16 holds row r16 (the four lane groups carry copies)
+        if (NW == 1 || wave == 0) {   // diagonal tile in registers: lane r16 holds row r16 (the four lane groups carry copies)
             double d[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) d[c] = T[ojj + c * 17 + r16];
@@ -891,16 +895,21 @@ __device__ __forceinline__ bool tiles_cholesky(double* __restrict__ T, int tp, i
 #pragma unroll
                 for (int l = j + 1; l < 16; ++l) d[l] = __builtin_fma(-d[j], readlane_f64(d[j], l), d[l]);
             }
-            if (bad) return true;
-            if (q4 == 0) {
+            if (bad) {
+                if constexpr (NW == 1) return true;
+                else if (lane == 0) *s_bad = 1;
+            } else if (q4 == 0) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) T[ojj + c * 17 + r16] = d[c];
             }
-            WAVE_SYNC();
+        }
+        group_sync<NW>();
+        if constexpr (NW > 1) {
+            if (*s_bad) return true;                            // uniform over the group
         }
         if (J + 1 == tp) break;
-        // panel: rows of the tiles below <- row L_JJ^-T, one row per lane, four tiles at a time
-        for (int I0 = J + 1; I0 < tp; I0 += 4) {
+        // panel: rows of the tiles below <- row L_JJ^-T, one row per lane, four tiles per wave at a time
+        for (int I0 = J + 1 + 4 * wave; I0 < tp; I0 += 4 * NW) {
             const int I = I0 + q4;
             const bool on = I < tp;
             const int o = tile_off(on ? I : J + 1, J);
@@ -918,32 +927,34 @@ __device__ __forceinline__ bool tiles_cholesky(double* __restrict__ T, int tp, i
                 for (int c = 0; c < 16; ++c) T[o + c * 17 + r16] = x[c];
             }
         }
-        WAVE_SYNC();
+        group_sync<NW>();
         // trailing tiles: C(I, L) -= P_I P_L' on the f64 matrix cores (A = -P_I: lane l has row l & 15, column 4 kk + (l >> 4);
-        // the result lane has column l & 15, rows (l >> 4) + 4 v)
-        for (int I = J + 1; I < tp; ++I) {
-            const int oa = tile_off(I, J);
-            double a[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) a[kk] = -T[oa + (4 * kk + q4) * 17 + r16];
-            for (int L = J + 1; L <= I; ++L) {
-                const int ob = tile_off(L, J), oc = tile_off(I, L);
+        // the result lane has column l & 15, rows (l >> 4) + 4 v); the tiles of the trailing triangle go round the waves
+        {
+            int I = J + 1, L = J + 1;
+            for (int s = 0; s < wave; ++s)
+                if (++L > I) { ++I; L = J + 1; }
+            while (I < tp) {
+                const int oa = tile_off(I, J), ob = tile_off(L, J), oc = tile_off(I, L);
                 f64x4_t acc;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) acc[v] = T[oc + r16 * 17 + q4 + 4 * v];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], T[ob + (4 * kk + q4) * 17 + r16], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[oa + (4 * kk + q4) * 17 + r16], T[ob + (4 * kk + q4) * 17 + r16], acc, 0, 0, 0);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) T[oc + r16 * 17 + q4 + 4 * v] = acc[v];
+#pragma unroll
+                for (int s = 0; s < NW; ++s)
+                    if (++L > I) { ++I; L = J + 1; }
             }
         }
-        WAVE_SYNC();
+        group_sync<NW>();
     }
     return false;
 }
 
-// zs <- (L L')^-1 zs on the factored tiles (zs has 16 tp entries; those beyond t are solved against the identity rows)
+// zs <- (L L')^-1 zs on the factored tiles (zs has 16 tp entries; those beyond t are solved against the identity rows); one wave
 __device__ __forceinline__ void tiles_solve(const double* __restrict__ T, double* __restrict__ zs, int tp, int lane)
 {
     const int r16 = lane & 15, q4 = lane >> 4;
@@ -995,25 +1006,55 @@ __device__ __forceinline__ void tiles_solve(const double* __restrict__ T, double
     }
 }
 
-__global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict__ X, double* __restrict__ Y, int k, int KP, i64 N,
+// gather + factor + solve of one exchange on the tiles at T (LDS or the group's panel of global scratch); zs in, zs out
+template <int NW>
+__device__ __forceinline__ bool tiles_exchange(double* __restrict__ T, const double* __restrict__ Msrc, int KP, const int* idx, int t,
+                                               double* __restrict__ zs, int lane, int wave, int* s_bad)
+{
+    const int tpx = (t + 15) / 16;
+    tiles_gather<NW>(T, Msrc, KP, idx, t, tpx, lane, wave);
+    group_sync<NW>();
+    const bool bad = tiles_cholesky<NW>(T, tpx, lane, wave, s_bad);
+    if (!bad && (NW == 1 || wave == 0)) tiles_solve(T, zs, tpx, lane);
+    group_sync<NW>();
+    return bad;
+}
+
+// per-group LDS slice: [tiles: tile_count(tp_lds)][xs ys rs zs vs: 5 x kq doubles][idx: kq ints][pas: kq bytes][8 ints], kq = k
+// rounded up to 64.  Blocks of more than 16 tp_lds rows go to the workgroup's panel of global scratch (NW = 4 only).
+static inline size_t tile_slice_bytes(int k, int tp_lds)
+{
+    const int kq = (k + 63) / 64 * 64;
+    return ((size_t)tile_count(tp_lds) * TILE_ELEMS * 8 + (size_t)5 * kq * 8 + (size_t)kq * 4 + (size_t)kq + 32 + 15) / 16 * 16;
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void nnls_wide_tile_kernel(double* __restrict__ X, double* __restrict__ Y, int k, int KP, i64 N,
                                                              PartialView R, const double* __restrict__ G,
                                                              const double* __restrict__ Ginv, const int* __restrict__ status,
                                                              int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
-                                                             int slice_bytes, const double* __restrict__ V)
+                                                             int slice_bytes, const double* __restrict__ V, int tp_lds,
+                                                             double* __restrict__ panels)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wave_lds[];
-    if (*status == 0) return;                                   // the workgroup kernel takes this launch
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int kq = (k + 63) / 64 * 64, tpl = ((k + 1) / 2 + 15) / 16;
-    unsigned char* base = wave_lds + (size_t)wave * slice_bytes;
-    double* Mp = (double*)base;
-    double* xs = Mp + tile_count(tpl) * TILE_ELEMS;
+    if (*status == 0) return;                                   // nnls_wide_kernel takes this launch
+    const int lane = threadIdx.x & 63;
+    const int wave = NW == 1 ? 0 : (int)(threadIdx.x >> 6);     // this wave inside its group
+    const int grp = NW == 1 ? (int)(threadIdx.x >> 6) : 0, ngrp = NW == 1 ? (int)(blockDim.x >> 6) : 1;
+    const int gt = NW == 1 ? lane : (int)threadIdx.x;           // thread inside the group
+    constexpr int GS = 64 * NW;
+    const int kq = (k + 63) / 64 * 64;
+    unsigned char* base = wave_lds + (size_t)grp * slice_bytes;
+    double* Tl = (double*)base;
+    double* xs = Tl + tile_count(tp_lds) * TILE_ELEMS;
     double* ys = xs + kq;
     double* rs = ys + kq;
     double* zs = rs + kq;
     double* vs = zs + kq;
     int* idx = (int*)(vs + kq);
     unsigned char* pas = (unsigned char*)(idx + kq);
+    int* sc = (int*)(pas + kq);                                 // t, comp, ng, last, bad (NW > 1: wave 0 decides, all read)
+    double* Tg = panels ? panels + (size_t)blockIdx.x * KP * KP : nullptr;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int failed_any = 0;
 #ifdef SMK_WIDE_PROFILE
@@ -1021,38 +1062,42 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
     unsigned long long tp = WP_NOW();
 #endif
 
-    for (i64 col = col_begin + (i64)blockIdx.x * nwaves + wave; col < N; col += (i64)gridDim.x * nwaves) {
+    for (i64 col = col_begin + (i64)blockIdx.x * ngrp + grp; col < N; col += (i64)gridDim.x * ngrp) {
 #ifdef SMK_WIDE_PROFILE
         wp[8] += 1;
         tp = WP_NOW();
 #endif
-        for (int e = lane; e < kq; e += 64) {
+        for (int e = gt; e < kq; e += GS) {
             const bool in = e < k;
             const double x0 = in ? X[col * KP + e] : 0.0;
             rs[e] = in ? rhs_elem(R, col, e) : 0.0;
+            vs[e] = in ? V[(size_t)(col - col_begin) * KP + e] : 0.0;      // v = Ginv r (ginv_rhs_wide_kernel)
             xs[e] = x0;
             pas[e] = in && x0 > 0.0;                            // passive_set = (X > 0), nnls.hpp:157
         }
-        WAVE_SYNC();
-        for (int e = lane; e < kq; e += 64) vs[e] = (e < k) ? V[(size_t)(col - col_begin) * KP + e] : 0.0;   // v = Ginv r (ginv_rhs_wide_kernel)
-        WAVE_SYNC();
+        group_sync<NW>();
         WP_ADD(0, tp);
 
         int ng = 0, last = -1;
         // one block-pivot solve for the current passive set; leaves xs, ys and the violation count / largest violator
         auto solve_and_classify = [&](bool zeroize) -> bool {
-            int p = 0;
-            for (int e0 = 0; e0 < kq; e0 += 64) p += __popcll(__ballot(pas[e0 + lane] != 0));
-            const bool comp = (k - p) <= p;                     // the smaller block
             int t = 0;
-            for (int e0 = 0; e0 < kq; e0 += 64) {
-                const int e = e0 + lane;
-                const bool sel = (e < k) && ((pas[e] != 0) != comp);
-                const unsigned long long m = __ballot(sel);
-                if (sel) idx[t + __popcll(m & lt_mask)] = e;
-                t += __popcll(m);
+            bool comp = false;
+            if (NW == 1 || wave == 0) {
+                int p = 0;
+                for (int e0 = 0; e0 < kq; e0 += 64) p += __popcll(__ballot(pas[e0 + lane] != 0));
+                comp = (k - p) <= p;                            // the smaller block
+                for (int e0 = 0; e0 < kq; e0 += 64) {
+                    const int e = e0 + lane;
+                    const bool sel = (e < k) && ((pas[e] != 0) != comp);
+                    const unsigned long long m = __ballot(sel);
+                    if (sel) idx[t + __popcll(m & lt_mask)] = e;
+                    t += __popcll(m);
+                }
+                if (NW > 1 && lane == 0) { sc[0] = t; sc[1] = comp ? 1 : 0; sc[4] = 0; }
             }
-            WAVE_SYNC();
+            group_sync<NW>();
+            if constexpr (NW > 1) { t = sc[0]; comp = sc[1] != 0; }
 #ifdef SMK_WIDE_PROFILE
             wp[9] += 1;
             wp[10] += t;
@@ -1060,17 +1105,13 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
             WP_ADD(1, tp);
             const double* Msrc = comp ? Ginv : G;
             const int tpx = (t + 15) / 16;
-            tiles_gather(Mp, Msrc, KP, idx, t, tpx, lane);
-            for (int a = lane; a < 16 * tpx; a += 64) zs[a] = (a < t) ? (comp ? -vs[idx[a]] : rs[idx[a]]) : 0.0;
-            WAVE_SYNC();
-            WP_ADD(2, tp);
-            const bool bad = tiles_cholesky(Mp, tpx, lane);
+            for (int a = gt; a < 16 * tpx; a += GS) zs[a] = (a < t) ? (comp ? -vs[idx[a]] : rs[idx[a]]) : 0.0;
+            bool bad;
+            if (tpx <= tp_lds) bad = tiles_exchange<NW>(Tl, Msrc, KP, idx, t, zs, lane, wave, sc + 4);
+            else bad = tiles_exchange<NW>(Tg, Msrc, KP, idx, t, zs, lane, wave, sc + 4);
             WP_ADD(3, tp);
-            if (!bad) tiles_solve(Mp, zs, tpx, lane);
-            WP_ADD(4, tp);
-            // out = base + Msrc[:, T] u  with base = v (complement) or -r (direct)
+            // out = base + Msrc[:, T] u  with base = v (complement) or -r (direct); up to four entries per thread
             {
-                const int nsl = kq >> 6;
                 double acc[4][2] = {};
                 if (!bad) {
                     int a = 0;
@@ -1078,9 +1119,9 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
                         double g[4][8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            const size_t row = (size_t)idx[a + u] * KP + lane;
+                            const size_t row = (size_t)idx[a + u] * KP + gt;
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) g[v][u] = (v < nsl) ? Msrc[row + 64 * v] : 0.0;
+                            for (int v = 0; v < 4; ++v) g[v][u] = (gt + GS * v < kq) ? Msrc[row + GS * v] : 0.0;
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
@@ -1090,59 +1131,60 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
                         }
                     }
                     for (; a < t; ++a) {
-                        const size_t row = (size_t)idx[a] * KP + lane;
+                        const size_t row = (size_t)idx[a] * KP + gt;
                         const double za = zs[a];
 #pragma unroll
                         for (int v = 0; v < 4; ++v)
-                            if (v < nsl) acc[v][0] = __builtin_fma(Msrc[row + 64 * v], za, acc[v][0]);
+                            if (gt + GS * v < kq) acc[v][0] = __builtin_fma(Msrc[row + GS * v], za, acc[v][0]);
                     }
                 }
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (v < nsl) {
-                        const int e = 64 * v + lane;
+                for (int v = 0; v < 4; ++v) {
+                    const int e = gt + GS * v;
+                    if (e < kq) {
                         const double o = (comp ? vs[e] : -rs[e]) + (acc[v][0] + acc[v][1]);
                         const bool pe = pas[e] != 0;
                         xs[e] = comp ? (pe ? o : 0.0) : 0.0;    // the block's own entries are scattered below
                         ys[e] = comp ? 0.0 : (pe ? 0.0 : o);
                     }
+                }
             }
-            WAVE_SYNC();
+            group_sync<NW>();
             WP_ADD(5, tp);
             if (!bad)
-                for (int a = lane; a < t; a += 64) {
+                for (int a = gt; a < t; a += GS) {
                     if (comp) ys[idx[a]] = zs[a];
                     else xs[idx[a]] = zs[a];
                 }
-            WAVE_SYNC();
+            group_sync<NW>();
             ng = 0;
             last = -1;
-            for (int e0 = 0; e0 < kq; e0 += 64) {
-                const int e = e0 + lane;
-                double x = xs[e], y = ys[e];
-                if (zeroize) {                                  // ZeroizeSmallValues, nnls.hpp:213,224-225
-                    if (fabs(x) < 1.0e-12) x = 0.0;
-                    if (fabs(y) < 1.0e-12) y = 0.0;
-                    xs[e] = x;
-                    ys[e] = y;
+            if (NW == 1 || wave == 0) {
+                for (int e0 = 0; e0 < kq; e0 += 64) {
+                    const int e = e0 + lane;
+                    double x = xs[e], y = ys[e];
+                    if (zeroize) {                              // ZeroizeSmallValues, nnls.hpp:213,224-225
+                        if (fabs(x) < 1.0e-12) x = 0.0;
+                        if (fabs(y) < 1.0e-12) y = 0.0;
+                        xs[e] = x;
+                        ys[e] = y;
+                    }
+                    const bool pe = pas[e] != 0, in = e < k;
+                    const bool viol = in && ((!pe && y < 0.0) || (pe && x < 0.0));
+                    const unsigned long long m = __ballot(viol);
+                    if (m) { ng += __popcll(m); last = e0 + 63 - __clzll(m); }
+                    // remember the violation in bit 1 of the mask byte for the exchange below
+                    pas[e] = (unsigned char)((pe ? 1 : 0) | (viol ? 2 : 0));
                 }
-                const bool pe = pas[e] != 0, in = e < k;
-                const bool viol = in && ((!pe && y < 0.0) || (pe && x < 0.0));
-                const unsigned long long m = __ballot(viol);
-                if (m) { ng += __popcll(m); last = e0 + 63 - __clzll(m); }
-                // remember the violation in bit 1 of the mask byte for the exchange below
-                pas[e] = (unsigned char)((pe ? 1 : 0) | (viol ? 2 : 0));
+                if (NW > 1 && lane == 0) { sc[2] = ng; sc[3] = last; }
             }
-            WAVE_SYNC();
+            group_sync<NW>();
+            if constexpr (NW > 1) { ng = sc[2]; last = sc[3]; }
             WP_ADD(6, tp);
             return bad;
         };
         // NOTE: after solve_and_classify pas[e] carries bit 0 = passive, bit 1 = violates; the (pas[e] != 0) tests above see
         // only clean bytes because every exchange below rewrites them to 0 / 1 first.
-        auto clean = [&]() {
-            for (int e = lane; e < kq; e += 64) pas[e] &= 1;
-            WAVE_SYNC();
-        };
 
         bool failed = solve_and_classify(false);
         int Pc = 3, Ninf = k + 1, iter = 0;                     // PBAR = 3, nnls.hpp:152,170
@@ -1154,34 +1196,33 @@ __global__ __launch_bounds__(256) void nnls_wide_wave_kernel(double* __restrict_
             if (ng < Ninf) { Pc = 3; Ninf = ng; }
             else if (Pc >= 1) { Pc -= 1; }
             if (full) {
-                for (int e = lane; e < kq; e += 64) {
+                for (int e = gt; e < kq; e += GS) {
                     const unsigned char b = pas[e];
                     pas[e] = (b & 2) ? (unsigned char)((b & 1) ^ 1) : (unsigned char)(b & 1);   // violators change side
                 }
             } else {
-                for (int e = lane; e < kq; e += 64) {
+                for (int e = gt; e < kq; e += GS) {
                     const unsigned char b = pas[e];
                     pas[e] = (e == last) ? (unsigned char)((b & 1) ^ 1) : (unsigned char)(b & 1);   // backup rule: the largest violator
                 }
             }
-            WAVE_SYNC();
+            group_sync<NW>();
             failed = solve_and_classify(true);
             ++iter;
         }
-        clean();
-        for (int e = lane; e < k; e += 64) {
+        for (int e = gt; e < k; e += GS) {
             X[col * KP + e] = xs[e];
             if (Y) Y[col * KP + e] = ys[e];
         }
         failed_any |= failed ? 1 : 0;
-        WAVE_SYNC();
+        group_sync<NW>();
         WP_ADD(7, tp);
     }
 #ifdef SMK_WIDE_PROFILE
-    if (lane == 0)
+    if (lane == 0 && wave == 0)
         for (int q = 0; q < 12; ++q) atomicAdd(&g_wprof[q], wp[q]);
 #endif
-    if (failed_any && lane == 0) atomicMin(fail_flag, iter_tag);
+    if (failed_any && gt == 0) atomicMin(fail_flag, iter_tag);
 }
 
 #ifdef SMK_WIDE_PROFILE
@@ -1244,27 +1285,48 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
         SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set = true;
     }
-    // k <= 256 and G invertible: one wave per column, no workgroup barriers; otherwise (and as the fallback that
-    // reproduces a "not SPD" failure) one workgroup per column
+    // G invertible: the tile kernel -- a wave per column with the block's tiles in LDS where four values per lane cover a
+    // column (k <= 256) and SMK_WIDE_NW=1 asks for it, else the workgroup on one column with as many tile rows in LDS as fit
+    // and larger blocks in the workgroup's panel of global scratch.  nnls_wide_kernel below runs only when G is not safely
+    // invertible (direct form only: the reference's own computation, including its "not SPD" failure).
     int took_wave = 0;
-    if (use_inv && k <= 256) {
-        const size_t slice = (wave_slice_bytes(k) + 15) / 16 * 16;
-        int waves = (int)((150 * 1024) / slice);
-        if (waves > 4) waves = 4;
-        if (waves >= 1) {
-            const int wlds = (int)(slice * waves);
-            static int attr_wave = 0;
-            if (attr_wave < wlds) {
-                SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-                attr_wave = 152 * 1024;
-            }
+    if (use_inv) {
+        static const int nw_env = [] { const char* e = getenv("SMK_WIDE_NW"); return e ? atoi(e) : 0; }();
+        const int tp_full = ((k + 1) / 2 + 15) / 16;
+        // measured, 12 iterations at 16384 x 8192: k = 160 4.4 ms per iteration with a wave per column (three columns per CU)
+        // against 5.0 with the workgroup on one; k = 192 6.2 against 5.8; k = 256 13.7 against 11.0
+        const bool fits3 = k <= 256 && tile_slice_bytes(k, tp_full) * 3 <= 156 * 1024;
+        const bool one_wave = (nw_env == 1 && k <= 256) || (nw_env == 0 && fits3);
+        static bool attr_tile = false;
+        if (!attr_tile) {
+            SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_tile_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            attr_tile = true;
+        }
+        if (one_wave) {
+            const size_t slice = tile_slice_bytes(k, tp_full);
+            int waves = (int)((156 * 1024) / slice);
+            if (waves > 4) waves = 4;
             i64 g2 = (ncols + waves - 1) / waves;
             if (g2 > (i64)num_cus * 2) g2 = (i64)num_cus * 2;
-            nnls_wide_wave_kernel<<<(unsigned)g2, 64 * waves, wlds, st>>>(X, Y, k, KP, col_end, R, G, Ginv, status, fail_flag, iter_tag,
-                                                                     col_begin, (int)slice, V);
-            SMK_HIP(hipGetLastError());
-            took_wave = 1;
+            nnls_wide_tile_kernel<1><<<(unsigned)g2, 64 * waves, (unsigned)(slice * waves), st>>>(X, Y, k, KP, col_end, R, G, Ginv, status, fail_flag,
+                                                                                              iter_tag, col_begin, (int)slice, V, tp_full,
+                                                                                              nullptr);
+        } else {
+            int tp_lds = tp_full, per_cu = 1;
+            if (tile_slice_bytes(k, tp_full) <= 78 * 1024) per_cu = 2;             // whole blocks in LDS, two columns per CU
+            else
+                while (tile_slice_bytes(k, tp_lds) > 156 * 1024) --tp_lds;
+            const size_t slice = tile_slice_bytes(k, tp_lds);
+            i64 g4 = (i64)num_cus * per_cu;
+            if (tp_lds < tp_full && g4 > wgs) g4 = wgs;                           // one scratch panel per workgroup
+            if (g4 > ncols) g4 = ncols;
+            nnls_wide_tile_kernel<4><<<(unsigned)g4, 256, (unsigned)slice, st>>>(X, Y, k, KP, col_end, R, G, Ginv, status, fail_flag, iter_tag,
+                                                                            col_begin, (int)slice, V, tp_lds,
+                                                                            tp_lds < tp_full ? scratch : nullptr);
         }
+        SMK_HIP(hipGetLastError());
+        took_wave = 1;
     }
     i64 grid = wgs;                                              // as many workgroups as their LDS panels let be resident
     if (grid > ncols) grid = ncols;
