@@ -148,7 +148,9 @@ int launch_spmm_gather_wide(const i64* colptr, const unsigned* rowidx, const dou
                             double* P, int kpp, hipStream_t st);
 size_t nnls_wide_scratch_elems(int k, int num_cus, i64 ncols);   // ncols: the most columns one launch will solve
 int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G, int* fail_flag,
-                         int iter_tag, double* scratch, int num_cus, hipStream_t st);
+                         int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st);
+// L, Ginv and the status word of `scratch` from G (what launch_nnls_bpp_wide does first unless inverse_ready)
+int launch_gram_inverse_wide(const double* G, int k, double* scratch, int num_cus, hipStream_t st);
 
 int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
 int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);

@@ -664,7 +664,7 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
                     double* gram_partials, int* gram_nblk)
 {
     if (gram_nblk) *gram_nblk = 0;
-    if (is_wide(k)) return launch_nnls_bpp_wide(X, Y, k, col_begin, col_end, R, G, fail_flag, iter_tag, scratch, num_cus, st);
+    if (is_wide(k)) return launch_nnls_bpp_wide(X, Y, k, col_begin, col_end, R, G, fail_flag, iter_tag, scratch, inverse_ready, num_cus, st);
     const int KPv = kp_of(k);
     const int gpb = 256 / KPv;
     const i64 ncols = col_end - col_begin;

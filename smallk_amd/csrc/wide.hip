@@ -459,14 +459,15 @@ __device__ __forceinline__ bool chol_solve_panel(double* Mp, int t, double* zs, 
 // L = chol(G) (lower, column-major, leading dimension KP) as a sequence of launches, right-looking by panels of CH_NB columns
 // (one workgroup walking the whole matrix through L2 took 1.1 ms at k = 192 and 15 ms at k = 512 -- half of a warm
 // block-pivoting iteration; this takes 0.2 / 0.7 ms).  Panel J: `chol_panel_kernel` factors the CH_NB x CH_NB diagonal block
-// in LDS (every workgroup for itself, workgroup 0 stores it) and solves its 256 rows of the panel against it;
+// in LDS (every workgroup for itself; workgroup 0 stores it in a side buffer -- not in place, the others may still be reading
+// the block -- which `chol_diag_store_kernel` moves into L at the end) and solves its 256 rows of the panel against it;
 // `chol_trail_kernel` subtracts the panel's outer product from the trailing lower triangle in 64 x 64 tiles.  *status stays
 // non-zero when every pivot exceeds 1e-9 of its diagonal entry (the guard of gram_inverse_kernel); a smaller pivot clears it,
 // which every later launch and the block-pivoting kernels read.
 constexpr int CH_NB = 32;
 
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ L, const double* __restrict__ G, int k, int KP, int J,
-                                                         int* __restrict__ status)
+                                                         int* __restrict__ status, double* __restrict__ Dblk)
 {
     __shared__ double sD[CH_NB][CH_NB + 1];                     // sD[c][r] = block entry (r, c), r >= c
     __shared__ double sdiag[CH_NB], sguard[CH_NB];
@@ -507,10 +508,12 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ L,
         if (blockIdx.x == 0 && tid == 0) *status = 0;
         return;
     }
+    // the factored block goes to a side buffer, NOT back into L: the other workgroups of this launch read the unfactored block
+    // from L whenever they happen to start (chol_diag_store_kernel moves all blocks into L after the last panel)
     if (blockIdx.x == 0)
         for (int q = tid; q < nb * nb; q += 256) {
             const int rr = q % nb, c = q / nb;
-            if (rr >= c) L[(size_t)(J + c) * KP + J + rr] = sD[c][rr];
+            if (rr >= c) Dblk[(size_t)(J + c) * CH_NB + rr] = sD[c][rr];
         }
     // this thread's row of the panel: x <- x L_JJ^-T
     const int i = J + CH_NB + blockIdx.x * 256 + tid;
@@ -567,20 +570,33 @@ __global__ __launch_bounds__(256) void chol_trail_kernel(double* __restrict__ L,
         }
 }
 
+__global__ __launch_bounds__(256) void chol_diag_store_kernel(double* __restrict__ L, const double* __restrict__ Dblk, int k, int KP,
+                                                              const int* __restrict__ status)
+{
+    if (*status == 0) return;
+    const int J = blockIdx.x * CH_NB;
+    const int nb = (k - J < CH_NB) ? (k - J) : CH_NB;
+    for (int q = threadIdx.x; q < nb * nb; q += 256) {
+        const int rr = q % nb, c = q / nb;
+        if (rr >= c) L[(size_t)(J + c) * KP + J + rr] = Dblk[(size_t)(J + c) * CH_NB + rr];
+    }
+}
+
 // L = chol(G) on the stream: copy, then two launches per panel
-static int launch_chol_wide(const double* G, int k, int KP, double* L, int* status, hipStream_t st)
+static int launch_chol_wide(const double* G, int k, int KP, double* L, int* status, double* Dblk, hipStream_t st)
 {
     SMK_HIP(hipMemcpyAsync(L, G, (size_t)KP * KP * sizeof(double), hipMemcpyDeviceToDevice, st));
     SMK_HIP(hipMemsetAsync(status, 1, sizeof(int), st));         // any non-zero value reads as "invertible"
     for (int J = 0; J < k; J += CH_NB) {
         const int rest = k - J - CH_NB;                         // rows below the diagonal block
         const int g1 = rest > 0 ? (rest + 255) / 256 : 1;
-        chol_panel_kernel<<<g1, 256, 0, st>>>(L, G, k, KP, J, status);
+        chol_panel_kernel<<<g1, 256, 0, st>>>(L, G, k, KP, J, status, Dblk);
         if (rest > 0) {
             const int nt = (rest + 63) / 64;
             chol_trail_kernel<<<nt * (nt + 1) / 2, 256, 0, st>>>(L, k, KP, J, status);
         }
     }
+    chol_diag_store_kernel<<<(k + CH_NB - 1) / CH_NB, 256, 0, st>>>(L, Dblk, k, KP, status);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -1009,14 +1025,21 @@ __device__ __forceinline__ void tiles_solve(const double* __restrict__ T, double
 // gather + factor + solve of one exchange on the tiles at T (LDS or the group's panel of global scratch); zs in, zs out
 template <int NW>
 __device__ __forceinline__ bool tiles_exchange(double* __restrict__ T, const double* __restrict__ Msrc, int KP, const int* idx, int t,
-                                               double* __restrict__ zs, int lane, int wave, int* s_bad)
+                                               double* __restrict__ zs, int lane, int wave, int* s_bad
+#ifdef SMK_WIDE_PROFILE
+                                               , unsigned long long* wp, unsigned long long& tp
+#endif
+)
 {
     const int tpx = (t + 15) / 16;
     tiles_gather<NW>(T, Msrc, KP, idx, t, tpx, lane, wave);
     group_sync<NW>();
+    WP_ADD(2, tp);
     const bool bad = tiles_cholesky<NW>(T, tpx, lane, wave, s_bad);
+    WP_ADD(3, tp);
     if (!bad && (NW == 1 || wave == 0)) tiles_solve(T, zs, tpx, lane);
     group_sync<NW>();
+    WP_ADD(4, tp);
     return bad;
 }
 
@@ -1107,9 +1130,13 @@ __global__ __launch_bounds__(256) void nnls_wide_tile_kernel(double* __restrict_
             const int tpx = (t + 15) / 16;
             for (int a = gt; a < 16 * tpx; a += GS) zs[a] = (a < t) ? (comp ? -vs[idx[a]] : rs[idx[a]]) : 0.0;
             bool bad;
+#ifdef SMK_WIDE_PROFILE
+            if (tpx <= tp_lds) bad = tiles_exchange<NW>(Tl, Msrc, KP, idx, t, zs, lane, wave, sc + 4, wp, tp);
+            else { wp[11] += 1; bad = tiles_exchange<NW>(Tg, Msrc, KP, idx, t, zs, lane, wave, sc + 4, wp, tp); }
+#else
             if (tpx <= tp_lds) bad = tiles_exchange<NW>(Tl, Msrc, KP, idx, t, zs, lane, wave, sc + 4);
             else bad = tiles_exchange<NW>(Tg, Msrc, KP, idx, t, zs, lane, wave, sc + 4);
-            WP_ADD(3, tp);
+#endif
             // out = base + Msrc[:, T] u  with base = v (complement) or -r (direct); up to four entries per thread
             {
                 double acc[4][2] = {};
@@ -1251,15 +1278,35 @@ static inline int nnls_wide_wgs_per_cu(int k)
     const int w = (160 * 1024) / lds;
     return w < 1 ? 1 : (w > 2 ? 2 : w);
 }
-// scratch: [panels: wgs x KP x KP][L: KP x KP][Ginv: KP x KP][status: 8][V: ncols x KP]
+// scratch: [panels: wgs x KP x KP][L: KP x KP][Ginv: KP x KP][status: 8][diagonal blocks of L: KP x 32][V: ncols x KP]
 size_t nnls_wide_scratch_elems(int k, int num_cus, i64 ncols)
 {
     const size_t KP = (size_t)kp_of(k);
-    return ((size_t)num_cus * nnls_wide_wgs_per_cu(k) + 2) * KP * KP + 8 + (size_t)ncols * KP;
+    return ((size_t)num_cus * nnls_wide_wgs_per_cu(k) + 2) * KP * KP + 8 + KP * CH_NB + (size_t)ncols * KP;
+}
+
+static inline bool wide_use_inverse()
+{
+    static const bool use_inv = [] { const char* e = getenv("SMK_NNLS_INV"); return !(e && e[0] == '0'); }();
+    return use_inv;
+}
+
+int launch_gram_inverse_wide(const double* G, int k, double* scratch, int num_cus, hipStream_t st)
+{
+    if (!scratch || !wide_use_inverse()) return 0;
+    const int KP = kp_of(k);
+    double* L = scratch + (size_t)num_cus * nnls_wide_wgs_per_cu(k) * KP * KP;
+    double* Ginv = L + (size_t)KP * KP;
+    int* status = (int*)(Ginv + (size_t)KP * KP);
+    double* Dblk = Ginv + (size_t)KP * KP + 8;
+    if (launch_chol_wide(G, k, KP, L, status, Dblk, st)) return -100;
+    inv_cols_wide_kernel<<<k, 256, 0, st>>>(L, k, KP, Ginv, status);
+    SMK_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G, int* fail_flag,
-                         int iter_tag, double* scratch, int num_cus, hipStream_t st)
+                         int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st)
 {
     const i64 ncols = col_end - col_begin;
     if (ncols <= 0) return 0;
@@ -1269,12 +1316,10 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
     double* L = scratch + (size_t)wgs * KP * KP;
     double* Ginv = L + (size_t)KP * KP;
     int* status = (int*)(Ginv + (size_t)KP * KP);
-    double* V = Ginv + (size_t)KP * KP + 8;                      // ncols x KP: the caller sized the scratch for its columns
-    static const bool use_inv = [] { const char* e = getenv("SMK_NNLS_INV"); return !(e && e[0] == '0'); }();
+    double* V = Ginv + (size_t)KP * KP + 8 + (size_t)KP * CH_NB; // ncols x KP: the caller sized the scratch for its columns
+    const bool use_inv = wide_use_inverse();
     if (use_inv) {
-        if (launch_chol_wide(G, k, KP, L, status, st)) return -100;
-        inv_cols_wide_kernel<<<k, 256, 0, st>>>(L, k, KP, Ginv, status);
-        SMK_HIP(hipGetLastError());
+        if (!inverse_ready && launch_gram_inverse_wide(G, k, scratch, num_cus, st)) return -100;
         ginv_rhs_wide_kernel<<<dim3((unsigned)((ncols + 63) / 64), (unsigned)(KP / 64)), 256, 0, st>>>(R, Ginv, status, k, KP, col_begin,
                                                                                                   col_end, V);
         SMK_HIP(hipGetLastError());

@@ -20,6 +20,6 @@ for it in (1, 2, 4, 8, 16):
     assert lib.smk_debug_wide_profile(out) == 0
     v = list(out)
     tot = sum(v[:8])
-    print(f"--- iterations 1..{it}: {r.elapsed_us / 1000:.1f} ms; columns {v[8]}, exchanges per column {v[9] / max(v[8], 1):.2f}, mean block {v[10] / max(v[9], 1):.1f}")
+    print(f"--- iterations 1..{it}: {r.elapsed_us / 1000:.1f} ms; columns {v[8]}, exchanges per column {v[9] / max(v[8], 1):.2f}, mean block {v[10] / max(v[9], 1):.1f}, exchanges in global scratch {100.0 * v[11] / max(v[9], 1):.1f} %")
     for q in range(8):
         print(f"   {names[q]:22s} {100.0 * v[q] / max(tot, 1):5.1f} %   {v[q] / max(v[9], 1):10.0f} clocks per exchange")
