@@ -498,6 +498,83 @@ __global__ __launch_bounds__(256) void pack_f16x2_kernel(const double* __restric
     }
 }
 
+// k in (8, 16], fp16 two-term form, Gram partials left behind by the NNLS launch (nnls_bpp_kernel<16>): reduce + pack as ONE
+// launch.  Workgroups 0 .. 15 are gram_reduce_kernel's (the matrix, the row scales and the output scales of the product);
+// every other workgroup packs, after adding up the 16 diagonal entries itself in gram_reduce_kernel's order (same sums, same
+// power-of-two scales).  No workgroup waits for another.  C2: 4.6 + 5.3 us and a launch boundary become one launch.
+__global__ __launch_bounds__(256) void reduce_pack_f16x2_k16_kernel(const double* __restrict__ Gp, int nblk, double* __restrict__ G,
+                                                                    double* __restrict__ xscale, double* __restrict__ oscale,
+                                                                    double ascale, const double* __restrict__ X, int k, int ldx, i64 N,
+                                                                    i64 nq, unsigned char* __restrict__ out)
+{
+    constexpr int KP = 16, ELEMS = 256;
+    __shared__ double sh[16][17];
+    __shared__ double sxs[16];
+    const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const bool reducer = blockIdx.x < 16;
+    const int e = reducer ? (int)blockIdx.x * 16 + el : el * (KP + 1);     // packers: diagonal entry el
+    double s = 0.0;
+    // packers read the compact copy of the diagonal the NNLS launch left behind the partials (contiguous 128-byte rows)
+    const double* src = reducer ? Gp + e : Gp + (i64)NNLS_GRAM_MAX * ELEMS + el;
+    const int stride = reducer ? ELEMS : KP;
+    for (int b0 = g; b0 < nblk; b0 += 16 * 32) {                // 32 loads in flight, added in gram_reduce_kernel's order
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = (b0 + 16 * u < nblk) ? src[(i64)(b0 + 16 * u) * stride] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s += v[u];                 // (s + 0.0 == s: the padding changes nothing)
+    }
+    sh[g][el] = s;
+    __syncthreads();
+    if (g == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sh[i][el];
+        if (reducer) G[e] = t;
+        if (!reducer || e % (KP + 1) == 0) {            // the rule of gram_reduce_kernel
+            const int r = e / (KP + 1);
+            int ex = 0;
+            double xs = 1.0;
+            if (t > 0.0 && t < 1.0e300) {
+                (void)frexp(t, &ex);
+                const int half = (ex >= 0) ? (ex + 1) / 2 : -((-ex) / 2);
+                xs = ldexp(1.0, 14 - half);
+            }
+            if (reducer) {
+                xscale[r] = xs;
+                oscale[r] = 1.0 / (xs * ascale);
+            } else {
+                sxs[r] = xs;
+            }
+        }
+    }
+    if (reducer) return;
+    __syncthreads();
+    const i64 gid = (i64)(blockIdx.x - 16) * blockDim.x + threadIdx.x;     // pack_f16x2_kernel with KT = 1
+    const int lane = (int)(gid & 63);
+    const i64 q = gid >> 6;
+    if (q >= nq) return;
+    const int r = lane & 31;
+    const i64 row0 = (2 * q + (lane >> 5)) * 8;
+    const double sc = (r < k) ? sxs[r & 15] : 0.0;
+    double res[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const i64 row = row0 + i;
+        res[i] = (row < N && r < k) ? X[row * ldx + r] * sc : 0.0;
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+        f16x8_t h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            h[i] = (_Float16)(float)res[i];
+            res[i] = (res[i] - (double)(float)h[i]) * F16X2_LO_SCALE;
+        }
+        *(f16x8_t*)(out + ((q * 2 + t2) * 64 + lane) * 16) = h;
+    }
+}
+
 // The packed operand layout does not depend on the stage height: it is a sequence of 1-KiB
 // blocks indexed by the global chunk-pair q; rows are padded to a multiple of 128.
 // operand format: bf16 fragments (E = 8) for bf16 storage and for the fp32 "bf16x3" emulation
@@ -567,6 +644,19 @@ int launch_pack_own_blocks(const double* X, int ldx, int k0, int kg, i64 N, i64 
     PackMap pm;
     pm.bq = blk / E2; pm.world = world; pm.rank = rank;
     return launch_pack_rows_mapped(X, ldx, k0, kg, N, (i64)nblocks * pm.bq, storage, nsplit, out, st, xscale, pm);
+}
+
+// see reduce_pack_f16x2_k16_kernel; returns 1 when the shape is not the fused one
+int launch_reduce_pack_f16x2(const double* Gp, int nblk, int k, double* G, double* xscale, double* oscale, double ascale,
+                             const double* X, i64 N, int storage, void* out, hipStream_t st)
+{
+    if (kp_of(k) != 16 || nblk < 1) return 1;
+    const i64 nq = pack_nq(storage, NSPLIT_F16X2, N);
+    const i64 threads = nq * 64;
+    const unsigned grid = 16u + (unsigned)((threads + 255) / 256);
+    reduce_pack_f16x2_k16_kernel<<<grid, 256, 0, st>>>(Gp, nblk, G, xscale, oscale, ascale, X, k, 16, N, nq, (unsigned char*)out);
+    SMK_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st, const double* xscale)

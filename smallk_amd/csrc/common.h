@@ -80,6 +80,10 @@ size_t packed_row_offset(int storage, int kg, int nsplit, i64 r0);
 // zeros); block j lands at rows ((j world + rank) blk ...) of the operand starting at `out`
 int launch_pack_own_blocks(const double* X, int ldx, int k0, int kg, i64 N, i64 blk, int nblocks, int world, int rank,
                            int storage, int nsplit, void* out, hipStream_t st, const double* xscale = nullptr);
+// k in (8, 16], fp16 two-term form: the Gram partials of an NNLS launch reduced AND the operand packed in one launch (returns 1
+// for any other shape)
+int launch_reduce_pack_f16x2(const double* Gp, int nblk, int k, double* G, double* xscale, double* oscale, double ascale,
+                             const double* X, i64 N, int storage, void* out, hipStream_t st);
 int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* out, hipStream_t st, const double* xscale = nullptr);
 // rows [k0, k0 + kg) of a factor stored with leading dimension ldx
 int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st,

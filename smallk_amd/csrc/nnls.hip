@@ -212,6 +212,8 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
                 __syncthreads();
             }
             Gp[(i64)blockIdx.x * KP * KP + threadIdx.x] = gs[threadIdx.x];
+            // the diagonal once more, compact, behind the partials: what reduce_pack_f16x2_k16_kernel's packers add up
+            if (threadIdx.x < KP) Gp[(i64)NNLS_GRAM_MAX * KP * KP + (i64)blockIdx.x * KP + threadIdx.x] = gs[threadIdx.x * (KP + 1)];
         }
     }
 }

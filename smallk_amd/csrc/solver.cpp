@@ -905,7 +905,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     rc |= dev_alloc(&s->Gh_own, kk);
     {
         size_t gs = gram_scratch_elems(s->k, GRAM_BLOCKS);
-        if (s->KP == 16 && opts->algorithm == SMK_ALG_BPP) gs = std::max(gs, (size_t)NNLS_GRAM_MAX * 256 + 8);   // partials from the NNLS launch
+        if (s->KP == 16 && opts->algorithm == SMK_ALG_BPP) gs = std::max(gs, (size_t)NNLS_GRAM_MAX * (256 + 16) + 8);   // partials from the NNLS launch
         rc |= dev_alloc(&s->gram_scratch, gs);
         if (s->o.algorithm == SMK_ALG_RANK2) {
             const size_t e1 = rank2_gram_scratch_elems(std::max(s->m, s->n)), e2 = rank2_progress_scratch_elems(s->m, s->n);
@@ -1522,12 +1522,21 @@ static int gram_factor(smk_solver* s, int side)
         if (s->nnls_gram_nblk[ns] > 0) {
             const int nb = s->nnls_gram_nblk[ns];
             s->nnls_gram_nblk[ns] = 0;
+            // ... and packs it in the same launch (the packing workgroups add up the 16 diagonal entries themselves)
+            static const bool fuse_pack = [] { const char* e = getenv("SMK_REDUCE_PACK"); return !(e && e[0] == '0'); }();
+            if (fuse_pack && !s->a->sparse) {
+                const int rc = launch_reduce_pack_f16x2(s->gram_scratch, nb, s->k, G, s->xscale[side], s->oscale[side], (double)s->a->ascale, X, N,
+                                                        s->a->storage, side == 0 ? s->packW : s->packH, s->st);
+                if (rc == 0) { s->packed_fresh[side] = true; return 0; }
+                if (rc != 1) return rc;
+            }
             return launch_gram_reduce(s->gram_scratch, nb, s->k, G, s->st, s->xscale[side], s->oscale[side], (double)s->a->ascale);
         }
         return launch_gram(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->st, s->xscale[side], s->oscale[side], (double)s->a->ascale);
     }
-    // (round 3, again: leaving the partial sums to the pack launch -- every pack thread adding up its diagonal entry, workgroup 0
-    // finishing the matrix -- costs 12 us where reduce + pack cost 9.5: C2 went from 119 to 130 us per iteration.  Not kept.)
+    // (k > 16.  Leaving the partial sums to the pack launch -- every pack thread adding up its diagonal entry, workgroup 0
+    // finishing the matrix -- costs 12 us where reduce + pack cost 9.5; what works, at k <= 16 above, is separate reducer
+    // workgroups in the same launch and packers that read a compact copy of the diagonal partials.)
     if (!s->a->sparse && s->o.algorithm != SMK_ALG_RANK2 && s->nsplit != NSPLIT_F64) {
         const int rc = launch_gram_pack(X, s->k, N, G, s->gram_scratch, GRAM_BLOCKS, s->a->storage, s->nsplit,
                                         side == 0 ? s->packW : s->packH, s->st);

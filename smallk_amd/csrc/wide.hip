@@ -1142,6 +1142,23 @@ __global__ __launch_bounds__(256) void nnls_wide_tile_kernel(double* __restrict_
                 double acc[4][2] = {};
                 if (!bad) {
                     int a = 0;
+                    if (kq <= 2 * GS) {                         // at most two entries per thread: 16 rows' loads in flight
+                        for (; a + 16 <= t; a += 16) {
+                            double g[2][16];
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) {
+                                const size_t row = (size_t)idx[a + u] * KP + gt;
+#pragma unroll
+                                for (int v = 0; v < 2; ++v) g[v][u] = (gt + GS * v < kq) ? Msrc[row + GS * v] : 0.0;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) {
+                                const double za = zs[a + u];
+#pragma unroll
+                                for (int v = 0; v < 2; ++v) acc[v][u & 1] = __builtin_fma(g[v][u], za, acc[v][u & 1]);
+                            }
+                        }
+                    }
                     for (; a + 8 <= t; a += 8) {
                         double g[4][8];
 #pragma unroll
