@@ -2,7 +2,7 @@
 # Round-3 judged artefacts, regenerated on the GPU box into gpurun_out/r03/ (copied to profiles/ afterwards):
 #   bench JSON lines: C4 (the default bench, exactly as the driver runs it), C3, C2, a C4 shard, rank 0 of 2 / 4 / 8 emulated
 #   kernel tables (rocprofv3 --kernel-trace --stats): C4 whole, C3, C2, rank-0-of-8, the C5-shaped HierNMF2 run, a root-sized
-#     RANK2 iteration
+#     RANK2 iteration, block pivoting at k = 192 and k = 512 (the general path) + its times per iteration beside MU's
 #   HBM traffic of the streaming kernels (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, C4 and C3) -> hbm_traffic.json
 #     with the hash of the kernel source it was measured on
 #   counter passes for the kernels the round-2 review had no counter evidence for: the rank-2 gather product, the k = 64
@@ -42,6 +42,9 @@ kt c2_bpp_f32 $B --workload c2 --steps 50 --warmup 5
 kt c4_rank0_of_8 $B --emulate-world 8 --steps 10 --warmup 3
 kt c5_hiernmf2_1M python3 $ROOT/tools/c5_hier.py 1000000 16 8
 kt rank2_iteration_1M python3 $ROOT/tools/r2_iter.py 1000000 16 30
+kt wide_bpp_k192 python3 $ROOT/tools/wide_run.py 16384 8192 192 BPP 12 1
+kt wide_bpp_k512 python3 $ROOT/tools/wide_run.py 16384 8192 512 BPP 12 1
+for k in 160 192 256 384 512; do (cd $ROOT && python3 tools/wide_run.py 16384 8192 $k BPP 12 1 2>/dev/null | tail -1; python3 tools/wide_run.py 16384 8192 $k MU 12 1 2>/dev/null | tail -1) >> $OUT/r03_wide_rank_times.txt; done
 SMK_CLUST_TIMING=1 python3 $ROOT/tools/c5_hier.py 1000000 16 8 2>&1 | grep "smk_clust\|hier_nmf2\|purity" > $OUT/r03_c5_hiernmf2_1M_timing.txt
 # ---- HBM traffic of the streaming kernels (separate passes) ----
 pmc c4_fetch FETCH_SIZE $B --workload c4 --steps 3 --warmup 1
