@@ -1369,7 +1369,10 @@ static int launch_f3_f16(const BigProdPlan& pl, const void* B, i64 ldb, const vo
 // Workgroup = 4 waves, tile = 64 columns (16 per wave) x 64 rows per stage, both operands staged through LDS
 // (B: coalesced along the contraction, X: 64 x kg slab); one group of <= 64 factor rows per launch, as the other forms.
 // ==========================================================================
-template <int EBYTES>
+// KT16: live 16-row tiles of the group (a template parameter: with a run-time bound on the tile loop the compiler keeps ONE
+// accumulator block in AGPRs and copies all four through it around every matrix instruction -- 62 VALU instructions and
+// the full result latency per MFMA, 8 TFLOP/s; unrolled it is four independent chains)
+template <int EBYTES, int KT16>
 __global__ __launch_bounds__(256) void bigprod_f64_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                           const double* __restrict__ X, int ldx, int kvalid, i64 len,
                                                           double* __restrict__ P, i64 stages, i64 nst, i64 tiles, i64 ncols_pad,
@@ -1385,37 +1388,50 @@ __global__ __launch_bounds__(256) void bigprod_f64_kernel(const unsigned char* _
     i64 st0 = (i64)split * nst, st1 = st0 + nst;
     if (st1 > stages) st1 = stages;
     const i64 col0 = tile * NB;
-    const int kt16 = (kvalid + 15) / 16;                     // live 16-row tiles of this group (<= 4)
     typedef __attribute__((ext_vector_type(4))) double f64x4;
-    f64x4 acc[4];
+    f64x4 acc[KT16];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < KT16; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
     const int l15 = lane & 15, l4 = lane >> 4;
-    for (i64 st = st0; st < st1; ++st) {
+    // a stage's operands travel global -> registers -> LDS; the registers of stage st + 1 are loaded while the matrix cores
+    // work on stage st.  B tile: consecutive threads take consecutive rows of a column (contiguous in memory; padding rows /
+    // columns are zero).  X slab: 64 contraction rows x the group's factor rows (zero beyond the factor / the length).
+    float bv[(NB * MB) / 256];
+    double xv[(MB * KG) / 256];
+    auto fetch = [&](i64 st) {
         const i64 r0 = st * MB;
-        // B tile: consecutive threads take consecutive rows of a column (contiguous in memory; padding rows / columns are zero)
 #pragma unroll
         for (int i = 0; i < (NB * MB) / 256; ++i) {
             const int idx = i * 256 + tid, c = idx / MB, r = idx % MB;
             const unsigned char* src = B + (col0 + c) * ldb_bytes + (r0 + r) * EBYTES;
-            float v;
-            if constexpr (EBYTES == 2) v = bf16_bits_to_f32(*(const unsigned short*)src);
-            else v = *(const float*)src;
-            Bs[c][r] = v;
+            if constexpr (EBYTES == 2) bv[i] = bf16_bits_to_f32(*(const unsigned short*)src);
+            else bv[i] = *(const float*)src;
         }
-        // X slab: 64 contraction rows x the group's factor rows (zero beyond the factor / the contraction length)
 #pragma unroll
         for (int i = 0; i < (MB * KG) / 256; ++i) {
             const int idx = i * 256 + tid, r = idx / KG, kk = idx % KG;
-            Xs[r][kk] = (r0 + r < len && kk < kvalid) ? X[(r0 + r) * ldx + kk] : 0.0;
+            xv[i] = (r0 + r < len && kk < kvalid) ? X[(r0 + r) * ldx + kk] : 0.0;
+        }
+    };
+    if (st0 < st1) fetch(st0);
+    for (i64 st = st0; st < st1; ++st) {
+#pragma unroll
+        for (int i = 0; i < (NB * MB) / 256; ++i) {
+            const int idx = i * 256 + tid;
+            Bs[idx / MB][idx % MB] = bv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < (MB * KG) / 256; ++i) {
+            const int idx = i * 256 + tid;
+            Xs[idx / KG][idx % KG] = xv[i];
         }
         __syncthreads();
-#pragma unroll 4
+        if (st + 1 < st1) fetch(st + 1);
+#pragma unroll
         for (int q = 0; q < MB / 4; ++q) {
             const double b = (double)Bs[16 * wave + l15][4 * q + l4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (t < kt16) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[4 * q + l4][16 * t + l15], b, acc[t], 0, 0, 0);
+            for (int t = 0; t < KT16; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[4 * q + l4][16 * t + l15], b, acc[t], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -1428,7 +1444,7 @@ __global__ __launch_bounds__(256) void bigprod_f64_kernel(const unsigned char* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * t + l4 + 4 * r;
-                double v = acc[t][r];
+                double v = (t < KT16) ? acc[t < KT16 ? t : 0][r] : 0.0;      // tiles past the live ones are written as zeros
                 if (accum) v += pout[row];
                 pout[row] = v;
             }
@@ -1441,12 +1457,15 @@ static int launch_bigprod_f64(const BigProdPlan& pl, const void* B, i64 ldb, con
     // the factor's live rows of this group: kg of them, never past the padded rank
     const int kvalid = pl.kg < pl.ldx - pl.k0 ? pl.kg : pl.ldx - pl.k0;
     const int ktw = 2 * kt_of(pl.kg);                      // 16-row tiles covering the group's 32-row k tiles
-    if (pl.storage == STORE_BF16)
-        bigprod_f64_kernel<2><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * 2, (const double*)X, pl.ldx, kvalid, len, P,
-                                                              pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum);
-    else
-        bigprod_f64_kernel<4><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * 4, (const double*)X, pl.ldx, kvalid, len, P,
-                                                              pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum);
+    const int kt16 = (kvalid + 15) / 16;                     // live 16-row tiles of this group (1 .. 4)
+#define SMK_F64(EB, T) bigprod_f64_kernel<EB, T><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * EB, (const double*)X, pl.ldx, kvalid, \
+                                                                              len, P, pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum)
+    if (pl.storage == STORE_BF16) {
+        switch (kt16) { case 1: SMK_F64(2, 1); break; case 2: SMK_F64(2, 2); break; case 3: SMK_F64(2, 3); break; default: SMK_F64(2, 4); break; }
+    } else {
+        switch (kt16) { case 1: SMK_F64(4, 1); break; case 2: SMK_F64(4, 2); break; case 3: SMK_F64(4, 3); break; default: SMK_F64(4, 4); break; }
+    }
+#undef SMK_F64
     SMK_HIP(hipGetLastError());
     return 0;
 }

@@ -142,10 +142,11 @@ int launch_gram_pack(const double* X, int k, i64 N, double* G, double* scratch, 
 // functions below and in nnls.hip, which branch on is_wide(k)
 int launch_gram_wide_partials(const double* X, int KP, i64 N, double* scratch, int max_blocks, int* nblk_out, hipStream_t st);
 int gram_wide_blocks(int KP, i64 N, int max_blocks);
-int launch_mu_update_wide(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
+// tmp (optional, N x KP doubles): Y = X G as one product on the f64 matrix cores instead of a matrix-vector product per column
+int launch_mu_update_wide(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st, double* tmp);
 int launch_hals_sweep_wide(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
 int launch_grad_pg_wide(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out, double* pg_partials,
-                        int* grid_out, hipStream_t st);
+                        int* grid_out, hipStream_t st, double* tmp);
 int hals_w_wide_blocks(i64 M);
 int launch_hals_w_update_wide(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, hipStream_t st);
 int launch_spmm_gather_wide(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X, int k,
@@ -156,13 +157,13 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
 // L, Ginv and the status word of `scratch` from G (what launch_nnls_bpp_wide does first unless inverse_ready)
 int launch_gram_inverse_wide(const double* G, int k, double* scratch, int num_cus, hipStream_t st);
 
-int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
+int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st, double* wide_tmp = nullptr);
 int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
 // gradient G*X - R, optional store, projected-gradient partial sums -> pg_accum[slot] += sum
 int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
-                   double* pg_partials, double* pg_accum, int slot, hipStream_t st);
+                   double* pg_partials, double* pg_accum, int slot, hipStream_t st, double* wide_tmp = nullptr);
 int launch_grad_pg_partials(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
-                            double* pg_partials, int* grid_out, hipStream_t st);
+                            double* pg_partials, int* grid_out, hipStream_t st, double* wide_tmp = nullptr);
 int launch_sum_partials(const double* partials, int n, double* out, hipStream_t st);
 // both factors in two launches; also mirrors *flag into pg_accum[flag_slot] (as a double)
 int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,

@@ -1049,9 +1049,9 @@ static int coltile_lds(K kern, int KP)
         default: { COLTILE_CASE(128, KERN, GRID, __VA_ARGS__) }                           \
     }
 
-int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st)
+int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st, double* wide_tmp)
 {
-    if (is_wide(k)) return launch_mu_update_wide(X, k, N, R, G, st);
+    if (is_wide(k)) return launch_mu_update_wide(X, k, N, R, G, st, wide_tmp);
     const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
     COLTILE_LAUNCH(mu_update_kernel, grid, X, k, N, R, G);
     SMK_HIP(hipGetLastError());
@@ -1070,9 +1070,9 @@ int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, h
 // the per-workgroup partial sums only (*grid_out of them); several calls with partials offsets (row segments of a
 // factor) followed by ONE launch_sum_partials give the sum over the union
 int launch_grad_pg_partials(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
-                            double* pg_partials, int* grid_out, hipStream_t st)
+                            double* pg_partials, int* grid_out, hipStream_t st, double* wide_tmp)
 {
-    if (is_wide(k)) return launch_grad_pg_wide(X, k, N, R, G, grad_out, pg_partials, grid_out, st);
+    if (is_wide(k)) return launch_grad_pg_wide(X, k, N, R, G, grad_out, pg_partials, grid_out, st, wide_tmp);
     const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
     COLTILE_LAUNCH(grad_pg_kernel, grid, X, k, N, R, G, grad_out, pg_partials);
     SMK_HIP(hipGetLastError());
@@ -1088,10 +1088,10 @@ int launch_sum_partials(const double* partials, int n, double* out, hipStream_t 
 }
 
 int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
-                   double* pg_partials, double* pg_accum, int slot, hipStream_t st)
+                   double* pg_partials, double* pg_accum, int slot, hipStream_t st, double* wide_tmp)
 {
     int g = 0;
-    const int rc = launch_grad_pg_partials(X, k, N, R, G, grad_out, pg_partials, &g, st);
+    const int rc = launch_grad_pg_partials(X, k, N, R, G, grad_out, pg_partials, &g, st, wide_tmp);
     if (rc) return rc;
     return launch_sum_partials(pg_partials, g, pg_accum + slot, st);
 }

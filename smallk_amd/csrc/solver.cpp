@@ -120,6 +120,7 @@ struct smk_solver {
     hipStream_t st = nullptr;
     double *H = nullptr, *Wt = nullptr, *Gw = nullptr, *Gh = nullptr, *gram_scratch = nullptr;
     double *Wprev = nullptr, *hals_scratch = nullptr, *pg_partials = nullptr, *scal = nullptr, *tmpW = nullptr;
+    double* wide_tmp = nullptr;           // k > 128: max(m, n) x KP, the product X G of the MU rule and of the gradients
     double* tmpH = nullptr;               // k x n compact copy of H for the host (get_factors)
     // RANK2 (rank2.hip): scratch of the fused solve / progress kernels (ticket + partial sums), W'W of the W just solved
     // (before its normalisation), and -- sparse A -- compact N x 2 copies of the factors for the gather products
@@ -918,6 +919,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
         if (!rc && hipMemsetAsync(s->gram_scratch, 0, gs * sizeof(double), s->st) != hipSuccess) rc |= 1;   // incl. the ticket word
     }
     rc |= dev_alloc(&s->tmpW, (size_t)s->KP * s->m);
+    if (is_wide(s->k)) rc |= dev_alloc(&s->wide_tmp, (size_t)s->KP * std::max(s->m, s->n));
     // one partial per workgroup of the column-tile kernels (grid = N*(KP/4)/256 blocks) and at most
     // 2 x 512 for delta_fnorm
     s->pg_half = (size_t)((std::max(s->m, s->n) * (s->KP / 4) + 255) / 256) + 1024;
@@ -966,7 +968,7 @@ void smk_solver_destroy(smk_solver* s)
     if (s->st_inv) (void)hipStreamSynchronize(s->st_inv);
     void* ptrs[] = {s->H, s->Wt_own, s->Gw, s->Gh_own, s->gram_scratch, s->tmpW, s->pg_partials, s->scal_own,
                     s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH, s->nnls_scratch, s->W0c, s->H0c,
-                    s->xscale[0], s->xscale[1], s->oscale[0], s->oscale[1], s->r2_scratch, s->r2_prog, s->Graw, s->Hc, s->Wc};
+                    s->xscale[0], s->xscale[1], s->oscale[0], s->oscale[1], s->r2_scratch, s->r2_prog, s->Graw, s->Hc, s->Wc, s->wide_tmp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int w = 0; w < 3; ++w)
@@ -1605,15 +1607,15 @@ static int solver_iteration(smk_solver* s)
     const PartialView r1 = view1(s), r2 = view2(s);
     switch (s->o.algorithm) {
         case SMK_ALG_MU:   // nmf_solver_mu.hpp:121-164
-            rc = launch_mu_update(s->H, s->k, s->n, r1, s->Gw, s->st);  if (rc) return rc;
+            rc = launch_mu_update(s->H, s->k, s->n, r1, s->Gw, s->st, s->wide_tmp);  if (rc) return rc;
             rc = gram_h(s);   if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
             rc = wait_r2(s);  if (rc) return rc;
             if (s->w_sharded) {       // own blocks only (back to back in Wown, their rows of the summed (AH')' in R2own)
-                if (s->n_own > 0) { rc = launch_mu_update(s->Wown, s->k, s->n_own, view_own(s), s->Gh, s->st); if (rc) return rc; }
+                if (s->n_own > 0) { rc = launch_mu_update(s->Wown, s->k, s->n_own, view_own(s), s->Gh, s->st, s->wide_tmp); if (rc) return rc; }
                 s->w_full = false;
             } else {
-                rc = launch_mu_update(s->Wt, s->k, s->m, r2, s->Gh, s->st); if (rc) return rc;
+                rc = launch_mu_update(s->Wt, s->k, s->m, r2, s->Gh, s->st, s->wide_tmp); if (rc) return rc;
             }
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
@@ -1737,13 +1739,13 @@ static int enqueue_progress_kernels(smk_solver* s)
     } else {
         // gradW = W*HHt - AHt  (slot 0, replicated), gradH = WtW*H - WtA (slot 1, local shard)
         if (w_rows_sharded(s)) {      // only this rank's rows of the summed (AH')' exist here: partial sum, joined in dist_agree
-            rc = s->n_own > 0 ? launch_grad_pg(s->Wown, s->k, s->n_own, view_own(s), s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st)
+            rc = s->n_own > 0 ? launch_grad_pg(s->Wown, s->k, s->n_own, view_own(s), s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st, s->wide_tmp)
                               : launch_zero_f64(s->scal, 1, s->st);
         } else {
-            rc = launch_grad_pg(s->Wt, s->k, s->m, view2(s), s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st);
+            rc = launch_grad_pg(s->Wt, s->k, s->m, view2(s), s->Gh, nullptr, s->pg_partials, s->scal, 0, s->st, s->wide_tmp);
         }
         if (rc) return rc;
-        rc = launch_grad_pg(s->H, s->k, s->n, view1(s), s->Gw, nullptr, s->pg_partials + s->pg_half, s->scal, 1, s->st);
+        rc = launch_grad_pg(s->H, s->k, s->n, view1(s), s->Gw, nullptr, s->pg_partials + s->pg_half, s->scal, 1, s->st, s->wide_tmp);
         if (rc) return rc;
     }
     if (is_dist(s)) { rc = dist_agree(s); if (rc) return rc; }
@@ -2076,7 +2078,7 @@ int smk_solver_nnls_hals(smk_solver* s, double tol, int verbose, int max_iter, i
     int i = 0;
     for (i = 0; i < max_iter; ++i) {
         rc = launch_hals_sweep(s->H, s->k, s->n, view1(s), s->Gw, s->st);
-        if (!rc) rc = launch_grad_pg(s->H, s->k, s->n, view1(s), s->Gw, nullptr, s->pg_partials + s->pg_half, s->scal, 1, s->st);
+        if (!rc) rc = launch_grad_pg(s->H, s->k, s->n, view1(s), s->Gw, nullptr, s->pg_partials + s->pg_half, s->scal, 1, s->st, s->wide_tmp);
         if (rc) return rc;
         double sum = 0.0;
         SMK_HIP(hipMemcpyAsync(&sum, s->scal + 1, sizeof(double), hipMemcpyDeviceToHost, s->st));

@@ -121,6 +121,60 @@ __device__ __forceinline__ double wide_dot(const double* __restrict__ Grow, cons
     return wave_sum(a);
 }
 
+// Y = S M for all the columns of a launch at once, M symmetric k x k, S either the summed partial products R (block pivoting:
+// V = R Ginv, i.e. v = Ginv r of every column) or a factor itself (MU and the gradients: Y = X G).  The per-column kernels
+// formed these as matrix-vector products, streaming the k x k matrix from L2 for every column -- a quarter of a warm
+// block-pivoting iteration at k = 192, most of an MU iteration.  One workgroup per 64 columns x 64 entries, chunks of 16
+// along c staged in LDS, f64 matrix cores (wave w: columns 16 w .. 16 w + 15, four 16 x 16 tiles).
+// Y[(col - col_begin) * KP + e]; entries e >= k come out as zero when M's padding is zero.
+template <bool FROM_VIEW>
+__global__ __launch_bounds__(256) void rows_times_sym_wide_kernel(PartialView R, const double* __restrict__ S,
+                                                                  const double* __restrict__ M, const int* __restrict__ status, int k,
+                                                                  int KP, i64 col_begin, i64 N, double* __restrict__ Y)
+{
+    __shared__ double sR[16][64 + 1], sG[16][64 + 1];
+    if (status && *status == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const i64 c0 = col_begin + (i64)blockIdx.x * 64;
+    const int e0 = blockIdx.y * 64;
+    f64x4_t acc[4] = {};
+    for (int cb = 0; cb < k; cb += 16) {
+        {   // S chunk: thread -> column tid / 4, entries 4 (tid % 4) .. + 3
+            const i64 col = c0 + (tid >> 2);
+            const int cc = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double v = 0.0;
+                if (col < N && cb + cc + u < k) {
+                    if constexpr (FROM_VIEW) v = (cb + cc + u < R.kpp) ? rhs_elem(R, col, cb + cc + u) : 0.0;
+                    else v = S[col * KP + cb + cc + u];
+                }
+                sR[cc + u][tid >> 2] = v;
+            }
+            // M chunk: thread -> row tid / 16, entries 4 (tid % 16) .. + 3
+            const int gr = tid >> 4, ge = (tid & 15) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sG[gr][ge + u] = (cb + gr < k) ? M[(size_t)(cb + gr) * KP + e0 + ge + u] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double a = sR[4 * kk + (lane >> 4)][16 * w + (lane & 15)];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sG[4 * kk + (lane >> 4)][16 * jt + (lane & 15)], acc[jt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const i64 col = c0 + 16 * w + (lane >> 4) + 4 * v;
+            if (col < N) Y[(size_t)(col - col_begin) * KP + e0 + 16 * jt + (lane & 15)] = acc[jt][v];
+        }
+}
+
 // MU: x <- x .* R ./ (G x + 1e-13)   (mu_update_kernel)
 template <int V>
 __global__ __launch_bounds__(256) void mu_wide_kernel(double* __restrict__ X, int k, int KP, i64 N, PartialView R,
@@ -224,9 +278,51 @@ __global__ __launch_bounds__(256) void grad_pg_wide_kernel(const double* __restr
         default: set_error("wide kernels: KP must be 192 .. 1024"); return -100; \
     }
 
-int launch_mu_update_wide(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st)
+// x <- x .* R ./ (y + 1e-13) with y = (X G) of the same column from rows_times_sym_wide_kernel; a thread per entry
+__global__ __launch_bounds__(256) void mu_apply_wide_kernel(double* __restrict__ X, int k, int KP, i64 N, PartialView R,
+                                                            const double* __restrict__ Y)
+{
+    const i64 gid = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 col = gid / KP;
+    const int e = (int)(gid % KP);
+    if (col >= N || e >= k) return;
+    const double b = (e < R.kpp) ? rhs_elem(R, col, e) : 0.0;
+    X[col * KP + e] = X[col * KP + e] * (b / (Y[col * KP + e] + 1.0e-13));
+}
+
+// gradient y - R (optionally stored) and its projected-gradient partial sum per workgroup, y = (X G) as above
+__global__ __launch_bounds__(256) void grad_pg_apply_wide_kernel(const double* __restrict__ X, int k, int KP, i64 N, PartialView R,
+                                                                 const double* __restrict__ Y, double* __restrict__ grad_out,
+                                                                 double* __restrict__ partials)
+{
+    __shared__ double sh[16];
+    double sum = 0.0;
+    for (i64 gid = (i64)blockIdx.x * 256 + threadIdx.x; gid < N * KP; gid += (i64)gridDim.x * 256) {
+        const i64 col = gid / KP;
+        const int e = (int)(gid % KP);
+        double g = 0.0;
+        if (e < k) {
+            const double b = (e < R.kpp) ? rhs_elem(R, col, e) : 0.0;
+            g = Y[gid] - b;
+            if (g < 0.0 || X[gid] > 0.0) sum += g * g;
+        }
+        if (grad_out) grad_out[gid] = g;
+    }
+    const double t = block_sum(sum, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+int launch_mu_update_wide(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st, double* tmp)
 {
     const int KP = kp_of(k);
+    if (tmp) {      // Y = X G on the matrix cores, then the elementwise rule
+        rows_times_sym_wide_kernel<false><<<dim3((unsigned)((N + 63) / 64), (unsigned)(KP / 64)), 256, 0, st>>>(PartialView{}, X, G, nullptr, k, KP, 0, N,
+                                                                                                         tmp);
+        SMK_HIP(hipGetLastError());
+        mu_apply_wide_kernel<<<(unsigned)((N * KP + 255) / 256), 256, 0, st>>>(X, k, KP, N, R, tmp);
+        SMK_HIP(hipGetLastError());
+        return 0;
+    }
     const unsigned grid = (unsigned)((N + 3) / 4);
     WIDE_DISPATCH(KP, (mu_wide_kernel<V><<<grid, 256, 0, st>>>(X, k, KP, N, R, G)));
     SMK_HIP(hipGetLastError());
@@ -242,10 +338,19 @@ int launch_hals_sweep_wide(double* X, int k, i64 N, PartialView R, const double*
 }
 // partial sums land in pg_partials[0 .. *grid_out)
 int launch_grad_pg_wide(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out, double* pg_partials,
-                        int* grid_out, hipStream_t st)
+                        int* grid_out, hipStream_t st, double* tmp)
 {
     const int KP = kp_of(k);
     const unsigned grid = (unsigned)((N + 3) / 4);
+    if (tmp) {
+        rows_times_sym_wide_kernel<false><<<dim3((unsigned)((N + 63) / 64), (unsigned)(KP / 64)), 256, 0, st>>>(PartialView{}, X, G, nullptr, k, KP, 0, N,
+                                                                                                         tmp);
+        SMK_HIP(hipGetLastError());
+        grad_pg_apply_wide_kernel<<<grid, 256, 0, st>>>(X, k, KP, N, R, tmp, grad_out, pg_partials);   // as many partials as before
+        SMK_HIP(hipGetLastError());
+        *grid_out = (int)grid;
+        return 0;
+    }
     WIDE_DISPATCH(KP, (grad_pg_wide_kernel<V><<<grid, 256, 0, st>>>(X, k, KP, N, R, G, grad_out, pg_partials)));
     SMK_HIP(hipGetLastError());
     *grid_out = (int)grid;
@@ -397,7 +502,7 @@ int launch_spmm_gather_wide(const i64* colptr, const unsigned* rowidx, const dou
 // NNLS by block principal pivoting (nnls.hpp:144-244, src/nnls.cpp:18-74, normal_eq.hpp:27-54), one workgroup per column.
 //
 // As for k in (32, 128] (nnls.hip) the common work is moved into the inverse of the Gram matrix: Ginv = G^-1 once per
-// launch (launch_chol_wide + inv_cols_wide_kernel), V = R Ginv for all columns (ginv_rhs_wide_kernel), and a passive set F is solved either
+// launch (launch_chol_wide + inv_cols_wide_kernel), V = R Ginv for all columns (rows_times_sym_wide_kernel), and a passive set F is solved either
 // directly, G[F,F] x_F = r_F, y = G[:,F] x_F - r, or through its complement Z: y_Z = -(Ginv[Z,Z])^-1 v_Z,
 // x = v + Ginv[:,Z] y_Z -- whichever block is smaller.  The block (t = min(|F|, |Z|) rows) is gathered into a panel
 // (LDS when t <= 128, else this workgroup's panel of global scratch; the code is the same through generic pointers),
@@ -627,49 +732,6 @@ __global__ __launch_bounds__(256) void inv_cols_wide_kernel(const double* __rest
     for (int e = tid; e < KP; e += 256) Ginv[(size_t)c * KP + e] = (e < k) ? z[e] : 0.0;
 }
 
-// V = R Ginv for all the columns of a launch at once (v = Ginv r of every column, Ginv symmetric): the block-pivoting kernels
-// used to form it per column as a matrix-vector product, streaming the k x k inverse from L2 for every column -- a quarter of
-// a warm iteration at k = 192.  One workgroup per 64 columns x 64 entries, chunks of 16 along c staged in LDS, f64 matrix
-// cores (wave w: columns 16 w .. 16 w + 15, four 16 x 16 tiles).  V[(col - col_begin) * KP + e].
-__global__ __launch_bounds__(256) void ginv_rhs_wide_kernel(PartialView R, const double* __restrict__ Ginv, const int* __restrict__ status,
-                                                            int k, int KP, i64 col_begin, i64 N, double* __restrict__ V)
-{
-    __shared__ double sR[16][64 + 1], sG[16][64 + 1];
-    if (*status == 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const i64 c0 = col_begin + (i64)blockIdx.x * 64;
-    const int e0 = blockIdx.y * 64;
-    f64x4_t acc[4] = {};
-    for (int cb = 0; cb < k; cb += 16) {
-        {   // R chunk: thread -> column tid / 4, entries 4 (tid % 4) .. + 3
-            const i64 col = c0 + (tid >> 2);
-            const int cc = (tid & 3) * 4;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sR[cc + u][tid >> 2] = (col < N && cb + cc + u < k) ? rhs_elem(R, col, cb + cc + u) : 0.0;
-            // Ginv chunk: thread -> row tid / 16, entries 4 (tid % 16) .. + 3
-            const int gr = tid >> 4, ge = (tid & 15) * 4;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sG[gr][ge + u] = (cb + gr < k) ? Ginv[(size_t)(cb + gr) * KP + e0 + ge + u] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const double a = sR[4 * kk + (lane >> 4)][16 * w + (lane & 15)];
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-                acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sG[4 * kk + (lane >> 4)][16 * jt + (lane & 15)], acc[jt], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const i64 col = c0 + 16 * w + (lane >> 4) + 4 * v;
-            if (col < N) V[(size_t)(col - col_begin) * KP + e0 + 16 * jt + (lane & 15)] = acc[jt][v];
-        }
-}
-
 __global__ __launch_bounds__(256) void nnls_wide_kernel(double* __restrict__ X, double* __restrict__ Y, int k, int KP, i64 N,
                                                         PartialView R, const double* __restrict__ G,
                                                         const double* __restrict__ Ginv, const int* __restrict__ status,
@@ -703,7 +765,7 @@ __global__ __launch_bounds__(256) void nnls_wide_kernel(double* __restrict__ X, 
             pas[e] = x0 > 0.0;                      // passive_set = (X > 0), nnls.hpp:157
         }
         __syncthreads();
-        if (use_inv) {                              // v = Ginv r (ginv_rhs_wide_kernel)
+        if (use_inv) {                              // v = Ginv r (rows_times_sym_wide_kernel)
             for (int e = tid; e < k; e += 256) vs[e] = V[(size_t)(col - col_begin) * KP + e];
             __syncthreads();
         }
@@ -1094,7 +1156,7 @@ __global__ __launch_bounds__(256) void nnls_wide_tile_kernel(double* __restrict_
             const bool in = e < k;
             const double x0 = in ? X[col * KP + e] : 0.0;
             rs[e] = in ? rhs_elem(R, col, e) : 0.0;
-            vs[e] = in ? V[(size_t)(col - col_begin) * KP + e] : 0.0;      // v = Ginv r (ginv_rhs_wide_kernel)
+            vs[e] = in ? V[(size_t)(col - col_begin) * KP + e] : 0.0;      // v = Ginv r (rows_times_sym_wide_kernel)
             xs[e] = x0;
             pas[e] = in && x0 > 0.0;                            // passive_set = (X > 0), nnls.hpp:157
         }
@@ -1337,8 +1399,8 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
     const bool use_inv = wide_use_inverse();
     if (use_inv) {
         if (!inverse_ready && launch_gram_inverse_wide(G, k, scratch, num_cus, st)) return -100;
-        ginv_rhs_wide_kernel<<<dim3((unsigned)((ncols + 63) / 64), (unsigned)(KP / 64)), 256, 0, st>>>(R, Ginv, status, k, KP, col_begin,
-                                                                                                  col_end, V);
+        rows_times_sym_wide_kernel<true><<<dim3((unsigned)((ncols + 63) / 64), (unsigned)(KP / 64)), 256, 0, st>>>(R, nullptr, Ginv, status, k, KP,
+                                                                                                              col_begin, col_end, V);
         SMK_HIP(hipGetLastError());
     }
     const int lds = nnls_wide_lds_bytes(k);
