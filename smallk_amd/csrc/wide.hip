@@ -949,87 +949,116 @@ __device__ __forceinline__ void tiles_gather(double* __restrict__ T, const doubl
     }
 }
 
-// In-place Cholesky of the tiled block, right-looking by tile columns; the diagonal keeps 1 / L_jj.  Returns true when a
-// pivot is not positive (*s_bad, cleared by the caller before the group's last sync, carries that to the other waves).
+// ---- pieces of the tiled Cholesky (one wave each) ----
+// diagonal tile (J, J) in registers: lane r16 holds row r16 (the four lane groups carry copies); leaves 1 / L_jj on the
+// diagonal.  Returns true (and stores nothing) when a pivot is not positive.
+__device__ __forceinline__ bool tile_factor_diag(double* __restrict__ T, int J, int lane)
+{
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int ojj = tile_off(J, J);
+    double d[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d[c] = T[ojj + c * 17 + r16];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double piv = readlane_f64(d[j], j);
+        bad |= !(piv > 0.0);                                    // no early exit: what follows a bad pivot is never used
+        double id = __builtin_amdgcn_rsq(piv);                  // 1 / sqrt(piv): hardware estimate + two Newton steps
+        id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
+        id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
+        d[j] = (r16 == j) ? id : d[j] * id;
+#pragma unroll
+        for (int l = j + 1; l < 16; ++l) d[l] = __builtin_fma(-d[j], readlane_f64(d[j], l), d[l]);
+    }
+    if (!bad && q4 == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) T[ojj + c * 17 + r16] = d[c];
+    }
+    return bad;
+}
+// panel: the rows of tiles (I0 + 0 .. 3, J) <- row L_JJ^-T, one row per lane (lane group q4 takes tile I0 + q4)
+__device__ __forceinline__ void tile_panel_rows(double* __restrict__ T, int I0, int J, int tp, int lane)
+{
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int ojj = tile_off(J, J);
+    const int I = I0 + q4;
+    const bool on = I < tp;
+    const int o = tile_off(on ? I : J + 1, J);
+    double x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x[c] = T[o + c * 17 + r16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {                              // right-looking: the updates behind a column are independent
+        x[c] *= T[ojj + c * 17 + c];
+#pragma unroll
+        for (int q = c + 1; q < 16; ++q) x[q] = __builtin_fma(-x[c], T[ojj + c * 17 + q], x[q]);
+    }
+    if (on) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) T[o + c * 17 + r16] = x[c];
+    }
+}
+// trailing tile: C(I, L) -= P_I P_L' with P = tile column J, on the f64 matrix cores (A = -P_I: lane l has row l & 15, column
+// 4 kk + (l >> 4); the result lane has column l & 15, rows (l >> 4) + 4 v)
+__device__ __forceinline__ void tile_trailing(double* __restrict__ T, int I, int L, int J, int lane)
+{
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int oa = tile_off(I, J), ob = tile_off(L, J), oc = tile_off(I, L);
+    f64x4_t acc;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] = T[oc + r16 * 17 + q4 + 4 * v];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[oa + (4 * kk + q4) * 17 + r16], T[ob + (4 * kk + q4) * 17 + r16], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) T[oc + r16 * 17 + q4 + 4 * v] = acc[v];
+}
+
+// In-place Cholesky of the tiled block, right-looking by tile columns.  Returns true when a pivot is not positive (*s_bad,
+// cleared by the caller before the group's last sync, carries that to the other waves).
+// NW = 1: diagonal tile, panel, trailing tiles, one after the other.  NW > 1, with look-ahead: behind panel J the tiles of
+// column J + 1 are brought up to date first (all waves); then wave 0 factors the NEXT diagonal tile while the other waves
+// finish the rest of the trailing triangle (wave 0 joins them for what exceeds its own 16 dependent pivots' worth).
 template <int NW>
 __device__ __forceinline__ bool tiles_cholesky(double* __restrict__ T, int tp, int lane, int wave, int* s_bad)
 {
-    const int r16 = lane & 15, q4 = lane >> 4;
-    for (int J = 0; J < tp; ++J) {
-        const int ojj = tile_off(J, J);
-        if (NW == 1 || wave == 0) {   // diagonal tile in registers: lane r16 holds row r16 (the four lane groups carry copies)
-            double d[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) d[c] = T[ojj + c * 17 + r16];
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double piv = readlane_f64(d[j], j);
-                bad |= !(piv > 0.0);                            // no early exit: what follows a bad pivot is never used
-                double id = __builtin_amdgcn_rsq(piv);          // 1 / sqrt(piv): hardware estimate + two Newton steps
-                id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
-                id = id * __builtin_fma(-0.5 * piv * id, id, 1.5);
-                d[j] = (r16 == j) ? id : d[j] * id;
-#pragma unroll
-                for (int l = j + 1; l < 16; ++l) d[l] = __builtin_fma(-d[j], readlane_f64(d[j], l), d[l]);
-            }
-            if (bad) {
-                if constexpr (NW == 1) return true;
-                else if (lane == 0) *s_bad = 1;
-            } else if (q4 == 0) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) T[ojj + c * 17 + r16] = d[c];
-            }
+    if constexpr (NW == 1) {
+        for (int J = 0; J < tp; ++J) {
+            if (tile_factor_diag(T, J, lane)) return true;
+            WAVE_SYNC();
+            if (J + 1 == tp) break;
+            for (int I0 = J + 1; I0 < tp; I0 += 4) tile_panel_rows(T, I0, J, tp, lane);
+            WAVE_SYNC();
+            for (int I = J + 1; I < tp; ++I)
+                for (int L = J + 1; L <= I; ++L) tile_trailing(T, I, L, J, lane);
+            WAVE_SYNC();
         }
-        group_sync<NW>();
-        if constexpr (NW > 1) {
-            if (*s_bad) return true;                            // uniform over the group
-        }
-        if (J + 1 == tp) break;
-        // panel: rows of the tiles below <- row L_JJ^-T, one row per lane, four tiles per wave at a time
-        for (int I0 = J + 1 + 4 * wave; I0 < tp; I0 += 4 * NW) {
-            const int I = I0 + q4;
-            const bool on = I < tp;
-            const int o = tile_off(on ? I : J + 1, J);
-            double x[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) x[c] = T[o + c * 17 + r16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {                      // right-looking: the updates behind a column are independent
-                x[c] *= T[ojj + c * 17 + c];
-#pragma unroll
-                for (int q = c + 1; q < 16; ++q) x[q] = __builtin_fma(-x[c], T[ojj + c * 17 + q], x[q]);
+        return false;
+    } else {
+        constexpr int AHEAD = 12 * (NW - 1);                    // trailing tiles the other waves take while wave 0 factors (~12 each)
+        if (tp > 0 && wave == 0 && tile_factor_diag(T, 0, lane) && lane == 0) *s_bad = 1;
+        __syncthreads();
+        if (*s_bad) return true;                                // uniform over the group
+        for (int J = 0; J + 1 < tp; ++J) {
+            for (int I0 = J + 1 + 4 * wave; I0 < tp; I0 += 4 * NW) tile_panel_rows(T, I0, J, tp, lane);
+            __syncthreads();
+            for (int I = J + 1 + wave; I < tp; I += NW) tile_trailing(T, I, J + 1, J, lane);     // tile column J + 1 first
+            __syncthreads();
+            if (wave == 0 && tile_factor_diag(T, J + 1, lane) && lane == 0) *s_bad = 1;
+            {   // the rest of the trailing triangle: tiles (I, L), J + 2 <= L <= I
+                int p = 0;
+                for (int I = J + 2; I < tp; ++I)
+                    for (int L = J + 2; L <= I; ++L, ++p) {
+                        const int owner = (p < AHEAD) ? 1 + p % (NW - 1) : (p - AHEAD) % NW;
+                        if (owner == wave) tile_trailing(T, I, L, J, lane);
+                    }
             }
-            if (on) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) T[o + c * 17 + r16] = x[c];
-            }
+            __syncthreads();
+            if (*s_bad) return true;
         }
-        group_sync<NW>();
-        // trailing tiles: C(I, L) -= P_I P_L' on the f64 matrix cores (A = -P_I: lane l has row l & 15, column 4 kk + (l >> 4);
-        // the result lane has column l & 15, rows (l >> 4) + 4 v); the tiles of the trailing triangle go round the waves
-        {
-            int I = J + 1, L = J + 1;
-            for (int s = 0; s < wave; ++s)
-                if (++L > I) { ++I; L = J + 1; }
-            while (I < tp) {
-                const int oa = tile_off(I, J), ob = tile_off(L, J), oc = tile_off(I, L);
-                f64x4_t acc;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[v] = T[oc + r16 * 17 + q4 + 4 * v];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[oa + (4 * kk + q4) * 17 + r16], T[ob + (4 * kk + q4) * 17 + r16], acc, 0, 0, 0);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) T[oc + r16 * 17 + q4 + 4 * v] = acc[v];
-#pragma unroll
-                for (int s = 0; s < NW; ++s)
-                    if (++L > I) { ++I; L = J + 1; }
-            }
-        }
-        group_sync<NW>();
+        return false;
     }
-    return false;
 }
 
 // zs <- (L L')^-1 zs on the factored tiles (zs has 16 tp entries; those beyond t are solved against the identity rows); one wave

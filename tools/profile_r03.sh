@@ -44,7 +44,8 @@ kt c5_hiernmf2_1M python3 $ROOT/tools/c5_hier.py 1000000 16 8
 kt rank2_iteration_1M python3 $ROOT/tools/r2_iter.py 1000000 16 30
 kt wide_bpp_k192 python3 $ROOT/tools/wide_run.py 16384 8192 192 BPP 12 1
 kt wide_bpp_k512 python3 $ROOT/tools/wide_run.py 16384 8192 512 BPP 12 1
-for k in 160 192 256 384 512; do (cd $ROOT && python3 tools/wide_run.py 16384 8192 $k BPP 12 1 2>/dev/null | tail -1; python3 tools/wide_run.py 16384 8192 $k MU 12 1 2>/dev/null | tail -1) >> $OUT/r03_wide_rank_times.txt; done
+for k in 100 160 192 256 384 512; do (cd $ROOT && for alg in BPP MU HALS; do python3 tools/wide_run.py 16384 8192 $k $alg 12 1 2>/dev/null | tail -1; done) >> $OUT/r03_wide_rank_times.txt; done
+(cd $ROOT && SMK_NSPLIT=8 python3 bench.py --workload c4s --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1) > $OUT/r03_bench_c4s_accurate_form.json
 SMK_CLUST_TIMING=1 python3 $ROOT/tools/c5_hier.py 1000000 16 8 2>&1 | grep "smk_clust\|hier_nmf2\|purity" > $OUT/r03_c5_hiernmf2_1M_timing.txt
 # ---- HBM traffic of the streaming kernels (separate passes) ----
 pmc c4_fetch FETCH_SIZE $B --workload c4 --steps 3 --warmup 1
