@@ -28,6 +28,9 @@ inline int kp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : k <=
 constexpr int MAX_K = 1024;                    // larger ranks: SMK_UNSUPPORTED
 constexpr int MAX_GROUPS = MAX_K / 64;         // the streaming product takes 64 factor rows per pass over A
 inline bool is_wide(int k) { return k > 128; }
+// block pivoting takes the tile kernels of wide.hip (and their scratch layout) from this rank on: everything above 128, and
+// k in (64, 128] unless SMK_NNLS_TILE128=0 asks for nnls_bpp_inv128_kernel
+bool nnls_uses_tiles(int k);
 // number of 32-wide k tiles of the streaming product
 inline int kt_of(int k) { return (k + 31) / 32; }
 

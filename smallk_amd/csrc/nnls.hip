@@ -644,6 +644,14 @@ __global__ __launch_bounds__(NT) void nnls_bpp_inv128_kernel(double* __restrict_
     if (failed_any && lane == 0) atomicMin(fail_flag, iter_tag);
 }
 
+bool nnls_uses_tiles(int k)
+{
+    // default: from k = 65 (measured on 16384 x 8192, 12 iterations: k = 80 / 100 / 128 3.96 / 4.53 / 5.27 -> 2.39 / 2.84 / 3.12 ms per
+    // iteration against nnls_bpp_inv128_kernel); SMK_NNLS_TILE128=0 keeps that kernel, =2 also sends k in (32, 64] here (A/B)
+    static const int level = [] { const char* e = getenv("SMK_NNLS_TILE128"); return e ? atoi(e) : 1; }();
+    return is_wide(k) || (level >= 1 && k > 64) || (level >= 2 && k > 32);
+}
+
 size_t nnls_scratch_elems(int k) { return (size_t)kp_of(k) * kp_of(k) + 8; }     // k <= 128; above: nnls_wide_scratch_elems
 
 // k > 32: Ginv and the path selector into `scratch` (nnls_scratch_elems(k) doubles).  One workgroup, ~0.1 ms: the
@@ -666,7 +674,7 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
                     double* gram_partials, int* gram_nblk)
 {
     if (gram_nblk) *gram_nblk = 0;
-    if (is_wide(k)) return launch_nnls_bpp_wide(X, Y, k, col_begin, col_end, R, G, fail_flag, iter_tag, scratch, inverse_ready, num_cus, st);
+    if (nnls_uses_tiles(k)) return launch_nnls_bpp_wide(X, Y, k, col_begin, col_end, R, G, fail_flag, iter_tag, scratch, inverse_ready, num_cus, st);
     const int KPv = kp_of(k);
     const int gpb = 256 / KPv;
     const i64 ncols = col_end - col_begin;

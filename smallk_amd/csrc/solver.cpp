@@ -941,10 +941,10 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     }
     if (opts->algorithm == SMK_ALG_BPP) {
         // k <= 128: two (inverse + selector) halves; above: one Cholesky panel per resident workgroup (wide.hip)
-        rc |= dev_alloc(&s->nnls_scratch, is_wide(s->k) ? nnls_wide_scratch_elems(s->k, g_cus, std::max(s->m, s->n)) : 2 * nnls_scratch_elems(s->k));
+        rc |= dev_alloc(&s->nnls_scratch, nnls_uses_tiles(s->k) ? nnls_wide_scratch_elems(s->k, g_cus, std::max(s->m, s->n)) : 2 * nnls_scratch_elems(s->k));
         // (above k = 128 the inverse stays in stream order: beside the product it gained 1-2 % -- measured -- and the two sides
         // share one scratch there)
-        if (s->KP >= 64 && !is_wide(s->k)) {
+        if (s->KP >= 64 && !nnls_uses_tiles(s->k)) {
             if (hipStreamCreateWithFlags(&s->st_inv, hipStreamNonBlocking) != hipSuccess) rc |= 1;
             for (int i = 0; i < 2 && !rc; ++i) {
                 if (hipEventCreateWithFlags(&s->ev_g[i], hipEventDisableTiming) != hipSuccess) rc |= 1;
@@ -1267,7 +1267,7 @@ static int wait_r2(smk_solver* s)
 // side stream as soon as the matrix exists; the streaming product that follows on the main stream hides it.
 static inline double* inv_scratch(smk_solver* s, int side)
 {
-    return is_wide(s->k) ? s->nnls_scratch : s->nnls_scratch + (size_t)side * nnls_scratch_elems(s->k);
+    return nnls_uses_tiles(s->k) ? s->nnls_scratch : s->nnls_scratch + (size_t)side * nnls_scratch_elems(s->k);
 }
 // `after`: the event that makes G final when that is not the main stream's current position (the HH' all-reduce of a
 // sharded run finishes on the second stream)
@@ -2131,7 +2131,7 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
     rc |= dev_alloc(&dr, hr.size());
     rc |= dev_alloc(&dx, hx.size());
     rc |= dev_alloc(&dy, hx.size());
-    rc |= dev_alloc(&dscratch, is_wide(k) ? nnls_wide_scratch_elems(k, g_cus, ncols) : nnls_scratch_elems(k));
+    rc |= dev_alloc(&dscratch, nnls_uses_tiles(k) ? nnls_wide_scratch_elems(k, g_cus, ncols) : nnls_scratch_elems(k));
     rc |= dev_alloc(&dflag, (size_t)1);
     struct Free { std::vector<void*> p; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } guard{{dg, dr, dx, dy, dscratch, dflag}};
     if (rc) return SMK_DEVICE_ERROR;
