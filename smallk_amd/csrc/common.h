@@ -151,6 +151,9 @@ int launch_hals_sweep_wide(double* X, int k, i64 N, PartialView R, const double*
 int launch_grad_pg_wide(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out, double* pg_partials,
                         int* grid_out, hipStream_t st, double* tmp);
 int hals_w_wide_blocks(i64 M);
+// k > 64: the W sweep by blocks of 16 columns (one product over W per block + a small launch per column)
+size_t hals_w_blocked_scratch_elems(int k, i64 M);
+int launch_hals_w_update_blocked(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, hipStream_t st);
 int launch_hals_w_update_wide(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, hipStream_t st);
 int launch_spmm_gather_wide(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, const double* X, int k,
                             double* P, int kpp, hipStream_t st);

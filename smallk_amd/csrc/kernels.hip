@@ -1396,12 +1396,19 @@ __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ W
     }
 }
 
+static inline bool hals_w_use_blocked(int k)
+{
+    static const bool on = [] { const char* e = getenv("SMK_HALS_W_BLOCKED"); return !(e && e[0] == '0'); }();
+    return on && k > 64;
+}
+
 size_t hals_w_scratch_elems(int k, i64 M)
 {
-    if (is_wide(k)) return (size_t)(2 * (i64)k * hals_w_wide_blocks(M));
+    if (is_wide(k)) return std::max((size_t)(2 * (i64)k * hals_w_wide_blocks(M)), hals_w_blocked_scratch_elems(k, M));
     const size_t multi = (size_t)(2 * (i64)k * hals_w_blocks(kp_of(k), M));
     const size_t fused = (size_t)2 * k * 1024;      // two slot buffers (8 bytes per slot), generous
-    return multi > fused ? multi : fused;
+    const size_t blocked = k > 64 ? hals_w_blocked_scratch_elems(k, M) : 0;
+    return std::max(std::max(multi, fused), blocked);
 }
 
 // `parity` alternates between the two slot buffers of the fused sweep (both must be all-ones before the first call:
@@ -1415,6 +1422,7 @@ int hals_w_scratch_init(double* scratch, int k, i64 M, hipStream_t st)
 int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, int num_cus,
                          int* fail_flag, int parity, int force_multi, hipStream_t st)
 {
+    if (hals_w_use_blocked(k)) return launch_hals_w_update_blocked(Wt, k, M, R, G, scratch, st);
     if (is_wide(k)) return launch_hals_w_update_wide(Wt, k, M, R, G, scratch, st);
     const int KPv = kp_of(k);
     static int mode = -1;                            // SMK_HALS_W=multi forces the one-launch-per-column path

@@ -463,6 +463,161 @@ int launch_hals_w_update_wide(double* Wt, int k, i64 M, PartialView R, const dou
 }
 
 // --------------------------------------------------------------------------------------------------------------------
+// HALS W sweep for k > 64, by blocks of 16 columns.  The per-column launches above read every row of W in full to form
+// w_i . G[:, c] -- k passes over W per sweep (k = 100 on 16384 rows: 101 launches of 14 us, 43 % of the iteration; k = 512:
+// 9.8 of 18.5 ms).  Here the dots of a block's 16 columns come from ONE product Y = W G[:, block] on the matrix cores
+// (rows_times_cols16_kernel, one pass over W per block), and a column's launch corrects its entry for what changed since:
+//     w_i . G[:, c] = Y[i][c - c0] + sum_s Delta[i][s] G[col_s][c],
+// Delta[i][0] = the normalisation of column c0 - 1 (applied by launch c0, after the product saw the raw column), Delta[i][1 + q]
+// = final minus old value of block column c0 + q (update, then normalisation by the next launch).  A launch is a thread per row
+// and touches ~150 bytes per row; the global column norms still cost one launch per column (same update order, same guards,
+// same partial sums as hals_w_col_kernel / nmf_solver_hals.hpp:66-117).
+// scratch: [ss: k x nblk][nz: k x nblk][Yt: 16 x M][Dl: 17 x M]
+// --------------------------------------------------------------------------------------------------------------------
+constexpr int HW_NB = 16;
+
+// Yt[q][i] = sum_e Wt[i][e] G[c0 + q][e], q < ncb <= 16 (zero above): 64 rows per workgroup, chunks of 16 along e through LDS
+__global__ __launch_bounds__(256) void rows_times_cols16_kernel(const double* __restrict__ Wt, const double* __restrict__ G, int k, int KP,
+                                                                int c0, int ncb, i64 M, double* __restrict__ Yt)
+{
+    __shared__ double sR[16][64 + 1], sG[16][16 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const i64 r0 = (i64)blockIdx.x * 64;
+    f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int cb = 0; cb < k; cb += 16) {
+        {
+            const i64 row = r0 + (tid >> 2);
+            const int cc = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sR[cc + u][tid >> 2] = (row < M && cb + cc + u < k) ? Wt[row * KP + cb + cc + u] : 0.0;
+            const int ee = tid >> 4, q = tid & 15;
+            sG[ee][q] = (q < ncb && cb + ee < k) ? G[(size_t)(c0 + q) * KP + cb + ee] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sR[4 * kk + (lane >> 4)][16 * w + (lane & 15)], sG[4 * kk + (lane >> 4)][lane & 15], acc, 0, 0, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const i64 row = r0 + 16 * w + (lane >> 4) + 4 * v;
+        if (row < M) Yt[(i64)(lane & 15) * M + row] = acc[v];
+    }
+}
+
+// launch c of the sweep (0 .. k): normalise column c - 1 from its partial sums, then update column c; a thread per row
+__global__ __launch_bounds__(256) void hals_w_blk_col_kernel(double* __restrict__ Wt, int k, int KP, i64 M, PartialView R,
+                                                             const double* __restrict__ G, int c, int c0, int nblk,
+                                                             double* __restrict__ ss, double* __restrict__ nz,
+                                                             const double* __restrict__ Yt, double* __restrict__ Dl)
+{
+    __shared__ double sh[34];
+    __shared__ double sg[HW_NB + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double scale_prev = 1.0, fill_prev = -1.0;
+    if (c > 0) {                                                // exactly the prologue of hals_w_col_wide_kernel
+        double s2 = 0.0, zc = 0.0;
+        for (int t = threadIdx.x; t < nblk; t += blockDim.x) {
+            s2 += ss[(i64)(c - 1) * nblk + t];
+            zc += nz[(i64)(c - 1) * nblk + t];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s2 += __shfl_down(s2, off, 64);
+            zc += __shfl_down(zc, off, 64);
+        }
+        if (lane == 0) { sh[wave] = s2; sh[16 + wave] = zc; }
+        __syncthreads();
+        s2 = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        zc = (sh[16] + sh[17]) + (sh[18] + sh[19]);
+        __syncthreads();
+        if (zc >= (double)M) {                                  // all-zero column guard (nmf_solver_hals.hpp:105-111)
+            const double eps = DBL_EPSILON;
+            const double nrm = sqrt((double)M * eps * eps);
+            fill_prev = eps * (1.0 / nrm);
+        } else {
+            scale_prev = 1.0 / sqrt(s2);
+        }
+    }
+    // G[col_s][c] of the columns that changed since the block's product: slot 0 = c0 - 1, slot 1 + q = c0 + q (q < c - c0)
+    const int nq = c - c0;                                      // finished block columns before c
+    if (c < k && threadIdx.x <= nq) {
+        const int col = (threadIdx.x == 0) ? c0 - 1 : c0 + (int)threadIdx.x - 1;
+        sg[threadIdx.x] = (col >= 0) ? G[(size_t)col * KP + c] : 0.0;
+    }
+    __syncthreads();
+    const double gcc = (c < k) ? G[(size_t)c * KP + c] : 1.0;
+    double v2 = 0.0, zero = 0.0;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < M; i += (i64)gridDim.x * 256) {
+        if (c > 0) {
+            const int p = c - 1;
+            const double wp = Wt[i * KP + p];
+            const double np = (fill_prev >= 0.0) ? fill_prev : wp * scale_prev;
+            Wt[i * KP + p] = np;
+            if (c < k) {
+                if (p < c0) Dl[i] = np - wp;                                    // slot 0: the product saw the raw column c0 - 1
+                else Dl[(i64)(1 + p - c0) * M + i] += np - wp;                  // update (stored by launch p) + normalisation
+            }
+        }
+        if (c < k) {
+            double dot = Yt[(i64)nq * M + i];
+            if (c0 > 0) dot = __builtin_fma(Dl[i], sg[0], dot);
+            for (int q = 0; q < nq; ++q) dot = __builtin_fma(Dl[(i64)(1 + q) * M + i], sg[1 + q], dot);
+            const double wold = Wt[i * KP + c];
+            const double rhs = rhs_elem(R, i, c);
+            double t = wold + (rhs - dot) / gcc;
+            if (isnan(t) || t < 0.0) { t = 0.0; zero += 1.0; }
+            Wt[i * KP + c] = t;
+            Dl[(i64)(1 + nq) * M + i] = t - wold;
+            v2 += t * t;
+        }
+    }
+    if (c < k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            v2 += __shfl_down(v2, off, 64);
+            zero += __shfl_down(zero, off, 64);
+        }
+        if (lane == 0) { sh[wave] = v2; sh[16 + wave] = zero; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ss[(i64)c * nblk + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+            nz[(i64)c * nblk + blockIdx.x] = (sh[16] + sh[17]) + (sh[18] + sh[19]);
+        }
+    }
+}
+
+int hals_w_blocked_blocks(i64 M)
+{
+    i64 nblk = (M + 255) / 256;
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    return (int)nblk;
+}
+size_t hals_w_blocked_scratch_elems(int k, i64 M) { return (size_t)2 * k * hals_w_blocked_blocks(M) + (size_t)(2 * HW_NB + 1) * M; }
+
+int launch_hals_w_update_blocked(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, hipStream_t st)
+{
+    const int KP = kp_of(k), nblk = hals_w_blocked_blocks(M);
+    double* ss = scratch;
+    double* nz = ss + (i64)k * nblk;
+    double* Yt = nz + (i64)k * nblk;
+    double* Dl = Yt + (i64)HW_NB * M;
+    int c0 = 0;
+    for (int c = 0; c <= k; ++c) {
+        if (c < k && c % HW_NB == 0) {
+            c0 = c;
+            const int ncb = k - c0 < HW_NB ? k - c0 : HW_NB;
+            rows_times_cols16_kernel<<<(unsigned)((M + 63) / 64), 256, 0, st>>>(Wt, G, k, KP, c0, ncb, M, Yt);
+        }
+        hals_w_blk_col_kernel<<<nblk, 256, 0, st>>>(Wt, k, KP, M, R, G, c, c0, nblk, ss, nz, Yt, Dl);
+    }
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------------------------------
 // sparse gather product: out[:, j] = sum over the stored entries p of column j of val[p] * X[:, row[p]]; a wave per column
 // --------------------------------------------------------------------------------------------------------------------
 template <int V>
