@@ -17,51 +17,49 @@ namespace smk {
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 
 // --------------------------------------------------------------------------------------------------------------------
-// Gram partials: grid (nblk, KP / 16, KP / 64); a workgroup owns tile row a (16 rows of G) x 4 tile columns (64 columns of
-// G) for its share of the N columns of X, one v_mfma_f64_16x16x4 per tile and 4 columns of X (as gram_mfma_rows_kernel)
+// Gram partials: grid (nblk, KP / 64, KP / 64); a workgroup owns one 64 x 64 tile of G for its share of the N columns of X,
+// both 64-entry slices of 16 columns at a time through LDS (coalesced 512-byte reads), wave w rows 16 w .. 16 w + 15 of the
+// tile on v_mfma_f64_16x16x4.  (Round 2's kernel gave a workgroup a 16 x 64 strip and read its operands straight from
+// global memory: 2.7 GB of L2 reads per Gram matrix at k = 512, 250 us; this one reads 1 GB.)
 // --------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gram_wide_kernel(const double* __restrict__ X, int KP, i64 N, i64 cols_per_wave,
+__global__ __launch_bounds__(256) void gram_wide_kernel(const double* __restrict__ X, int KP, i64 N, i64 cols_per_wg,
                                                         double* __restrict__ Gp)
 {
-    __shared__ double red[16 * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int a = blockIdx.y, cb = blockIdx.z;
-    const i64 wg = (i64)blockIdx.x * 4 + wave;
-    const i64 c_begin = wg * cols_per_wave;
-    i64 c_end = c_begin + cols_per_wave;
+    __shared__ double sA[16][64 + 1], sB[16][64 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ia = blockIdx.y, ib = blockIdx.z;
+    const i64 c_begin = (i64)blockIdx.x * cols_per_wg;
+    i64 c_end = c_begin + cols_per_wg;
     if (c_end > N) c_end = N;
     f64x4_t acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = f64x4_t{0.0, 0.0, 0.0, 0.0};
-    const int kc = lane >> 4, r16 = lane & 15;
-    for (i64 c0 = c_begin; c0 < c_end; c0 += 4) {
-        const i64 col = c0 + kc;
+    const int cc = tid >> 4, r4 = (tid & 15) * 4;
+    for (i64 c0 = c_begin; c0 < c_end; c0 += 16) {
+        const i64 col = c0 + cc;
         const bool ok = col < c_end;
-        const double fa = ok ? X[col * KP + 16 * a + r16] : 0.0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const double fb = ok ? X[col * KP + 64 * cb + 16 * b + r16] : 0.0;
-            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc[b], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+            sA[cc][r4 + u] = ok ? X[col * KP + 64 * ia + r4 + u] : 0.0;
+            sB[cc][r4 + u] = ok ? X[col * KP + 64 * ib + r4 + u] : 0.0;
         }
-    }
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double fa = sA[4 * kk + (lane >> 4)][16 * w + (lane & 15)];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = kc + 4 * r, colm = 16 * b + r16;
-                    const int idx = colm * 16 + row;
-                    red[idx] = (w == 0) ? acc[b][r] : red[idx] + acc[b][r];
-                }
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, sB[4 * kk + (lane >> 4)][16 * b + (lane & 15)], acc[b], 0, 0, 0);
         }
         __syncthreads();
     }
+    // D: column = lane & 15, row = (lane >> 4) + 4 reg; G is stored column-major with leading dimension KP
     double* out = Gp + (i64)blockIdx.x * KP * KP;
-    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
-        const int colm = i / 16, row = i % 16;
-        out[(i64)(64 * cb + colm) * KP + 16 * a + row] = red[i];
-    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            out[(i64)(64 * ib + 16 * b + (lane & 15)) * KP + 64 * ia + 16 * w + (lane >> 4) + 4 * r] = acc[b][r];
 }
 
 int gram_wide_blocks(int KP, i64 N, int max_blocks)
@@ -79,9 +77,9 @@ int gram_wide_blocks(int KP, i64 N, int max_blocks)
 int launch_gram_wide_partials(const double* X, int KP, i64 N, double* scratch, int max_blocks, int* nblk_out, hipStream_t st)
 {
     const int nblk = gram_wide_blocks(KP, N, max_blocks);
-    i64 cpw = (N + (i64)nblk * 4 - 1) / ((i64)nblk * 4);
+    i64 cpw = (N + nblk - 1) / nblk;                    // columns per workgroup, in whole chunks of 16
     cpw = (cpw + 15) / 16 * 16;
-    gram_wide_kernel<<<dim3(nblk, KP / 16, KP / 64), 256, 0, st>>>(X, KP, N, cpw, scratch);
+    gram_wide_kernel<<<dim3(nblk, KP / 64, KP / 64), 256, 0, st>>>(X, KP, N, cpw, scratch);
     SMK_HIP(hipGetLastError());
     *nblk_out = nblk;
     return 0;
