@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -108,3 +109,21 @@ print("STEPWISE", rc, np.linalg.norm(W - ref2.W) / np.linalg.norm(ref2.W))
     step = [l for l in r.stdout.splitlines() if l.startswith("STEPWISE")][0].split()
     assert int(step[1]) == 0 and float(step[2]) < 1e-4
     assert r.stderr.count("repeating the run on the per-column path") == 2
+
+
+def test_hals_blocked_w_sweep_with_more_rows_than_threads(gpu):
+    """HALS above k = 64 sweeps W by blocks of 16 columns with a thread per row (wide.hip: launch_hals_w_update_blocked); the
+    grid stops at 1024 workgroups of 256, so beyond 262144 rows a thread takes a second row -- a path no other test reaches.
+    Two iterations on 270000 x 96 at k = 70 (five blocks, the last one of six columns) against the oracle."""
+    import oracle
+    m, n, k = 270000, 96, 70
+    rng = np.random.default_rng(3)
+    A = (rng.random((m, k)) * (rng.random((m, k)) > 0.7)) @ (rng.random((k, n)) * (rng.random((k, n)) > 0.5)) + 0.05 * rng.random((m, n))
+    A = oracle.quantize(A, 0)
+    W0, H0 = oracle.fill_uniform(m, k, 5), oracle.fill_uniform(k, n, 6)
+    ref = oracle.nmf(A, W0, H0, "HALS", min_iter=2, max_iter=2)
+    got = gpu.nmf(A, W0, H0, "HALS", min_iter=2, max_iter=2)
+    assert got.result == ref.result == 0 and got.iteration_count == ref.iteration_count
+    assert np.linalg.norm(got.W - ref.W) / np.linalg.norm(ref.W) < 1e-4
+    assert np.linalg.norm(got.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
+
