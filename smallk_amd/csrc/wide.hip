@@ -1168,6 +1168,31 @@ __device__ __forceinline__ void tile_trailing(double* __restrict__ T, int I, int
     for (int v = 0; v < 4; ++v) T[oc + r16 * 17 + q4 + 4 * v] = acc[v];
 }
 
+// two trailing tiles at once: all loads first, the two chains of matrix instructions interleaved, then the stores (a block in
+// global scratch waits one round trip for the pair instead of one per tile)
+__device__ __forceinline__ void tile_trailing2(double* __restrict__ T, int I1, int L1, int I2, int L2, int J, int lane)
+{
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int oa1 = tile_off(I1, J), ob1 = tile_off(L1, J), oc1 = tile_off(I1, L1);
+    const int oa2 = tile_off(I2, J), ob2 = tile_off(L2, J), oc2 = tile_off(I2, L2);
+    f64x4_t acc1, acc2;
+    double a1[4], b1[4], a2[4], b2[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { acc1[v] = T[oc1 + r16 * 17 + q4 + 4 * v]; acc2[v] = T[oc2 + r16 * 17 + q4 + 4 * v]; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a1[kk] = -T[oa1 + (4 * kk + q4) * 17 + r16]; b1[kk] = T[ob1 + (4 * kk + q4) * 17 + r16];
+        a2[kk] = -T[oa2 + (4 * kk + q4) * 17 + r16]; b2[kk] = T[ob2 + (4 * kk + q4) * 17 + r16];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b1[kk], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[kk], b2[kk], acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { T[oc1 + r16 * 17 + q4 + 4 * v] = acc1[v]; T[oc2 + r16 * 17 + q4 + 4 * v] = acc2[v]; }
+}
+
 // In-place Cholesky of the tiled block, right-looking by tile columns.  Returns true when a pivot is not positive (*s_bad,
 // cleared by the caller before the group's last sync, carries that to the other waves).
 // NW = 1: diagonal tile, panel, trailing tiles, one after the other.  NW > 1, with look-ahead: behind panel J the tiles of
@@ -1199,13 +1224,16 @@ __device__ __forceinline__ bool tiles_cholesky(double* __restrict__ T, int tp, i
             for (int I = J + 1 + wave; I < tp; I += NW) tile_trailing(T, I, J + 1, J, lane);     // tile column J + 1 first
             __syncthreads();
             if (wave == 0 && tile_factor_diag(T, J + 1, lane) && lane == 0) *s_bad = 1;
-            {   // the rest of the trailing triangle: tiles (I, L), J + 2 <= L <= I
-                int p = 0;
+            {   // the rest of the trailing triangle: tiles (I, L), J + 2 <= L <= I, a wave's tiles two at a time
+                int p = 0, pI = -1, pL = -1;
                 for (int I = J + 2; I < tp; ++I)
                     for (int L = J + 2; L <= I; ++L, ++p) {
                         const int owner = (p < AHEAD) ? 1 + p % (NW - 1) : (p - AHEAD) % NW;
-                        if (owner == wave) tile_trailing(T, I, L, J, lane);
+                        if (owner != wave) continue;
+                        if (pI < 0) { pI = I; pL = L; }
+                        else { tile_trailing2(T, pI, pL, I, L, J, lane); pI = -1; }
                     }
+                if (pI >= 0) tile_trailing(T, pI, pL, J, lane);
             }
             __syncthreads();
             if (*s_bad) return true;
