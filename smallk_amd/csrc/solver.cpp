@@ -847,6 +847,11 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     // the stored A against the fp64 factor on the fp64 matrix cores), ~3x the product time.  SMK_NSPLIT=8 selects it anywhere.
     int nsplit_default = (a->storage == SMK_STORE_F32 && !hals && opts->k <= 64) ? NSPLIT_F16X2 : 3;
     if (hals && opts->k > 64 && !a->sparse) nsplit_default = NSPLIT_F64;
+    // Block pivoting above k = 64 as well: the Gram matrix of a uniform start has condition ~3k, so 1e-8-class products are
+    // 2e-6 in the factors after ONE iteration at k = 100, and on data with sparse planted factors that grows ~1.3x per iteration
+    // (tools/wide_long_run.py: 1200 x 1000, k = 100, bf16x3: 1.2e-4 after 20 iterations, 1.1e-3 after 30; k = 160: 4e-5 after 25;
+    // the accurate form: 8.5e-12 after 30).  At k <= 64 the same data stays below 2e-5 over 30 iterations with the fp16 form.
+    if (opts->algorithm == SMK_ALG_BPP && opts->k > 64 && !a->sparse) nsplit_default = NSPLIT_F64;
     // Column scales of A more than 2^28 apart: the small columns fall below what fp32-class products resolve next to the
     // large ones (HALS / BPP leave the bar at 2^+-20, tests/test_gpu_parity.py) -- the accurate form as well.
     if (!env && !a->sparse && opts->algorithm != SMK_ALG_RANK2) {
