@@ -546,3 +546,23 @@ def test_rank_above_128_stopping_rule_and_solver_object(gpu, alg):
         assert rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
     s.close()
     D.close()
+
+
+@pytest.mark.parametrize("alg,m,n,k,iters", [("BPP", 1200, 1000, 100, 30), ("BPP", 1500, 1200, 160, 25), ("HALS", 900, 800, 100, 40)])
+def test_long_runs_above_k64_stay_inside_the_bar(gpu, alg, m, n, k, iters):
+    """Long runs on data with sparse planted factors, where a perturbation of the factors grows ~1.3x per iteration at these ranks:
+    with 1e-8-class products block pivoting at k = 100 is 2e-6 off after ONE iteration (the Gram matrix of a uniform start has
+    condition ~3k) and 1.1e-3 off after 30 -- outside north_star's 1e-4.  HALS and BPP above k = 64 therefore take the accurate
+    product form by default (solver.cpp); this asserts 1e-4 and observes ~1e-11 (profiles/r03_long_run*)."""
+    import oracle
+    rng = np.random.default_rng(7)
+    r = k + 2
+    A = (rng.random((m, r)) * (rng.random((m, r)) > 0.7)) @ (rng.random((r, n)) * (rng.random((r, n)) > 0.7)) + 0.05 * rng.random((m, n))
+    A = oracle.quantize(A, 0)
+    W0, H0 = oracle.fill_uniform(m, k, 11), oracle.fill_uniform(k, n, 12)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, tol=1e-14)
+    got = gpu.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, tol=1e-14)
+    assert got.result == ref.result == 0 and got.iteration_count == ref.iteration_count
+    assert np.linalg.norm(got.W - ref.W) / np.linalg.norm(ref.W) < 1e-4
+    assert np.linalg.norm(got.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
+
