@@ -68,3 +68,56 @@ def sharded_bpp_reference(A_local, W0, H_local, iters, coll, rank, world, chunks
         gather_w()
         WtA = wta()
     return W[:m].copy(), H
+
+
+def sharded_mu_reference(A_local, W0, H_local, iters, coll, rank, world, chunks=None):
+    """The same exchange with the multiplicative updates (nmf_solver_mu.hpp:121-164, solver.cpp MU schedule with a row-sharded W):
+    H_g <- H_g .* (W'A_g) ./ (W'W H_g + 1e-13) on the local columns; every rank updates the rows of W it owns,
+    W_b <- W_b .* own ./ (W_b HH' + 1e-13), from its reduce-scattered block of (A H')'."""
+    m, k = W0.shape
+    blk, nchunk, rows_cap = chunk_geometry(m, world, chunks)
+    mine = own_blocks(m, world, rank, blk, nchunk)
+    W = np.zeros((rows_cap, k))
+    W[:m] = W0
+    H = H_local.copy()
+
+    def gram_w():
+        g = np.zeros((k, k))
+        for a, b in mine:
+            g += W[a:b].T @ W[a:b]
+        return coll.allreduce(g)
+
+    def gather_w():
+        for j in range(nchunk):
+            r0 = j * world * blk
+            W[r0:r0 + world * blk] = coll.allgather(W[r0 + rank * blk:r0 + (rank + 1) * blk])
+
+    def wta():
+        acc = np.zeros((k, A_local.shape[1]))
+        for j in range(nchunk):
+            r0, r1 = j * world * blk, min((j + 1) * world * blk, m)
+            if r1 > r0:
+                acc += W[r0:r1].T @ A_local[r0:r1]
+        return acc
+
+    WtW = gram_w()
+    WtA = wta()
+    for _ in range(iters):
+        H = H * (WtA / (WtW @ H + 1.0e-13))
+        HHt = coll.allreduce(H @ H.T)
+        for j in range(nchunk):
+            r0 = j * world * blk
+            part = np.zeros((world * blk, k))
+            r1 = min(r0 + world * blk, m)
+            if r1 > r0:
+                part[:r1 - r0] = A_local[r0:r1] @ H.T
+            own = coll.reduce_scatter(part, blk)
+            a = r0 + rank * blk
+            b = min(a + blk, m)
+            if b > a:
+                W[a:b] = W[a:b] * (own[:b - a] / (W[a:b] @ HHt + 1.0e-13))
+        WtW = gram_w()
+        gather_w()
+        WtA = wta()
+    return W[:m].copy(), H
+

@@ -84,10 +84,10 @@ def test_sharded_hals_equals_unsharded_oracle(world):
     assert len(results[0][5]) == 2 * (iters + 1)
 
 
-def _bpp_worker(rank, world, port, m, n, k, iters, chunks, q):
+def _bpp_worker(rank, world, port, m, n, k, iters, chunks, q, alg="BPP"):
     import torch
     import torch.distributed as dist
-    from dist_reference import sharded_bpp_reference
+    from dist_reference import sharded_bpp_reference, sharded_mu_reference
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -123,7 +123,7 @@ def _bpp_worker(rank, world, port, m, n, k, iters, chunks, q):
                 calls.append(("allgather", block.shape))
                 return np.concatenate([o.numpy() for o in out], axis=0)
 
-        W, H = sharded_bpp_reference(A_loc, W0, H_loc, iters, Coll(), rank, world, chunks)
+        W, H = (sharded_bpp_reference if alg == "BPP" else sharded_mu_reference)(A_loc, W0, H_loc, iters, Coll(), rank, world, chunks)
         q.put((rank, c0, nc, W, H, calls))
     finally:
         dist.destroy_process_group()
@@ -164,3 +164,31 @@ def test_sharded_bpp_exchange_equals_unsharded_oracle(m, n, chunks):
     assert kinds.count("reduce_scatter") == nchunk * iters and kinds.count("allgather") == nchunk * (iters + 0)
     # exchanged objects: k x k sums, (world * blk) x k row chunks, blk x k blocks -- nothing of the size of A
     assert {c[1] for c in results[0][5]} <= {(k, k), (world * blk, k), (blk, k)}
+
+
+@pytest.mark.parametrize("m,n,chunks", [(700, 45, 1), (1030, 51, 2)])
+def test_sharded_mu_exchange_equals_unsharded_oracle(m, n, chunks):
+    """world size 2 over gloo: MU with the W update row-sharded like block pivoting's (round 3) -- the same reduce-scatter /
+    all-reduce / all-gather choreography, the multiplicative rule on the own blocks -- reproduces the unsharded oracle."""
+    import torch.multiprocessing as mp
+    world, k, iters = 2, 5, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bpp_worker, args=(r, world, port, m, n, k, iters, chunks, q, "MU")) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    ref = oracle.nmf(A, W0, H0, "MU", min_iter=iters, max_iter=iters, normalize=False)
+    H = np.concatenate([r[4] for r in results], axis=1)
+    for r in results:
+        assert np.linalg.norm(r[3] - ref.W) / np.linalg.norm(ref.W) < 1e-9
+    assert np.linalg.norm(H - ref.H) / np.linalg.norm(ref.H) < 1e-9
+    assert np.array_equal(results[0][3], results[1][3])
+
