@@ -1,17 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- NMF iterations/sec of the MI355X dense NMF path on synthetic data.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c4|c3|c2|c1]
+  python bench.py --gpus N --steps K --warmup W [--workload c4|c3|c2|c1] [--single-process]
 
 A "step" is one NMF iteration (one pass of the hot path: both streaming products over A plus the
 factor updates).  Default workload = BASELINE.json configs[3] ("C4"): dense 262144 x 65536, k = 64, BPP, fp32 --
 the configuration north_star's 1/2/4/8-GPU throughput and >= 6x target are quoted on, and the largest one that
 fits a single MI355X (137 GB of A and A').  `--workload c3` is configs[2] (65536 x 16384, k = 32, HALS, bf16 A,
-the MFMA-roofline run; its line is kept in profiles/), c2 is configs[1].  With N > 1 (launched by
-torch.distributed.run) the SAME matrix is column-sharded over the ranks ("strong" scaling: the named (m,n,k) at
-1/2/4/8 GPUs); exchange = RCCL all-reduce of HH' and (AH')' (+ an all-gather of W for BPP), issued from C by
-libsmallk_amd.so on the solver's streams -- no Python inside the iteration loop.  torch.distributed (gloo, CPU)
-is used only to broadcast the RCCL unique id and for the timing barrier.
+the MFMA-roofline run; its line is kept in profiles/), c2 is configs[1].
+
+N > 1: the SAME matrix is column-sharded over the ranks ("strong" scaling: the named (m,n,k) at 1/2/4/8 GPUs).
+The exchange per iteration is issued from C by libsmallk_amd.so on the solver's second stream -- no Python inside
+the iteration loop: an all-reduce of HH' (k x k); the sum of (AH')' pipelined in row chunks behind the H*At pass
+(all-reduce for HALS, REDUCE-SCATTER for BPP / MU, whose rows of W are independent problems that each rank solves
+for its own row blocks); an all-reduce of W'W; and an all-gather per chunk of the PACKED streaming operand of the
+own blocks behind the W'A pass (the fp64 rows of W are gathered only when results are read).
+
+How N ranks come to exist (`--gpus N`, N > 1):
+  * under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (WORLD_SIZE set): this
+    process is one rank;
+  * as plain `python bench.py --gpus N ...` (WORLD_SIZE unset): this process NEVER touches a GPU.  It starts the
+    ranks as a child process group (torch.distributed.run on 127.0.0.1 and a free port), relays rank 0's single
+    JSON line and exits with the children's worst return code.  A watchdog follows the ranks' heartbeat: a run whose
+    rendezvous, communicator set-up or first collective stalls is killed (its own process group only), the RCCL
+    log excerpt is printed, and -- unless --no-fallback -- the second, independent path is tried:
+  * `--single-process`: ONE process drives all N devices, one host thread per device, communicators from
+    ncclCommInitAll (smk_comm_init_all) -- no torch.distributed, no rendezvous.
+torch.distributed (gloo, CPU) is used only to broadcast the RCCL unique id and for the timing barrier.
 
 The K timed steps are one window; the window is repeated (5 times, and until >= 0.5 s have been timed) and
 the MEDIAN window is reported, so `value`, `ms_per_step` are per K steps as the contract asks while short
@@ -28,6 +43,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -47,6 +63,86 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
+
+# ---- heartbeat + watchdog ------------------------------------------------------------------------------------------
+# Every rank reports the stage it has reached (`beat`).  Two watchdogs read it:
+#   * inside each rank, a daemon thread: no beat for longer than the stage's limit -> Python stacks of all threads and
+#     the RCCL log excerpt on stderr, exit code 3 (torch.distributed.run then ends the other ranks);
+#   * in the launching parent (plain `python bench.py --gpus N`): the ranks append their beats to one file; no new line
+#     for the limit + a margin, or the overall --watchdog-s, -> the children's process group is killed.
+# A C call that never returns (a collective whose peer is missing) does not hold the GIL, so the thread gets to run.
+_hb = {"stage": "start", "t": time.monotonic(), "limit": 300.0, "rank": 0, "file": os.environ.get("SMK_BENCH_HEARTBEAT"), "armed": False}
+_hb_lock = threading.Lock()
+
+
+def beat(stage, limit=None, rank=None):
+    """this rank has reached `stage`; it must reach the next one within `limit` seconds (default: --stall-s)"""
+    with _hb_lock:
+        _hb["stage"], _hb["t"] = stage, time.monotonic()
+        if limit is not None:
+            _hb["limit"] = float(limit)
+        r = _hb["rank"] if rank is None else rank
+    if _hb["file"]:
+        try:
+            with open(_hb["file"], "a") as f:
+                f.write(f"{r} {stage} {time.time():.3f}\n")
+        except OSError:
+            pass
+    if os.environ.get("SMK_BENCH_VERBOSE"):
+        print(f"[bench rank {r}] {stage}", file=sys.stderr, flush=True)
+    hang = os.environ.get("SMK_BENCH_TEST_HANG")          # TEST HOOK "rank:stage": that rank stops for good at that stage
+    if hang:
+        hr, _, hs = hang.partition(":")
+        if int(hr) == r and stage.startswith(hs):
+            print(f"[bench rank {r}] TEST HOOK: hanging at stage '{stage}'", file=sys.stderr, flush=True)
+            time.sleep(1e6)
+
+
+def rccl_log_excerpt(max_lines=60, out=sys.stderr):
+    """RCCL's own description of what it built (rings / trees / transport per channel), from the per-rank files that
+    NCCL_DEBUG_FILE names"""
+    import glob
+    import re
+    pat = re.compile(r"Channel|Ring|Tree|Trees|XGMI|xgmi|P2P|SHM|NET|algo|Algo|proto|Connected|nChannels|comm 0x|WARN|error|fail", re.I)
+    files = sorted(glob.glob(os.environ.get("SMK_BENCH_RCCL_LOG_GLOB", "/tmp/smk_rccl_*.log")), key=os.path.getmtime, reverse=True)
+    for fn in files[:1]:
+        try:
+            lines = [l.rstrip() for l in open(fn, errors="replace") if pat.search(l)]
+            print(f"[bench] RCCL log excerpt ({fn}, {len(lines)} matching lines, first {max_lines}):", file=out)
+            for l in lines[:max_lines]:
+                print("[rccl] " + l[:220], file=out)
+        except Exception as e:      # pragma: no cover
+            print(f"[bench] no RCCL log: {e}", file=out)
+    if not files:
+        print("[bench] no RCCL log files (/tmp/smk_rccl_*.log)", file=out)
+    out.flush()
+
+
+def start_rank_watchdog(stall_s):
+    """daemon thread of a rank: exit(3) with diagnostics when the heartbeat stops"""
+    if _hb["armed"] or os.environ.get("SMK_BENCH_NO_RANK_WATCHDOG"):      # TEST HOOK: leave a hung rank to the parent's watchdog
+        return
+    _hb["armed"] = True
+
+    def watch():
+        import faulthandler
+        while True:
+            time.sleep(1.0)
+            with _hb_lock:
+                idle, stage, limit, r = time.monotonic() - _hb["t"], _hb["stage"], _hb["limit"], _hb["rank"]
+            if stage == "done":
+                return
+            if idle > limit:
+                print(f"[bench rank {r}] WATCHDOG: no progress for {idle:.0f} s in stage '{stage}' (limit {limit:.0f} s); "
+                      "Python stacks of all threads follow, then the RCCL log excerpt; exiting with code 3", file=sys.stderr, flush=True)
+                try:
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                    rccl_log_excerpt()
+                except Exception:
+                    pass
+                os._exit(3)
+    _hb["limit"] = max(_hb["limit"], stall_s)
+    threading.Thread(target=watch, name="bench-watchdog", daemon=True).start()
 
 
 def cpu_baseline(m, n, k, alg, quant, budget_s=20.0):
@@ -128,20 +224,284 @@ def kernel_source_sha16():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def main():
+def lim(args, floor):
+    """stage limit: long stages (matrix fill, solver set-up, the first collectives, the CPU baseline) get `floor` seconds
+    unless --stall-s was lowered below a minute -- then the caller wants failures fast and gets exactly that"""
+    return max(args.stall_s, floor) if args.stall_s >= 60.0 else args.stall_s
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 without torch.distributed: one process, one host thread per device, communicators from "
+                         "ncclCommInitAll (smk_comm_init_all)")
+    ap.add_argument("--no-fallback", action="store_true",
+                    help="plain `--gpus N` launch: do not try --single-process when the torch.distributed.run ranks fail or stall")
+    ap.add_argument("--stall-s", type=float, default=90.0,
+                    help="watchdog: a rank that makes no progress for this long (rendezvous, communicator, first collective, a "
+                         "timed window) ends the run with a non-zero code; start-up (imports) gets 300 s")
+    ap.add_argument("--watchdog-s", type=float, default=1500.0, help="overall wall-clock limit of a launched run")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="MEASUREMENT HOOK, one GPU: run as rank 0 of a world of this many ranks -- its column shard, the chunk "
                          "geometry and the row blocks of that world, every collective issued through RCCL with ONE rank "
                          "(device-local).  Times the per-rank work of an N-GPU run without the xGMI transfers; the factors "
                          "it produces are meaningless (the other ranks' blocks never arrive)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ---- the launching parent: plain `python bench.py --gpus N` ------------------------------------------------------------
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_plan(name, cmd, env, args, deadline):
+    """one attempt: the command as a process group of its own, stdout captured, stderr passed through; returns
+    (return code, JSON line or None, reason)"""
+    import signal
+    import subprocess
+    import tempfile
+    hb = tempfile.NamedTemporaryFile(prefix="smk_bench_hb_", suffix=".txt", delete=False)
+    hb.close()
+    env = dict(env, SMK_BENCH_HEARTBEAT=hb.name)
+    print(f"[bench] launching plan '{name}': {' '.join(cmd)}", file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
+    out_lines = []
+    reader = threading.Thread(target=lambda: out_lines.extend(p.stdout.readlines()), daemon=True)
+    reader.start()
+    last_size, last_change, reason = 0, time.monotonic(), ""
+    startup = True                                       # until the first beat: imports of a cold image take minutes
+    while p.poll() is None:
+        time.sleep(0.25)
+        try:
+            size = os.path.getsize(hb.name)
+        except OSError:
+            size = last_size
+        now = time.monotonic()
+        if size != last_size:
+            last_size, last_change, startup = size, now, False
+        limit = (300.0 if startup else args.stall_s) + 15.0    # the ranks' own watchdogs fire first: they know more
+        if now - last_change > limit:
+            reason = f"no heartbeat from any rank for {now - last_change:.0f} s"
+        elif now > deadline:
+            reason = f"overall limit --watchdog-s {args.watchdog_s:.0f} s reached"
+        if reason:
+            try:
+                stages = {}
+                for l in open(hb.name):
+                    r, st, _ = l.split(" ", 2)
+                    stages[r] = st
+                print(f"[bench] WATCHDOG ({name}): {reason}; last stage per rank: {stages}", file=sys.stderr, flush=True)
+            except Exception:
+                print(f"[bench] WATCHDOG ({name}): {reason}", file=sys.stderr, flush=True)
+            rccl_log_excerpt()
+            for sig, wait in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):      # OUR process group only
+                try:
+                    os.killpg(p.pid, sig)
+                except ProcessLookupError:
+                    break
+                t_end = time.monotonic() + wait
+                while p.poll() is None and time.monotonic() < t_end:
+                    time.sleep(0.1)
+                if p.poll() is not None:
+                    break
+            break
+    rc = p.wait()
+    reader.join(timeout=5.0)
+    try:
+        os.unlink(hb.name)
+    except OSError:
+        pass
+    line = None
+    for l in out_lines:
+        l = l.strip()
+        if l.startswith("{"):
+            try:
+                if "metric" in json.loads(l):
+                    line = l
+            except ValueError:
+                pass
+    if reason and rc == 0:
+        rc = 3
+    return rc, line, reason
+
+
+def launch(args):
+    """Plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE).  This process imports neither torch nor the library and
+    makes no GPU call: the ranks are fresh children.  Plan A = torch.distributed.run (one process per GPU), plan B =
+    one process with a thread per device (--single-process).  Rank 0's JSON line is relayed with a `launcher` object."""
+    t_start = time.monotonic()
+    deadline = t_start + args.watchdog_s
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    common = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload,
+              "--stall-s", str(args.stall_s)]
+    if args.no_cpu_baseline:
+        common.append("--no-cpu-baseline")
+    me = os.path.join(ROOT, "bench.py")
+    plans = []
+    if not args.single_process:
+        plans.append(("torch.distributed.run, one process per GPU",
+                      [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                       "--master-addr", "127.0.0.1", "--master-port", str(free_port()), me] + common))
+    if args.single_process or not args.no_fallback:
+        plans.append(("single process, one host thread per device (ncclCommInitAll)",
+                      [sys.executable, me, "--single-process", "--in-child"] + common))
+    attempts = []
+    for name, cmd in plans:
+        if time.monotonic() > deadline - 30.0 and attempts:
+            break
+        t0 = time.monotonic()
+        rc, line, reason = run_plan(name, cmd, env, args, deadline)
+        attempts.append({"plan": name, "rc": rc, "seconds": round(time.monotonic() - t0, 1), "stopped_by_watchdog": reason or None})
+        if rc == 0 and line:
+            out = json.loads(line)
+            out["launcher"] = {"mode": "self-launched children (the parent makes no GPU call)", "attempts": attempts}
+            print(json.dumps(out), flush=True)
+            return 0
+        print(f"[bench] plan '{name}' ended with code {rc}" + (f" ({reason})" if reason else "") + (", no JSON line" if not line else ""),
+              file=sys.stderr, flush=True)
+    print(f"[bench] no plan produced a result: {json.dumps(attempts)}", file=sys.stderr, flush=True)
+    worst = max((abs(a["rc"]) for a in attempts), default=1)
+    return worst if 0 < worst < 256 else 1
+
+
+# ---- report ---------------------------------------------------------------------------------------------------------
+def build_report(args, world, elapsed, windows, rank0, ranks_report, collectives, parallelism):
+    """the ONE JSON line.  rank0: dict with the timers of rank 0's solver (ms0, c0, ms1, c1, bytes, flops)"""
+    m, n, k, alg, storage, desc = WORKLOADS[args.workload]
+    sharded = world > 1 or args.emulate_world > 1
+    avg_ms = (rank0["ms0"] + rank0["ms1"]) / max(rank0["c0"] + rank0["c1"], 1)
+    achieved_gbs = rank0["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    mfma_tf = rank0["flops"] / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "NMF iterations/sec",
+        "value": args.steps / elapsed,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": storage if storage == "bf16" else "f32",
+        "data": "synthetic",
+        "config": {"workload": desc, "m": m, "n": n, "k": k, "algorithm": alg, "A_storage": storage,
+                   "state": "W,H,Gram fp64; big products: MFMA with fp32 accumulation folded into fp64",
+                   "parallelism": parallelism, "collectives": collectives},
+        # useful flops (2 k per matrix entry) of the streaming products.  fp32 storage computes them as three fp16
+        # MFMAs per product (DESIGN 5.1), so its ratio is against the NATIVE fp32 matrix peak that this replaces
+        # and may exceed 1; the bound that matters for this path is roofline.frac (HBM).
+        "useful_tflops_big_products": mfma_tf,
+        "useful_tflops_vs_native_mfma_peak": mfma_tf / MFMA_PEAK_TF[storage],
+        "whole_iteration_tflops": 4.0 * m * n * k / (elapsed / args.steps) / 1e12,
+        "collectives_ms_per_step_rank0": ranks_report[0]["collectives_ms_per_step"] if sharded else None,
+        "per_rank": ranks_report if sharded else None,
+        "windows": len(windows), "windows_ms": [round(w * 1e3, 4) for w in windows],
+        "timed_region_s": sum(windows),
+        "roofline": {
+            "bound": "hbm",
+            "kernel": ("smk::bigprod_kernel" if storage == "bf16" else "smk::bigprod_f3_kernel (fp32 A as two fp16 terms)")
+                      + " (W'A and H*At passes)",
+            "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": avg_ms, "launches": rank0["c0"] + rank0["c1"],
+            "pass_WtA_ms": rank0["ms0"] / max(rank0["c0"], 1), "pass_HAt_ms": rank0["ms1"] / max(rank0["c1"], 1),
+            "algorithmic_bytes_per_launch": rank0["bytes"],
+        },
+    }
+    # HBM traffic comes from separate rocprofv3 --pmc passes (tools/profile.sh -> profiles/hbm_traffic.json).  The
+    # entry records the hash of the kernel source it was measured on: a figure from an older kernel is not printed.
+    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(prof) and args.emulate_world <= 1:
+        try:
+            pj = json.load(open(prof))
+            key = f"{args.workload}_n{world}"
+            if key in pj:
+                if pj[key].get("kernel_source_sha16") == kernel_source_sha16():
+                    out["roofline"]["traffic"] = pj[key]["bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = pj[key].get("source", "profiles/")
+                else:
+                    out["roofline"]["traffic_stale"] = ("profiles/hbm_traffic.json was measured on another version of "
+                                                        "smallk_amd/csrc/bigprod.hip; rerun tools/profile.sh")
+        except Exception:
+            pass
+    return out
+
+
+def per_rank_report(rank, args, k, windows, ms0, c0, ms1, c1, msc, cc):
+    """per rank and per step: both streaming passes, the collectives' own spans, and what the step spends outside the
+    passes.  If the collectives take longer than that remainder, the difference was hidden behind the products:
+    overlap_lower_bound = max(0, 1 - outside / collectives)."""
+    timed_steps = max(len(windows) * args.steps, 1)
+    ngroups = max((k + 63) // 64, 1)
+    pr = {"rank": rank, "ms_per_step": sum(windows) / timed_steps * 1e3,
+          "products_ms_per_step": (ms0 + ms1) / timed_steps, "collectives_ms_per_step": msc / timed_steps,
+          "collective_calls_per_step": cc / timed_steps, "passes_per_step": (c0 + c1) / ngroups / timed_steps}
+    pr["outside_products_ms_per_step"] = pr["ms_per_step"] - pr["products_ms_per_step"]
+    pr["overlap_lower_bound"] = (max(0.0, 1.0 - pr["outside_products_ms_per_step"] / pr["collectives_ms_per_step"])
+                                 if pr["collectives_ms_per_step"] > 0 else None)
+    return pr
+
+
+def rccl_env_defaults(set_keys):
+    """RCCL's own description of what it built goes to a file per rank (an excerpt is printed after the run, or by the
+    watchdog); on one node its bootstrap sockets stay on the loopback interface (the container's hostname may not
+    resolve) and no InfiniBand probing -- the data path is xGMI either way.  The caller's settings win."""
+    if "NCCL_DEBUG" not in os.environ:
+        os.environ["NCCL_DEBUG"] = "INFO"
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH" + (",TUNING" if os.environ.get("SMK_BENCH_RCCL_TUNING") else ""))
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/smk_rccl_%h_%p.log")
+    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+        for key, val in (("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1")):
+            if key not in os.environ:
+                os.environ[key] = val
+                set_keys.append(key)
+
+
+class StdoutGuard:
+    """RCCL prints a version banner on stdout when a communicator is created (and INFO lines at the first collectives if
+    NCCL_DEBUG_FILE is not honoured): fd 1 points at stderr while it can, stdout carries ONLY the JSON line"""
+
+    def __init__(self, active):
+        self.saved = None
+        if active:
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+
+    def restore(self):
+        if self.saved is None:
+            return
+        sys.stdout.flush()
+        try:                                # what sits in the C library's stdio buffer goes out while fd 1 is still stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        self.saved = None
+
+
+# ---- one rank per process (N = 1, or under torch.distributed.run) ----------------------------------------------------
+def run_rank(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    _hb["rank"] = rank
+    if world > 1 or args.emulate_world > 1:
+        start_rank_watchdog(args.stall_s)
+    beat("imports", limit=300.0)
     import numpy as np
     import torch
     import smallk_amd
@@ -150,54 +510,38 @@ def main():
     if args.emulate_world > 1:
         os.environ["SMK_COMM_FORCE"] = "1"
         os.environ["SMK_COMM_EMULATE_WORLD"] = str(args.emulate_world)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks, or run plain `python bench.py --gpus {args.gpus}`")
     # Test hooks for a 1-GPU box (the multi-rank path otherwise only runs on the driver's 8-GPU node):
     # SMK_BENCH_SHARE_GPU=1 puts every rank on device 0, SMK_BENCH_BACKEND=gloo replaces RCCL (which refuses
     # two ranks on one device) by gloo on device tensors.  Numbers from such a run mean nothing.
     share = os.environ.get("SMK_BENCH_SHARE_GPU", "0") == "1"
     backend = os.environ.get("SMK_BENCH_BACKEND", "nccl")
     device_index = 0 if share else local_rank
-    torch.cuda.set_device(device_index)
-    dev = torch.device("cuda", device_index)
     native = backend == "nccl"          # default: RCCL from C (comm.cpp); "gloo": the round-1 callback hook (tests)
     rccl_defaults_set = []              # environment defaults this script added (taken back for plan B)
     if world > 1:
         import torch.distributed as dist
+        beat("rendezvous (gloo side channel)", limit=args.stall_s)
         dist.init_process_group("gloo")                 # CPU side channel only: unique id, barrier, max of the clocks
-        # RCCL's own description of what it built (rings / trees / transport per channel) goes to a file per rank; rank 0
-        # prints an excerpt to stderr after the run so that a scaling run explains itself.  The caller's settings win.
-        if "NCCL_DEBUG" not in os.environ:
-            os.environ["NCCL_DEBUG"] = "INFO"
-            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH" + (",TUNING" if os.environ.get("SMK_BENCH_RCCL_TUNING") else ""))
-            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/smk_rccl_%h_%p.log")
-        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
-            # one node: RCCL's bootstrap sockets stay on the loopback interface (the container's hostname may not
-            # resolve) and no InfiniBand probing; the data path is xGMI either way.  The caller's settings win.
-            for key, val in (("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1")):
-                if key not in os.environ:
-                    os.environ[key] = val
-                    rccl_defaults_set.append(key)
+        rccl_env_defaults(rccl_defaults_set)
+    beat("device init", limit=args.stall_s)
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     smallk_amd.initialize(device_index)
     comm, fallback_group, collectives = None, None, "none"
-    # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the one JSON line
-    saved_stdout = None
-    if world > 1 or args.emulate_world > 1:
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
+    guard = StdoutGuard(world > 1 or args.emulate_world > 1)
     if world > 1 and native:
         # RCCL communicator created by libsmallk_amd.so itself; every collective of the iteration is issued from C
         ok = 1
         try:
+            beat("communicator (ncclCommInitRank)", limit=args.stall_s)
             uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
                 uid = torch.tensor(list(smallk_amd.Comm.unique_id()), dtype=torch.uint8)
             torch.distributed.broadcast(uid, 0)
             comm = smallk_amd.Comm.init_rank(bytes(uid.tolist()), rank, world)
+            beat("communicator self-test (first collectives)", limit=args.stall_s)
             comm.selftest()                 # known sums through RCCL before the run is trusted to it
         except Exception as e:              # pragma: no cover  (multi-GPU nodes only)
             print(f"[bench rank {rank}] native RCCL communicator failed: {e}", file=sys.stderr, flush=True)
@@ -213,6 +557,7 @@ def main():
             native = False
             for key in rccl_defaults_set:   # plan B runs with RCCL's own defaults
                 os.environ.pop(key, None)
+            beat("torch.distributed nccl group (native communicator failed)", limit=args.stall_s)
             fallback_group = torch.distributed.new_group(backend="nccl")
             collectives = "torch.distributed nccl through the callback hook (native communicator failed)"
     elif world > 1:
@@ -227,23 +572,9 @@ def main():
         col0, ncols = sdist.shard_columns(n, args.emulate_world, 0)
         comm = smallk_amd.Comm.init_all(1)[0]
         collectives = f"EMULATED rank 0 of {args.emulate_world}: RCCL calls with one rank (device-local)"
-    def restore_stdout():
-        """fd 1 was pointed at stderr while RCCL could print (its banner at communicator creation, INFO lines at the first
-        collectives if NCCL_DEBUG_FILE is not honoured): stdout carries ONLY the JSON line, so it comes back right before it"""
-        nonlocal saved_stdout
-        if saved_stdout is None:
-            return
-        sys.stdout.flush()
-        try:                                # what sits in the C library's stdio buffer goes out while fd 1 is still stderr
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
-        saved_stdout = None
 
     total_iters = args.warmup + args.steps
+    beat("matrix fill", limit=lim(args, 180.0))
     A = smallk_amd.DenseMatrix(m, n, col0=col0, ncols=ncols, storage=storage)
     A.fill_uniform(42)
     W0 = smallk_amd.uniform_host(m, k, 43)
@@ -251,6 +582,7 @@ def main():
     # W update clamp every entry to zero and the run would iterate on the all-eps guard columns.)
     H0 = smallk_amd.uniform_host(k, ncols, 44, c0=col0, gheight=k) * (2.0 / k)
     opts = smallk_amd.make_options(m, n, k, alg, min_iter=total_iters, max_iter=total_iters)
+    beat("solver set-up", limit=lim(args, 180.0))
     solver = smallk_amd.NmfSolver(A, opts)
     if comm is not None:
         solver.attach_comm(comm)
@@ -262,6 +594,7 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    beat("warm-up iterations (first collectives of the solver)", limit=lim(args, 120.0))
     solver.iterate(args.warmup)                  # includes solver.Init
     rc = solver.sync()
     assert rc == 0, f"solver failed during warm-up: {rc}"
@@ -286,10 +619,14 @@ def main():
         return dt
 
     test_hook = bool(os.environ.get("SMK_BENCH_DUMP_W"))          # the 2-process test compares W after exactly K steps
+    beat("window 0", limit=lim(args, 120.0))
     windows = [window()]
+    wlimit = max(args.stall_s, 30.0 * windows[0])
     while not test_hook and (len(windows) < 5 or sum(windows) < 0.5) and len(windows) < 200:
+        beat(f"window {len(windows)}", limit=wlimit)
         windows.append(window())
     elapsed = sorted(windows)[len(windows) // 2]
+    beat("report", limit=lim(args, 400.0))
 
     dump = os.environ.get("SMK_BENCH_DUMP_W")        # test hook: W (replicated) after the timed steps, rank 0
     if dump:
@@ -302,104 +639,174 @@ def main():
     sharded = world > 1 or args.emulate_world > 1
     msc, cc = solver.kernel_time(2) if sharded else (0.0, 0)    # spans of the collectives on the second stream, this rank
     bytes_per_launch, flops_per_launch = solver.kernel_work(0)
-    avg_ms = (ms0 + ms1) / max(c0 + c1, 1)
-    achieved_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    mfma_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12
-    # per rank and per step: both streaming passes, the collectives' own spans, and what the step spends outside the
-    # passes.  If the collectives take longer than that remainder, the difference was hidden behind the products:
-    # overlap_lower_bound = max(0, 1 - outside / collectives).
-    timed_steps = max(len(windows) * args.steps, 1)
-    ngroups = max((k + 63) // 64, 1)
-    per_rank = {"rank": rank, "ms_per_step": sum(windows) / timed_steps * 1e3,
-                "products_ms_per_step": (ms0 + ms1) / timed_steps, "collectives_ms_per_step": msc / timed_steps,
-                "collective_calls_per_step": cc / timed_steps, "passes_per_step": (c0 + c1) / ngroups / timed_steps}
-    per_rank["outside_products_ms_per_step"] = per_rank["ms_per_step"] - per_rank["products_ms_per_step"]
-    per_rank["overlap_lower_bound"] = (max(0.0, 1.0 - per_rank["outside_products_ms_per_step"] / per_rank["collectives_ms_per_step"])
-                                       if per_rank["collectives_ms_per_step"] > 0 else None)
+    per_rank = per_rank_report(rank, args, k, windows, ms0, c0, ms1, c1, msc, cc)
     ranks_report = [per_rank]
     if world > 1:
         ranks_report = [None] * world
         torch.distributed.all_gather_object(ranks_report, per_rank)
 
     if rank == 0:
-        out = {
-            "metric": "NMF iterations/sec",
-            "value": args.steps / elapsed,
-            "unit": "iterations/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": storage if storage == "bf16" else "f32",
-            "data": "synthetic",
-            "config": {"workload": desc, "m": m, "n": n, "k": k, "algorithm": alg, "A_storage": storage,
-                       "state": "W,H,Gram fp64; big products: MFMA with fp32 accumulation folded into fp64",
-                       "parallelism": (f"column-shard x{world}" if world > 1 else
-                                       f"EMULATED rank 0 of {args.emulate_world} on one GPU (not a benchmark line)" if args.emulate_world > 1
-                                       else "single GPU"),
-                       "collectives": collectives},
-            # useful flops (2 k per matrix entry) of the streaming products.  fp32 storage computes them as three fp16
-            # MFMAs per product, so its ratio is against the NATIVE fp32 matrix peak that this replaces
-            # and may exceed 1; the bound that matters for this path is roofline.frac (HBM).
-            "useful_tflops_big_products": mfma_tf,
-            "useful_tflops_vs_native_mfma_peak": mfma_tf / MFMA_PEAK_TF[storage],
-            "whole_iteration_tflops": 4.0 * m * n * k / (elapsed / args.steps) / 1e12,
-            "collectives_ms_per_step_rank0": per_rank["collectives_ms_per_step"] if sharded else None,
-            "per_rank": ranks_report if sharded else None,
-            "windows": len(windows), "windows_ms": [round(w * 1e3, 4) for w in windows],
-            "timed_region_s": sum(windows),
-            "roofline": {
-                "bound": "hbm",
-                "kernel": ("smk::bigprod_kernel" if storage == "bf16" else "smk::bigprod_f3_kernel (fp32 A as two fp16 terms)")
-                          + " (W'A and H*At passes)",
-                "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_ms": avg_ms, "launches": c0 + c1,
-                "pass_WtA_ms": ms0 / max(c0, 1), "pass_HAt_ms": ms1 / max(c1, 1),
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-            },
-        }
-        # HBM traffic comes from separate rocprofv3 --pmc passes (tools/profile_r03.sh -> profiles/hbm_traffic.json).  The
-        # entry records the hash of the kernel source it was measured on: a figure from an older kernel is not printed.
-        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(prof) and args.emulate_world <= 1:
-            try:
-                pj = json.load(open(prof))
-                key = f"{args.workload}_n{world}"
-                if key in pj:
-                    if pj[key].get("kernel_source_sha16") == kernel_source_sha16():
-                        out["roofline"]["traffic"] = pj[key]["bytes_per_launch"]
-                        out["roofline"]["traffic_source"] = pj[key].get("source", "profiles/")
-                    else:
-                        out["roofline"]["traffic_stale"] = ("profiles/hbm_traffic.json was measured on another version of "
-                                                            "smallk_amd/csrc/bigprod.hip; rerun tools/profile_r03.sh")
-            except Exception:
-                pass
+        parallelism = (f"column-shard x{world}, one process per GPU" if world > 1 else
+                       f"EMULATED rank 0 of {args.emulate_world} on one GPU (not a benchmark line)" if args.emulate_world > 1
+                       else "single GPU")
+        out = build_report(args, world, elapsed, windows,
+                           {"ms0": ms0, "c0": c0, "ms1": ms1, "c1": c1, "bytes": bytes_per_launch, "flops": flops_per_launch},
+                           ranks_report, collectives, parallelism)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, n, k, alg, 1 if storage == "bf16" else 0)
-        restore_stdout()
+        guard.restore()
         print(json.dumps(out), flush=True)
     if rank == 0 and world > 1:
-        import glob
-        import re
-        pat = re.compile(r"Channel|Ring|Tree|Trees|XGMI|xgmi|P2P|SHM|NET|algo|Algo|proto|Connected|nChannels|comm 0x", re.I)
-        for fn in sorted(glob.glob("/tmp/smk_rccl_*.log"))[:1]:
-            try:
-                lines = [l.rstrip() for l in open(fn, errors="replace") if pat.search(l)]
-                print(f"[bench] RCCL log excerpt ({fn}, {len(lines)} matching lines, first 60):", file=sys.stderr)
-                for l in lines[:60]:
-                    print("[rccl] " + l[:220], file=sys.stderr)
-            except Exception as e:      # pragma: no cover
-                print(f"[bench] no RCCL log: {e}", file=sys.stderr)
+        rccl_log_excerpt()
+    beat("teardown", limit=lim(args, 60.0))
     barrier()
     if comm is not None:
         solver.close()
         comm.close()
     if world > 1:
         torch.distributed.destroy_process_group()
+    beat("done")
+
+
+# ---- one process, one host thread per device (--single-process) -------------------------------------------------------
+def run_single_process(args):
+    """N column shards on N devices driven by ONE process: a host thread per device with a library context of its own
+    (smk_thread_context_begin), communicators from ncclCommInitAll (smk_comm_init_all).  No torch.distributed, no
+    rendezvous, no sockets -- a path that shares nothing with the one-process-per-GPU launch except the solver.
+    SMK_BENCH_SHARE_GPU=1 (test hook, one GPU): every thread on device 0, the in-process stand-in instead of RCCL."""
+    N = args.gpus
+    _hb["rank"] = 0
+    start_rank_watchdog(args.stall_s)
+    beat("imports", limit=300.0)
+    import numpy as np
+    import smallk_amd
+    from smallk_amd import _lib as L
+    from smallk_amd import dist as sdist
+    lib = L.lib()
+    share = os.environ.get("SMK_BENCH_SHARE_GPU", "0") == "1"
+    ndev = lib.smk_device_count()
+    if not share and ndev < N:
+        raise SystemExit(f"--gpus {N} --single-process: only {ndev} device(s) visible")
+    rccl_env_defaults([])
+    guard = StdoutGuard(True)
+    beat("communicators (ncclCommInitAll)", limit=args.stall_s)
+    smallk_amd.initialize(0)
+    comms = smallk_amd.Comm.init_local(N) if share else smallk_amd.Comm.init_all(N)
+    collectives = ("in-process stand-in, all shards on device 0 (TEST HOOK)" if share else
+                   "RCCL from C (comm.cpp), communicators from ncclCommInitAll, one host thread per device")
+    m, n, k, alg, storage, desc = WORKLOADS[args.workload]
+    total_iters = args.warmup + args.steps
+    gate = threading.Barrier(N)
+    shared = {"go_on": True, "dts": [0.0] * N, "err": [None] * N, "reports": [None] * N, "rank0": None, "W": None}
+    test_hook = bool(os.environ.get("SMK_BENCH_DUMP_W"))
+    windows = []
+
+    def wait():
+        gate.wait(timeout=lim(args, 600.0))
+
+    def worker(r):
+        try:
+            smallk_amd.thread_context_begin(0 if share else r)
+            comms[r].selftest()             # known sums through the communicator before the run is trusted to it
+            col0, ncols = sdist.shard_columns(n, N, r)
+            A = smallk_amd.DenseMatrix(m, n, col0=col0, ncols=ncols, storage=storage)
+            A.fill_uniform(42)
+            W0 = smallk_amd.uniform_host(m, k, 43)
+            H0 = smallk_amd.uniform_host(k, ncols, 44, c0=col0, gheight=k) * (2.0 / k)
+            opts = smallk_amd.make_options(m, n, k, alg, min_iter=total_iters, max_iter=total_iters)
+            solver = smallk_amd.NmfSolver(A, opts)
+            solver.attach_comm(comms[r])
+            solver.set_factors(W0, H0)
+            if r == 0:
+                beat("warm-up iterations (first collectives of the solver)", limit=lim(args, 120.0))
+            wait()
+            solver.iterate(args.warmup)
+            rc = solver.sync()
+            assert rc == 0, f"solver failed during warm-up: {rc}"
+            lib.smk_device_synchronize()
+            solver.enable_timing(True)
+            while True:
+                # EXACTLY args.steps iterations between barrier + device-synchronize pairs; max over the ranks
+                if r == 0:
+                    beat(f"window {len(windows)}", limit=max(lim(args, 120.0), 30.0 * (windows[0] if windows else 0.0)))
+                wait()
+                lib.smk_device_synchronize()
+                t0 = time.perf_counter()
+                solver.iterate(args.steps)
+                rcw = solver.sync()
+                lib.smk_device_synchronize()
+                wait()
+                shared["dts"][r] = time.perf_counter() - t0
+                assert rcw == 0, f"solver failed: {rcw}"
+                wait()
+                if r == 0:
+                    windows.append(max(shared["dts"]))
+                    shared["go_on"] = not test_hook and (len(windows) < 5 or sum(windows) < 0.5) and len(windows) < 200
+                wait()
+                if not shared["go_on"]:
+                    break
+            if test_hook:
+                Wd, _ = solver.factors(normalize=False)         # every rank takes part in the gather of W
+                if r == 0:
+                    shared["W"] = Wd
+            ms0, c0 = solver.kernel_time(0)
+            ms1, c1 = solver.kernel_time(1)
+            msc, cc = solver.kernel_time(2)
+            shared["reports"][r] = per_rank_report(r, args, k, windows, ms0, c0, ms1, c1, msc, cc)
+            if r == 0:
+                b, f = solver.kernel_work(0)
+                shared["rank0"] = {"ms0": ms0, "c0": c0, "ms1": ms1, "c1": c1, "bytes": b, "flops": f}
+            wait()
+            solver.close()
+            A.close()
+            smallk_amd.thread_context_end()
+        except BaseException as e:      # a rank that gives up releases the others (they would wait in a collective)
+            shared["err"][r] = repr(e)
+            print(f"[bench thread {r}] failed: {e!r}", file=sys.stderr, flush=True)
+            try:
+                gate.abort()
+                lib.smk_comm_abort(comms[r]._h)
+            except Exception:
+                pass
+
+    beat("matrix fill + solver set-up", limit=lim(args, 240.0))
+    threads = [threading.Thread(target=worker, args=(r,), name=f"shard-{r}") for r in range(N)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if any(shared["err"]):
+        guard.restore()
+        print(f"[bench] single-process run failed: {shared['err']}", file=sys.stderr, flush=True)
+        rccl_log_excerpt()
+        beat("done")
+        return 1
+    beat("report", limit=lim(args, 60.0))
+    elapsed = sorted(windows)[len(windows) // 2]
+    if test_hook and shared["W"] is not None:
+        np.save(os.environ["SMK_BENCH_DUMP_W"], shared["W"])
+    out = build_report(args, N, elapsed, windows, shared["rank0"], shared["reports"], collectives,
+                       f"column-shard x{N}, ONE process, one host thread per device")
+    guard.restore()
+    print(json.dumps(out), flush=True)
+    if not share:
+        rccl_log_excerpt()
+    for c in comms:
+        c.close()
+    beat("done")
+    return 0
+
+
+def main():
+    args_list = [a for a in sys.argv[1:] if a != "--in-child"]
+    in_child = len(args_list) != len(sys.argv) - 1
+    args = parse_args(args_list)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not in_child:
+        # plain invocation: this process starts the ranks and makes no GPU call itself
+        sys.exit(launch(args))
+    if args.single_process and args.gpus > 1:
+        sys.exit(run_single_process(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -118,6 +118,7 @@ int smk_thread_context_begin(int device_ordinal);
 void smk_thread_context_end(void);
 int smk_device_count(void);
 int smk_current_device(void);
+int smk_device_synchronize(void);   /* hipDeviceSynchronize on the calling thread's current device */
 /* sparse A in CSC (replaces SparseMatrix<double>, common/include/sparse_matrix_decl.hpp:21-132): the local
  * columns [col0, col0+ncols_local); 32-bit indices as in the reference, duplicates allowed (they add up).
  * The transpose is built here too (the reference does it in Solver_Generic_BPP::Init, nmf_solver_bpp.hpp:319). */

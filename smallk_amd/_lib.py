@@ -78,6 +78,7 @@ SYMBOLS = {
     "smk_thread_context_end": (None, []),
     "smk_device_count": (C.c_int, []),
     "smk_current_device": (C.c_int, []),
+    "smk_device_synchronize": (C.c_int, []),
     "smk_matrix_create_sparse": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _i64, _i64, C.POINTER(C.c_uint),
                                            C.POINTER(C.c_uint), _dp]),
     "smk_nmf_sparse": (C.c_int, [C.POINTER(Options), C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint),

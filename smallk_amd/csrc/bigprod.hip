@@ -1450,6 +1450,97 @@ __global__ __launch_bounds__(256) void bigprod_f64_kernel(const unsigned char* _
             }
 }
 
+// The accurate form for a factor of ONE or TWO rows (dense RANK2: every node factorisation of HierNMF2 on dense A): 2 fp64
+// multiply-adds per stored entry are nothing for the vector ALUs (78 TFLOP/s of fp64 against 2 x 1.5 T entries/s at the HBM
+// rate), so this product streams like the 16-bit forms AND is the fp64 product of the stored data to rounding -- no packed
+// operand, no matrix cores.  Same plan as bigprod_f64_kernel (64-column tiles, 64-row stages, S row splits, P layout).
+// Workgroup = 4 waves, 16 columns per wave; per block of 256 rows the factor rows are staged through LDS once (16 B per
+// row) and lane l takes rows 4l .. 4l+3 of 8 columns at a time: 8 loads of 16 B (fp32; 8 B bf16) in flight per lane, each
+// wave load one contiguous KB of a column.  Two accumulators per column per lane, joined across the wave at the end.
+template <int EBYTES>
+__global__ __launch_bounds__(256) void bigprod_f64_k2_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
+                                                             const double* __restrict__ X, int ldx, int kvalid, i64 len,
+                                                             double* __restrict__ P, i64 stages, i64 nst, i64 tiles, i64 ncols_pad,
+                                                             int S, int pstride, int ktw, int accum)
+{
+    constexpr int NB = 64, RB = 256, CW = 16, CG = 8;
+    __shared__ double xs[RB][2];
+    __shared__ double red[NB][2];
+    const i64 tile = blockIdx.x / S;
+    const int split = (int)(blockIdx.x % S);
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    i64 st0 = (i64)split * nst, st1 = st0 + nst;
+    if (st1 > stages) st1 = stages;
+    const i64 ra = st0 * 64, rz = st1 * 64;                  // rows of this split (the matrix is zero padded to whole stages)
+    const i64 col0 = tile * NB + CW * wave;
+    double acc[CW][2];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) acc[c][0] = acc[c][1] = 0.0;
+    for (i64 rb = ra; rb < rz; rb += RB) {
+        __syncthreads();
+        {
+            const i64 r = rb + tid;
+            const bool live = r < len && r < rz;
+            xs[tid][0] = live ? X[r * ldx] : 0.0;
+            xs[tid][1] = (live && kvalid > 1) ? X[r * ldx + 1] : 0.0;
+        }
+        __syncthreads();
+        const i64 r = rb + 4 * lane;
+        if (r < rz) {
+            double x[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i][0] = xs[4 * lane + i][0]; x[i][1] = xs[4 * lane + i][1]; }
+#pragma unroll
+            for (int cg = 0; cg < CW / CG; ++cg) {
+                float v[CG][4];
+#pragma unroll
+                for (int j = 0; j < CG; ++j) {
+                    const unsigned char* src = B + (col0 + cg * CG + j) * ldb_bytes + r * EBYTES;
+                    if constexpr (EBYTES == 2) {
+                        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                        const u32x2 u = __builtin_nontemporal_load((const u32x2*)src);
+                        v[j][0] = bf16_bits_to_f32((unsigned short)(u[0] & 0xFFFFu)); v[j][1] = bf16_bits_to_f32((unsigned short)(u[0] >> 16));
+                        v[j][2] = bf16_bits_to_f32((unsigned short)(u[1] & 0xFFFFu)); v[j][3] = bf16_bits_to_f32((unsigned short)(u[1] >> 16));
+                    } else {
+                        typedef __attribute__((ext_vector_type(4))) float f32x4v;
+                        const f32x4v u = __builtin_nontemporal_load((const f32x4v*)src);
+                        v[j][0] = u[0]; v[j][1] = u[1]; v[j][2] = u[2]; v[j][3] = u[3];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < CG; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double b = (double)v[j][i];
+                        acc[cg * CG + j][0] = fma(b, x[i][0], acc[cg * CG + j][0]);
+                        acc[cg * CG + j][1] = fma(b, x[i][1], acc[cg * CG + j][1]);
+                    }
+            }
+        }
+    }
+    // join the 64 lanes of a column (fixed butterfly order: the result does not depend on scheduling)
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double v = acc[c][j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) red[CW * wave + c][j] = v;
+        }
+    __syncthreads();
+    if (tid < NB) {
+        double* pout = P + ((i64)split * ncols_pad + tile * NB + tid) * pstride;
+        double v0 = red[tid][0], v1 = red[tid][1];
+        if (accum) { v0 += pout[0]; v1 += pout[1]; }
+        pout[0] = v0;
+        pout[1] = v1;
+        if (!accum)                        // the rest of the group's 32-row k tiles as zeros, like the other forms
+            for (int r = 2; r < 16 * ktw; ++r) pout[r] = 0.0;
+    }
+}
+
 static int launch_bigprod_f64(const BigProdPlan& pl, const void* B, i64 ldb, const void* X, double* P, i64 len, hipStream_t st)
 {
     const i64 grid = pl.tiles * pl.S;
@@ -1457,6 +1548,16 @@ static int launch_bigprod_f64(const BigProdPlan& pl, const void* B, i64 ldb, con
     // the factor's live rows of this group: kg of them, never past the padded rank
     const int kvalid = pl.kg < pl.ldx - pl.k0 ? pl.kg : pl.ldx - pl.k0;
     const int ktw = 2 * kt_of(pl.kg);                      // 16-row tiles covering the group's 32-row k tiles
+    if (kvalid <= 2) {                                     // rank 1 / 2: the vector-ALU kernel at the streaming rate
+        if (pl.storage == STORE_BF16)
+            bigprod_f64_k2_kernel<2><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * 2, (const double*)X, pl.ldx, kvalid, len, P,
+                                                                    pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum);
+        else
+            bigprod_f64_k2_kernel<4><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * 4, (const double*)X, pl.ldx, kvalid, len, P,
+                                                                    pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum);
+        SMK_HIP(hipGetLastError());
+        return 0;
+    }
     const int kt16 = (kvalid + 15) / 16;                     // live 16-row tiles of this group (1 .. 4)
 #define SMK_F64(EB, T) bigprod_f64_kernel<EB, T><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * EB, (const double*)X, pl.ldx, kvalid, \
                                                                               len, P, pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum)

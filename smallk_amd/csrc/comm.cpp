@@ -2,9 +2,10 @@
 // solver's own streams: RCCL (ncclAllReduce / ncclAllGather over xGMI) or, for several shards on ONE device
 // (tests, a box with fewer GPUs than shards), an in-process stand-in with the same semantics.
 //
-// The reference has no distributed code; north_star fixes the exchange steps: sum-all-reduce of HH' (k x k) and
-// of (AH')' (k x m) per iteration, one scalar when the stopping rule is evaluated, and -- BPP only -- an
-// all-gather of the row slices of W each rank solved.
+// The reference has no distributed code; north_star fixes the exchange steps: sum-all-reduce of HH' (k x k), the sum of
+// (AH')' (k x m) per iteration in row chunks (all-reduce for HALS; reduce-scatter for BPP / MU, whose ranks each solve their
+// own row blocks of W), an all-reduce of W'W, an all-gather per chunk of the packed streaming operand of those blocks
+// (the fp64 rows only when results are read), and one 3-element all-reduce when the stopping rule is evaluated.
 #include "common.h"
 #include "comm.h"
 #include "../../include/smallk_amd.h"
@@ -39,6 +40,10 @@ struct LocalGroup {
     {
         std::unique_lock<std::mutex> lk(mu);
         if (my_err && !err) err = my_err;
+        if (err) {                                // a failed group fails fast: nobody waits for a rank that has left
+            arrived = 0; ++generation; cv.notify_all();
+            return err;
+        }
         const long gen = generation;
         if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
         else if (!cv.wait_for(lk, std::chrono::seconds(300), [&] { return generation != gen; })) {

@@ -745,8 +745,9 @@ __global__ __launch_bounds__(256) void colrange_kernel(const T* __restrict__ A, 
 
 int launch_colrange(const void* A, int storage, i64 ld, i64 rows, i64 cols, unsigned* out2, hipStream_t st)
 {
-    const unsigned init[2] = {0u, 0xFFFFFFFFu};
-    SMK_HIP(hipMemcpyAsync(out2, init, sizeof(init), hipMemcpyHostToDevice, st));
+    // initialised on the device: an async copy from this frame's stack could be read after the frame is gone
+    SMK_HIP(hipMemsetAsync(out2, 0, sizeof(unsigned), st));
+    SMK_HIP(hipMemsetAsync(out2 + 1, 0xFF, sizeof(unsigned), st));
     i64 grid = (cols * 64 + 255) / 256;
     if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;

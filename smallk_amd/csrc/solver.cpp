@@ -26,6 +26,7 @@
 #include <vector>
 #include <algorithm>
 #include <thread>
+#include <mutex>
 
 struct smk_matrix;
 
@@ -80,6 +81,7 @@ struct smk_matrix {
     i64 m = 0, n_global = 0, c0 = 0, n = 0;
     int storage = SMK_STORE_F32;
     hipStream_t st = nullptr;                        // stream of the context that created it
+    smk::DeviceCtx* owner = nullptr;                 // the context whose registry lists it (nullptr once that context is gone)
     mutable float ascale = 0.f;                      // fp16 two-term products: power of two with max|A| ascale in [2^13, 2^14); 0 = not yet measured
     mutable int col_spread_log2 = -1;                // log2(largest / smallest non-zero column maximum of |A|); -1 = not yet measured
     void* A = nullptr;  i64 ldA = 0, colsA = 0;      // m_pad x n_pad
@@ -101,15 +103,34 @@ struct smk_matrix {
 static const int MAX_CHUNKS = 8;
 static void repoint_matrices(hipStream_t st);
 
+// The registries of all contexts share one lock: a matrix may be destroyed from another thread than the one that created
+// it (Python's collector, the workers of smk_nmf_dense_sharded), and it leaves the registry of the context that OWNS it.
+static std::mutex g_mats_mu;
 static void repoint_matrices(hipStream_t st)
 {
+    std::lock_guard<std::mutex> lk(g_mats_mu);
     for (smk_matrix* a : ctx().mats) a->st = st;
 }
-static void register_matrix(smk_matrix* a) { ctx().mats.push_back(a); }
+// the context goes away: its matrices stay alive without an owner (they take the next context's stream)
+static void orphan_matrices()
+{
+    std::lock_guard<std::mutex> lk(g_mats_mu);
+    for (smk_matrix* a : ctx().mats) { a->st = nullptr; a->owner = nullptr; }
+    ctx().mats.clear();
+}
+static void register_matrix(smk_matrix* a)
+{
+    std::lock_guard<std::mutex> lk(g_mats_mu);
+    a->owner = &ctx();
+    a->owner->mats.push_back(a);
+}
 static void unregister_matrix(smk_matrix* a)
 {
-    auto& v = ctx().mats;
+    std::lock_guard<std::mutex> lk(g_mats_mu);
+    if (!a->owner) return;
+    auto& v = a->owner->mats;
     v.erase(std::remove(v.begin(), v.end(), a), v.end());
+    a->owner = nullptr;
 }
 
 struct smk_solver {
@@ -191,7 +212,7 @@ struct smk_solver {
     // on C2, where that was 23 of 119 us per iteration): passes shorter than ~0.2 ms are timed one launch in `timing_stride`
     // and the totals scaled back up, so that measuring does not change what is measured
     int timing_stride = 1;
-    unsigned pass_counter[2] = {0, 0};
+    unsigned pass_counter[2] = {0, 0}, pass_sampled[2] = {0, 0};     // passes seen / passes that carried events since enable_timing
     bool pass_timed[2] = {false, false};     // this W'A / H*At pass (all of its launches, and the collectives behind it) is a timed sample
     struct TimedSpan { hipEvent_t e0, e1; int counts; };     // counts: this span completes one launch (a pass cut into chunks is ONE launch)
     std::vector<TimedSpan> ev[3];         // 0: W'A passes, 1: H*At passes, 2: the big collectives of a sharded run (on st2)
@@ -226,7 +247,7 @@ void smk_finalize(void)
 {
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     if (g_own_stream && g_stream) (void)hipStreamDestroy(g_stream);
-    repoint_matrices(nullptr);            // a matrix that outlives the context takes the next context's stream
+    orphan_matrices();                    // a matrix that outlives the context takes the next context's stream
     g_stream = nullptr;
     g_own_stream = false;
     g_init = false;
@@ -258,6 +279,12 @@ int smk_current_device(void)
 {
     int d = 0;
     return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
+
+int smk_device_synchronize(void)
+{
+    SMK_HIP(hipDeviceSynchronize());
+    return SMK_OK;
 }
 
 const char* smk_last_error(void) { return g_err.c_str(); }
@@ -808,6 +835,52 @@ static int matrix_measure_scale(const smk_matrix* a, hipStream_t st)
     return 0;
 }
 
+// Everything that depends on the product form (s->nsplit): the launch plans of both passes and the fp16 row scales ...
+static int plan_products(smk_solver* s)
+{
+    const smk_matrix* a = s->a;
+    if (s->nsplit == NSPLIT_F16X2 && a->ascale == 0.f) {
+        const int rc0 = matrix_measure_scale(a, s->st);
+        if (rc0) return rc0;
+    }
+    s->ng = plan_bigprod_groups(a->storage, s->k, s->m, s->n, s->nsplit, g_cus, s->pg1);
+    (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
+    if (s->nsplit == NSPLIT_F64)
+        for (int g = 0; g < s->ng; ++g) { s->pg1[g].ldx = s->KP; s->pg2[g].ldx = s->KP; }
+    s->pl1 = s->pg1[0];
+    s->pl2 = s->pg2[0];
+    if (s->nsplit == NSPLIT_F16X2) {
+        int rc = 0;
+        for (int side = 0; side < 2 && !rc; ++side) {
+            if (!s->xscale[side]) rc |= dev_alloc(&s->xscale[side], (size_t)MAX_K);
+            if (!s->oscale[side]) rc |= dev_alloc(&s->oscale[side], (size_t)MAX_K);
+        }
+        if (rc) return SMK_DEVICE_ERROR;
+        for (int g = 0; g < s->ng; ++g) {
+            s->pg1[g].oscale = s->oscale[0] + s->pg1[g].k0;  s->pg1[g].ascale = a->ascale;
+            s->pg2[g].oscale = s->oscale[1] + s->pg2[g].k0;  s->pg2[g].ascale = a->ascale;
+        }
+        s->pl1 = s->pg1[0];
+        s->pl2 = s->pg2[0];
+    }
+    return 0;
+}
+// ... and the buffers sized by those plans: the packed operands and the partial products (dense A)
+static int alloc_product_buffers(smk_solver* s)
+{
+    int rc = 0;
+    void** bufs[] = {&s->packW, &s->packH, (void**)&s->P1, (void**)&s->P2};
+    for (void** b : bufs)
+        if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (!s->a->sparse) {
+        rc |= dev_alloc((unsigned char**)&s->packW, packed_bytes(s->a->storage, s->k, s->m, s->nsplit));
+        rc |= dev_alloc((unsigned char**)&s->packH, packed_bytes(s->a->storage, s->k, s->n, s->nsplit));
+    }
+    rc |= dev_alloc(&s->P1, s->pl1.p_elems);
+    rc |= dev_alloc(&s->P2, s->pl2.p_elems);
+    return rc;
+}
+
 int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matrix* a)
 {
     if (!out) return SMK_BAD_PARAM;
@@ -852,6 +925,11 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     // (tools/wide_long_run.py: 1200 x 1000, k = 100, bf16x3: 1.2e-4 after 20 iterations, 1.1e-3 after 30; k = 160: 4e-5 after 25;
     // the accurate form: 8.5e-12 after 30).  At k <= 64 the same data stays below 2e-5 over 30 iterations with the fp16 form.
     if (opts->algorithm == SMK_ALG_BPP && opts->k > 64 && !a->sparse) nsplit_default = NSPLIT_F64;
+    // Dense RANK2 (every node factorisation of HierNMF2 / flatclust on dense A runs 100 .. 1000 iterations to a tight
+    // tolerance): the accurate form costs nothing at two factor rows -- bigprod_f64_k2_kernel does its 2 fp64 multiply-adds
+    // per stored entry on the vector ALUs at the streaming rate -- and leaves only summation order between this path and
+    // the reference's fp64 arithmetic (common/src/nmf.cpp:33).
+    if (opts->algorithm == SMK_ALG_RANK2 && !a->sparse) nsplit_default = NSPLIT_F64;
     // Column scales of A more than 2^28 apart: the small columns fall below what fp32-class products resolve next to the
     // large ones (HALS / BPP leave the bar at 2^+-20, tests/test_gpu_parity.py) -- the accurate form as well.
     if (!env && !a->sparse && opts->algorithm != SMK_ALG_RANK2) {
@@ -860,31 +938,11 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     }
     s->nsplit = env ? atoi(env) : nsplit_default;
     if (s->nsplit != NSPLIT_F64 && (s->nsplit < 1 || s->nsplit > NSPLIT_F16X2)) s->nsplit = nsplit_default;
-    if (s->nsplit == NSPLIT_F64 && (a->sparse || opts->algorithm == SMK_ALG_RANK2)) s->nsplit = 3;      // those paths form their products elsewhere
+    if (s->nsplit == NSPLIT_F64 && a->sparse) s->nsplit = 3;      // sparse A: gather products in fp64 already
     // the fp16 two-term form applies to fp32 storage; RANK2 keeps its Gram matrices inside its own solve kernel
     if (s->nsplit == NSPLIT_F16X2 && (a->storage != SMK_STORE_F32 || a->sparse || opts->algorithm == SMK_ALG_RANK2)) s->nsplit = 3;
-    if (s->nsplit == NSPLIT_F16X2 && a->ascale == 0.f) {
-        const int rc0 = matrix_measure_scale(a, s->st);
-        if (rc0) { --g_live_solvers; delete s; return rc0; }
-    }
-    s->ng = plan_bigprod_groups(a->storage, s->k, s->m, s->n, s->nsplit, g_cus, s->pg1);
-    (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
-    if (s->nsplit == NSPLIT_F64)
-        for (int g = 0; g < s->ng; ++g) { s->pg1[g].ldx = s->KP; s->pg2[g].ldx = s->KP; }
-    s->pl1 = s->pg1[0];
-    s->pl2 = s->pg2[0];
-    int rc = 0;
-    if (s->nsplit == NSPLIT_F16X2) {
-        for (int side = 0; side < 2 && !rc; ++side) {
-            rc |= dev_alloc(&s->xscale[side], (size_t)MAX_K);
-            rc |= dev_alloc(&s->oscale[side], (size_t)MAX_K);
-        }
-        if (rc) { smk_solver_destroy(s); return SMK_DEVICE_ERROR; }
-        for (int g = 0; g < s->ng; ++g) {
-            s->pg1[g].oscale = s->oscale[0] + s->pg1[g].k0;  s->pg1[g].ascale = a->ascale;
-            s->pg2[g].oscale = s->oscale[1] + s->pg2[g].k0;  s->pg2[g].ascale = a->ascale;
-        }
-    }
+    int rc = plan_products(s);
+    if (rc) { smk_solver_destroy(s); return rc; }
     if (a->sparse) {   // gather products write one slab, as dense as the factor layout (KP values per column; RANK2: the 2 live ones)
         s->kpp = (opts->algorithm == SMK_ALG_RANK2) ? 2 : s->KP;
         int nb1 = 1, nb2 = 1;
@@ -932,12 +990,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     rc |= dev_alloc(&s->pg_partials, 2 * s->pg_half);
     rc |= dev_alloc(&s->scal_own, (size_t)8);
     rc |= dev_alloc(&s->fail_flag, (size_t)1);
-    if (!a->sparse) {
-        rc |= dev_alloc((unsigned char**)&s->packW, packed_bytes(a->storage, s->k, s->m, s->nsplit));
-        rc |= dev_alloc((unsigned char**)&s->packH, packed_bytes(a->storage, s->k, s->n, s->nsplit));
-    }
-    rc |= dev_alloc(&s->P1, s->pl1.p_elems);
-    rc |= dev_alloc(&s->P2, s->pl2.p_elems);
+    rc |= alloc_product_buffers(s);
     if (opts->algorithm == SMK_ALG_HALS) {
         rc |= dev_alloc(&s->hals_scratch, hals_w_scratch_elems(s->k, s->m));
         rc |= dev_alloc(&s->W0c, (size_t)s->KP * s->m);
@@ -1060,6 +1113,25 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
     // Times a rank's work without the transfers; the blocks of the other ranks never arrive, so the factors mean nothing.
     if (const char* e = getenv("SMK_COMM_EMULATE_WORLD"))
         if (comm->world == 1 && atoi(e) > 1 && atoi(e) <= 64) { s->world = atoi(e); s->rank = 0; }
+    // The ranks must run ONE exchange protocol.  The product form is chosen per solver, and one input of that choice -- the
+    // spread of the column scales -- is measured on the rank's LOCAL column shard: a rank whose shard alone spans more than
+    // 2^28 would take the accurate form (and with it other buffers and other collectives) while its peers do not.  So the
+    // form is agreed here, first thing, over the communicator: any rank that wants the accurate form moves all of them.
+    // Every rank of the communicator calls attach, so this is a collective like the ones that follow.
+    if (comm->world > 1) {
+        double want = s->nsplit == NSPLIT_F64 ? 1.0 : 0.0;
+        SMK_HIP(hipMemcpy(s->scal_own, &want, sizeof(double), hipMemcpyHostToDevice));
+        int arc = comm_allreduce(comm, s->scal_own, 1, 1, s->st);
+        if (arc) { s->comm = nullptr; return arc; }
+        SMK_HIP(hipStreamSynchronize(s->st));
+        SMK_HIP(hipMemcpy(&want, s->scal_own, sizeof(double), hipMemcpyDeviceToHost));
+        if (want > 0.0 && s->nsplit != NSPLIT_F64 && !s->a->sparse) {
+            s->nsplit = NSPLIT_F64;
+            arc = plan_products(s);
+            if (!arc && alloc_product_buffers(s)) arc = SMK_DEVICE_ERROR;
+            if (arc) { s->comm = nullptr; return arc; }
+        }
+    }
     // chunk geometry: blocks of >= 4096 rows, at most 4 chunks (SMK_COMM_CHUNKS overrides: 1 .. 8), block a multiple of
     // 256 rows (the column tile of the streaming kernels and a whole number of packed chunk pairs)
     {
@@ -1316,7 +1388,10 @@ static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, Partial
 // every pass starts here: is it one of the timed samples?
 static inline void begin_pass(smk_solver* s, int which)
 {
-    s->pass_timed[which] = s->timing && (s->timing_stride <= 1 || (s->pass_counter[which]++ % (unsigned)s->timing_stride) == 0);
+    if (!s->timing) { s->pass_timed[which] = false; return; }
+    const unsigned c = s->pass_counter[which]++;
+    s->pass_timed[which] = s->timing_stride <= 1 || (c % (unsigned)s->timing_stride) == 0;
+    if (s->pass_timed[which]) ++s->pass_sampled[which];
 }
 
 // one launch of the streaming product, bracketed by events when timing is on; `counts`: this launch completes a pass
@@ -1692,9 +1767,8 @@ static int resolve_events(smk_solver* s)
         for (auto& e : s->ev[w]) {
             float ms = 0.f;
             SMK_HIP(hipEventElapsedTime(&ms, e.e0, e.e1));
-            const int scale = s->timing_stride;                        // a sampled pass stands for `stride` passes
-            s->acc_ms[w] += (double)ms * scale;
-            s->launches[w] += e.counts * scale;
+            s->acc_ms[w] += (double)ms;                                // sampled totals; smk_solver_kernel_time scales them by passes seen / passes sampled
+            s->launches[w] += e.counts;
             (void)hipEventDestroy(e.e0);
             (void)hipEventDestroy(e.e1);
         }
@@ -2075,7 +2149,16 @@ int smk_solver_nnls_hals(smk_solver* s, double tol, int verbose, int max_iter, i
     if (!s->have_factors) { set_error("set_factors() first"); return SMK_BAD_PARAM; }
     if (is_dist(s)) { set_error("NnlsHals: not available on a sharded solver"); return SMK_UNSUPPORTED; }
     if (verbose) printf("\nRunning NNLS solver...\n");
-    int rc = gram_w(s);
+    int rc = 0;
+    // W'A is formed ONCE and every sweep of the loop below reads it: the accurate product form (the fp64 product of the stored
+    // data) for the price of one slower pass, so that the converged H differs from the reference's by summation order only
+    if (!s->a->sparse && s->nsplit != NSPLIT_F64 && !getenv("SMK_NSPLIT")) {
+        s->nsplit = NSPLIT_F64;
+        rc = plan_products(s);
+        if (!rc && alloc_product_buffers(s)) rc = SMK_DEVICE_ERROR;
+        if (rc) return rc;
+    }
+    rc = gram_w(s);
     if (!rc) rc = prod1(s);
     if (rc) return rc;
     bool success = false;
@@ -2211,6 +2294,7 @@ int smk_solver_enable_timing(smk_solver* s, int on)
     }
     if (const char* e = getenv("SMK_TIMING_STRIDE")) s->timing_stride = std::max(1, atoi(e));
     s->pass_counter[0] = s->pass_counter[1] = 0;
+    s->pass_sampled[0] = s->pass_sampled[1] = 0;
     s->acc_ms[0] = s->acc_ms[1] = s->acc_ms[2] = 0.0;
     s->launches[0] = s->launches[1] = s->launches[2] = 0;
     return SMK_OK;
@@ -2219,8 +2303,13 @@ int smk_solver_enable_timing(smk_solver* s, int on)
 int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* launches)
 {
     if (!s || which < 0 || which > 2) return SMK_BAD_PARAM;      // 2: the (AH')' sum and the W all-gather of a sharded run
-    if (total_ms) *total_ms = s->acc_ms[which];
-    if (launches) *launches = s->launches[which];
+    // one pass in `timing_stride` carries events: totals are scaled by the TRUE ratio passes seen / passes sampled (100 passes
+    // at stride 8 are 13 samples standing for 100, not for 104); the collectives (slot 2) are sampled with either pass
+    const unsigned seen = which < 2 ? s->pass_counter[which] : s->pass_counter[0] + s->pass_counter[1];
+    const unsigned sampled = which < 2 ? s->pass_sampled[which] : s->pass_sampled[0] + s->pass_sampled[1];
+    const double f = sampled > 0 ? (double)seen / (double)sampled : 1.0;
+    if (total_ms) *total_ms = s->acc_ms[which] * f;
+    if (launches) *launches = (int)llround((double)s->launches[which] * f);
     return SMK_OK;
 }
 

@@ -65,6 +65,7 @@ int smk_thread_context_begin(int) { return SMK_OK; }
 void smk_thread_context_end(void) {}
 int smk_device_count(void) { return 1; }
 int smk_current_device(void) { return 0; }
+int smk_device_synchronize(void) { return 0; }
 int smk_matrix_clone(const smk_matrix* src, smk_matrix** out)
 {
     if (!src || !out) return SMK_BAD_PARAM;

@@ -123,4 +123,4 @@ def test_flatclust_cli(tmp_path, alg):
     assert (tmp_path / "clusters_4.xml").read_text() == of.results_text(labels, of.top_terms(ref.W, 4), dictionary, "XML",
                                                                           4, n, k)
     got = np.loadtxt(tmp_path / "assignments_fuzzy_4.csv", delimiter=",")
-    assert np.allclose(got, of.compute_fuzzy_assignments(ref.H).T, atol=2e-3)
+    assert np.allclose(got, of.compute_fuzzy_assignments(ref.H).T, atol=1e-4)

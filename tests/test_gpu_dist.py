@@ -137,9 +137,105 @@ def test_bench_two_processes_match_one(tmp_path):
     line = [l for l in r2.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1                                  # rank 0 prints ONE JSON line
     out = json.loads(line[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["config"]["parallelism"] == "column-shard x2"
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["config"]["parallelism"].startswith("column-shard x2")
     W1, W2 = np.load(tmp_path / "w1.npy"), np.load(tmp_path / "w2.npy")
     assert np.linalg.norm(W1 - W2) / np.linalg.norm(W1) < 1e-5
+
+
+def _bench_env(tmp_path, name):
+    return dict(os.environ, SMK_BENCH_SHARE_GPU="1", SMK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+                SMK_BENCH_DUMP_W=str(tmp_path / name))
+
+
+def test_bench_plain_invocation_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run around it (how the driver starts the N = 1 run, and may start
+    the others): the process starts two fresh child ranks itself -- it makes no GPU call of its own --, relays rank 0's
+    single JSON line and exits 0.  Both ranks on this box's one GPU, gloo instead of RCCL (as the test above)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--workload", "c2", "--no-cpu-baseline"]
+    env = _bench_env(tmp_path, "w2.npy")
+    env.pop("WORLD_SIZE", None)
+    r2 = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--no-fallback"] + common, cwd=root, capture_output=True, text=True,
+                        timeout=600, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    line = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r2.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
+    assert len(out["per_rank"]) == 2 and [p["rank"] for p in out["per_rank"]] == [0, 1]
+    assert out["launcher"]["attempts"][0]["rc"] == 0 and len(out["launcher"]["attempts"]) == 1
+    r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=root, capture_output=True, text=True,
+                        timeout=600, env=_bench_env(tmp_path, "w1.npy"))
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    W1, W2 = np.load(tmp_path / "w1.npy"), np.load(tmp_path / "w2.npy")
+    assert np.linalg.norm(W1 - W2) / np.linalg.norm(W1) < 1e-5
+
+
+@pytest.mark.parametrize("workload,shards", [("c2", 2), ("c1", 3)])
+def test_bench_single_process_mode(tmp_path, workload, shards):
+    """`--single-process`: one process, one host thread and one library context per shard, no torch.distributed.  On a
+    multi-GPU node the communicators come from ncclCommInitAll; here every shard sits on device 0 and the in-process
+    stand-in carries the collectives.  W after K steps = the one-GPU W; also reached as the launcher's plan B."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"]
+    env = _bench_env(tmp_path, "ws.npy")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(shards), "--single-process"] + common, cwd=root, capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == shards and len(out["per_rank"]) == shards and out["value"] > 0
+    assert "ONE process" in out["config"]["parallelism"]
+    r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=root, capture_output=True, text=True,
+                        timeout=600, env=_bench_env(tmp_path, "w1.npy"))
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    W1, Ws = np.load(tmp_path / "w1.npy"), np.load(tmp_path / "ws.npy")
+    assert np.linalg.norm(W1 - Ws) / np.linalg.norm(W1) < 1e-5
+
+
+def test_bench_falls_back_to_the_single_process_plan(tmp_path):
+    """plan A (torch.distributed.run) is made to stall in its first solver collectives; the watchdog ends it and plan B --
+    the single-process path -- produces the line.  The whole thing stays under two minutes."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMK_BENCH_SHARE_GPU="1", SMK_BENCH_BACKEND="gloo", SMK_BENCH_TEST_HANG="1:warm-up")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--stall-s", "15", "--steps", "3", "--warmup", "1", "--workload", "c1",
+                        "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    dt = time.monotonic() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    att = out["launcher"]["attempts"]
+    assert len(att) == 2 and att[0]["rc"] != 0 and att[1]["rc"] == 0 and out["n_gpus"] == 2
+    assert "WATCHDOG" in r.stderr and dt < 120, dt
+
+
+def test_bench_hung_rank_ends_nonzero(tmp_path):
+    """a rank that stops for good inside the run (TEST HOOK) ends the plain invocation with a non-zero code in well under
+    two minutes, with the stage and the Python stacks on stderr"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMK_BENCH_SHARE_GPU="1", SMK_BENCH_BACKEND="gloo", SMK_BENCH_TEST_HANG="1:warm-up")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--no-fallback", "--stall-s", "15", "--steps", "3", "--warmup", "1",
+                        "--workload", "c1", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and time.monotonic() - t0 < 120
+    assert "WATCHDOG" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 # ---- native communicators (comm.cpp): collectives issued from C on the solver's streams ------------------------
