@@ -226,6 +226,31 @@ int launch_rank2_progress(const double* Wt, i64 m, PartialView R2, const double*
                           const double* Gw, double* partials, const int* flag, double* snap, hipStream_t st);
 int rank2_progress_blocks(i64 m, i64 n);
 size_t rank2_progress_scratch_elems(i64 m, i64 n);
+// ---- rank2_persist.hip: a whole RANK2 factorisation of a sparse matrix (driver loop, stopping rule, final state) in ONE
+// launch of resident workgroups with two grid-wide barriers per iteration
+enum { R2P_RUNNING = 0, R2P_CONVERGED = 1, R2P_EXHAUSTED = 2, R2P_SOLVER_FAILED = 3, R2P_NAN = 4, R2P_ABORTED = 5 };   // out[0]
+struct R2PersistArgs {
+    const i64 *colptr, *colptr_t;              // CSC of A (n columns) and of A' (m columns)
+    const unsigned *rowidx, *rowidx_t;
+    const double *val, *val_t;
+    i64 m, n;
+    const double* Gw0;                         // W'W of the start (KP = 8 layout)
+    PartialView R1;                            // W'A of the start
+    double *Wc, *Hc0, *Hc1, *R2c;              // compact N x 2 work arrays
+    double *gp_h, *gp_w, *pgp;                 // [workgroups][8] partial sums
+    unsigned* sync;                            // rank2_persist_sync_bytes(), zeroed by the launch function
+    int min_iter, max_iter, tolcount;
+    double tol;
+    int iter_tag0;                             // iterations done before this run (failure tags count from it)
+    double *Wt, *H, *Gw;                       // results (KP = 8 layout), written by the epilogue only
+    int* fail_flag;
+    unsigned lds_bytes;                        // dynamic LDS per workgroup (rank2_persist_lds_bytes())
+    double* out;                               // [16] device: status, NmfStats::iteration_count, iterations performed, pg0, last metric, failure tag; [8..11]: us spent in B1 / phase W / B2 / phase G (workgroup 0)
+};
+size_t rank2_persist_sync_bytes();
+size_t rank2_persist_lds_bytes();
+int rank2_persist_workgroups(i64 m, i64 n, i64 nnz, int num_cus);      // 0: not for this matrix
+int launch_rank2_persist(const R2PersistArgs& a, int workgroups, hipStream_t st);
 // sparse A (CSC): out[:, j] = sum_p val[p] * X[:, row[p]] over the nonzeros of column j
 // X: the gathered factor, row pitch ldx doubles (KP, or 2 for the compact copy of a rank-2 factor)
 // nnz_hint: number of stored entries (picks the lanes per column of the rank-2 kernel; <= 0: unknown)

@@ -12,6 +12,7 @@
 //                           lets the driver undo a speculative iteration, in one launch
 // The two products with A run between them (spmm.hip for sparse A, bigprod.hip for dense A).
 #include "devutil.h"
+#include "rank2_math.h"
 
 namespace smk {
 
@@ -64,52 +65,22 @@ __global__ __launch_bounds__(256) void rank2_solve_kernel(double* __restrict__ X
     constexpr int KP = 8;
     __shared__ double shg[4][3];
     __shared__ double sh[16];
-    const double eps = DBL_EPSILON;
     double a00, a01, a11;
     gram2_load(gin, sh, a00, a01, a11);
-    const double a10 = a01;                                      // the Gram matrix is symmetric (G[1] == G[KP])
     if (gin.nb != 0 && Gstore && blockIdx.x == 0 && threadIdx.x < KP * KP) {
         const int e = threadIdx.x;
         Gstore[e] = (e == 0) ? a00 : (e == 1 || e == KP) ? a01 : (e == KP + 1) ? a11 : 0.0;
     }
-    bool bad = (fabs(a00) < eps) && (fabs(a01) < eps);          // "singular matrix"
-    const bool cosine = fabs(a00) >= fabs(a01);
-    double t, a2, b2, d2;
-    if (side == 0) {
-        if (cosine) { t = -a10 / a00; a2 = a00 - t * a10; b2 = a01 - t * a11; d2 = a11 + t * a01; }
-        else        { t = -a00 / a10; a2 = -a10 + t * a00; b2 = -a11 + t * a01; d2 = a01 + t * a11; }
-    } else {
-        if (cosine) { t = a01 / a00; a2 = a00 + t * a01; b2 = a10 + t * a11; d2 = a11 - t * a10; }
-        else        { t = a00 / a01; a2 = -a01 - t * a00; b2 = -a11 - t * a10; d2 = a10 - t * a11; }
-    }
-    const double inv_a2 = 1.0 / a2, inv_d2 = 1.0 / d2;
-    if (fabs(d2 / a2) < eps) bad = true;
-    if (bad) {
+    const R2Solve sv = r2_prepare(a00, a01, a11, side);           // rank2_math.h: the reference's formulas
+    if (sv.bad) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicMin(fail_flag, iter_tag);
         return;
     }
-    const double inv0 = 1.0 / a00, inv1 = 1.0 / a11, sq0 = sqrt(a00), sq1 = sqrt(a11);
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = j < N;
     double x0 = 0.0, x1 = 0.0;
     if (valid) {
-        const double b0 = rhs_elem(R, j, 0), b1 = rhs_elem(R, j, 1);
-        double e2, f2;
-        if (side == 0) {
-            if (cosine) { e2 = b0 - t * b1; f2 = b1 + t * b0; }
-            else        { e2 = -b1 + t * b0; f2 = b0 + t * b1; }
-        } else {
-            if (cosine) { e2 = b0 + t * b1; f2 = b1 - t * b0; }
-            else        { e2 = -b1 - t * b0; f2 = b0 - t * b1; }
-        }
-        x1 = f2 * inv_d2;
-        x0 = (e2 - b2 * x1) * inv_a2;
-        if (x0 <= 0.0 || x1 <= 0.0) {               // OptimalActiveSet
-            double v1 = b0 * inv0, v2 = b1 * inv1;
-            if (v1 * sq0 >= v2 * sq1) v2 = 0.0; else v1 = 0.0;
-            x0 = v1;
-            x1 = v2;
-        }
+        r2_apply(sv, side, rhs_elem(R, j, 0), rhs_elem(R, j, 1), x0, x1);
         f64x2_t v;
         v[0] = x0;
         v[1] = x1;

@@ -147,6 +147,11 @@ struct smk_solver {
     // (before its normalisation), and -- sparse A -- compact N x 2 copies of the factors for the gather products
     double *r2_scratch = nullptr, *r2_prog = nullptr, *Graw = nullptr, *Hc = nullptr, *Wc = nullptr;
     double* pin_r2[2] = {nullptr, nullptr};      // pinned copies of the progress partials (the host sums them)
+    // the whole RANK2 factorisation as one resident launch (rank2_persist.hip): second H buffer, the rows of (AH')', partial
+    // sums, barrier words, result slots (device + pinned); latched off after an aborted launch
+    double *r2p_hc1 = nullptr, *r2p_r2c = nullptr, *r2p_part = nullptr, *r2p_out = nullptr, *r2p_pin = nullptr;
+    unsigned* r2p_sync = nullptr;
+    bool r2p_off = false;
     bool wc_valid = false;
     double* nnls_scratch = nullptr;       // BPP: inverses of W'W and HH' + path selectors (k > 32), two halves
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
@@ -1036,6 +1041,8 @@ void smk_solver_destroy(smk_solver* s)
         if (s->pev[b]) (void)hipEventDestroy(s->pev[b]);
     }
     if (s->pin) (void)hipHostFree(s->pin);
+    { void* r2p[] = {s->r2p_hc1, s->r2p_r2c, s->r2p_part, s->r2p_out, s->r2p_sync}; for (void* q : r2p) if (q) (void)hipFree(q); }
+    if (s->r2p_pin) (void)hipHostFree(s->r2p_pin);
     for (int b = 0; b < 2; ++b) if (s->pin_r2[b]) (void)hipHostFree(s->pin_r2[b]);
     if (s->comm_ws) (void)hipFree(s->comm_ws);
     if (s->Wown) (void)hipFree(s->Wown);
@@ -2038,6 +2045,81 @@ int smk_solver_run(smk_solver* s, smk_stats* stats)
     return rc;
 }
 
+// ---- RANK2 on sparse A: the driver loop below as ONE launch (rank2_persist.hip) -------------------------------------------
+// For small and medium node matrices an iteration is six 7 - 12 us launches on a few MB: launch-latency bound.  The
+// resident kernel carries the loop, the stopping rule (PG_RATIO, min_iter / tolcount as NmfSolve<>), the per-iteration
+// normalisation and the final state; the host waits for one 128-byte result.  Measured on the C5-shaped run
+// (profiles/r04_c5_*): 54 -> 37 us per iteration on the 1 M-entry nodes (the two gather products alone are 24 us at the
+// chip's ~84 G random 16-byte gathers per second), and it also wins on the large nodes (9 M entries: 495 -> 291 us, the
+// 16 M-entry root 645 -> 556 us) because its entry-parallel products issue exactly one gather per stored entry with all of
+// a chunk's gathers in flight -- so there is no size limit by default (SMK_R2_PERSIST_NNZ sets one, SMK_R2_PERSIST=0 turns
+// the kernel off).
+static bool rank2_persist_eligible(const smk_solver* s)
+{
+    static const int mode = [] { const char* e = getenv("SMK_R2_PERSIST"); return e ? atoi(e) : 1; }();
+    static const i64 max_nnz = [] { const char* e = getenv("SMK_R2_PERSIST_NNZ"); return e ? (i64)atoll(e) : (i64)1 << 40; }();
+    if (!mode || s->r2p_off) return false;
+    if (s->o.algorithm != SMK_ALG_RANK2 || !s->a->sparse || s->o.prog_est_algorithm != SMK_PROG_PG_RATIO) return false;
+    if (is_dist(s) || s->comm || s->o.verbose || s->timing || !s->Hc || !s->Wc) return false;
+    if (rank2_persist_workgroups(s->m, s->n, s->a->nnz, g_cus) < 1) return false;      // more than 4096 rows per workgroup
+    return s->a->nnz <= max_nnz || mode == 2;
+}
+
+// returns 0 with *status = one of R2P_*: CONVERGED / EXHAUSTED (factors, W'W, counters in place), SOLVER_FAILED / NAN (the
+// failure flag is set as the launch-per-kernel loop sets it), ABORTED (nothing was touched: the caller runs the classic loop)
+static int rank2_persist_run(smk_solver* s, int* status, int* count)
+{
+    const int nwg = rank2_persist_workgroups(s->m, s->n, s->a->nnz, g_cus);
+    if (nwg < 1 || nwg > 1024) { *status = R2P_ABORTED; return 0; }
+    if (!s->r2p_sync) {
+        int rc = dev_alloc(&s->r2p_hc1, (size_t)2 * s->n);
+        rc |= dev_alloc(&s->r2p_r2c, (size_t)2 * s->m);
+        rc |= dev_alloc(&s->r2p_part, (size_t)3 * 8 * 1024);                  // three arrays of [workgroups <= 1024][8]
+        rc |= dev_alloc(&s->r2p_out, (size_t)16);
+        rc |= dev_alloc((unsigned char**)&s->r2p_sync, rank2_persist_sync_bytes());
+        if (rc) return SMK_DEVICE_ERROR;
+        SMK_HIP(hipHostMalloc((void**)&s->r2p_pin, 16 * sizeof(double)));
+    }
+    R2PersistArgs a;
+    a.colptr = s->a->colptr; a.rowidx = s->a->rowidx; a.val = s->a->val;
+    a.colptr_t = s->a->colptr_t; a.rowidx_t = s->a->rowidx_t; a.val_t = s->a->val_t;
+    a.m = s->m; a.n = s->n;
+    a.Gw0 = s->Gw; a.R1 = view1(s);
+    a.Wc = s->Wc; a.Hc0 = s->Hc; a.Hc1 = s->r2p_hc1; a.R2c = s->r2p_r2c;
+    a.gp_h = s->r2p_part; a.gp_w = s->r2p_part + 8 * 1024; a.pgp = s->r2p_part + 2 * 8 * 1024;
+    a.sync = s->r2p_sync;
+    a.min_iter = s->o.min_iter; a.max_iter = s->o.max_iter; a.tolcount = s->o.tolcount; a.tol = s->o.tol;
+    a.iter_tag0 = s->iter;
+    a.Wt = s->Wt; a.H = s->H; a.Gw = s->Gw;
+    a.fail_flag = s->fail_flag;
+    a.lds_bytes = (unsigned)rank2_persist_lds_bytes();
+    a.out = s->r2p_out;
+    int rc = launch_rank2_persist(a, nwg, s->st);
+    if (rc) return rc;
+    SMK_HIP(hipMemcpyAsync(s->r2p_pin, s->r2p_out, 16 * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    SMK_HIP(hipStreamSynchronize(s->st));
+    *status = (int)s->r2p_pin[0];
+    *count = (int)s->r2p_pin[1];
+    {
+        static const bool prof = [] { const char* e = getenv("SMK_R2P_PROFILE"); return e && atoi(e) != 0; }();
+        if (prof) {
+            const double it = std::max(1.0, s->r2p_pin[2]);
+            fprintf(stderr, "[r2p] %ld x %ld nnz %ld: %d workgroups, status %d, %.0f iterations; per iteration (workgroup 0): "
+                    "B1 %.1f us, phase W %.1f, B2 %.1f, phase G %.1f\n", (long)s->m, (long)s->n, (long)s->a->nnz, nwg, *status, it,
+                    s->r2p_pin[8] / it, s->r2p_pin[9] / it, s->r2p_pin[10] / it, s->r2p_pin[11] / it);
+        }
+    }
+    if (*status == R2P_CONVERGED || *status == R2P_EXHAUSTED) {
+        s->iter += (int)s->r2p_pin[2];
+        s->pg0 = s->r2p_pin[3];
+        s->last_metric = s->r2p_pin[4];
+        s->normalized = false;
+        s->inited = false;             // HH' and the stored products were never materialised: a later run starts from solver.Init
+        s->wc_valid = false;
+    }
+    return 0;
+}
+
 static int solver_run_once(smk_solver* s, smk_stats* stats)
 {
     if (!s) return SMK_BAD_PARAM;
@@ -2048,8 +2130,37 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
     int rc = 0, result = SMK_OK;
     bool success = false;
     int iter = 0, success_count = 0, fail_iter = INT_MAX;
+    static std::mutex r2p_device_mu[64];
+    std::unique_lock<std::mutex> r2p_lock;
 
     if (!s->inited) { rc = solver_init(s); if (rc) { result = rc; goto done; } }
+
+    // One resident kernel per device at a time: two of them launched together (two host threads with a context each on ONE
+    // device, the two-device HierNMF2 test) would each get part of the CUs and wait for workgroups that cannot start.  The
+    // second caller WAITS (it does not take the other path: which path runs must not depend on timing, the two differ in the
+    // last bits and the tree search is discrete).  Contexts on different devices do not meet here.
+    if (rank2_persist_eligible(s)) {
+        const int dev = smk_current_device();
+        r2p_lock = std::unique_lock<std::mutex>(r2p_device_mu[dev >= 0 && dev < 64 ? dev : 0]);
+    }
+    if (r2p_lock.owns_lock()) {
+        int status = R2P_ABORTED, count = 0;
+        rc = rank2_persist_run(s, &status, &count);
+        r2p_lock.unlock();
+        if (rc) { result = rc; goto done; }
+        if (status == R2P_CONVERGED || status == R2P_EXHAUSTED) {
+            success = true;
+            iter = count;
+            goto finish;
+        }
+        if (status == R2P_NAN) { set_error("ProjectedGradientNorm: NaN"); iter = count; result = SMK_FAILURE; goto done; }
+        if (status == R2P_SOLVER_FAILED) { result = SMK_FAILURE; goto failed_check; }
+        // ABORTED: some workgroup never became resident (or the deadline passed); the solver state is the one solver.Init
+        // left, so the launch-per-kernel loop below takes over, latched for the life of the handle
+        s->r2p_off = true;
+        s->wc_valid = false;           // the compact copy of W served as the kernel's work array
+        fprintf(stderr, "smallk_amd: the resident RANK2 kernel could not synchronise its workgroups; continuing on the launch-per-kernel path\n");
+    }
 
     // The stopping rule of iteration i (NmfSolve, nmf_solve_generic.hpp:81-121) is evaluated AFTER
     // iteration i+1 has been enqueued: the host never leaves the GPU idle waiting for a scalar.  When
@@ -2110,6 +2221,7 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
         }
     }
 
+finish:
     rc = gather_w(s);
     if (rc) { result = rc; goto done; }
     if (o.normalize) { rc = normalize_device(s); if (rc) { result = rc; goto done; } }

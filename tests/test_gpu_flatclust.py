@@ -59,8 +59,8 @@ def test_nnls_hals_matches_oracle(gpu, sparse, k):
     rc, Wg, Hg, its = gpu.flatclust.nnls_hals(A, W, H0, tol=1e-6, max_iter=2000)
     ok, Wo, Ho, ito = of.nnls_hals(Ad, W, H0, 1e-6, 2000)
     assert ok and rc == L.OK
-    assert abs(its - ito) <= (0 if sparse else 1)
-    tol = 1e-8 if sparse else 1e-4            # dense: W'A in the accurate product form (round 4; 2e-4 before)
+    assert its == ito
+    tol = 1e-8            # dense too: W'A in the accurate product form (round 4; 2e-4 before, measured now 1e-14)
     assert relerr(Wg, Wo) < tol and relerr(Hg, Ho) < tol
     # iteration limit -> FAILURE, factors left un-normalised (nnls.hpp:311-315)
     rc, Wg, Hg, its = gpu.flatclust.nnls_hals(A, W, H0, tol=1e-14, max_iter=3)
@@ -78,7 +78,7 @@ def test_hier_with_flat(gpu, sparse):
     res = gpu.hier_nmf2(A, 4, seed=5, flat=True)
     otree, _ = oh.hier_nmf2(Ad, 4, seed=5, flat=True)
     W, H = res.flat_factors()
-    tol = 1e-7 if sparse else 1e-4
+    tol = 1e-7
     assert relerr(W, otree.flat_W) < tol and relerr(H, otree.flat_H) < tol
     assert list(res.get_assignments()) == list(otree.assignments)
     assert res.draws == otree.draws
@@ -117,10 +117,10 @@ def test_facade_hiernmf2_with_flat(gpu, tmp_path):
     assert open(tmp_path / "clusters_4.json").read() == of.results_text(labels, of.top_terms(otree.flat_W, 3), dictionary,
                                                                         "JSON", 3, 200, 4)
     got = np.loadtxt(tmp_path / "assignments_fuzzy_4.csv", delimiter=",")
-    assert got.shape == (200, 4) and np.allclose(got, of.compute_fuzzy_assignments(otree.flat_H).T, atol=1e-4)
+    assert got.shape == (200, 4) and np.allclose(got, of.compute_fuzzy_assignments(otree.flat_H).T, atol=1e-4)     # the file carries 4 significant digits
     # W / H of the flat run are what LockedBufferW/H now expose
     Wf = api.get_W()
-    assert Wf.shape == (120, 4) and relerr(Wf, otree.flat_W) < 1e-4
+    assert Wf.shape == (120, 4) and relerr(Wf, otree.flat_W) < 1e-7
 
 
 def test_pysmallk_style_classes(gpu, tmp_path):

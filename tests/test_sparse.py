@@ -166,3 +166,19 @@ print("ASSIGN", ",".join(str(int(x)) for x in t.get_assignments()))
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("ASSIGN")][0])
     assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_resident_rank2_kernel_matches_the_launch_per_kernel_loop():
+    import os
+    """RANK2 on sparse A runs as ONE resident launch (rank2_persist.hip: the NmfSolve<> loop, stopping rule and
+    per-iteration normalisation inside the kernel, two grid-wide barriers per iteration).  tools/r2_persist_check.py runs
+    the same problems -- converging with a tolerance, min_iter = max_iter, rectangular, one and two iterations -- in two
+    processes, SMK_R2_PERSIST=0 and on, and asks for equal result codes and iteration counts and factors equal to 1e-9
+    (they differ by summation order: 1e-16 measured)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "tools/r2_persist_check.py", "quick"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "fell back" not in r.stdout

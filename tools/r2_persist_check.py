@@ -1,0 +1,79 @@
+"""The resident RANK2 kernel (rank2_persist.hip) against the launch-per-kernel loop on sparse problems: same result codes and
+iteration counts, factors to rounding; then time per iteration of both on C5-node-shaped matrices.
+  python3 tools/r2_persist_check.py [quick]"""
+import os, subprocess, sys, time, json
+sys.path.insert(0, os.getcwd())
+import numpy as np, scipy.sparse as sp
+
+def graph(n, deg, seed, rect=None):
+    rng = np.random.default_rng(seed)
+    if rect:
+        m = rect
+        nnz = n * deg
+        A = sp.coo_matrix((rng.random(nnz) + 0.1, (rng.integers(0, m, size=nnz), rng.integers(0, n, size=nnz))), shape=(m, n)).tocsc()
+        A.sum_duplicates()
+        return A
+    nh = n * deg // 2
+    comm = rng.integers(0, 2, size=n)
+    src = rng.integers(0, n, size=nh); dst = rng.integers(0, n, size=nh)
+    same = rng.random(nh) < 0.8
+    dst[same] = (dst[same] // 2) * 2 + comm[src[same]]          # planted two-community structure: the run converges
+    dst = np.minimum(dst, n - 1)
+    A = sp.coo_matrix((np.ones(nh), (src, dst)), shape=(n, n)); A = (A + A.T).tocsc(); A.sum_duplicates()
+    return A
+
+def child(mode, cases):
+    import smallk_amd
+    smallk_amd.initialize(0)
+    out = []
+    for (n, deg, seed, rect, kw) in cases:
+        A = graph(n, deg, seed, rect)
+        m = A.shape[0]
+        W0 = smallk_amd.uniform_host(m, 2, 43 + seed); H0 = smallk_amd.uniform_host(2, n, 44 + seed)
+        best = None
+        for rep in range(3):
+            r = smallk_amd.nmf_sparse(A, W0, H0, "RANK2", **kw)
+            us = r.elapsed_us / max(r.iteration_count, 1)
+            best = us if best is None else min(best, us)
+        np.save(f"/tmp/r2p_{mode}_{n}_{deg}_{seed}.npy", np.concatenate([r.W.ravel(), r.H.ravel()]))
+        out.append(dict(n=n, m=m, deg=deg, nnz=int(A.nnz), result=r.result, iters=r.iteration_count, us_per_iter=best))
+    print("RESULT " + json.dumps(out), flush=True)
+
+CASES_QUICK = [(3000, 6, 1, None, dict(min_iter=5, max_iter=400, tol=1e-4)),
+               (50000, 16, 2, None, dict(min_iter=5, max_iter=60, tol=1e-9)),
+               (20000, 5, 3, 61000, dict(min_iter=3, max_iter=300, tol=1e-3)),
+               (700, 3, 4, None, dict(min_iter=1, max_iter=1, tol=1e-4)),
+               (900, 4, 5, None, dict(min_iter=2, max_iter=2, tol=0.9))]
+CASES_TIME = [(62000, 16, 7, 192000, dict(min_iter=300, max_iter=300, tol=1e-9)),        # the C5 run's two long nodes
+              (187000, 16, 8, 481000, dict(min_iter=100, max_iter=100, tol=1e-9)),
+              (250000, 16, 9, 588000, dict(min_iter=100, max_iter=100, tol=1e-9)),
+              (1000000, 16, 10, None, dict(min_iter=30, max_iter=30, tol=1e-9))]
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "child":
+        child(sys.argv[2], CASES_QUICK + ([] if sys.argv[3] == "quick" else CASES_TIME))
+        sys.exit(0)
+    quick = "quick" if len(sys.argv) > 1 and sys.argv[1] == "quick" else "full"
+    res = {}
+    for mode, env in (("classic", {"SMK_R2_PERSIST": "0"}), ("resident", {"SMK_R2_PERSIST": "2"})):
+        p = subprocess.run([sys.executable, __file__, "child", mode, quick], env=dict(os.environ, **env), capture_output=True, text=True)
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+        if not line:
+            print(mode, "FAILED", p.stdout[-2000:], p.stderr[-3000:]); sys.exit(1)
+        res[mode] = json.loads(line[0][7:])
+        for l in p.stderr.splitlines():
+            if l.startswith("[r2p]"):
+                print(l)
+        if "could not synchronise" in p.stderr:
+            print("NOTE:", mode, "fell back to the classic path")
+    bad = 0
+    for a, b in zip(res["classic"], res["resident"]):
+        x = np.load(f"/tmp/r2p_classic_{a['n']}_{a['deg']}_{[c[2] for c in CASES_QUICK + CASES_TIME if c[0] == a['n'] and c[1] == a['deg']][0]}.npy")
+        y = np.load(f"/tmp/r2p_resident_{a['n']}_{a['deg']}_{[c[2] for c in CASES_QUICK + CASES_TIME if c[0] == a['n'] and c[1] == a['deg']][0]}.npy")
+        err = float(np.linalg.norm(x - y) / max(np.linalg.norm(x), 1e-300))
+        ok = a["result"] == b["result"] and a["iters"] == b["iters"] and err < 1e-9
+        bad += 0 if ok else 1
+        print(f"{a['m']} x {a['n']} nnz {a['nnz']}: result {a['result']}/{b['result']} iterations {a['iters']}/{b['iters']} rel diff {err:.2e}  "
+              f"us/iteration classic {a['us_per_iter']:.1f} resident {b['us_per_iter']:.1f}  {'ok' if ok else 'MISMATCH'}")
+    print("ALL OK" if bad == 0 else f"{bad} MISMATCHES")
+    sys.exit(1 if bad else 0)
