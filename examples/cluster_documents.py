@@ -12,7 +12,8 @@ import numpy as np
 import scipy.sparse as sp
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from smallk_amd import Hierclust, SmallkAPI  # noqa: E402
+from smallk_amd import SmallkAPI  # noqa: E402
+from pyclust import Hierclust  # noqa: E402  (examples/pyclust.py)
 
 
 def synthetic(m=2000, n=3000, topics=8, seed=0):

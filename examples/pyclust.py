@@ -3,6 +3,9 @@ MI355X library: same method names, keyword arguments and defaults (``load_matrix
 ``cluster``, ``get_top_indices``, ``get_assignments``, ``get_top_terms``, ``write_output``, ``parser``,
 ``finalize``).  Python 3; the numeric work is ``smallk_amd.flatclust`` / ``smallk_amd.hierclust``
 (C ABI, GPU only, no CPU fallback).  New keyword-only extras: ``seed`` and ``storage``.
+
+An EXAMPLE of building on the package, not part of it: SURVEY.md section 2 lists pysmallk's clustering classes as out of
+scope for the hot path (#21), so they live here (round 4; rounds 1-3 shipped them as ``smallk_amd/pyclust.py``).
 """
 from __future__ import annotations
 
@@ -12,10 +15,10 @@ import time
 
 import numpy as np
 
-from . import _lib as L
-from . import flatclust as _flat
-from . import hierclust as _hier
-from .solver import initialize, is_initialized, finalize, uniform_host, load_matrix_market
+from smallk_amd import _lib as L
+from smallk_amd import flatclust as _flat
+from smallk_amd import hierclust as _hier
+from smallk_amd.solver import initialize, is_initialized, finalize, uniform_host, load_matrix_market
 
 
 def _load_csv(path):

@@ -161,6 +161,11 @@ int smk_solver_progress(smk_solver* s, double* metric);
 /* optional final NormalizeAndScale (normalize.hpp:118-140), then copy factors to the host */
 int smk_solver_get_factors(smk_solver* s, int normalize, double* W, int64_t ldW, double* H, int64_t ldH);
 int smk_solver_iteration_count(const smk_solver* s);
+/* the product form in use (SMK_NSPLIT numbering: 3 = bf16x3, 4 = fp16 two-term, 8 = the accurate fp64 form) and what the
+ * opt-in run-time guard (BPP, SMK_GUARD_EVERY=n) has done so far: every n iterations it compares the fast form with the
+ * accurate one on a column sample and changes to the accurate form when cond(Gram) x (product discrepancy) says one
+ * iteration could move the factors by 1e-4 */
+int smk_solver_product_form(const smk_solver* s, int* guard_checks, int* guard_fired, double* guard_last);
 
 /* bool NnlsBlockpivot(LHS, RHS, X, Y), common/include/nnls.hpp:144-244, by itself (the reference's
  * tests/src/test_bpp.cpp drives the solver this way): LHS k x k SPD, RHS k x ncols, X in/out (warm start:

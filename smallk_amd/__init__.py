@@ -12,7 +12,6 @@ from .api import SmallkAPI
 from . import hierclust
 from . import flatclust
 from .hierclust import hier_nmf2, TreeResults
-from .pyclust import Flatclust, Hierclust
 
 __all__ = ["DenseMatrix", "SparseMatrix", "nmf_sparse", "load_matrix_market", "NmfSolver", "NmfResult", "nmf", "initialize", "finalize", "is_initialized",
-           "make_options", "uniform_host", "nnls_blockpivot", "nmf_sharded", "Comm", "set_stream", "thread_context_begin", "thread_context_end", "SmallkAPI", "hierclust", "flatclust", "hier_nmf2", "TreeResults", "Flatclust", "Hierclust", "_lib"]
+           "make_options", "uniform_host", "nnls_blockpivot", "nmf_sharded", "Comm", "set_stream", "thread_context_begin", "thread_context_end", "SmallkAPI", "hierclust", "flatclust", "hier_nmf2", "TreeResults", "_lib"]

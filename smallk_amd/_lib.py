@@ -103,6 +103,7 @@ SYMBOLS = {
     "smk_solver_progress": (C.c_int, [_vp, _dp]),
     "smk_solver_get_factors": (C.c_int, [_vp, C.c_int, _dp, _i64, _dp, _i64]),
     "smk_solver_iteration_count": (C.c_int, [_vp]),
+    "smk_solver_product_form": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
     "smk_nnls_blockpivot": (C.c_int, [C.c_int, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp, _i64]),
     "smk_solver_enable_timing": (C.c_int, [_vp, C.c_int]),
     "smk_solver_kernel_time": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int)]),

@@ -757,6 +757,34 @@ int launch_colrange(const void* A, int storage, i64 ld, i64 rows, i64 cols, unsi
     return 0;
 }
 
+// run-time guard of the product form (solver.cpp): sum of squared differences between the fast-form product (P1, all row
+// splits) and the accurate-form product of the same `ncols` sampled columns, and the accurate product's sum of squares
+__global__ __launch_bounds__(256) void guard_compare_kernel(PartialView fast, const unsigned* __restrict__ cols, int ncols,
+                                                            const double* __restrict__ acc, int S_acc, i64 slab_acc, int kpp, int k,
+                                                            double* __restrict__ out2)
+{
+    __shared__ double sh[16];
+    double num = 0.0, den = 0.0;
+    for (int idx = threadIdx.x; idx < ncols * k; idx += blockDim.x) {
+        const int i = idx / k, r = idx % k;
+        const double f = rhs_elem(fast, (i64)cols[i], r);
+        double a = 0.0;
+        for (int s = 0; s < S_acc; ++s) a += acc[s * slab_acc + (i64)i * kpp + r];
+        num += (f - a) * (f - a);
+        den += a * a;
+    }
+    const double tn = block_sum(num, sh);
+    const double td = block_sum(den, sh);
+    if (threadIdx.x == 0) { out2[0] = tn; out2[1] = td; }
+}
+int launch_guard_compare(PartialView fast, const unsigned* cols, int ncols, const double* acc, int S_acc, i64 slab_acc, int kpp, int k,
+                         double* out2, hipStream_t st)
+{
+    guard_compare_kernel<<<1, 256, 0, st>>>(fast, cols, ncols, acc, S_acc, slab_acc, kpp, k, out2);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_absmax_f32(const float* A, i64 elems, unsigned* out, hipStream_t st)
 {
     SMK_HIP(hipMemsetAsync(out, 0, sizeof(unsigned), st));

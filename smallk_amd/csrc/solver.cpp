@@ -152,6 +152,16 @@ struct smk_solver {
     double *r2p_hc1 = nullptr, *r2p_r2c = nullptr, *r2p_part = nullptr, *r2p_out = nullptr, *r2p_pin = nullptr;
     unsigned* r2p_sync = nullptr;
     bool r2p_off = false;
+    // run-time guard of the product form (guard_step): a column sample of A, its accurate-form product, the comparison scalars
+    // + both Gram matrices on their way to the host
+    void* guard_As = nullptr;
+    unsigned* guard_cols = nullptr;
+    double *guard_P = nullptr, *guard_dev = nullptr, *guard_pin = nullptr;
+    hipEvent_t guard_ev = nullptr;
+    BigProdPlan guard_pl[MAX_GROUPS];
+    int guard_ncols = 0, guard_checks = 0, guard_fired = 0;
+    bool guard_pending = false, guard_off = false;
+    double guard_last = 0.0;               // cond * delta of the last check
     bool wc_valid = false;
     double* nnls_scratch = nullptr;       // BPP: inverses of W'W and HH' + path selectors (k > 32), two halves
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
@@ -1041,6 +1051,9 @@ void smk_solver_destroy(smk_solver* s)
         if (s->pev[b]) (void)hipEventDestroy(s->pev[b]);
     }
     if (s->pin) (void)hipHostFree(s->pin);
+    { void* gq[] = {s->guard_As, s->guard_cols, s->guard_P, s->guard_dev}; for (void* q : gq) if (q) (void)hipFree(q); }
+    if (s->guard_pin) (void)hipHostFree(s->guard_pin);
+    if (s->guard_ev) (void)hipEventDestroy(s->guard_ev);
     { void* r2p[] = {s->r2p_hc1, s->r2p_r2c, s->r2p_part, s->r2p_out, s->r2p_sync}; for (void* q : r2p) if (q) (void)hipFree(q); }
     if (s->r2p_pin) (void)hipHostFree(s->r2p_pin);
     for (int b = 0; b < 2; ++b) if (s->pin_r2[b]) (void)hipHostFree(s->pin_r2[b]);
@@ -1161,8 +1174,9 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
     }
     // BPP and MU update the rows of W independently of each other: every rank takes its own blocks (HALS normalises column by
     // column over ALL rows inside its sweep and keeps the replicated update)
-    s->w_sharded = (s->o.algorithm == SMK_ALG_BPP || s->o.algorithm == SMK_ALG_MU) && !s->a->sparse && s->nsplit != NSPLIT_F64 &&
-                   (s->world > 1 || comm_forced());
+    // (also under the accurate product form: its W'A pass reads the fp64 factor itself, so the fp64 own blocks are gathered per
+    // chunk in place of the packed operand -- prod1_sharded)
+    s->w_sharded = (s->o.algorithm == SMK_ALG_BPP || s->o.algorithm == SMK_ALG_MU) && !s->a->sparse && (s->world > 1 || comm_forced());
     const size_t bytes = comm_bytes(s);
     if (hipMalloc(&s->comm_ws, bytes) != hipSuccess) { s->comm = nullptr; s->w_sharded = false; set_error("hipMalloc(comm workspace)"); return SMK_DEVICE_ERROR; }
     SMK_HIP(hipMemsetAsync(s->comm_ws, 0, bytes, s->st));
@@ -1450,9 +1464,10 @@ static int prod1_sharded(smk_solver* s)
     begin_pass(s, 0);
     const int storage = s->a->storage;
     const size_t es = (size_t)elem_size(storage);
+    const bool f64 = s->nsplit == NSPLIT_F64;       // the accurate form reads the fp64 factor: gather the fp64 own blocks into W itself
     int rc = 0;
     // one launch per group of 64 factor rows: this rank's blocks into their places in the operand (padding rows as zeros)
-    for (int g = 0; g < s->ng && !rc; ++g)
+    for (int g = 0; g < s->ng && !rc && !f64; ++g)
         rc = launch_pack_own_blocks(s->Wown, s->KP, s->pg1[g].k0, s->pg1[g].kg, s->n_own, s->blk, s->nchunk, s->world, s->rank, storage,
                                     s->nsplit, (unsigned char*)s->packW + s->pg1[g].pack_offset, s->st, s->xscale[0]);
     if (rc) return rc;
@@ -1462,6 +1477,8 @@ static int prod1_sharded(smk_solver* s)
         i64 r0, r1;
         chunk_rows(s, j, &r0, &r1);
         rc = timed_collective(s, 0, [&] {
+            if (f64)        // block r of chunk j from every rank, straight into its rows of the full fp64 W
+                return comm_allgather_to(s->comm, s->Wown + (i64)j * s->blk * s->KP, s->Wt + r0 * s->KP, s->blk * s->KP, 1, s->st2);
             for (int g = 0; g < s->ng; ++g) {
                 const size_t per = packed_row_offset(storage, s->pg1[g].kg, s->nsplit, s->blk);          // bytes per block
                 unsigned char* base = (unsigned char*)s->packW + s->pg1[g].pack_offset + packed_row_offset(storage, s->pg1[g].kg, s->nsplit, r0);
@@ -1486,12 +1503,14 @@ static int prod1_sharded(smk_solver* s)
             pl.stages = (rows + pl.mb - 1) / pl.mb;
             pl.nst = (pl.stages + pl.S - 1) / pl.S;
             pl.accum = first ? 0 : 1;
-            const unsigned char* Xp = (const unsigned char*)s->packW + pl.pack_offset + packed_row_offset(storage, pl.kg, s->nsplit, r0);
+            const void* Xp = (const unsigned char*)s->packW + pl.pack_offset + packed_row_offset(storage, pl.kg, s->nsplit, r0);
+            if (f64) { pl.len = rows; Xp = s->Wt + r0 * s->KP + pl.k0; }     // rows [r0, r0 + rows) of the gathered W, this group's factor rows
             rc = timed_bigprod(s, 0, pl, (const unsigned char*)s->a->A + (size_t)r0 * es, s->a->ldA, Xp, s->P1 + pl.k0, last ? 1 : 0);
             if (rc) return rc;
         }
         first = false;
     }
+    if (f64) s->w_full = true;       // every row of the fp64 W is current again (a by-product of the accurate form's gather)
     return 0;
 }
 
@@ -1999,6 +2018,156 @@ static int hals_fail_soft(smk_solver* s)
     return 1;
 }
 
+// ---- run-time guard of the product form ------------------------------------------------------------------------------
+// Which product form a run takes is decided when the solver is created (rank, algorithm, the spread of the column scales:
+// thresholds found by sweeps).  A matrix outside the swept families must not leave the 1e-4 bar silently, so the choice is
+// can be re-examined while the run goes on (OPT-IN: SMK_GUARD_EVERY=16; default 0 = off, see the note at the end).  Every
+// SMK_GUARD_EVERY iterations of a BPP run the solver forms W'A for a sample
+// of 64 columns in the ACCURATE form (fp64 factor against the stored data, bigprod_f64_kernel) and compares it with what the
+// fast form has just produced for the same columns: delta = ||P_fast - P_acc||_F / ||P_acc||_F, the product error ON THIS
+// DATA (4e-8 for well-scaled data; much more when small entries sit next to large ones).  To first order an error delta in
+// the right-hand sides moves the solution of the k x k normal equations by at most cond(G) delta, G = W'W or HH', and the
+// condition numbers are cheap: both Gram matrices come back with the two sums (k <= 256: Cholesky + inverse on the host,
+// 1-norm).  When max(cond) * delta exceeds SMK_GUARD_TAU (default 1e-4: ONE iteration could move the factors by the parity
+// bar) the solver changes to the accurate form for the rest of the run: plans and buffers are rebuilt and solver.Init is
+// repeated on the current factors, exactly what a fresh solver given them would do.  The check is asynchronous -- enqueued
+// behind one iteration, read GUARD_EVERY iterations later -- so it never stalls the stream (C4: one 67 MB pass per 16
+// iterations of 137 GB each; measured -1.1 % on C4, -8 % on the 0.09 ms iterations of C2 where the host runs at most 16
+// iterations ahead).  Not for sharded runs (every rank would have to agree; their form is agreed once, at attach).
+// WHY IT IS NOT ON BY DEFAULT (round 4, profiles/r04_guard_cases.txt): cond(G) delta is a worst-case bound, and the
+// non-negativity constraints take the ill-conditioned directions out of the problems that are actually solved.  HALS on
+// uniform noise at k = 8 shows cond(HH') = 2.3e4, delta = 1.2e-8, product 2.6e-4 > tau, while the run ends 1.7e-6 from the
+// oracle after 40 iterations; with the guard on, C3 (HALS, k = 32) changes to the accurate form and runs at 253 instead of
+// 1160 iterations/s.  For block pivoting -- where the bound describes the solves that are really done -- the cases measured
+// separate cleanly (noise: 2e-6 .. 7e-6 over 40 iterations; a planted factor with nearly collinear columns: > 1e-2), so the
+// guard is offered for BPP runs on data outside the swept families, and the static rules of smk_solver_create stay the default.
+static bool guard_applies(const smk_solver* s)
+{
+    static const int every = [] { const char* e = getenv("SMK_GUARD_EVERY"); return e ? atoi(e) : 0; }();
+    if (every <= 0 || s->guard_off || s->a->sparse || s->nsplit == NSPLIT_F64 || is_dist(s) || s->comm) return false;
+    if (s->o.algorithm != SMK_ALG_BPP) return false;
+    return s->k <= 256 && s->n >= 64 && s->iter > 0 && s->iter % every == 0;
+}
+
+// 1-norm condition number of the live k x k block of a KP x KP symmetric matrix (inf when it is not positive definite)
+static double cond1_spd(const double* G, int KP, int k)
+{
+    std::vector<double> L((size_t)k * k, 0.0), X((size_t)k * k, 0.0);
+    double n1 = 0.0;
+    for (int c = 0; c < k; ++c) { double sum = 0.0; for (int r = 0; r < k; ++r) sum += std::fabs(G[(size_t)c * KP + r]); n1 = std::max(n1, sum); }
+    for (int j = 0; j < k; ++j) {                                  // G = L L'
+        double d = G[(size_t)j * KP + j];
+        for (int p = 0; p < j; ++p) d -= L[(size_t)j * k + p] * L[(size_t)j * k + p];
+        if (!(d > 0.0)) return INFINITY;
+        const double ljj = std::sqrt(d);
+        L[(size_t)j * k + j] = ljj;
+        for (int i = j + 1; i < k; ++i) {
+            double v = G[(size_t)j * KP + i];
+            for (int p = 0; p < j; ++p) v -= L[(size_t)i * k + p] * L[(size_t)j * k + p];
+            L[(size_t)i * k + j] = v / ljj;
+        }
+    }
+    double ninv = 0.0;
+    std::vector<double> y((size_t)k);
+    for (int c = 0; c < k; ++c) {                                  // column c of the inverse: L y = e_c, L' x = y
+        for (int i = 0; i < k; ++i) {
+            double v = i == c ? 1.0 : 0.0;
+            for (int p = 0; p < i; ++p) v -= L[(size_t)i * k + p] * y[(size_t)p];
+            y[(size_t)i] = v / L[(size_t)i * k + i];
+        }
+        double sum = 0.0;
+        for (int i = k - 1; i >= 0; --i) {
+            double v = y[(size_t)i];
+            for (int p = i + 1; p < k; ++p) v -= L[(size_t)p * k + i] * X[(size_t)p];
+            X[(size_t)i] = v / L[(size_t)i * k + i];
+            sum += std::fabs(X[(size_t)i]);
+        }
+        ninv = std::max(ninv, sum);
+    }
+    return n1 * ninv;
+}
+
+static int guard_resolve(smk_solver* s)
+{
+    if (!s->guard_pending) return 0;
+    s->guard_pending = false;
+    SMK_HIP(hipEventSynchronize(s->guard_ev));
+    static const double tau = [] { const char* e = getenv("SMK_GUARD_TAU"); return e ? atof(e) : 1e-4; }();
+    const double* p = s->guard_pin;
+    const double delta = p[1] > 0.0 ? std::sqrt(p[0] / p[1]) : 0.0;
+    const size_t kk = (size_t)s->KP * s->KP;
+    const double cond = std::max(cond1_spd(p + 2, s->KP, s->k), cond1_spd(p + 2 + kk, s->KP, s->k));
+    s->guard_checks += 1;
+    s->guard_last = cond * delta;
+    static const bool verbose = [] { const char* e = getenv("SMK_GUARD_VERBOSE"); return e && atoi(e) != 0; }();
+    if (verbose) fprintf(stderr, "[smk guard] iteration %d: delta %.3e, cond %.3e, product %.3e (tau %.1e)\n", s->iter, delta, cond, cond * delta, tau);
+    if (!(cond * delta > tau)) return 0;
+    // change to the accurate form: new plans and buffers, then solver.Init on the current factors
+    s->guard_fired += 1;
+    s->nsplit = NSPLIT_F64;
+    int rc = plan_products(s);
+    if (!rc && alloc_product_buffers(s)) rc = SMK_DEVICE_ERROR;
+    if (rc) return rc;
+    s->packed_fresh[0] = s->packed_fresh[1] = false;
+    s->nnls_gram_nblk[0] = s->nnls_gram_nblk[1] = 0;
+    const int iter_keep = s->iter;
+    rc = solver_init(s);
+    s->iter = iter_keep;
+    return rc;
+}
+
+static int guard_enqueue(smk_solver* s)
+{
+    const size_t kk = (size_t)s->KP * s->KP;
+    if (!s->guard_As) {                    // first use: the sample (64 columns, evenly spaced), plans, buffers
+        const int nc = 64;
+        std::vector<unsigned> cols((size_t)nc);
+        for (int i = 0; i < nc; ++i) cols[(size_t)i] = (unsigned)((i64)i * s->n / nc);
+        const i64 es = elem_size(s->a->storage);
+        int rc = dev_alloc(&s->guard_cols, (size_t)nc);
+        rc |= dev_alloc((unsigned char**)&s->guard_As, (size_t)s->a->ldA * COL_PAD * es);
+        rc |= dev_alloc(&s->guard_dev, 2 + 2 * kk);
+        if (rc) return SMK_DEVICE_ERROR;
+        SMK_HIP(hipMemsetAsync(s->guard_As, 0, (size_t)s->a->ldA * COL_PAD * es, s->st));
+        SMK_HIP(hipMemcpyAsync(s->guard_cols, cols.data(), (size_t)nc * sizeof(unsigned), hipMemcpyHostToDevice, s->st));
+        rc = launch_gather_cols(s->a->A, s->a->ldA * es, s->guard_cols, nc, s->guard_As, s->a->ldA * es, s->a->ldA * es, s->st);
+        if (rc) return rc;
+        SMK_HIP(hipStreamSynchronize(s->st));              // `cols` leaves scope
+        const int ng = plan_bigprod_groups(s->a->storage, s->k, s->m, nc, NSPLIT_F64, g_cus, s->guard_pl);
+        for (int g = 0; g < ng; ++g) s->guard_pl[g].ldx = s->KP;
+        if (dev_alloc(&s->guard_P, s->guard_pl[0].p_elems)) return SMK_DEVICE_ERROR;
+        SMK_HIP(hipHostMalloc((void**)&s->guard_pin, (2 + 2 * kk) * sizeof(double)));
+        SMK_HIP(hipEventCreateWithFlags(&s->guard_ev, hipEventDisableTiming));
+        s->guard_ncols = nc;
+    }
+    // the full fp64 W (s->Wt) against the sampled columns, one launch per group of 64 factor rows
+    for (int g = 0; g < s->ng; ++g) {
+        const int rc = launch_bigprod(s->guard_pl[g], s->guard_As, s->a->ldA, s->Wt + s->guard_pl[g].k0, s->guard_P + s->guard_pl[g].k0, s->st);
+        if (rc) return rc;
+    }
+    const BigProdPlan& gp = s->guard_pl[0];
+    int rc = launch_guard_compare(view1(s), s->guard_cols, s->guard_ncols, s->guard_P, gp.S, (i64)gp.ncols_pad * gp.pstride, gp.pstride, s->k,
+                                  s->guard_dev, s->st);
+    if (rc) return rc;
+    SMK_HIP(hipMemcpyAsync(s->guard_dev + 2, s->Gw, kk * sizeof(double), hipMemcpyDeviceToDevice, s->st));
+    SMK_HIP(hipMemcpyAsync(s->guard_dev + 2 + kk, s->Gh, kk * sizeof(double), hipMemcpyDeviceToDevice, s->st));
+    SMK_HIP(hipMemcpyAsync(s->guard_pin, s->guard_dev, (2 + 2 * kk) * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    SMK_HIP(hipEventRecord(s->guard_ev, s->st));
+    s->guard_pending = true;
+    return 0;
+}
+
+// after every iteration: read the check enqueued GUARD_EVERY iterations ago, enqueue the next one
+static int guard_step(smk_solver* s)
+{
+    if (!guard_applies(s)) return 0;
+    int rc = guard_resolve(s);
+    if (rc || s->nsplit == NSPLIT_F64) return rc;
+    rc = wait_r2(s);                      // HH' / the stored products are final
+    if (rc) return rc;
+    return guard_enqueue(s);
+}
+
 int smk_solver_iterate(smk_solver* s, int iters)
 {
     if (!s || iters < 0) return SMK_BAD_PARAM;
@@ -2008,8 +2177,21 @@ int smk_solver_iterate(smk_solver* s, int iters)
     for (int i = 0; i < iters; ++i) {
         rc = solver_iteration(s);
         if (rc) return rc;
+        rc = guard_step(s);
+        if (rc) return rc;
     }
     return SMK_OK;
+}
+
+// which product form the solver is using now (SMK_NSPLIT numbering; 8 = the accurate form), how often the run-time guard has
+// looked and how often it changed the form, and cond * delta of its last look
+int smk_solver_product_form(const smk_solver* s, int* guard_checks, int* guard_fired, double* guard_last)
+{
+    if (!s) return SMK_BAD_PARAM;
+    if (guard_checks) *guard_checks = s->guard_checks;
+    if (guard_fired) *guard_fired = s->guard_fired;
+    if (guard_last) *guard_last = s->guard_last;
+    return s->nsplit;
 }
 
 int smk_solver_sync(smk_solver* s)
@@ -2190,6 +2372,8 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
         };
         for (iter = 0; iter < o.max_iter; ++iter) {
             rc = solver_iteration(s);
+            if (rc) { result = rc; goto done; }
+            rc = guard_step(s);
             if (rc) { result = rc; goto done; }
             const bool check = (iter == 0) || (iter >= o.min_iter);
             if (sync_mode) {

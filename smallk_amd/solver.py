@@ -221,6 +221,12 @@ class NmfSolver:
             L.check(rc, "smk_solver_get_factors")
         return W, H
 
+    def product_form(self):
+        """(form, guard_checks, guard_fired, cond x delta of the last check); form: 3 bf16x3, 4 fp16 two-term, 8 accurate"""
+        c, f, v = C.c_int(0), C.c_int(0), C.c_double(0)
+        form = L.lib().smk_solver_product_form(self._h, C.byref(c), C.byref(f), C.byref(v))
+        return form, c.value, f.value, v.value
+
     def enable_timing(self, on=True):
         L.check(L.lib().smk_solver_enable_timing(self._h, int(on)), "smk_solver_enable_timing")
 

@@ -262,6 +262,30 @@ def test_sharded_one_shot_matches_single_and_oracle(gpu, alg, storage, quant, k,
     assert rel(many.W, ref.W) < TOL and rel(many.H, ref.H) < TOL
 
 
+@pytest.mark.parametrize("alg,k", [("BPP", 12), ("MU", 12), ("BPP", 40), ("HALS", 12)])
+def test_ranks_agree_on_the_product_form_when_one_shard_has_widely_scaled_columns(gpu, alg, k):
+    """The accurate product form is selected when the column maxima of A are more than 2^28 apart -- measured per solver, i.e.
+    on the rank's LOCAL columns.  Here only the second shard's columns are scaled by 2^+-20: alone it would pick the accurate
+    form (other buffers, other collectives: fp64 blocks gathered instead of the packed operand) while rank 0 would not, and the
+    mismatched collectives would hang or corrupt the run.  smk_solver_attach_comm agrees the form over the communicator first.
+    Also the row-sharded W update UNDER the accurate form (round 4): reduce-scatter, own-block NNLS / MU, fp64 all-gather per
+    chunk."""
+    m, n, iters = 900, 640, 6
+    A = oracle.fill_uniform(m, n, 42)
+    A[:, 320::2] *= 2.0 ** 20
+    A[:, 321::2] *= 2.0 ** -20
+    A = oracle.quantize(A, 0)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    kw = dict(min_iter=iters, max_iter=iters, tol=1e-9)
+    ref = oracle.nmf(A, W0, H0, alg, **kw)
+    one = gpu.nmf(A, W0, H0, alg, **kw)
+    many = gpu.nmf_sharded(A, W0, H0, alg, 2, local_stub=True, **kw)
+    assert one.result == many.result == ref.result == 0
+    assert rel(many.W, one.W) < 1e-5 and rel(many.H, one.H) < 1e-5
+    assert rel(many.W, ref.W) < TOL and rel(many.H, ref.H) < TOL
+
+
 @pytest.mark.parametrize("m,shards", [(1001, 3), (1001, 7), (1280, 5)])
 def test_sharded_bpp_rows_of_w_in_uneven_chunks(gpu, m, shards):
     """BPP: (AH')' is reduce-scattered by row chunks of ceil(m / shards) rows, each rank solves its own rows of W and the

@@ -127,3 +127,27 @@ def test_hals_blocked_w_sweep_with_more_rows_than_threads(gpu):
     assert np.linalg.norm(got.W - ref.W) / np.linalg.norm(ref.W) < 1e-4
     assert np.linalg.norm(got.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
 
+
+
+def test_runtime_guard_of_the_product_form():
+    """Opt-in (SMK_GUARD_EVERY=n, BPP): every n iterations the solver compares the fast product form with the accurate one on a
+    column sample and changes to the accurate form when cond(Gram) x (product discrepancy) says that one iteration could move
+    the factors by the 1e-4 bar (solver.cpp: guard_step).  On data whose planted factor has nearly collinear columns the guard
+    must fire at k = 8 -- far below the static k > 64 rule -- and the run must end inside the bar; on uniform noise it must look
+    and leave the fast form alone.  Without the switch nothing looks.  (Own processes: the switches are read once per process.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for kind, every in (("ill", "4"), ("well", "4"), ("off", "0")):
+        r = subprocess.run([sys.executable, "tools/guard_case.py", "ill" if kind == "off" else kind, "BPP", "8", "40"], cwd=root,
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, SMK_GUARD_EVERY=every))
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[kind] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ill, well, off = out["ill"], out["well"], out["off"]
+    assert ill["form_start"] != 8 and ill["guard_fired"] == 1 and ill["form_end"] == 8, ill
+    assert ill["rc"] == ill["ref_rc"] == 0 and ill["relW"] < 1e-4 and ill["relH"] < 1e-4, ill
+    assert well["guard_checks"] >= 5 and well["guard_fired"] == 0 and well["form_end"] == well["form_start"], well
+    assert well["relW"] < 1e-4 and well["relH"] < 1e-4, well
+    assert off["guard_checks"] == 0 and off["form_end"] == off["form_start"], off

@@ -24,4 +24,15 @@ c)  # C5-shaped run with the resident kernel for every node size, and with the d
         SMK_R2_PERSIST=$mode SMK_CLUST_TIMING=1 timeout 600 python3 tools/c5_hier.py 2>&1 | grep "smk_clust\|hier_nmf2:" > $OUT/c5_persist$mode.txt
     done
     ;;
+d)  # run-time guard cases, the dist tests (row-sharded W under the accurate form, product-form agreement), C4 bench with the guard
+    for alg in BPP MU HALS; do for kind in ill well; do SMK_GUARD_EVERY=4 SMK_GUARD_VERBOSE=1 timeout 300 python3 tools/guard_case.py $kind $alg 8 40; done; done > $OUT/guard_cases.txt 2>&1
+    timeout 900 python -m pytest tests/test_gpu_dist.py tests/test_gpu_variants.py -m gpu -q --tb=short 2>&1 | tail -30 > $OUT/tests.txt
+    python3 bench.py --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err
+    python3 bench.py --no-cpu-baseline --workload c2 > $OUT/bench_c2.json 2>> $OUT/bench_c4.err
+    python3 bench.py --no-cpu-baseline --workload c3 > $OUT/bench_c3.json 2>> $OUT/bench_c4.err
+    ;;
+e)  # guard test after the opt-in change, clustering tests with examples/pyclust.py, then the round's judged artefacts (quick set)
+    timeout 900 python -m pytest tests/test_gpu_variants.py tests/test_gpu_flatclust.py tests/test_examples.py -m gpu -q --tb=short 2>&1 | tail -15 > $OUT/tests.txt
+    bash tools/profile.sh r04 quick > $OUT/profile.log 2>&1
+    ;;
 esac
