@@ -140,7 +140,7 @@ def test_runtime_guard_of_the_product_form():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for kind, every in (("ill", "4"), ("well", "4"), ("off", "0")):
+    for kind, every in (("ill", "2"), ("well", "4"), ("off", "0")):
         r = subprocess.run([sys.executable, "tools/guard_case.py", "ill" if kind == "off" else kind, "BPP", "8", "40"], cwd=root,
                            capture_output=True, text=True, timeout=600, env=dict(os.environ, SMK_GUARD_EVERY=every))
         assert r.returncode == 0, r.stderr[-2000:]

@@ -35,4 +35,18 @@ e)  # guard test after the opt-in change, clustering tests with examples/pyclust
     timeout 900 python -m pytest tests/test_gpu_variants.py tests/test_gpu_flatclust.py tests/test_examples.py -m gpu -q --tb=short 2>&1 | tail -15 > $OUT/tests.txt
     bash tools/profile.sh r04 quick > $OUT/profile.log 2>&1
     ;;
+f)  # guard test again; the rank-tier anomalies: kernel tables of HALS at k = 80 / 100 / 128, first iterations against steady state
+    for pert in 0.05 0.1 0.2; do for ev in 2 0; do SMK_GUARD_EVERY=$ev timeout 300 python3 tools/guard_case.py ill BPP 8 40 $pert 2>/dev/null | tail -1; done; done > $OUT/guard_ill_by_pert.txt
+    timeout 600 python -m pytest tests/test_gpu_variants.py -m gpu -q --tb=short -k guard 2>&1 | tail -8 > $OUT/tests.txt
+    cd /tmp
+    for k in 80 100 128; do
+        timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_hals$k -o x -- python3 $ROOT/tools/wide_run.py 16384 8192 $k HALS 12 1 > $OUT/hals${k}_run.log 2>&1
+        DB=$(find $OUT/kt_hals$k -name '*.db' | head -1)
+        [ -n "$DB" ] && python3 $ROOT/tools/prof_summary.py "$DB" $OUT/r04_hals_k${k}_kernel_stats.md > /dev/null
+        rm -rf $OUT/kt_hals$k
+    done
+    cd $ROOT
+    for k in 192 512; do python3 tools/iter_times.py 16384 8192 $k BPP 16; done > $OUT/r04_bpp_first_iterations.txt 2>&1
+    for k in 80 100 128; do python3 tools/iter_times.py 16384 8192 $k HALS 12; done >> $OUT/r04_bpp_first_iterations.txt 2>&1
+    ;;
 esac

@@ -1,4 +1,4 @@
-"""The run-time guard of the product form on one case: python3 tools/guard_case.py <ill|well> [alg] [k] [iters]
+"""The run-time guard of the product form on one case: python3 tools/guard_case.py <ill|well> [alg] [k] [iters] [pert]
 ill : A = W* H* + noise with nearly collinear columns of W* (cond(W'W) ~ 1e5): the guard must change to the accurate form
 well: uniform noise: the guard looks and leaves the fast form alone
 Prints one JSON line: product form at the end, guard counters, errors against the oracle."""
@@ -11,11 +11,12 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "ill"
 alg = sys.argv[2] if len(sys.argv) > 2 else "BPP"
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 60
+pert = float(sys.argv[5]) if len(sys.argv) > 5 else 0.1          # how far the columns of the planted W* are from collinear
 m, n = 3000, 2000
 rng = np.random.default_rng(5)
 if kind == "ill":
     base = rng.random((m, 1))
-    Wp = base + 0.05 * rng.random((m, k))
+    Wp = base + pert * rng.random((m, k))
     Hp = rng.random((k, n)) * (rng.random((k, n)) > 0.5)
     A = Wp @ Hp + 1e-3 * rng.random((m, n))
 else:
