@@ -1452,86 +1452,113 @@ __global__ __launch_bounds__(256) void bigprod_f64_kernel(const unsigned char* _
 
 // The accurate form for a factor of ONE or TWO rows (dense RANK2: every node factorisation of HierNMF2 on dense A): 2 fp64
 // multiply-adds per stored entry are nothing for the vector ALUs (78 TFLOP/s of fp64 against 2 x 1.5 T entries/s at the HBM
-// rate), so this product streams like the 16-bit forms AND is the fp64 product of the stored data to rounding -- no packed
-// operand, no matrix cores.  Same plan as bigprod_f64_kernel (64-column tiles, 64-row stages, S row splits, P layout).
-// Workgroup = 4 waves, 16 columns per wave; per block of 256 rows the factor rows are staged through LDS once (16 B per
-// row) and lane l takes rows 4l .. 4l+3 of 8 columns at a time: 8 loads of 16 B (fp32; 8 B bf16) in flight per lane, each
-// wave load one contiguous KB of a column.  Two accumulators per column per lane, joined across the wave at the end.
+// rate), so this product can stream AND be the fp64 product of the stored data to rounding -- no packed operand, no matrix
+// cores, no LDS in the loop.  Same plan as bigprod_f64_kernel (64-column plan tiles, 64-row stages, S row splits, P layout);
+// a workgroup takes HALF a plan tile: 4 waves x 8 columns.  Lane l owns 4 consecutive rows (one 16-byte fp32 / 8-byte bf16
+// load per column) of a block of 256 rows; the 8 column loads and the lane's rows of the factor (from L2: 16 B per row) of
+// block b + 1 are issued before the multiply-adds of block b (register double buffer); the factor rows of a block travel
+// through a double-buffered LDS slab, one barrier per block.  Two accumulators per column per lane, joined at the end.
+// Measured on the C3 matrix (tools/r2_dense_rate.py): fp32 A 6.0 - 6.7 TB/s (the bf16x3 MFMA form: 5.9), bf16 A 4.7 - 5.0
+// (6.0).  (The first version staged the factor rows through LDS with two barriers per block and loaded 8 of 16 columns at
+// a time: 4.4 / 3.6 TB/s.)
 template <int EBYTES>
 __global__ __launch_bounds__(256) void bigprod_f64_k2_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                              const double* __restrict__ X, int ldx, int kvalid, i64 len,
                                                              double* __restrict__ P, i64 stages, i64 nst, i64 tiles, i64 ncols_pad,
                                                              int S, int pstride, int ktw, int accum)
 {
-    constexpr int NB = 64, RB = 256, CW = 16, CG = 8;
-    __shared__ double xs[RB][2];
-    __shared__ double red[NB][2];
-    const i64 tile = blockIdx.x / S;
+    constexpr int CW = 8, NBW = 32;                       // columns per wave / per workgroup
+    constexpr int RPL = 4;                                // rows per lane and block: one 16-byte (fp32) / 8-byte (bf16) load per column
+    constexpr int RB = 64 * RPL;                          // rows per block
+    typedef __attribute__((ext_vector_type(EBYTES))) unsigned u32x4v;      // EBYTES words = 4 rows (bf16: a register pair -- half the
+                                                                           // registers of the fp32 variant, so more waves cover the narrower loads)
+    __shared__ double red[NBW][2];
+    const i64 half = blockIdx.x / S;                      // half a plan tile
     const int split = (int)(blockIdx.x % S);
-    if (tile >= tiles) return;
+    if (half >= 2 * tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     i64 st0 = (i64)split * nst, st1 = st0 + nst;
     if (st1 > stages) st1 = stages;
-    const i64 ra = st0 * 64, rz = st1 * 64;                  // rows of this split (the matrix is zero padded to whole stages)
-    const i64 col0 = tile * NB + CW * wave;
+    const i64 ra = st0 * 64, rz = st1 * 64;               // rows of this split (the matrix is zero padded to whole stages)
+    const i64 col0 = half * NBW + CW * wave;
+    const unsigned char* bcol = B + col0 * ldb_bytes;
     double acc[CW][2];
 #pragma unroll
     for (int c = 0; c < CW; ++c) acc[c][0] = acc[c][1] = 0.0;
-    for (i64 rb = ra; rb < rz; rb += RB) {
-        __syncthreads();
-        {
-            const i64 r = rb + tid;
+
+    // the factor rows of a block go through LDS (one row per thread per 256 rows, double buffered: ONE barrier per block);
+    // the column loads of block b + 1 are in flight while block b is consumed
+    __shared__ double xs[2][RB][2];
+    u32x4v v[2][CW];
+    auto fetch = [&](int buf, i64 rb) {
+        const i64 r = rb + (i64)RPL * lane;
+        const bool rows_in = r < rz;                      // RPL divides 64: a lane's rows are inside the split or outside together
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            v[buf][c] = u32x4v{};
+            if (rows_in) v[buf][c] = __builtin_nontemporal_load((const u32x4v*)(bcol + c * ldb_bytes + r * EBYTES));
+        }
+    };
+    double xr[RB / 256][2];
+    auto load_x = [&](i64 rb) {
+#pragma unroll
+        for (int u = 0; u < RB / 256; ++u) {
+            const i64 r = rb + tid + 256 * u;
             const bool live = r < len && r < rz;
-            xs[tid][0] = live ? X[r * ldx] : 0.0;
-            xs[tid][1] = (live && kvalid > 1) ? X[r * ldx + 1] : 0.0;
+            xr[u][0] = live ? X[r * ldx] : 0.0;
+            xr[u][1] = (live && kvalid > 1) ? X[r * ldx + 1] : 0.0;
         }
-        __syncthreads();
-        const i64 r = rb + 4 * lane;
-        if (r < rz) {
-            double x[4][2];
+    };
+    auto store_x = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { x[i][0] = xs[4 * lane + i][0]; x[i][1] = xs[4 * lane + i][1]; }
+        for (int u = 0; u < RB / 256; ++u) { xs[buf][tid + 256 * u][0] = xr[u][0]; xs[buf][tid + 256 * u][1] = xr[u][1]; }
+    };
+    auto consume = [&](int buf) {
+        double x[RPL][2];
 #pragma unroll
-            for (int cg = 0; cg < CW / CG; ++cg) {
-                float v[CG][4];
+        for (int i = 0; i < RPL; ++i) { x[i][0] = xs[buf][RPL * lane + i][0]; x[i][1] = xs[buf][RPL * lane + i][1]; }
 #pragma unroll
-                for (int j = 0; j < CG; ++j) {
-                    const unsigned char* src = B + (col0 + cg * CG + j) * ldb_bytes + r * EBYTES;
-                    if constexpr (EBYTES == 2) {
-                        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-                        const u32x2 u = __builtin_nontemporal_load((const u32x2*)src);
-                        v[j][0] = bf16_bits_to_f32((unsigned short)(u[0] & 0xFFFFu)); v[j][1] = bf16_bits_to_f32((unsigned short)(u[0] >> 16));
-                        v[j][2] = bf16_bits_to_f32((unsigned short)(u[1] & 0xFFFFu)); v[j][3] = bf16_bits_to_f32((unsigned short)(u[1] >> 16));
-                    } else {
-                        typedef __attribute__((ext_vector_type(4))) float f32x4v;
-                        const f32x4v u = __builtin_nontemporal_load((const f32x4v*)src);
-                        v[j][0] = u[0]; v[j][1] = u[1]; v[j][2] = u[2]; v[j][3] = u[3];
-                    }
+        for (int c = 0; c < CW; ++c)
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                double b;
+                if constexpr (EBYTES == 2) {
+                    const unsigned w = v[buf][c][i >> 1];
+                    b = (double)__builtin_bit_cast(float, (i & 1) ? (w & 0xFFFF0000u) : (w << 16));
+                } else {
+                    b = (double)__builtin_bit_cast(float, v[buf][c][i]);
                 }
-#pragma unroll
-                for (int j = 0; j < CG; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const double b = (double)v[j][i];
-                        acc[cg * CG + j][0] = fma(b, x[i][0], acc[cg * CG + j][0]);
-                        acc[cg * CG + j][1] = fma(b, x[i][1], acc[cg * CG + j][1]);
-                    }
+                acc[c][0] = fma(b, x[i][0], acc[c][0]);
+                acc[c][1] = fma(b, x[i][1], acc[c][1]);
             }
+    };
+    if (ra < rz) { fetch(0, ra); load_x(ra); store_x(0); }
+    __syncthreads();
+    int cur = 0;
+    for (i64 rb = ra; rb < rz; rb += RB) {
+        const bool more = rb + RB < rz;
+        if (more) {
+            if (cur == 0) fetch(1, rb + RB); else fetch(0, rb + RB);
+            load_x(rb + RB);
         }
+        if (cur == 0) consume(0); else consume(1);
+        if (more) store_x(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
     }
     // join the 64 lanes of a column (fixed butterfly order: the result does not depend on scheduling)
 #pragma unroll
     for (int c = 0; c < CW; ++c)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            double v = acc[c][j];
+            double t = acc[c][j];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0) red[CW * wave + c][j] = v;
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            if (lane == 0) red[CW * wave + c][j] = t;
         }
     __syncthreads();
-    if (tid < NB) {
-        double* pout = P + ((i64)split * ncols_pad + tile * NB + tid) * pstride;
+    if (tid < NBW) {
+        double* pout = P + ((i64)split * ncols_pad + half * NBW + tid) * pstride;
         double v0 = red[tid][0], v1 = red[tid][1];
         if (accum) { v0 += pout[0]; v1 += pout[1]; }
         pout[0] = v0;
@@ -1550,10 +1577,10 @@ static int launch_bigprod_f64(const BigProdPlan& pl, const void* B, i64 ldb, con
     const int ktw = 2 * kt_of(pl.kg);                      // 16-row tiles covering the group's 32-row k tiles
     if (kvalid <= 2) {                                     // rank 1 / 2: the vector-ALU kernel at the streaming rate
         if (pl.storage == STORE_BF16)
-            bigprod_f64_k2_kernel<2><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * 2, (const double*)X, pl.ldx, kvalid, len, P,
+            bigprod_f64_k2_kernel<2><<<(unsigned)(2 * grid), 256, 0, st>>>((const unsigned char*)B, ldb * 2, (const double*)X, pl.ldx, kvalid, len, P,
                                                                     pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum);
         else
-            bigprod_f64_k2_kernel<4><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * 4, (const double*)X, pl.ldx, kvalid, len, P,
+            bigprod_f64_k2_kernel<4><<<(unsigned)(2 * grid), 256, 0, st>>>((const unsigned char*)B, ldb * 4, (const double*)X, pl.ldx, kvalid, len, P,
                                                                     pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum);
         SMK_HIP(hipGetLastError());
         return 0;

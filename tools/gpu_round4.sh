@@ -49,4 +49,11 @@ f)  # guard test again; the rank-tier anomalies: kernel tables of HALS at k = 80
     for k in 192 512; do python3 tools/iter_times.py 16384 8192 $k BPP 16; done > $OUT/r04_bpp_first_iterations.txt 2>&1
     for k in 80 100 128; do python3 tools/iter_times.py 16384 8192 $k HALS 12; done >> $OUT/r04_bpp_first_iterations.txt 2>&1
     ;;
+g)  # streaming rate of the accurate rank-2 product
+    python3 tools/r2_dense_rate.py 65536 16384 bf16 > $OUT/r2_dense_rate.txt 2>&1
+    python3 tools/r2_dense_rate.py 65536 16384 f32 >> $OUT/r2_dense_rate.txt 2>&1
+    python3 tools/r2_dense_rate.py 8192 4096 f32 >> $OUT/r2_dense_rate.txt 2>&1
+    SMK_NSPLIT=3 python3 tools/r2_dense_rate.py 65536 16384 bf16 >> $OUT/r2_dense_rate.txt 2>&1
+    SMK_NSPLIT=3 python3 tools/r2_dense_rate.py 65536 16384 f32 >> $OUT/r2_dense_rate.txt 2>&1
+    ;;
 esac
