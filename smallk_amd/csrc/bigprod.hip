@@ -1,6 +1,7 @@
 // smallk_amd/csrc/bigprod.hip -- the streaming products W'A and H*At (the dominant kernels) and the
 // packing of their skinny operand.  See kernels.hip for the kernel map.
 #include "devutil.h"
+#include <type_traits>
 
 namespace smk {
 
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
     for (int c = 0; c < CW; ++c) {
         const i64 jg = col0 + (cwv * CW + c) * 32 + (lane & 31);
         double* pout = P + ((i64)split * ncols_pad + jg) * pstride + kw * KTW * 32;
+        const int prows = pstride < 32 ? pstride : 1 << 30;          // rows of this group a column of P has room for
 #pragma unroll
         for (int kt = 0; kt < KTW; ++kt) {
             const int n = c * KTW + kt;
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
                         }
                         v[u] = tsum;
                     }
+                    if (kw * KTW * 32 + kt * 32 + 8 * g >= prows) continue;      // k <= 16: a column of P holds 8 / 16 rows, not 32 (kpp_of)
                     if (accum) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);   // a later row chunk of the same product
                     *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
                 }
@@ -954,6 +957,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
                     v[0] *= os[0];
                     v[1] *= os[1];
                 }
+                if (pstride < 32 && kt * 32 + 8 * g >= pstride) continue;      // k <= 16: a column of P holds 8 / 16 rows, not 32 (kpp_of)
                 if (accum) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);
                 *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
             }
@@ -1204,6 +1208,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
                     v[0] *= os[0];
                     v[1] *= os[1];
                 }
+                if (pstride < 32 && kt * 32 + 8 * g >= pstride) continue;      // k <= 16: a column of P holds 8 / 16 rows, not 32 (kpp_of)
                 if (accum) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);
                 *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
             }
@@ -1444,6 +1449,7 @@ __global__ __launch_bounds__(256) void bigprod_f64_kernel(const unsigned char* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * t + l4 + 4 * r;
+                if (pstride < 32 && row >= pstride) continue;             // k <= 16: a column of P holds 8 / 16 rows (kpp_of)
                 double v = (t < KT16) ? acc[t < KT16 ? t : 0][r] : 0.0;      // tiles past the live ones are written as zeros
                 if (accum) v += pout[row];
                 pout[row] = v;
@@ -1458,8 +1464,8 @@ __global__ __launch_bounds__(256) void bigprod_f64_kernel(const unsigned char* _
 // load per column) of a block of 256 rows; the 8 column loads and the lane's rows of the factor (from L2: 16 B per row) of
 // block b + 1 are issued before the multiply-adds of block b (register double buffer); the factor rows of a block travel
 // through a double-buffered LDS slab, one barrier per block.  Two accumulators per column per lane, joined at the end.
-// Measured on the C3 matrix (tools/r2_dense_rate.py): fp32 A 6.0 - 6.7 TB/s (the bf16x3 MFMA form: 5.9), bf16 A 4.7 - 5.0
-// (6.0).  (The first version staged the factor rows through LDS with two barriers per block and loaded 8 of 16 columns at
+// Measured on the C3 matrix (tools/r2_dense_rate.py): fp32 A 6.2 - 6.6 TB/s (the bf16x3 MFMA form: 5.9 - 6.1), bf16 A
+// 4.8 - 5.2 (6.1 - 6.2).  (The first version staged the factor rows through LDS with two barriers per block and loaded 8 of 16 columns at
 // a time: 4.4 / 3.6 TB/s.)
 template <int EBYTES>
 __global__ __launch_bounds__(256) void bigprod_f64_k2_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
@@ -1470,8 +1476,12 @@ __global__ __launch_bounds__(256) void bigprod_f64_k2_kernel(const unsigned char
     constexpr int CW = 8, NBW = 32;                       // columns per wave / per workgroup
     constexpr int RPL = 4;                                // rows per lane and block: one 16-byte (fp32) / 8-byte (bf16) load per column
     constexpr int RB = 64 * RPL;                          // rows per block
-    typedef __attribute__((ext_vector_type(EBYTES))) unsigned u32x4v;      // EBYTES words = 4 rows (bf16: a register pair -- half the
-                                                                           // registers of the fp32 variant, so more waves cover the narrower loads)
+    // 4 rows = 4 words (fp32) or 2 words (bf16: a register pair -- half the registers of the fp32 variant, so more waves cover
+    // the narrower loads).  Two fixed typedefs and .x/.y/.z/.w on purpose: with a vector type whose length depended on the
+    // template parameter the compiler dropped the element index (every row of a lane read word 0; tools/r2_dense_dbg.py).
+    typedef __attribute__((ext_vector_type(4))) unsigned words4_t;
+    typedef __attribute__((ext_vector_type(2))) unsigned words2_t;
+    typedef typename std::conditional<EBYTES == 4, words4_t, words2_t>::type u32x4v;
     __shared__ double red[NBW][2];
     const i64 half = blockIdx.x / S;                      // half a plan tile
     const int split = (int)(blockIdx.x % S);
@@ -1523,10 +1533,11 @@ __global__ __launch_bounds__(256) void bigprod_f64_k2_kernel(const unsigned char
             for (int i = 0; i < RPL; ++i) {
                 double b;
                 if constexpr (EBYTES == 2) {
-                    const unsigned w = v[buf][c][i >> 1];
+                    const unsigned w = (i >> 1) ? v[buf][c].y : v[buf][c].x;
                     b = (double)__builtin_bit_cast(float, (i & 1) ? (w & 0xFFFF0000u) : (w << 16));
                 } else {
-                    b = (double)__builtin_bit_cast(float, v[buf][c][i]);
+                    const unsigned w = i == 0 ? v[buf][c].x : i == 1 ? v[buf][c].y : i == 2 ? v[buf][c].z : v[buf][c].w;
+                    b = (double)__builtin_bit_cast(float, w);
                 }
                 acc[c][0] = fma(b, x[i][0], acc[c][0]);
                 acc[c][1] = fma(b, x[i][1], acc[c][1]);
@@ -1564,7 +1575,7 @@ __global__ __launch_bounds__(256) void bigprod_f64_k2_kernel(const unsigned char
         pout[0] = v0;
         pout[1] = v1;
         if (!accum)                        // the rest of the group's 32-row k tiles as zeros, like the other forms
-            for (int r = 2; r < 16 * ktw; ++r) pout[r] = 0.0;
+            for (int r = 2; r < 16 * ktw && (pstride >= 32 || r < pstride); ++r) pout[r] = 0.0;
     }
 }
 
@@ -1634,7 +1645,7 @@ int plan_bigprod_groups(int storage, int k, i64 len, i64 ncols, int nsplit, int 
 {
     int ng = 0;
     size_t off = 0;
-    const int pstride = kt_of(k) * 32;
+    const int pstride = kpp_of(k);
     for (int k0 = 0; k0 < k; k0 += 64, ++ng) {
         const int kg = k - k0 < 64 ? k - k0 : 64;
         BigProdPlan pl = plan_bigprod(storage, kg, len, ncols, nsplit, num_cus);
@@ -1655,7 +1666,7 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     BigProdPlan pl;
     pl.storage = storage;
     pl.kt = kt_of(k);
-    pl.k0 = 0; pl.kg = k; pl.pstride = kt_of(k) * 32; pl.pack_offset = 0;
+    pl.k0 = 0; pl.kg = k; pl.pstride = kpp_of(k); pl.pack_offset = 0;
     // fp32 storage: nsplit 3 selects the bf16x3 emulation (default), 1 the native fp32 MFMA
     pl.nsplit = storage == STORE_BF16 ? nsplit : (nsplit >= 2 ? nsplit : 1);
     if (nsplit == NSPLIT_F64) {            // the accurate form: fp64 matrix cores, 64 x 64 tiles
@@ -1670,7 +1681,7 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
         pl.S = S;
         pl.nst = (pl.stages + S - 1) / S;
         pl.len = len;
-        pl.p_elems = (size_t)S * pl.ncols_pad * pl.kt * 32;
+        pl.p_elems = (size_t)S * pl.ncols_pad * pl.pstride;
         return pl;
     }
     // measured best on MI355X: bf16 -> 64-row stages, 2-deep ring, 2 workgroups per CU (C3: 5.98 TB/s)
@@ -1713,7 +1724,7 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
         if (envS && atoi(envS) > 0) { S = 1; while (S < atoi(envS) && S < 64) S *= 2; }
         pl.S = S;
         pl.nst = (pl.stages + S - 1) / S;
-        pl.p_elems = (size_t)S * pl.ncols_pad * pl.kt * 32;
+        pl.p_elems = (size_t)S * pl.ncols_pad * pl.pstride;
         return pl;
     }
     if (v < 0 || v >= kNumVariants) v = 6;
@@ -1740,7 +1751,7 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     if (envS && atoi(envS) > 0) { S = 1; while (S < atoi(envS) && S < 64) S *= 2; }
     pl.S = S;
     pl.nst = (pl.stages + S - 1) / S;
-    pl.p_elems = (size_t)S * pl.ncols_pad * pl.kt * 32;   // doubles
+    pl.p_elems = (size_t)S * pl.ncols_pad * pl.pstride;   // doubles
     return pl;
 }
 

@@ -33,6 +33,9 @@ inline bool is_wide(int k) { return k > 128; }
 bool nnls_uses_tiles(int k);
 // number of 32-wide k tiles of the streaming product
 inline int kt_of(int k) { return (k + 31) / 32; }
+// doubles per column of the partial products of a dense pass: the k tiles of 32 rows -- but 8 / 16 for k <= 8 / 16 (half or a
+// quarter of the bytes written by the streaming pass and read by the update kernel behind it: C2 is k = 16)
+inline int kpp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : kt_of(k) * 32; }
 
 void set_error(const std::string& msg);
 

@@ -915,7 +915,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     s->a = a;
     s->k = opts->k;
     s->KP = kp_of(s->k);
-    s->kpp = kt_of(s->k) * 32;
+    s->kpp = kpp_of(s->k);
     s->m = a->m;
     s->n = a->n;
     s->st = a->st ? a->st : g_stream;

@@ -56,4 +56,12 @@ g)  # streaming rate of the accurate rank-2 product
     SMK_NSPLIT=3 python3 tools/r2_dense_rate.py 65536 16384 bf16 >> $OUT/r2_dense_rate.txt 2>&1
     SMK_NSPLIT=3 python3 tools/r2_dense_rate.py 65536 16384 f32 >> $OUT/r2_dense_rate.txt 2>&1
     ;;
+h)  # compact P columns for k <= 16: parity suite + C2 bench and kernel table
+    timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_nnls.py tests/test_gpu_variants.py tests/test_gpu_fullsize.py tests/test_gpu_dist.py tests/test_gpu_hierclust.py -m gpu -q --tb=short -x 2>&1 | tail -15 > $OUT/tests.txt
+    python3 bench.py --no-cpu-baseline --workload c2 --steps 200 --warmup 20 > $OUT/bench_c2.json 2> $OUT/bench.err
+    python3 bench.py --no-cpu-baseline --workload c1 --steps 200 --warmup 20 > $OUT/bench_c1.json 2>> $OUT/bench.err
+    cd /tmp
+    timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_c2 -o x -- python3 $ROOT/bench.py --no-cpu-baseline --workload c2 --steps 50 --warmup 5 > $OUT/c2_run.log 2>&1
+    DB=$(find $OUT/kt_c2 -name '*.db' | head -1); [ -n "$DB" ] && python3 $ROOT/tools/prof_summary.py "$DB" $OUT/r04_c2_bpp_f32_kernel_stats.md > /dev/null; rm -rf $OUT/kt_c2
+    ;;
 esac
