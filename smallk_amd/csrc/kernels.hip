@@ -1295,7 +1295,8 @@ template <int KP, int NT, int C>
 __device__ __forceinline__ void hals_w_fused_step(double (&w)[KP], double& rhs, bool& dead, const double* gs,
                                                   double* sh, int k, i64 M, i64 row, bool valid,
                                                   const PartialView& R, unsigned long long* __restrict__ slots,
-                                                  int nblk, int lane, int wave, unsigned spin_max)
+                                                  int nblk, int lane, int wave, unsigned spin_max,
+                                                  unsigned long long* __restrict__ gslots)
 {
     constexpr int NW = NT / 64;
     if (C >= k || dead) return;                     // uniform
@@ -1325,9 +1326,35 @@ __device__ __forceinline__ void hals_w_fused_step(double (&w)[KP], double& rhs, 
         if (lane == 0)
             __hip_atomic_store(col_slots + blockIdx.x, (unsigned long long)__double_as_longlong(t),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // gather every workgroup's partial: up to 4 slots per lane polled together (bounded spin)
         double acc = 0.0;
         bool ok = true;
+        if (gslots) {
+            // Two-level exchange (round 4).  Every workgroup polling every slot is an all-to-all of nblk x nblk loads per column
+            // (3.9 us per column at 256 workgroups: the guide's price for a broadcast + fan-in).  Here a workgroup polls only the
+            // slots of its GROUP (workgroups b with b % 8 == its own: 32 of 256 -- on this chip block b is observed to run on
+            // XCD b % 8, so these polls stay inside one XCD's L2; nothing depends on that, any placement gives the same bits),
+            // the group's first workgroup publishes the group sum, and everybody polls the 8 group sums.
+            const int grp = (int)(blockIdx.x & 7u), ngrp = nblk < 8 ? nblk : 8;
+            const int members = (nblk - grp + 7) / 8;                       // <= 64 for nblk <= 512
+            unsigned long long bits = lane < members ? kSlotEmpty : 0ull;
+            for (unsigned spin = 0; spin < spin_max; ++spin) {
+                if (bits == kSlotEmpty) bits = __hip_atomic_load(col_slots + grp + 8 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!__any(bits == kSlotEmpty)) break;
+            }
+            if (bits == kSlotEmpty) { ok = false; bits = 0ull; }
+            const double gsum = wave_sum(__longlong_as_double((long long)bits));
+            unsigned long long* col_g = gslots + (i64)C * 8;
+            if ((int)blockIdx.x < ngrp && lane == 0)                        // the group's first workgroup publishes its sum
+                __hip_atomic_store(col_g + grp, (unsigned long long)__double_as_longlong(gsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long gb = lane < ngrp ? kSlotEmpty : 0ull;
+            for (unsigned spin = 0; spin < spin_max; ++spin) {
+                if (gb == kSlotEmpty) gb = __hip_atomic_load(col_g + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!__any(gb == kSlotEmpty)) break;
+            }
+            if (gb == kSlotEmpty) { ok = false; gb = 0ull; }
+            acc = __longlong_as_double((long long)gb);
+        } else
+        // gather every workgroup's partial: up to 4 slots per lane polled together (bounded spin)
         for (int b0 = 0; b0 < nblk; b0 += 256) {
             unsigned long long bits[4];
             bool have[4];
@@ -1371,9 +1398,9 @@ __device__ __forceinline__ void hals_w_fused_all(std::integer_sequence<int, Cs..
                                                  bool& dead, const double* gs, double* sh, int k, i64 M, i64 row,
                                                  bool valid, const PartialView& R,
                                                  unsigned long long* __restrict__ slots, int nblk, int lane, int wave,
-                                                 unsigned spin_max)
+                                                 unsigned spin_max, unsigned long long* __restrict__ gslots)
 {
-    (hals_w_fused_step<KP, NT, Cs>(w, rhs, dead, gs, sh, k, M, row, valid, R, slots, nblk, lane, wave, spin_max), ...);
+    (hals_w_fused_step<KP, NT, Cs>(w, rhs, dead, gs, sh, k, M, row, valid, R, slots, nblk, lane, wave, spin_max, gslots), ...);
 }
 
 template <int KP, int NT>
@@ -1381,7 +1408,7 @@ __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ W
                                                           const double* __restrict__ G,
                                                           unsigned long long* __restrict__ slots,
                                                           unsigned long long* __restrict__ slots_other, int nblk,
-                                                          int* __restrict__ fail_flag, unsigned spin_max)
+                                                          int* __restrict__ fail_flag, unsigned spin_max, int two_level)
 {
     __shared__ __attribute__((aligned(16))) double gs[KP * KP];
     __shared__ double sh[40];
@@ -1389,6 +1416,9 @@ __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ W
     // the other slot buffer (used by the previous sweep, which is complete) is re-armed for the next one: no memset
     // launch per iteration
     if ((int)threadIdx.x < k) slots_other[(i64)threadIdx.x * nblk + blockIdx.x] = kSlotEmpty;
+    // the group sums of the two-level exchange live behind the k x 1024 slots of each buffer; workgroup 0 re-arms the other buffer's
+    unsigned long long* gslots = two_level ? slots + (i64)k * 1024 : nullptr;
+    if (two_level && blockIdx.x == 0 && (int)threadIdx.x < k * 8) (slots_other + (i64)k * 1024)[threadIdx.x] = kSlotEmpty;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const i64 row = (i64)blockIdx.x * NT + threadIdx.x;
@@ -1408,7 +1438,7 @@ __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ W
 
     bool dead = false;
     hals_w_fused_all<KP, NT>(std::make_integer_sequence<int, KP>{}, w, rhs, dead, gs, sh, k, M, row, valid, R, slots,
-                             nblk, lane, wave, spin_max);
+                             nblk, lane, wave, spin_max, gslots);
     if (dead) {
         if (threadIdx.x == 0) atomicMin(fail_flag, -3);
         return;
@@ -1435,7 +1465,7 @@ size_t hals_w_scratch_elems(int k, i64 M)
 {
     if (is_wide(k)) return std::max((size_t)(2 * (i64)k * hals_w_wide_blocks(M)), hals_w_blocked_scratch_elems(k, M));
     const size_t multi = (size_t)(2 * (i64)k * hals_w_blocks(kp_of(k), M));
-    const size_t fused = (size_t)2 * k * 1024;      // two slot buffers (8 bytes per slot), generous
+    const size_t fused = (size_t)2 * k * (1024 + 8);      // two slot buffers (8 bytes per slot), generous, each followed by its k x 8 group sums
     const size_t blocked = k > 64 ? hals_w_blocked_scratch_elems(k, M) : 0;
     return std::max(std::max(multi, fused), blocked);
 }
@@ -1472,10 +1502,13 @@ int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* 
         if (cand >= nt_min && (M + cand - 1) / cand <= (i64)num_cus) { nt = cand; break; }
     if (mode == 1 && nt != 0 && !force_multi && KPv <= 64) {
         const i64 nblk_f = (M + nt - 1) / nt;
-        unsigned long long* slots = (unsigned long long*)scratch + (size_t)(parity & 1) * k * 1024;
-        unsigned long long* other = (unsigned long long*)scratch + (size_t)((parity & 1) ^ 1) * k * 1024;
+        unsigned long long* slots = (unsigned long long*)scratch + (size_t)(parity & 1) * k * (1024 + 8);
+        unsigned long long* other = (unsigned long long*)scratch + (size_t)((parity & 1) ^ 1) * k * (1024 + 8);
         const int nb = (int)nblk_f;
-#define SMK_FUSED(KPX, NTX) hals_w_fused_kernel<KPX, NTX><<<nb, NTX, 0, st>>>(Wt, k, M, R, G, slots, other, nb, fail_flag, spin_max)
+        // SMK_HALS_EXCHANGE=1: every workgroup polls every slot (rounds 1-3); default: the two-level exchange from 16 workgroups on
+        static const int flat = [] { const char* e = getenv("SMK_HALS_EXCHANGE"); return e ? atoi(e) : 0; }();
+        const int two_level = (!flat && nb >= 16 && nb <= 512 && k * 8 <= nt) ? 1 : 0;
+#define SMK_FUSED(KPX, NTX) hals_w_fused_kernel<KPX, NTX><<<nb, NTX, 0, st>>>(Wt, k, M, R, G, slots, other, nb, fail_flag, spin_max, two_level)
         switch (KPv) {
             case 8: if (nt == 256) SMK_FUSED(8, 256); else if (nt == 512) SMK_FUSED(8, 512); else SMK_FUSED(8, 1024); break;
             case 16: if (nt == 256) SMK_FUSED(16, 256); else if (nt == 512) SMK_FUSED(16, 512); else SMK_FUSED(16, 1024); break;

@@ -64,4 +64,32 @@ h)  # compact P columns for k <= 16: parity suite + C2 bench and kernel table
     timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_c2 -o x -- python3 $ROOT/bench.py --no-cpu-baseline --workload c2 --steps 50 --warmup 5 > $OUT/c2_run.log 2>&1
     DB=$(find $OUT/kt_c2 -name '*.db' | head -1); [ -n "$DB" ] && python3 $ROOT/tools/prof_summary.py "$DB" $OUT/r04_c2_bpp_f32_kernel_stats.md > /dev/null; rm -rf $OUT/kt_c2
     ;;
+i)  # evidence on the current build: whole GPU suite, the poisoned suite, randomised sweeps (NMF parity, HierNMF2, wide BPP)
+    python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error|^FAILED|^ERROR" | tail -20 > $OUT/gpu_suite.txt
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke >> $OUT/gpu_suite.txt
+    bash tools/gpu_poison.sh > $OUT/poison.txt 2>&1
+    timeout 1500 python3 tools/fuzz_hier.py 120 7 > $OUT/fuzz_hier_120.log 2>&1
+    timeout 1500 python3 tools/fuzz_parity.py 600 11 1500 > $OUT/fuzz_parity_600.log 2>&1
+    timeout 900 python3 tools/fuzz_wide_bpp.py 60 3 > $OUT/fuzz_wide_bpp_60.log 2>&1
+    ;;
+j)  # FETCH_SIZE calibration for 16-byte gathers, then the counter on the resident RANK2 kernel; HALS exchange A/B on C3
+    cd /tmp
+    for mode in stream gather16 gather16L2; do
+        timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_$mode -o x -- $ROOT/tools/mb/mb_gather $mode 1024 16 > $OUT/mb_$mode.log 2>&1
+        DB=$(find $OUT/pmc_$mode -name '*.db' | head -1); [ -n "$DB" ] && python3 $ROOT/tools/pmc_dump.py "$DB" _kernel > $OUT/pmc_$mode.txt; rm -rf $OUT/pmc_$mode
+    done
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+        timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_r2p_$ctr -o x -- python3 $ROOT/tools/r2_iter.py 1000000 16 20 > $OUT/r2p_$ctr.log 2>&1
+        DB=$(find $OUT/pmc_r2p_$ctr -name '*.db' | head -1); [ -n "$DB" ] && python3 $ROOT/tools/pmc_dump.py "$DB" rank2_persist > $OUT/pmc_r2p_$ctr.txt; rm -rf $OUT/pmc_r2p_$ctr
+    done
+    cd $ROOT
+    { for f in stream gather16 gather16L2; do echo "== $f"; grep -v amdgpu $OUT/mb_$f.log | tail -2; cat $OUT/pmc_$f.txt; done; echo "== resident RANK2 kernel, 1 M x 1 M, 16 M entries, 20 iterations per launch"; cat $OUT/pmc_r2p_FETCH_SIZE.txt $OUT/pmc_r2p_WRITE_SIZE.txt; grep -v amdgpu $OUT/r2p_FETCH_SIZE.log | tail -2; } > $OUT/r04_fetch_size_calibration_16B_gathers.txt 2>&1
+    python3 bench.py --no-cpu-baseline --workload c3 > $OUT/bench_c3_two_level.json 2> $OUT/bench.err
+    SMK_HALS_EXCHANGE=1 python3 bench.py --no-cpu-baseline --workload c3 > $OUT/bench_c3_flat.json 2>> $OUT/bench.err
+    cd /tmp
+    timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_c3 -o x -- python3 $ROOT/bench.py --no-cpu-baseline --workload c3 --steps 20 --warmup 3 > $OUT/c3_run.log 2>&1
+    DB=$(find $OUT/kt_c3 -name '*.db' | head -1); [ -n "$DB" ] && python3 $ROOT/tools/prof_summary.py "$DB" $OUT/r04_c3_hals_bf16_kernel_stats.md > /dev/null; rm -rf $OUT/kt_c3
+    cd $ROOT
+    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_variants.py tests/test_gpu_fullsize.py tests/test_hals_blocked_reference.py -m gpu -q -k "hals or HALS or c3" 2>&1 | grep -E "passed|failed|^FAILED" > $OUT/tests_hals.txt
+    ;;
 esac
