@@ -1329,8 +1329,9 @@ __device__ __forceinline__ void hals_w_fused_step(double (&w)[KP], double& rhs, 
         double acc = 0.0;
         bool ok = true;
         if (gslots) {
-            // Two-level exchange (round 4).  Every workgroup polling every slot is an all-to-all of nblk x nblk loads per column
-            // (3.9 us per column at 256 workgroups: the guide's price for a broadcast + fan-in).  Here a workgroup polls only the
+            // Two-level exchange (round 4, SMK_HALS_EXCHANGE=2; NOT the default: it measured slower, see launch_hals_w_update).  Every
+            // workgroup polling every slot is an all-to-all of nblk x nblk loads per column (3.9 us per column at 256 workgroups: the
+            // guide's price for a broadcast + fan-in).  Here a workgroup polls only the
             // slots of its GROUP (workgroups b with b % 8 == its own: 32 of 256 -- on this chip block b is observed to run on
             // XCD b % 8, so these polls stay inside one XCD's L2; nothing depends on that, any placement gives the same bits),
             // the group's first workgroup publishes the group sum, and everybody polls the 8 group sums.
@@ -1505,9 +1506,12 @@ int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* 
         unsigned long long* slots = (unsigned long long*)scratch + (size_t)(parity & 1) * k * (1024 + 8);
         unsigned long long* other = (unsigned long long*)scratch + (size_t)((parity & 1) ^ 1) * k * (1024 + 8);
         const int nb = (int)nblk_f;
-        // SMK_HALS_EXCHANGE=1: every workgroup polls every slot (rounds 1-3); default: the two-level exchange from 16 workgroups on
-        static const int flat = [] { const char* e = getenv("SMK_HALS_EXCHANGE"); return e ? atoi(e) : 0; }();
-        const int two_level = (!flat && nb >= 16 && nb <= 512 && k * 8 <= nt) ? 1 : 0;
+        // Default: every workgroup polls every slot.  SMK_HALS_EXCHANGE=2 selects the two-level exchange (group sums first): built in
+        // round 4 on the expectation that 40 polled slots instead of 256 would cut the 3.9 us per column -- measured on C3 it is
+        // SLOWER, 155 us per sweep against 125 (4.8 us per column): the second dependent store -> poll hop costs more than the
+        // all-to-all's contention.  Kept selectable as the record of that measurement (profiles/r04_hals_exchange_two_level.txt).
+        static const int mode = [] { const char* e = getenv("SMK_HALS_EXCHANGE"); return e ? atoi(e) : 1; }();
+        const int two_level = (mode == 2 && nb >= 16 && nb <= 512 && k * 8 <= nt) ? 1 : 0;
 #define SMK_FUSED(KPX, NTX) hals_w_fused_kernel<KPX, NTX><<<nb, NTX, 0, st>>>(Wt, k, M, R, G, slots, other, nb, fail_flag, spin_max, two_level)
         switch (KPv) {
             case 8: if (nt == 256) SMK_FUSED(8, 256); else if (nt == 512) SMK_FUSED(8, 512); else SMK_FUSED(8, 1024); break;

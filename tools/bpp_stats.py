@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, smallk_amd, oracle
 smallk_amd.initialize(0)
 for (m, n, k) in ((16384, 4096, 64), (8192, 4096, 16)):

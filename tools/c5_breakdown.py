@@ -1,6 +1,6 @@
 """where the wall time of the C5-shaped HierNMF2 run goes: matrix creation (host transpose + upload) vs the clustering"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp
 import smallk_amd
 from smallk_amd import solver as S

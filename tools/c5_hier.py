@@ -1,7 +1,7 @@
 """C5-shaped run: HierNMF2 on a synthetic sparse symmetric adjacency (planted communities).
 usage: python tools/c5_hier.py [nodes] [avg_degree] [clusters]"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp
 import smallk_amd
 

@@ -4,7 +4,7 @@ flat factors, NnlsHals.  Run on the GPU box: python3 tools/dense_clust_errors.py
 import os
 import sys
 
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np
 import oracle
 import smallk_amd as gpu

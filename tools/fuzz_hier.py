@@ -1,7 +1,7 @@
 """Randomised HierNMF2 sweep: sparse inputs (fp64 end to end) must give trees IDENTICAL to the oracle's;
 dense inputs are reported (near-ties can legitimately flip).  usage: python tools/fuzz_hier.py [cases] [seed]"""
 import os, sys, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np
 import oracle, smallk_amd
 from oracle import hierclust as oh

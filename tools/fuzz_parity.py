@@ -2,7 +2,7 @@
 stopping rule; ranks up to 260: every kernel family incl. the general path above 128) through the C ABI against the
 oracle.  usage: python tools/fuzz_parity.py [cases] [seed] [max_dim]"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp
 import oracle, smallk_amd
 

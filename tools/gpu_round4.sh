@@ -92,4 +92,15 @@ j)  # FETCH_SIZE calibration for 16-byte gathers, then the counter on the reside
     cd $ROOT
     timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_variants.py tests/test_gpu_fullsize.py tests/test_hals_blocked_reference.py -m gpu -q -k "hals or HALS or c3" 2>&1 | grep -E "passed|failed|^FAILED" > $OUT/tests_hals.txt
     ;;
+k)  # FETCH_SIZE / WRITE_SIZE of the resident RANK2 kernel: a root-sized matrix (16 M entries) and a 2 M-entry one, 20 iterations each
+    cd /tmp
+    for shape in "1000000 16" "200000 10"; do
+        tag=$(echo $shape | tr ' ' '_')
+        for ctr in FETCH_SIZE WRITE_SIZE; do
+            timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/pmc_$tag$ctr -o x -- python3 $ROOT/tools/r2_iter.py $shape 20 > $OUT/r2p_${tag}_$ctr.log 2>&1
+            DB=$(find $OUT/pmc_$tag$ctr -name '*.db' | head -1); [ -n "$DB" ] && python3 $ROOT/tools/pmc_dump.py "$DB" rank2_persist > $OUT/pmc_r2p_${tag}_$ctr.txt; rm -rf $OUT/pmc_$tag$ctr
+        done
+        { echo "== resident RANK2 kernel, $shape (nodes, degree), 20 iterations per launch"; cat $OUT/pmc_r2p_${tag}_FETCH_SIZE.txt $OUT/pmc_r2p_${tag}_WRITE_SIZE.txt; grep "iterations" $OUT/r2p_${tag}_FETCH_SIZE.log | tail -2; } >> $OUT/r2p_counters.txt 2>&1
+    done
+    ;;
 esac

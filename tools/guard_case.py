@@ -3,7 +3,7 @@ ill : A = W* H* + noise with nearly collinear columns of W* (cond(W'W) ~ 1e5): t
 well: uniform noise: the guard looks and leaves the fast form alone
 Prints one JSON line: product form at the end, guard counters, errors against the oracle."""
 import json, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle, smallk_amd as gpu
 

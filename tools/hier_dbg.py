@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np, oracle, smallk_amd
 from oracle import hierclust as oh
 from hier_cases import planted

@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np, torch, smallk_amd, oracle, resource
 from hier_cases import planted
 smallk_amd.initialize(0)

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, smallk_amd
 smallk_amd.initialize(0)
 for (m, n, k, alg, st) in ((8192, 4096, 16, "BPP", "f32"), (65536, 16384, 32, "HALS", "bf16"), (2048, 1024, 8, "MU", "f32"), (512, 256, 8, "HALS", "f32")):

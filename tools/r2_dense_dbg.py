@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests/golden")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests/golden")
 import numpy as np, oracle, smallk_amd as gpu
 import make_golden as mg
 gpu.initialize(0)

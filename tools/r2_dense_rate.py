@@ -1,7 +1,7 @@
 """Streaming rate of the accurate rank-2 product (bigprod_f64_k2_kernel) inside dense RANK2 iterations:
    python3 tools/r2_dense_rate.py [m] [n] [storage] [iters]     (default 65536 x 16384 bf16 = the C3 matrix)"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import smallk_amd
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384

@@ -1,6 +1,6 @@
 """RANK2 iterations on a C5-shaped sparse matrix (for rocprofv3 kernel tables): python tools/r2_iter.py [nodes] [deg] [iters]"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp
 import smallk_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000

@@ -2,7 +2,7 @@
 iteration counts, factors to rounding; then time per iteration of both on C5-node-shaped matrices.
   python3 tools/r2_persist_check.py [quick]"""
 import os, subprocess, sys, time, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp
 
 def graph(n, deg, seed, rect=None):

@@ -2,7 +2,7 @@
 an N-way split on one GPU, the all-reduce callback a no-op (numerically meaningless, timing only).
 Gives the compute part of the strong-scaling curve; add the RCCL all-reduce time of 8 MB + 8 KB."""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, smallk_amd
 from smallk_amd import dist as sdist
 smallk_amd.initialize(0)

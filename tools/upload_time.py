@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, smallk_amd
 smallk_amd.initialize(0)
 for (m, n) in ((8192, 4096), (65536, 4096), (65536, 16384)):
