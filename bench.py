@@ -679,6 +679,10 @@ def run_single_process(args):
     start_rank_watchdog(args.stall_s)
     beat("imports", limit=300.0)
     import numpy as np
+    try:                                   # torch first, as in the one-process-per-GPU path: the process then runs on the same HIP
+        import torch  # noqa: F401         # runtime and the same librccl.so (torch's bundled ones) in both plans
+    except Exception:
+        pass
     import smallk_amd
     from smallk_amd import _lib as L
     from smallk_amd import dist as sdist

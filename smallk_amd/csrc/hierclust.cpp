@@ -70,8 +70,8 @@ void tree_init(smk_tree& t, unsigned node_count, i64 m, i64 n)      // Init :120
 {
     t.doc_count = n;
     t.term_count = m;
-    t.nodes.assign(node_count, Node());
-    for (Node& nd : t.nodes) nd.topic.assign((size_t)m, 0.0);
+    t.nodes.assign(node_count, Node());         // topic vectors are created when a node is opened (tree_partition): a node the search
+                                                // never reaches keeps an empty one, read as zeros (smk_tree_node_topic)
     t.is_leaf.assign(node_count, 0);
     t.active = 0;
 }
@@ -105,8 +105,8 @@ void tree_partition(smk_tree& t, const std::vector<unsigned>* source, const doub
         const unsigned doc = source ? (*source)[(size_t)c] : (unsigned)c;
         t.nodes[H[2 * c] > H[2 * c + 1] ? t.index0 : t.index1].docs.push_back(doc);
     }
-    std::copy(W, W + m, t.nodes[t.index0].topic.begin());
-    std::copy(W + m, W + 2 * m, t.nodes[t.index1].topic.begin());
+    t.nodes[t.index0].topic.assign(W, W + m);
+    t.nodes[t.index1].topic.assign(W + m, W + 2 * m);
 }
 
 void tree_split_root(smk_tree& t, const double* W, i64 m, const double* H, i64 w)
@@ -131,18 +131,35 @@ void tree_split(smk_tree& t, unsigned node, const double* W, i64 m, const double
 void tree_top_terms(smk_tree& t, int maxterms)     // ComputeTopTerms :282-299 + TopTerms, terms.hpp:25-58
 {
     t.maxterms = maxterms;
-    std::vector<int> order((size_t)t.term_count);
-    for (Node& nd : t.nodes) {
-        if (!nd.valid) continue;
-        std::iota(order.begin(), order.end(), 0);
+    // only the first `cnt` positions of the (value desc, index asc) order are needed: ONE pass over the topic vector with the
+    // current top `cnt` in a small sorted buffer (a term enters only if it beats the buffer's last entry; ties keep the lower
+    // index, which the scan order gives for free).  The full-length index array + partial_sort of rounds 1-3 cost ~8 ms per node
+    // at a million terms; the nodes are independent and go to a few host threads.
+    const i64 mterms = t.term_count;
+    auto one = [&](Node& nd) {
         const double* d = nd.topic.data();
         nd.terms.assign((size_t)maxterms, 0);
-        const size_t cnt = std::min<size_t>((size_t)maxterms, order.size());
-        // only the first `cnt` positions of the (value desc, index asc) order are needed
-        std::partial_sort(order.begin(), order.begin() + (std::ptrdiff_t)cnt, order.end(),
-                          [d](int a, int b) { return d[a] > d[b] || (d[a] == d[b] && a < b); });
-        std::copy(order.begin(), order.begin() + cnt, nd.terms.begin());
-    }
+        const size_t cnt = std::min<size_t>((size_t)maxterms, (size_t)mterms);
+        std::vector<int> top;
+        top.reserve(cnt + 1);
+        for (i64 i = 0; i < mterms; ++i) {
+            if (top.size() == cnt && !(d[i] > d[top.back()])) continue;
+            size_t pos = top.size();
+            while (pos > 0 && d[i] > d[top[pos - 1]]) --pos;          // equal values stay in front (lower index first)
+            top.insert(top.begin() + (std::ptrdiff_t)pos, (int)i);
+            if (top.size() > cnt) top.pop_back();
+        }
+        std::copy(top.begin(), top.end(), nd.terms.begin());
+    };
+    std::vector<Node*> todo;
+    for (Node& nd : t.nodes)
+        if (nd.valid && (i64)nd.topic.size() == mterms) todo.push_back(&nd);
+    if (mterms < 65536 || todo.size() < 2) { for (Node* nd : todo) one(*nd); return; }
+    const unsigned nth = (unsigned)std::min<size_t>(4, todo.size());
+    std::vector<std::thread> th;
+    for (unsigned w = 0; w < nth; ++w)
+        th.emplace_back([&, w] { for (size_t q = w; q < todo.size(); q += nth) one(*todo[q]); });
+    for (std::thread& x : th) x.join();
 }
 
 void tree_assignments(smk_tree& t)                 // ComputeAssignments :302-338
@@ -297,6 +314,7 @@ struct Stopwatch {       // SMK_CLUST_TIMING=1: where the wall time of a run goe
 
 struct Run {
     double t_subset = 0, t_factor = 0, t_priority = 0, t_init = 0;
+    double t_free = 0, t_tree = 0, t_scatter = 0, t_terms = 0, t_alloc = 0;      // inside "host bookkeeping": device frees, tree edits, scatter of W, top terms
     long iterations = 0;
     const smk_clust_options* o = nullptr;
     smk_matrix* full = nullptr;
@@ -393,8 +411,7 @@ int actual_split(Run& r, const std::vector<unsigned>& subset, const double* w_pa
                  std::vector<double>& H, std::vector<unsigned>& labels, double* priority)
 {
     const i64 m = r.m;
-    W.assign((size_t)m * 2, 0.0);
-    H.assign(subset.size() * 2, 0.0);
+    { Stopwatch sw(&r.t_alloc); W.assign((size_t)m * 2, 0.0); H.assign(subset.size() * 2, 0.0); }
     if (subset.size() <= 3) {
         labels.assign(subset.size(), 1u);
         *priority = -1.0;
@@ -411,9 +428,11 @@ int actual_split(Run& r, const std::vector<unsigned>& subset, const double* w_pa
     if (rc != SMK_OK) return rc;
     std::vector<double> Ws, Hs;
     rc = factor_node(r, sub, nh, (i64)subset.size(), r.new_to_old.data(), subset.data(), Ws, Hs, "Node");
-    smk_matrix_destroy(sub);
+    { Stopwatch sw(&r.t_free); smk_matrix_destroy(sub); }
     if (rc != SMK_OK) return rc;
     bool has0 = false, has1 = false;
+    {
+    Stopwatch sw_sc(&r.t_scatter);
     labels.clear();
     for (size_t c = 0; c < subset.size(); ++c) {
         if (Hs[2 * c] > Hs[2 * c + 1]) { labels.push_back(0u); has0 = true; }
@@ -424,6 +443,7 @@ int actual_split(Run& r, const std::vector<unsigned>& subset, const double* w_pa
         W[(size_t)(m + r.new_to_old[(size_t)i])] = Ws[(size_t)(nh + i)];
     }
     H = Hs;
+    }
     Stopwatch sw(&r.t_priority);
     *priority = (has0 && has1) ? priority_score(w_parent, W.data(), m) : -1.0;
     return SMK_OK;
@@ -616,14 +636,16 @@ int clust_hier(Run& r, smk_tree& tree)
                 printf("\nHierNMF2: no further factorization possible.\n\n");
                 break;
             }
+            Stopwatch sw(&r.t_tree);
             tree_split(tree, split_index, Wbuf[split_index].data(), m, Hbuf[split_index].data(),
                        (i64)(Hbuf[split_index].size() / 2));
             std::vector<double>().swap(Wbuf[split_index]);
             std::vector<double>().swap(Hbuf[split_index]);
         }
         const unsigned idx[2] = {tree.index0, tree.index1};
-        // the parent's topic vector may not alias a buffer that trial_split resizes
-        const std::vector<double> w_parent0(tree.nodes[idx[0]].topic), w_parent1(tree.nodes[idx[1]].topic);
+        // a child's own topic vector is the "parent" vector of its trial split; trial_split writes Wbuf / Hbuf / docs, never a
+        // topic vector, and tree.nodes is not resized during the search: references, not copies (2 x 8 MB per step at 1 M terms)
+        const std::vector<double>&w_parent0 = tree.nodes[idx[0]].topic, &w_parent1 = tree.nodes[idx[1]].topic;
         SplitTask spec;
         std::vector<unsigned> docs1_backup;
         bool speculated = false;
@@ -659,8 +681,11 @@ int clust_hier(Run& r, smk_tree& tree)
         }
         if (o.verbose) { printf("[%u] ", i + 1); fflush(stdout); }
     }
-    tree_top_terms(tree, o.maxterms);
-    tree_assignments(tree);
+    {
+        Stopwatch sw(&r.t_terms);
+        tree_top_terms(tree, o.maxterms);
+        tree_assignments(tree);
+    }
     printf("\n");
     return SMK_OK;
 }
@@ -733,15 +758,19 @@ int run_clust(const smk_clust_options* opts, smk_matrix* full, uint64_t seed, ui
     r.seed = seed; r.draws = draws ? *draws : 0;
     if (initdir) r.initdir = initdir;
     smk_tree* t = new smk_tree;
-    int rc = clust_hier(r, *t);
-    if (rc == SMK_OK && opts->flat) rc = clust_flat(r, *t);
+    double t_search = 0.0, t_flat = 0.0;
+    int rc;
+    { Stopwatch sw(&t_search); rc = clust_hier(r, *t); }
+    if (rc == SMK_OK && opts->flat) { Stopwatch sw(&t_flat); rc = clust_flat(r, *t); }
     if (draws) *draws = r.draws;
     if (stats) *stats = r.stats;
     smk::device_priority_release();        // workspace of the device-side priority score (kept between the calls of a run)
     if (const char* e = getenv("SMK_CLUST_TIMING"))
         if (atoi(e))
-            fprintf(stderr, "[smk_clust] subset %.3fs  factor %.3fs (%ld RANK2 iterations)  priority %.3fs  init %.3fs\n",
-                    r.t_subset, r.t_factor, r.iterations, r.t_priority, r.t_init);
+            fprintf(stderr, "[smk_clust] subset %.3fs  factor %.3fs (%ld RANK2 iterations)  priority %.3fs  init %.3fs  |  tree search %.3fs in all "
+                    "(host bookkeeping %.3fs: device frees %.3f, tree edits %.3f, labels + scatter of W %.3f, top terms + assignments %.3f, zero-filled W buffers %.3f)  flat step %.3fs\n",
+                    r.t_subset, r.t_factor, r.iterations, r.t_priority, r.t_init, t_search,
+                    t_search - r.t_subset - r.t_factor - r.t_priority - r.t_init, r.t_free, r.t_tree, r.t_scatter, r.t_terms, r.t_alloc, t_flat);
     // a failed flat step still returns the tree (RunClust, clust.cpp:53-61: the caller writes it)
     if (rc != SMK_OK && rc != SMK_FLATCLUST_FAILURE) { delete t; return rc; }
     *tree_out = t;
@@ -811,8 +840,14 @@ int smk_clust_sparse(const smk_clust_options* opts, int64_t nnz, const unsigned*
     int rc = precheck(opts, tree);
     if (rc != SMK_OK) return rc;
     smk_matrix* a = nullptr;
-    rc = smk_matrix_create_sparse(&a, opts->nmf.height, opts->nmf.width, 0, opts->nmf.width, nnz, col_offsets,
-                                  row_indices, data);
+    double t_create = 0.0;
+    {
+        Stopwatch sw(&t_create);
+        rc = smk_matrix_create_sparse(&a, opts->nmf.height, opts->nmf.width, 0, opts->nmf.width, nnz, col_offsets,
+                                      row_indices, data);
+    }
+    if (const char* e = getenv("SMK_CLUST_TIMING"))
+        if (atoi(e)) fprintf(stderr, "[smk_clust] matrix to the device (CSC upload + transpose): %.3fs\n", t_create);
     if (rc == SMK_OK) rc = run_clust(opts, a, seed, draws, initdir, tree, stats);
     smk_matrix_destroy(a);
     return rc;
@@ -854,7 +889,9 @@ int smk_tree_node_docs(const smk_tree* t, int q, unsigned* out)
 int smk_tree_node_topic(const smk_tree* t, int q, double* out)
 {
     if (!t || !out || q < 0 || q >= (int)t->nodes.size()) return SMK_BAD_PARAM;
-    std::copy(t->nodes[(size_t)q].topic.begin(), t->nodes[(size_t)q].topic.end(), out);
+    const std::vector<double>& tv = t->nodes[(size_t)q].topic;
+    if (tv.empty()) std::fill(out, out + t->term_count, 0.0);             // a node the search never opened
+    else std::copy(tv.begin(), tv.end(), out);
     return SMK_OK;
 }
 
