@@ -315,7 +315,8 @@ struct Stopwatch {       // SMK_CLUST_TIMING=1: where the wall time of a run goe
 struct Run {
     double t_subset = 0, t_factor = 0, t_priority = 0, t_init = 0;
     double t_free = 0, t_tree = 0, t_scatter = 0, t_terms = 0, t_alloc = 0;      // inside "host bookkeeping": device frees, tree edits, scatter of W, top terms
-    long iterations = 0;
+    long iterations = 0, lanes_tried = 0, lanes_accepted = 0;        // speculative steps on devices 3 .. 8 (clust_hier)
+    double t_round_max = 0, t_tasks = 0;    // sum over rounds of the longest trial split / sum of the trial splits kept: the multi-device projection
     const smk_clust_options* o = nullptr;
     smk_matrix* full = nullptr;
     i64 m = 0, n = 0;
@@ -451,9 +452,10 @@ int actual_split(Run& r, const std::vector<unsigned>& subset, const double* w_pa
 
 // TrialSplit, clust_hier_generic.hpp:203-327.  `subset` is the node's document list and is edited
 // in place when outliers are dropped.
-int trial_split(Run& r, std::vector<unsigned>& subset, double min_priority, const std::vector<double>& w_parent,
-                std::vector<double>& W, std::vector<double>& H, double* priority_out)
+int trial_split(Run& r, std::vector<unsigned>& subset, double min_priority, const double* w_parent,
+                std::vector<double>& W, std::vector<double>& H, double* priority_out, bool* used_min_priority = nullptr)
 {
+    if (used_min_priority) *used_min_priority = false;
     const smk_clust_options& o = *r.o;
     const std::vector<unsigned> backup(subset);
     std::vector<unsigned> small, labels, labels_small;
@@ -461,7 +463,7 @@ int trial_split(Run& r, std::vector<unsigned>& subset, double min_priority, cons
     int trial = 0;
     double pr = -2.0;
     while (trial < o.trial_allowance) {
-        int rc = actual_split(r, subset, w_parent.data(), W, H, labels, &pr);
+        int rc = actual_split(r, subset, w_parent, W, H, labels, &pr);
         if (rc != SMK_OK) return rc;
         if (pr < 0.0) break;
         int counts[2] = {0, 0};
@@ -475,6 +477,7 @@ int trial_split(Run& r, std::vector<unsigned>& subset, double min_priority, cons
         double pr_small = 0.0;
         rc = actual_split(r, small, W.data() + (size_t)lab * r.m, Wtmp, Htmp, labels_small, &pr_small);
         if (rc != SMK_OK) return rc;
+        if (used_min_priority) *used_min_priority = true;       // the only place the outcome depends on the other leaves' priorities
         if (!(pr_small < min_priority)) break;
         trial += 1;
         if (trial < o.trial_allowance) {
@@ -499,12 +502,24 @@ int trial_split(Run& r, std::vector<unsigned>& subset, double min_priority, cons
 // first child's; the worker assumes the first child takes its nominal share (one factorisation, or none for a node of
 // <= 3 documents) and the step is repeated for the second child on the main device if that turns out wrong (a retry or
 // an outlier trial consumed more) -- so the tree is the one-device tree, draw for draw.
+// MEASUREMENT HOOK (SMK_CLUST_SERIALIZE=1, contexts sharing one GPU): the trial splits of a round run one after the other, so
+// each one's wall time is what it would be on a device of its own and "sum over rounds of the longest" projects the run on
+// SMK_CLUST_DEVICES real devices.  The results are the same either way.
+std::mutex g_serialize_mu;
+inline bool serialize_trials()
+{
+    static const bool on = [] { const char* e = getenv("SMK_CLUST_SERIALIZE"); return e && atoi(e) != 0; }();
+    return on;
+}
+
 struct SplitTask {
     std::vector<unsigned>* docs = nullptr;
     double min_priority = 0.0;
-    const std::vector<double>* w_parent = nullptr;
+    const double* w_parent = nullptr;
     std::vector<double>*W = nullptr, *H = nullptr;
     double priority = 0.0;
+    bool used_min_priority = false;
+    double seconds = 0.0;                 // wall time of this trial split (projection of the multi-device critical path)
     uint64_t draws0 = 0, draws1 = 0;
     int counter0 = 0, counter1 = 0;
     int rc = SMK_OK;
@@ -544,7 +559,13 @@ struct Worker {
             run.init_counter = t->counter0;
             run.stats = smk_clust_stats{0, 0};              // per task: only an ACCEPTED speculation counts in the run's totals
             run.iterations = 0;
-            t->rc = (setup_rc == SMK_OK) ? trial_split(run, *t->docs, t->min_priority, *t->w_parent, *t->W, *t->H, &t->priority) : setup_rc;
+            {
+                std::unique_lock<std::mutex> one;
+                if (serialize_trials()) one = std::unique_lock<std::mutex>(g_serialize_mu);
+                Stopwatch sw(&t->seconds);
+                t->rc = (setup_rc == SMK_OK) ? trial_split(run, *t->docs, t->min_priority, t->w_parent, *t->W, *t->H, &t->priority, &t->used_min_priority)
+                                             : setup_rc;
+            }
             if (t->rc != SMK_OK) t->err = smk_last_error();
             t->draws1 = run.draws;
             t->counter1 = run.init_counter;
@@ -575,27 +596,33 @@ struct Worker {
     }
 };
 
-// a second worker for this run, or nullptr (one device, or it could not be set up)
-Worker* start_worker(const Run& r)
+// the workers of this run: SMK_CLUST_DEVICES - 1 of them (none: one device, or they could not be set up), worker j on device
+// cur + 1 + j (all on the current device with SMK_SHARDS_ON_ONE_GPU=1: tests)
+std::vector<Worker*> start_workers(const Run& r)
 {
+    std::vector<Worker*> out;
     const char* e = getenv("SMK_CLUST_DEVICES");
-    if (!e || atoi(e) < 2) return nullptr;
+    if (!e || atoi(e) < 2) return out;
+    const int want = std::min(atoi(e), 8);
     const int cur = smk_current_device(), ndev = smk_device_count();
-    if (cur < 0 || ndev < 1) return nullptr;
+    if (cur < 0 || ndev < 1) return out;
     const char* one = getenv("SMK_SHARDS_ON_ONE_GPU");
     const bool same = one && atoi(one) != 0;
-    if (!same && ndev < 2) return nullptr;
-    Worker* w = new Worker;
-    w->device = same ? cur : (cur + 1) % ndev;
-    w->src = r.full;
-    w->run.o = r.o; w->run.m = r.m; w->run.n = r.n; w->run.seed = r.seed; w->run.initdir = r.initdir;
-    w->th = std::thread([w] { w->body(); });
-    {
-        std::unique_lock<std::mutex> lk(w->mu);
-        w->cv.wait(lk, [&] { return w->ready; });
+    const int devices = same ? want : std::min(want, ndev);
+    for (int j = 0; j + 1 < devices; ++j) {
+        Worker* w = new Worker;
+        w->device = same ? cur : (cur + 1 + j) % ndev;
+        w->src = r.full;
+        w->run.o = r.o; w->run.m = r.m; w->run.n = r.n; w->run.seed = r.seed; w->run.initdir = r.initdir;
+        w->th = std::thread([w] { w->body(); });
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->ready; });
+        }
+        if (w->setup_rc != SMK_OK) { w->stop(); delete w; break; }
+        out.push_back(w);
     }
-    if (w->setup_rc != SMK_OK) { w->stop(); delete w; return nullptr; }
-    return w;
+    return out;
 }
 
 // ClustHier, clust_hier_generic.hpp:67-196
@@ -612,21 +639,46 @@ int clust_hier(Run& r, smk_tree& tree)
     if (rc != SMK_OK) return rc;
 
     struct WorkerGuard {
-        Worker* w;
+        std::vector<Worker*> ws;
         Run& r;
         ~WorkerGuard()
         {
-            if (!w) return;
-            w->stop();
-            r.t_subset += w->run.t_subset; r.t_factor += w->run.t_factor; r.t_priority += w->run.t_priority; r.t_init += w->run.t_init;
-            delete w;
+            for (Worker* w : ws) {
+                w->stop();
+                r.t_subset += w->run.t_subset; r.t_factor += w->run.t_factor; r.t_priority += w->run.t_priority; r.t_init += w->run.t_init;
+                delete w;
+            }
         }
-    } guard{start_worker(r), r};
-    Worker* worker = guard.w;
+    } guard{start_workers(r), r};
+    const std::vector<Worker*>& workers = guard.ws;
+    Worker* worker = workers.empty() ? nullptr : workers[0];
     std::vector<std::vector<double>> Wbuf(node_count), Hbuf(node_count);
     double min_priority = 0.0, max_priority = 0.0;
     unsigned split_index = 0;
-    for (unsigned i = 0; i + 1 < num_clusters; ++i) {
+
+    // ---- more than two devices: speculative steps (round 4) ----------------------------------------------------------------
+    // The reference's loop is sequential: split the leaf of highest priority, trial-split its two children, repeat.  Two devices
+    // take the two children of a step.  Further devices work AHEAD: while the children of step i are being factored, lane d
+    // (d = 1, 2, 3: devices 2d and 2d + 1) factors the children that step i + d will create IF it splits the d-th best of the
+    // leaves that exist now -- which it does unless a child created in between comes out with a higher priority.  A lane is
+    // accepted only if everything it assumed turns out true, in the reference's own order: the leaf it split is the arg-max when
+    // its step comes; the initialiser draws it used are the ones the sequential run would have handed it (every earlier trial
+    // took its nominal share); and the smallest positive leaf priority it was given -- which matters only inside an outlier
+    // trial -- is the one the sequential run would have passed, or was never consulted.  A lane that fails any test is dropped
+    // with all later lanes and the loop goes on from there, so the tree is the one-device tree draw for draw and bit for bit.
+    struct Lane {
+        unsigned node = 0;
+        std::vector<unsigned> docs[2];
+        std::vector<double> W[2], H[2];
+        SplitTask task[2];
+    };
+    const size_t max_lanes = workers.size() >= 3 ? (workers.size() - 1) / 2 : 0;
+    auto nominal = [&](size_t ndocs, uint64_t& draws, int& counter) {      // what one trial split takes when nothing is retried
+        if (ndocs > 3) { if (r.initdir.empty()) draws += 2; else counter += 1; }
+    };
+
+    unsigned i = 0;
+    while (i + 1 < num_clusters) {
         if (i == 0) {
             min_priority = INFINITY;
             tree_split_root(tree, W0.data(), m, H0.data(), n);
@@ -644,26 +696,75 @@ int clust_hier(Run& r, smk_tree& tree)
         }
         const unsigned idx[2] = {tree.index0, tree.index1};
         // a child's own topic vector is the "parent" vector of its trial split; trial_split writes Wbuf / Hbuf / docs, never a
-        // topic vector, and tree.nodes is not resized during the search: references, not copies (2 x 8 MB per step at 1 M terms)
-        const std::vector<double>&w_parent0 = tree.nodes[idx[0]].topic, &w_parent1 = tree.nodes[idx[1]].topic;
+        // topic vector, and tree.nodes is not resized during the search: pointers, not copies (2 x 8 MB per step at 1 M terms)
+        const double *w_parent0 = tree.nodes[idx[0]].topic.data(), *w_parent1 = tree.nodes[idx[1]].topic.data();
+        uint64_t cursor_draws = r.draws;
+        int cursor_counter = r.init_counter;
+        nominal(tree.nodes[idx[0]].docs.size(), cursor_draws, cursor_counter);
         SplitTask spec;
         std::vector<unsigned> docs1_backup;
         bool speculated = false;
         if (worker) {
             // second child on the other device, assuming the first one takes its nominal share of the initialisers
-            const bool first_factors = tree.nodes[idx[0]].docs.size() > 3;
             docs1_backup = tree.nodes[idx[1]].docs;
-            spec.docs = &tree.nodes[idx[1]].docs; spec.min_priority = min_priority; spec.w_parent = &w_parent1;
+            spec.docs = &tree.nodes[idx[1]].docs; spec.min_priority = min_priority; spec.w_parent = w_parent1;
             spec.W = &Wbuf[idx[1]]; spec.H = &Hbuf[idx[1]];
-            spec.draws0 = r.draws + (first_factors && r.initdir.empty() ? 2 : 0);
-            spec.counter0 = r.init_counter + (first_factors && !r.initdir.empty() ? 1 : 0);
+            spec.draws0 = cursor_draws;
+            spec.counter0 = cursor_counter;
             worker->submit(&spec);
             speculated = true;
         }
-        double pr0 = 0.0;
-        rc = trial_split(r, tree.nodes[idx[0]].docs, min_priority, w_parent0, Wbuf[idx[0]], Hbuf[idx[0]], &pr0);
+        nominal(tree.nodes[idx[1]].docs.size(), cursor_draws, cursor_counter);
+
+        // lanes: the steps after this one, on the leaves that exist now, best first
+        std::vector<Lane> lanes;
+        if (max_lanes > 0 && i > 0) {
+            std::vector<unsigned> cand;
+            for (unsigned q = 0; q < tree.is_leaf.size(); ++q)
+                if (tree.is_leaf[q] && q != idx[0] && q != idx[1] && !(tree.nodes[q].priority < 0.0)) cand.push_back(q);
+            std::stable_sort(cand.begin(), cand.end(), [&](unsigned a, unsigned b) { return tree.nodes[a].priority > tree.nodes[b].priority; });
+            const size_t steps_left = (size_t)(num_clusters - 1) - (size_t)(i + 1);
+            const size_t nl = std::min(std::min(max_lanes, cand.size()), steps_left);
+            lanes.resize(nl);
+            for (size_t d = 0; d < nl; ++d) {
+                Lane& ln = lanes[d];
+                ln.node = cand[d];
+                const std::vector<unsigned>& src = tree.nodes[ln.node].docs;
+                const std::vector<double>& Hn = Hbuf[ln.node];
+                for (size_t c = 0; c < src.size(); ++c) ln.docs[Hn[2 * c] > Hn[2 * c + 1] ? 0 : 1].push_back(src[c]);      // tree_partition's rule
+                // the smallest positive priority among the leaves the sequential run would see when this lane's step starts,
+                // as far as it is known now: the old leaves that have not been split by then (this lane's own leaf included)
+                double mn = std::numeric_limits<double>::max();
+                for (size_t c2 = d; c2 < cand.size(); ++c2) { const double p = tree.nodes[cand[c2]].priority; if (p > 0.0 && p < mn) mn = p; }
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    SplitTask& t = ln.task[sidx];
+                    t.docs = &ln.docs[sidx]; t.min_priority = mn; t.w_parent = Wbuf[ln.node].data() + (size_t)sidx * m;
+                    t.W = &ln.W[sidx]; t.H = &ln.H[sidx];
+                    t.draws0 = cursor_draws; t.counter0 = cursor_counter;
+                    nominal(ln.docs[sidx].size(), cursor_draws, cursor_counter);
+                    workers[1 + 2 * d + (size_t)sidx]->submit(&t);
+                }
+            }
+        }
+
+        double pr0 = 0.0, sec0 = 0.0;
+        {
+            std::unique_lock<std::mutex> one;
+            if (serialize_trials()) one = std::unique_lock<std::mutex>(g_serialize_mu);
+            Stopwatch sw(&sec0);
+            rc = trial_split(r, tree.nodes[idx[0]].docs, min_priority, w_parent0, Wbuf[idx[0]], Hbuf[idx[0]], &pr0);
+        }
         if (speculated) worker->wait();
+        for (size_t d = 0; d < lanes.size(); ++d) { workers[1 + 2 * d]->wait(); workers[2 + 2 * d]->wait(); }
         if (rc != SMK_OK) return rc;
+        {
+            // what this round costs when every task has a device of its own (the trial splits are measured one by one, whether
+            // they overlapped here or not), against the work of the tasks that end up in the tree
+            double longest = std::max(sec0, speculated ? spec.seconds : 0.0);
+            for (const Lane& ln : lanes) longest = std::max(longest, std::max(ln.task[0].seconds, ln.task[1].seconds));
+            r.t_round_max += longest;
+            r.t_tasks += sec0;
+        }
         tree.nodes[idx[0]].priority = pr0;
         if (speculated && spec.draws0 == r.draws && spec.counter0 == r.init_counter) {
             if (spec.rc != SMK_OK) { set_error(spec.err); return spec.rc; }
@@ -672,14 +773,56 @@ int clust_hier(Run& r, smk_tree& tree)
             r.init_counter = spec.counter1;
             r.stats.nmf_count += spec.stats.nmf_count; r.stats.max_count += spec.stats.max_count;
             r.iterations += spec.iterations;
+            r.t_tasks += spec.seconds;
         } else {
             if (speculated) tree.nodes[idx[1]].docs = docs1_backup;      // the first child took more initialisers: this one again, in order
-            double pr1 = 0.0;
-            rc = trial_split(r, tree.nodes[idx[1]].docs, min_priority, w_parent1, Wbuf[idx[1]], Hbuf[idx[1]], &pr1);
+            double pr1 = 0.0, sec1 = 0.0;
+            { Stopwatch sw(&sec1); rc = trial_split(r, tree.nodes[idx[1]].docs, min_priority, w_parent1, Wbuf[idx[1]], Hbuf[idx[1]], &pr1); }
+            r.t_round_max += sec1;
+            r.t_tasks += sec1;
             if (rc != SMK_OK) return rc;
             tree.nodes[idx[1]].priority = pr1;
         }
         if (o.verbose) { printf("[%u] ", i + 1); fflush(stdout); }
+        i += 1;
+
+        // ---- accept the lanes whose assumptions held, in order ----
+        for (size_t d = 0; d < lanes.size() && i + 1 < num_clusters; ++d) {
+            Lane& ln = lanes[d];
+            double mn = 0.0, mx = 0.0;
+            unsigned arg = 0;
+            tree_min_max(tree, mn, mx, arg);
+            if (mx < 0.0 || arg != ln.node) break;                                  // a newer child ranks higher (or the search is over)
+            SplitTask &t0 = ln.task[0], &t1 = ln.task[1];
+            if (t0.draws0 != r.draws || t0.counter0 != r.init_counter) break;     // an earlier trial took more initialisers than its share
+            if (t1.draws0 != t0.draws1 || t1.counter0 != t0.counter1) break;
+            if ((t0.used_min_priority && t0.min_priority != mn) || (t1.used_min_priority && t1.min_priority != mn)) break;
+            if (t0.rc != SMK_OK) { set_error(t0.err); return t0.rc; }               // what the sequential run would have hit, in its order
+            if (t1.rc != SMK_OK) { set_error(t1.err); return t1.rc; }
+            {
+                Stopwatch sw(&r.t_tree);
+                tree_split(tree, ln.node, Wbuf[ln.node].data(), m, Hbuf[ln.node].data(), (i64)(Hbuf[ln.node].size() / 2));
+                std::vector<double>().swap(Wbuf[ln.node]);
+                std::vector<double>().swap(Hbuf[ln.node]);
+            }
+            const unsigned cidx[2] = {tree.index0, tree.index1};
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                SplitTask& t = ln.task[sidx];
+                tree.nodes[cidx[sidx]].docs.swap(ln.docs[sidx]);                    // as trial_split left them (outliers dropped)
+                Wbuf[cidx[sidx]].swap(ln.W[sidx]);
+                Hbuf[cidx[sidx]].swap(ln.H[sidx]);
+                tree.nodes[cidx[sidx]].priority = t.priority;
+                r.stats.nmf_count += t.stats.nmf_count; r.stats.max_count += t.stats.max_count;
+                r.iterations += t.iterations;
+                r.t_tasks += t.seconds;
+            }
+            r.draws = t1.draws1;
+            r.init_counter = t1.counter1;
+            r.lanes_accepted += 1;
+            if (o.verbose) { printf("[%u] ", i + 1); fflush(stdout); }
+            i += 1;
+        }
+        r.lanes_tried += (long)lanes.size();
     }
     {
         Stopwatch sw(&r.t_terms);
@@ -768,9 +911,10 @@ int run_clust(const smk_clust_options* opts, smk_matrix* full, uint64_t seed, ui
     if (const char* e = getenv("SMK_CLUST_TIMING"))
         if (atoi(e))
             fprintf(stderr, "[smk_clust] subset %.3fs  factor %.3fs (%ld RANK2 iterations)  priority %.3fs  init %.3fs  |  tree search %.3fs in all "
-                    "(host bookkeeping %.3fs: device frees %.3f, tree edits %.3f, labels + scatter of W %.3f, top terms + assignments %.3f, zero-filled W buffers %.3f)  flat step %.3fs\n",
+                    "(host bookkeeping %.3fs: device frees %.3f, tree edits %.3f, labels + scatter of W %.3f, top terms + assignments %.3f, zero-filled W buffers %.3f)  flat step %.3fs  speculative steps accepted %ld of %ld; trial splits kept %.3fs, sum over rounds of the longest one %.3fs (= their time on "
+                    "SMK_CLUST_DEVICES real devices)\n",
                     r.t_subset, r.t_factor, r.iterations, r.t_priority, r.t_init, t_search,
-                    t_search - r.t_subset - r.t_factor - r.t_priority - r.t_init, r.t_free, r.t_tree, r.t_scatter, r.t_terms, r.t_alloc, t_flat);
+                    t_search - r.t_subset - r.t_factor - r.t_priority - r.t_init, r.t_free, r.t_tree, r.t_scatter, r.t_terms, r.t_alloc, t_flat, r.lanes_accepted, r.lanes_tried, r.t_tasks, r.t_round_max);
     // a failed flat step still returns the tree (RunClust, clust.cpp:53-61: the caller writes it)
     if (rc != SMK_OK && rc != SMK_FLATCLUST_FAILURE) { delete t; return rc; }
     *tree_out = t;

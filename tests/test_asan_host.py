@@ -114,7 +114,10 @@ def test_hierclust_two_device_step_gives_the_one_device_tree(built, data, init):
     if init == "initdir":
         common += ["--initdir", str(data) + "/"]
     outs = {}
-    for tag, extra in (("one", {}), ("two", {"SMK_CLUST_DEVICES": "2", "SMK_SHARDS_ON_ONE_GPU": "1"})):
+    runs = (("one", {}), ("two", {"SMK_CLUST_DEVICES": "2", "SMK_SHARDS_ON_ONE_GPU": "1"}),
+            ("four", {"SMK_CLUST_DEVICES": "4", "SMK_SHARDS_ON_ONE_GPU": "1"}),          # + one speculative step ahead (round 4)
+            ("eight", {"SMK_CLUST_DEVICES": "8", "SMK_SHARDS_ON_ONE_GPU": "1"}))         # + three
+    for tag, extra in runs:
         d = data / f"hier_{init}_{tag}"
         d.mkdir()
         r = subprocess.run(common + ["--assignfile", "asg.csv", "--treefile", "tree.json"], cwd=str(d), capture_output=True,
@@ -123,4 +126,4 @@ def test_hierclust_two_device_step_gives_the_one_device_tree(built, data, init):
         assert "AddressSanitizer" not in text and "runtime error:" not in text and "LeakSanitizer" not in text, text[-4000:]
         assert r.returncode == 0, text[-3000:]
         outs[tag] = ((d / "asg.csv").read_bytes(), (d / "tree.json").read_bytes())
-    assert outs["one"] == outs["two"]
+    assert outs["one"] == outs["two"] == outs["four"] == outs["eight"]

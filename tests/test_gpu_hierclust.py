@@ -330,17 +330,21 @@ def test_resident_matrix_is_reused(gpu):
     assert np.linalg.norm(W - ref.W) / np.linalg.norm(ref.W) < 1e-4
 
 
-@pytest.mark.parametrize("sparse,case", [(True, (300, 400, 6, 2, 0, 6)), (True, (150, 260, 3, 4, 5, 5)), (False, (120, 240, 3, 3, 4, 4))])
-def test_two_device_step_gives_the_one_device_tree(gpu, monkeypatch, sparse, case):
+@pytest.mark.parametrize("devices", [2, 4, 8])
+@pytest.mark.parametrize("sparse,case", [(True, (300, 400, 6, 2, 0, 6)), (True, (150, 260, 3, 4, 5, 5)), (False, (120, 240, 3, 3, 4, 4)),
+                                         (True, (400, 900, 12, 6, 0, 12)), (True, (350, 700, 9, 8, 6, 10))])
+def test_two_device_step_gives_the_one_device_tree(gpu, monkeypatch, sparse, case, devices):
     """SMK_CLUST_DEVICES=2 (the two TrialSplits of a step on two devices, clust_hier_generic.hpp:383-517 runs them one after
     the other): the second child is factored by a worker thread with a device context and a copy of A of its own -- on this
-    one-GPU box both contexts sit on device 0 (SMK_SHARDS_ON_ONE_GPU=1).  Same tree as the one-device run, node for node and
+    one-GPU box all contexts sit on device 0 (SMK_SHARDS_ON_ONE_GPU=1).  Same tree as the one-device run, node for node and
     bit for bit (it is the same arithmetic on the same initialiser draws), also when outlier trials make the speculation on
-    the first child's share of the draws fail (case with tiny clusters)."""
+    the first child's share of the draws fail (case with tiny clusters).  4 and 8 devices (round 4): the further devices
+    factor the children of the NEXT steps speculatively (the best remaining leaves); a speculative step is kept only if the
+    sequential search would have made the same split with the same draws, so the tree is still the one-device tree."""
     m, n, topics, seed, tiny, clusters = case
     A, _ = planted(m, n, topics, seed, sparse=sparse, tiny=tiny)
     one = gpu.hier_nmf2(A, clusters, seed=seed + 7)
-    monkeypatch.setenv("SMK_CLUST_DEVICES", "2")
+    monkeypatch.setenv("SMK_CLUST_DEVICES", str(devices))
     monkeypatch.setenv("SMK_SHARDS_ON_ONE_GPU", "1")
     two = gpu.hier_nmf2(A, clusters, seed=seed + 7)
     a, b = tree_arrays(one.nodes), tree_arrays(two.nodes)

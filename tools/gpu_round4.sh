@@ -103,4 +103,11 @@ k)  # FETCH_SIZE / WRITE_SIZE of the resident RANK2 kernel: a root-sized matrix 
         { echo "== resident RANK2 kernel, $shape (nodes, degree), 20 iterations per launch"; cat $OUT/pmc_r2p_${tag}_FETCH_SIZE.txt $OUT/pmc_r2p_${tag}_WRITE_SIZE.txt; grep "iterations" $OUT/r2p_${tag}_FETCH_SIZE.log | tail -2; } >> $OUT/r2p_counters.txt 2>&1
     done
     ;;
+l)  # HierNMF2 on 2 / 4 / 8 device contexts (all on this one GPU): identical trees (tests), accepted speculative steps and the projected critical path on the C5-shaped run
+    true
+    for d in 1 2 4 8; do
+        echo "== SMK_CLUST_DEVICES=$d (contexts on one GPU)" >> $OUT/c5_devices.txt
+        SMK_CLUST_DEVICES=$d SMK_SHARDS_ON_ONE_GPU=1 SMK_CLUST_SERIALIZE=1 SMK_CLUST_TIMING=1 timeout 900 python3 tools/c5_hier.py 2>&1 | grep "subset\|hier_nmf2:\|purity" >> $OUT/c5_devices.txt
+    done
+    ;;
 esac
