@@ -1223,11 +1223,10 @@ static int launch_f3p_t(const BigProdPlan& pl, const void* B, i64 ldb, const voi
         return -100;
     } else {
         constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
-        static bool attr_set = false;
+        static std::atomic<unsigned long long> attr_set{0};       // per device (first_use_on_this_device)
         auto kern = bigprod_f3p_kernel<KT, NSTAGE, NWL, FOLD, PIN, NS, FMT>;
-        if (!attr_set) {
+        if (first_use_on_this_device(attr_set)) {
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
         }
         int logS = 0;
         while ((1 << logS) < pl.S) ++logS;
@@ -1288,11 +1287,10 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
         return -100;
     } else {
         constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
-        static bool attr_set = false;
+        static std::atomic<unsigned long long> attr_set{0};       // per device (first_use_on_this_device)
         auto kern = bigprod_f3_kernel<KT, MB, NSTAGE, NWL, FOLD, WPS, NS, FMT>;
-        if (!attr_set) {
+        if (first_use_on_this_device(attr_set)) {
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
         }
         int logS = 0;
         while ((1 << logS) < pl.S) ++logS;
@@ -1760,11 +1758,10 @@ static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const
 {
     using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
     constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_set{0};       // per device (first_use_on_this_device)
     auto kern = bigprod_kernel<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
-    if (!attr_set) {
+    if (first_use_on_this_device(attr_set)) {
         SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
     }
     int logS = 0;
     while ((1 << logS) < pl.S) ++logS;

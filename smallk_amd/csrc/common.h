@@ -1,5 +1,6 @@
 // smallk_amd/csrc/common.h -- shared host-side declarations for the MI355X NMF library.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstddef>
@@ -33,6 +34,18 @@ inline bool is_wide(int k) { return k > 128; }
 bool nnls_uses_tiles(int k);
 // number of 32-wide k tiles of the streaming product
 inline int kt_of(int k) { return (k + 31) / 32; }
+// "do this once" for things that are per DEVICE (hipFuncSetAttribute applies to the function on the current device): one
+// process may drive several devices (smk_nmf_dense_sharded, bench.py --single-process, HierNMF2 with SMK_CLUST_DEVICES), and a
+// process-wide flag would opt the kernel in on the first device only.  Two threads on one device may both return true: harmless.
+inline bool first_use_on_this_device(std::atomic<unsigned long long>& mask)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_relaxed) & bit) return false;
+    mask.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+}
 // doubles per column of the partial products of a dense pass: the k tiles of 32 rows -- but 8 / 16 for k <= 8 / 16 (half or a
 // quarter of the bytes written by the streaming pass and read by the update kernel behind it: C2 is k = 16)
 inline int kpp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : kt_of(k) * 32; }

@@ -472,10 +472,9 @@ int launch_rank2_persist(const R2PersistArgs& a, int workgroups, hipStream_t st)
 {
     SMK_HIP(hipMemsetAsync(a.sync, 0, rank2_persist_sync_bytes(), st));
     SMK_HIP(hipMemsetAsync(a.out, 0, 16 * sizeof(double), st));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};       // per device (first_use_on_this_device)
+    if (first_use_on_this_device(attr_set)) {
         SMK_HIP(hipFuncSetAttribute((const void*)rank2_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R2P_LDS_BYTES));
-        attr_set = true;
     }
     rank2_persist_kernel<<<workgroups, 1024, a.lds_bytes, st>>>(a);
     SMK_HIP(hipGetLastError());
