@@ -215,7 +215,7 @@ int smk_comm_selftest(smk_comm* c)
     int rc = SMK_OK;
     auto fail = [&](const std::string& m) { set_error("communicator self-test: " + m); rc = SMK_DEVICE_ERROR; };
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { fail("hipStreamCreate"); return rc; }
-    if (hipMalloc((void**)&d, h.size() * sizeof(double)) != hipSuccess) { (void)hipStreamDestroy(st); fail("hipMalloc"); return rc; }
+    if (smk::dev_malloc((void**)&d, h.size() * sizeof(double)) != hipSuccess) { (void)hipStreamDestroy(st); fail("hipMalloc"); return rc; }
     // layout: [0] fp64 sum slot, [1] two fp32 sum slots, [2 .. 2 + W) gather slots (fp64)
     h[0] = (double)(c->rank + 1);
     float f2[2] = {(float)(c->rank + 1), 0.5f};
@@ -247,7 +247,7 @@ int smk_comm_selftest(smk_comm* c)
                 if (h[(size_t)(2 + r)] != 100.0 + r) { fail("all-gather slot " + std::to_string(r) + " is wrong"); break; }
         if (!rc && h[(size_t)(2 + W + c->rank)] != (c->rank + 1) * want) fail("reduce-scatter returned a wrong sum");
     }
-    (void)hipFree(d);
+    (void)smk::dev_free(d);
     (void)hipStreamDestroy(st);
     return rc;
 }

@@ -33,6 +33,13 @@ inline bool is_wide(int k) { return k > 128; }
 // k in (64, 128] unless SMK_NNLS_TILE128=0 asks for nnls_bpp_inv128_kernel
 bool nnls_uses_tiles(int k);
 // number of 32-wide k tiles of the streaming product
+// devmem.cpp: hipMalloc / hipFree with a per-device cache of freed blocks (solver, subset and sort workspaces come and go per
+// node of a clustering run); dev_trim returns the current device's cached blocks to the runtime
+hipError_t dev_malloc(void** p, size_t bytes);
+template <typename T> inline hipError_t dev_malloc(T** p, size_t bytes) { return dev_malloc((void**)p, bytes); }
+hipError_t dev_free(void* p);
+void dev_trim();
+void dev_cache_stats(unsigned long long* hits, unsigned long long* misses, size_t* cached_bytes);
 inline int kt_of(int k) { return (k + 31) / 32; }
 // "do this once" for things that are per DEVICE (hipFuncSetAttribute applies to the function on the current device): one
 // process may drive several devices (smk_nmf_dense_sharded, bench.py --single-process, HierNMF2 with SMK_CLUST_DEVICES), and a

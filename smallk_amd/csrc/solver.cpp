@@ -65,7 +65,7 @@ static int dev_alloc(T** p, size_t count)
 {
     *p = nullptr;
     if (count == 0) count = 1;
-    SMK_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    SMK_HIP(smk::dev_malloc((void**)p, count * sizeof(T)));
     // debugging aid: SMK_POISON=1 fills every fresh workspace with 0xFF bytes (NaN as fp64 / fp32, -1 as int), so that a
     // kernel reading memory nobody wrote shows up in every run instead of once in a hundred
     static const bool poison = [] { const char* e = getenv("SMK_POISON"); return e && atoi(e) != 0; }();
@@ -263,6 +263,7 @@ void smk_finalize(void)
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     if (g_own_stream && g_stream) (void)hipStreamDestroy(g_stream);
     orphan_matrices();                    // a matrix that outlives the context takes the next context's stream
+    dev_trim();                           // cached device blocks of this device go back to the runtime
     g_stream = nullptr;
     g_own_stream = false;
     g_init = false;
@@ -389,11 +390,11 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
     a->ldA = round_up(height, ROW_PAD);      a->colsA = round_up(ncols_local, COL_PAD);
     a->ldAt = round_up(ncols_local, ROW_PAD); a->colsAt = round_up(height, COL_PAD);
     const size_t es = (size_t)elem_size(storage);
-    hipError_t e1 = hipMalloc(&a->A, (size_t)a->ldA * a->colsA * es);
-    hipError_t e2 = (e1 == hipSuccess) ? hipMalloc(&a->At, (size_t)a->ldAt * a->colsAt * es) : e1;
+    hipError_t e1 = smk::dev_malloc(&a->A, (size_t)a->ldA * a->colsA * es);
+    hipError_t e2 = (e1 == hipSuccess) ? smk::dev_malloc(&a->At, (size_t)a->ldAt * a->colsAt * es) : e1;
     if (e1 != hipSuccess || e2 != hipSuccess) {
-        set_error(std::string("hipMalloc(A): ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-        if (a->A) (void)hipFree(a->A);
+        set_error(std::string("smk::dev_malloc(A): ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        if (a->A) (void)smk::dev_free(a->A);
         delete a;
         return SMK_DEVICE_ERROR;
     }
@@ -424,7 +425,7 @@ int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
     double* stage = nullptr;
     int rc = dev_alloc(&stage, (size_t)a->m * chunk);
     if (rc) return rc;
-    struct Free { void* p; ~Free() { if (p) (void)hipFree(p); } } stage_guard{stage};   // also on the error returns
+    struct Free { void* p; ~Free() { if (p) (void)smk::dev_free(p); } } stage_guard{stage};   // also on the error returns
     const size_t es = (size_t)elem_size(a->storage);
     for (i64 c = 0; c < a->n; c += chunk) {
         const i64 nc = (a->n - c < chunk) ? (a->n - c) : chunk;
@@ -487,7 +488,7 @@ void smk_matrix_destroy(smk_matrix* a)
     free_blocked_csc(&a->bAt);
     void* ptrs[] = {a->A, a->At, a->colptr, a->colptr_t, a->rowidx, a->rowidx_t, a->val, a->val_t};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)smk::dev_free(p);
     delete a;
 }
 
@@ -509,7 +510,7 @@ int smk_matrix_clone(const smk_matrix* src, smk_matrix** out)
     auto dup = [&](void** dst, const void* from, size_t bytes) {
         if (!ok || !from) return;
         if (bytes == 0) bytes = 8;
-        if (hipMalloc(dst, bytes) != hipSuccess || hipMemcpy(*dst, from, bytes, hipMemcpyDefault) != hipSuccess) ok = false;
+        if (smk::dev_malloc(dst, bytes) != hipSuccess || hipMemcpy(*dst, from, bytes, hipMemcpyDefault) != hipSuccess) ok = false;
     };
     if (src->sparse) {
         dup((void**)&a->colptr, src->colptr, (size_t)(src->n + 1) * sizeof(i64));
@@ -722,7 +723,7 @@ int smk_matrix_gather_cols(const smk_matrix* src, const unsigned* cols, int64_t 
             if (!rc) rc = matrix_make_transpose(a);
             if (!rc) e = hipStreamSynchronize(g_stream);
         }
-        (void)hipFree(dcols);
+        (void)smk::dev_free(dcols);
         if (e != hipSuccess) { set_error(std::string("gather_cols: ") + hipGetErrorString(e)); rc = SMK_DEVICE_ERROR; }
         if (rc) { smk_matrix_destroy(a); return rc; }
         if (new_to_old_rows) for (i64 r = 0; r < src->m; ++r) new_to_old_rows[r] = (unsigned)r;
@@ -827,12 +828,12 @@ static size_t comm_bytes(const smk_solver* s)
 static int matrix_measure_scale(const smk_matrix* a, hipStream_t st)
 {
     unsigned* d = nullptr;
-    SMK_HIP(hipMalloc((void**)&d, 2 * sizeof(unsigned)));
+    SMK_HIP(smk::dev_malloc((void**)&d, 2 * sizeof(unsigned)));
     unsigned bits[2] = {0, 0};
     int rc = launch_colrange(a->A, a->storage, a->ldA, a->m, a->n, d, st);
     if (!rc && hipMemcpyAsync(bits, d, sizeof(bits), hipMemcpyDeviceToHost, st) != hipSuccess) rc = SMK_DEVICE_ERROR;
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = SMK_DEVICE_ERROR;
-    (void)hipFree(d);
+    (void)smk::dev_free(d);
     if (rc) { set_error("could not measure max |A|"); return rc; }
     float mx, mn;
     memcpy(&mx, &bits[0], sizeof(mx));
@@ -886,7 +887,7 @@ static int alloc_product_buffers(smk_solver* s)
     int rc = 0;
     void** bufs[] = {&s->packW, &s->packH, (void**)&s->P1, (void**)&s->P2};
     for (void** b : bufs)
-        if (*b) { (void)hipFree(*b); *b = nullptr; }
+        if (*b) { (void)smk::dev_free(*b); *b = nullptr; }
     if (!s->a->sparse) {
         rc |= dev_alloc((unsigned char**)&s->packW, packed_bytes(s->a->storage, s->k, s->m, s->nsplit));
         rc |= dev_alloc((unsigned char**)&s->packH, packed_bytes(s->a->storage, s->k, s->n, s->nsplit));
@@ -1043,23 +1044,23 @@ void smk_solver_destroy(smk_solver* s)
                     s->fail_flag, s->packW, s->packH, s->P1, s->P2, s->hals_scratch, s->Wprev, s->tmpH, s->nnls_scratch, s->W0c, s->H0c,
                     s->xscale[0], s->xscale[1], s->oscale[0], s->oscale[1], s->r2_scratch, s->r2_prog, s->Graw, s->Hc, s->Wc, s->wide_tmp};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)smk::dev_free(p);
     for (int w = 0; w < 3; ++w)
         for (auto& e : s->ev[w]) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     for (int b = 0; b < 2; ++b) {
-        if (s->snap[b]) (void)hipFree(s->snap[b]);
+        if (s->snap[b]) (void)smk::dev_free(s->snap[b]);
         if (s->pev[b]) (void)hipEventDestroy(s->pev[b]);
     }
     if (s->pin) (void)hipHostFree(s->pin);
-    { void* gq[] = {s->guard_As, s->guard_cols, s->guard_P, s->guard_dev}; for (void* q : gq) if (q) (void)hipFree(q); }
+    { void* gq[] = {s->guard_As, s->guard_cols, s->guard_P, s->guard_dev}; for (void* q : gq) if (q) (void)smk::dev_free(q); }
     if (s->guard_pin) (void)hipHostFree(s->guard_pin);
     if (s->guard_ev) (void)hipEventDestroy(s->guard_ev);
-    { void* r2p[] = {s->r2p_hc1, s->r2p_r2c, s->r2p_part, s->r2p_out, s->r2p_sync}; for (void* q : r2p) if (q) (void)hipFree(q); }
+    { void* r2p[] = {s->r2p_hc1, s->r2p_r2c, s->r2p_part, s->r2p_out, s->r2p_sync}; for (void* q : r2p) if (q) (void)smk::dev_free(q); }
     if (s->r2p_pin) (void)hipHostFree(s->r2p_pin);
     for (int b = 0; b < 2; ++b) if (s->pin_r2[b]) (void)hipHostFree(s->pin_r2[b]);
-    if (s->comm_ws) (void)hipFree(s->comm_ws);
-    if (s->Wown) (void)hipFree(s->Wown);
-    if (s->R2own) (void)hipFree(s->R2own);
+    if (s->comm_ws) (void)smk::dev_free(s->comm_ws);
+    if (s->Wown) (void)smk::dev_free(s->Wown);
+    if (s->R2own) (void)smk::dev_free(s->R2own);
     if (s->st2) (void)hipStreamDestroy(s->st2);
     if (s->st_inv) (void)hipStreamDestroy(s->st_inv);
     for (int i = 0; i < 2; ++i) {
@@ -1178,13 +1179,13 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
     // chunk in place of the packed operand -- prod1_sharded)
     s->w_sharded = (s->o.algorithm == SMK_ALG_BPP || s->o.algorithm == SMK_ALG_MU) && !s->a->sparse && (s->world > 1 || comm_forced());
     const size_t bytes = comm_bytes(s);
-    if (hipMalloc(&s->comm_ws, bytes) != hipSuccess) { s->comm = nullptr; s->w_sharded = false; set_error("hipMalloc(comm workspace)"); return SMK_DEVICE_ERROR; }
+    if (smk::dev_malloc(&s->comm_ws, bytes) != hipSuccess) { s->comm = nullptr; s->w_sharded = false; set_error("smk::dev_malloc(comm workspace)"); return SMK_DEVICE_ERROR; }
     SMK_HIP(hipMemsetAsync(s->comm_ws, 0, bytes, s->st));
     carve_workspace(s, s->comm_ws);
     if (!s->a->sparse && s->pl2.S == 1 && s->red_f64) {
         // one row split and fp64 on the wire: the partial products ARE the send buffer.  They get room for the equal
         // blocks of the last chunk (rows past the padded row count are never written and stay zero).
-        if (s->P2) (void)hipFree(s->P2);
+        if (s->P2) (void)smk::dev_free(s->P2);
         s->P2 = nullptr;
         const size_t pe = (size_t)comm_rows(s) * s->kpp;
         if (dev_alloc(&s->P2, pe)) return SMK_DEVICE_ERROR;
@@ -1194,7 +1195,7 @@ int smk_solver_attach_comm(smk_solver* s, smk_comm* comm)
     }
     if (s->w_sharded) {
         // the packed operand of W is gathered in equal blocks: room for rows_cap rows, groups laid out for that length
-        if (s->packW) (void)hipFree(s->packW);
+        if (s->packW) (void)smk::dev_free(s->packW);
         s->packW = nullptr;
         const size_t pb = packed_bytes(s->a->storage, s->k, s->rows_cap, s->nsplit);
         if (dev_alloc((unsigned char**)&s->packW, pb)) return SMK_DEVICE_ERROR;
@@ -2517,7 +2518,7 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
     rc |= dev_alloc(&dy, hx.size());
     rc |= dev_alloc(&dscratch, nnls_uses_tiles(k) ? nnls_wide_scratch_elems(k, g_cus, ncols) : nnls_scratch_elems(k));
     rc |= dev_alloc(&dflag, (size_t)1);
-    struct Free { std::vector<void*> p; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } guard{{dg, dr, dx, dy, dscratch, dflag}};
+    struct Free { std::vector<void*> p; ~Free() { for (void* q : p) if (q) (void)smk::dev_free(q); } } guard{{dg, dr, dx, dy, dscratch, dflag}};
     if (rc) return SMK_DEVICE_ERROR;
     const int big = INT_MAX;
     SMK_HIP(hipMemcpyAsync(dg, hg.data(), hg.size() * sizeof(double), hipMemcpyHostToDevice, g_stream));
@@ -2708,12 +2709,12 @@ int smk_nmf_dense_sharded(const smk_options* opts, const double* A, int64_t ldA,
         // a shard that failed before the first collective would strand the others: agree on the setup first
         {
             double ok = (wrc == SMK_OK) ? 0.0 : 1.0, *dflag = nullptr;
-            if (hipMalloc((void**)&dflag, sizeof(double)) == hipSuccess) {
+            if (smk::dev_malloc((void**)&dflag, sizeof(double)) == hipSuccess) {
                 (void)hipMemcpy(dflag, &ok, sizeof(double), hipMemcpyHostToDevice);
                 (void)comm_allreduce(comms[(size_t)r], dflag, 1, 1, ctx().stream);
                 (void)hipStreamSynchronize(ctx().stream);
                 (void)hipMemcpy(&ok, dflag, sizeof(double), hipMemcpyDeviceToHost);
-                (void)hipFree(dflag);
+                (void)smk::dev_free(dflag);
             }
             if (ok != 0.0 && wrc == SMK_OK) wrc = SMK_FAILURE;
         }

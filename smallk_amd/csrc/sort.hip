@@ -42,12 +42,12 @@ int device_sort_desc(const double* const* keys_host, int* const* idx_host, doubl
         rc = -100;
     };
     if (e != hipSuccess) fail("hipcub size query", e);
-    if (!rc && (e = hipMalloc(&d_in, (size_t)n * 8)) != hipSuccess) fail("hipMalloc", e);
-    if (!rc && (e = hipMalloc(&d_keys, (size_t)n * 8)) != hipSuccess) fail("hipMalloc", e);
-    if (!rc && (e = hipMalloc(&d_keys_out, (size_t)n * 8)) != hipSuccess) fail("hipMalloc", e);
-    if (!rc && (e = hipMalloc(&d_idx, (size_t)n * 4)) != hipSuccess) fail("hipMalloc", e);
-    if (!rc && (e = hipMalloc(&d_idx_out, (size_t)n * 4)) != hipSuccess) fail("hipMalloc", e);
-    if (!rc && (e = hipMalloc(&d_temp, temp_bytes ? temp_bytes : 16)) != hipSuccess) fail("hipMalloc", e);
+    if (!rc && (e = smk::dev_malloc(&d_in, (size_t)n * 8)) != hipSuccess) fail("hipMalloc", e);
+    if (!rc && (e = smk::dev_malloc(&d_keys, (size_t)n * 8)) != hipSuccess) fail("hipMalloc", e);
+    if (!rc && (e = smk::dev_malloc(&d_keys_out, (size_t)n * 8)) != hipSuccess) fail("hipMalloc", e);
+    if (!rc && (e = smk::dev_malloc(&d_idx, (size_t)n * 4)) != hipSuccess) fail("hipMalloc", e);
+    if (!rc && (e = smk::dev_malloc(&d_idx_out, (size_t)n * 4)) != hipSuccess) fail("hipMalloc", e);
+    if (!rc && (e = smk::dev_malloc(&d_temp, temp_bytes ? temp_bytes : 16)) != hipSuccess) fail("hipMalloc", e);
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     for (int v = 0; v < count && !rc; ++v) {
         const bool pairs = idx_host[v] != nullptr;
@@ -66,7 +66,7 @@ int device_sort_desc(const double* const* keys_host, int* const* idx_host, doubl
     }
     void* ptrs[] = {d_in, d_keys, d_keys_out, d_idx, d_idx_out, d_temp};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)smk::dev_free(p);
     return rc;
 }
 
@@ -90,7 +90,7 @@ struct PrioWs {
     void release()
     {
         void* ptrs[] = {in, keys, keys_out, weight, wpart, partials, result, idx, idxp, idx1, idx2, pos1, pos2, seq, zfirst, temp};
-        for (void* p : ptrs) if (p) (void)hipFree(p);
+        for (void* p : ptrs) if (p) (void)smk::dev_free(p);
         if (host3) (void)hipHostFree(host3);
         *this = PrioWs();
     }
@@ -179,7 +179,7 @@ int device_priority_score(const double* wp, const double* wc, i64 n, i64 n_part,
         if (e != hipSuccess) return -2;
         w.temp_bytes = (tp > tk ? tp : tk) + 16;
         bool ok = true;
-        auto A = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) ok = false; };
+        auto A = [&](void** p, size_t bytes) { if (ok && smk::dev_malloc(p, bytes) != hipSuccess) ok = false; };
         A((void**)&w.in, (size_t)n * 24); A((void**)&w.keys, (size_t)n * 8); A((void**)&w.keys_out, (size_t)n * 8);
         A((void**)&w.weight, (size_t)n * 8); A((void**)&w.wpart, (size_t)n * 8); A((void**)&w.partials, (size_t)PRIO_BLOCKS * 3 * 8);
         A((void**)&w.result, 64);
@@ -279,11 +279,11 @@ int device_csc_transpose(i64 height, i64 ncols, i64 nnz, const i64* colptr, cons
     int rc = 0;
     auto fail = [&](const char* what) { set_error(std::string("device CSC transpose: ") + what); rc = -100; };
     if (e != hipSuccess) fail("size query");
-    if (!rc && hipMalloc((void**)&col_of, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
-    if (!rc && hipMalloc((void**)&pos, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
-    if (!rc && hipMalloc((void**)&rows_sorted, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
-    if (!rc && hipMalloc((void**)&perm, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
-    if (!rc && hipMalloc(&temp, tb + 16) != hipSuccess) fail("hipMalloc");
+    if (!rc && smk::dev_malloc((void**)&col_of, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
+    if (!rc && smk::dev_malloc((void**)&pos, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
+    if (!rc && smk::dev_malloc((void**)&rows_sorted, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
+    if (!rc && smk::dev_malloc((void**)&perm, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
+    if (!rc && smk::dev_malloc(&temp, tb + 16) != hipSuccess) fail("hipMalloc");
     if (!rc) {
         const int g1 = (int)((ncols * 64 + 255) / 256 < 8192 ? (ncols * 64 + 255) / 256 : 8192);
         tr_colids_kernel<<<g1 > 0 ? g1 : 1, 256, 0, st>>>(colptr, ncols, col_of, pos);
@@ -298,7 +298,7 @@ int device_csc_transpose(i64 height, i64 ncols, i64 nnz, const i64* colptr, cons
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) fail("kernels");
     }
     void* ptrs[] = {col_of, pos, rows_sorted, perm, temp};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (void* p : ptrs) if (p) (void)smk::dev_free(p);
     return rc;
 }
 

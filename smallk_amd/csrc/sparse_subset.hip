@@ -99,10 +99,10 @@ hipError_t exclusive_sum(const T* in, T* out, i64 count, void*& temp, size_t& te
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)count, st);
     if (e != hipSuccess) return e;
     if (need > temp_cap) {
-        if (temp) (void)hipFree(temp);
+        if (temp) (void)smk::dev_free(temp);
         temp = nullptr;
         temp_cap = 0;
-        if ((e = hipMalloc(&temp, need)) != hipSuccess) return e;
+        if ((e = smk::dev_malloc(&temp, need)) != hipSuccess) return e;
         temp_cap = need;
     }
     return hipcub::DeviceScan::ExclusiveSum(temp, need, in, out, (int)count, st);
@@ -132,12 +132,12 @@ int device_sparse_subset(const SparseDev& src, const unsigned* cols_host, i64 nc
             rc = -100;                                                                            \
         }                                                                                         \
     } while (0)
-    SUB_TRY(hipMalloc(&d_cols, (size_t)ncols * 4));
-    SUB_TRY(hipMalloc(&len, (size_t)(ncols + 1) * 8));
-    SUB_TRY(hipMalloc(&cp, (size_t)(ncols + 1) * 8));
-    SUB_TRY(hipMalloc(&colmap, (size_t)src.n * 4));
-    SUB_TRY(hipMalloc(&used, (size_t)(m + 1) * 4));
-    SUB_TRY(hipMalloc(&o2n, (size_t)(m + 1) * 4));
+    SUB_TRY(smk::dev_malloc(&d_cols, (size_t)ncols * 4));
+    SUB_TRY(smk::dev_malloc(&len, (size_t)(ncols + 1) * 8));
+    SUB_TRY(smk::dev_malloc(&cp, (size_t)(ncols + 1) * 8));
+    SUB_TRY(smk::dev_malloc(&colmap, (size_t)src.n * 4));
+    SUB_TRY(smk::dev_malloc(&used, (size_t)(m + 1) * 4));
+    SUB_TRY(smk::dev_malloc(&o2n, (size_t)(m + 1) * 4));
     SUB_TRY(hipMemcpyAsync(d_cols, cols_host, (size_t)ncols * 4, hipMemcpyHostToDevice, st));
     SUB_TRY(hipMemsetAsync(colmap, 0xFF, (size_t)src.n * 4, st));
     SUB_TRY(hipMemsetAsync(used, 0, (size_t)(m + 1) * 4, st));
@@ -149,8 +149,8 @@ int device_sparse_subset(const SparseDev& src, const unsigned* cols_host, i64 nc
         set_error("SparseMatrix::SubMatrixColsCompact: submatrix is the zero matrix");
         rc = -3;
     }
-    SUB_TRY(hipMalloc(&ri, (size_t)total * 4));
-    SUB_TRY(hipMalloc(&va, (size_t)total * 8));
+    SUB_TRY(smk::dev_malloc(&ri, (size_t)total * 4));
+    SUB_TRY(smk::dev_malloc(&va, (size_t)total * 8));
     if (!rc) {
         const unsigned grid = (unsigned)std::min<i64>((ncols + 3) / 4, 65536);
         sub_copy_kernel<<<grid, 256, 0, st>>>(src.colptr, src.rowidx, src.val, d_cols, ncols, cp, ri, va, used);
@@ -158,11 +158,11 @@ int device_sparse_subset(const SparseDev& src, const unsigned* cols_host, i64 nc
     SUB_TRY(exclusive_sum(used, o2n, m + 1, temp, temp_cap, st));
     SUB_TRY(hipMemcpyAsync(&nh, o2n + m, 4, hipMemcpyDeviceToHost, st));
     SUB_TRY(hipStreamSynchronize(st));
-    SUB_TRY(hipMalloc(&n2o, (size_t)(nh > 0 ? nh : 1) * 4));
-    SUB_TRY(hipMalloc(&rlen, (size_t)(nh + 1) * 8));
-    SUB_TRY(hipMalloc(&cpt, (size_t)(nh + 1) * 8));
-    SUB_TRY(hipMalloc(&rit, (size_t)total * 4));
-    SUB_TRY(hipMalloc(&vat, (size_t)total * 8));
+    SUB_TRY(smk::dev_malloc(&n2o, (size_t)(nh > 0 ? nh : 1) * 4));
+    SUB_TRY(smk::dev_malloc(&rlen, (size_t)(nh + 1) * 8));
+    SUB_TRY(smk::dev_malloc(&cpt, (size_t)(nh + 1) * 8));
+    SUB_TRY(smk::dev_malloc(&rit, (size_t)total * 4));
+    SUB_TRY(smk::dev_malloc(&vat, (size_t)total * 8));
     if (!rc) {
         const unsigned g1 = (unsigned)std::min<i64>((total + 255) / 256, 8192), g2 = (unsigned)std::min<i64>((m + 255) / 256, 8192);
         sub_remap_kernel<<<g1, 256, 0, st>>>(ri, total, o2n);
@@ -184,11 +184,11 @@ int device_sparse_subset(const SparseDev& src, const unsigned* cols_host, i64 nc
 #undef SUB_TRY
     void* scratch[] = {d_cols, len, colmap, used, o2n, n2o, rlen, temp};
     for (void* p : scratch)
-        if (p) (void)hipFree(p);
+        if (p) (void)smk::dev_free(p);
     if (rc) {
         void* res[] = {cp, ri, va, cpt, rit, vat};
         for (void* p : res)
-            if (p) (void)hipFree(p);
+            if (p) (void)smk::dev_free(p);
         return rc;
     }
     out->m = nh; out->n = ncols; out->nnz = total;

@@ -132,9 +132,9 @@ __global__ __launch_bounds__(256) void spmm_blocked2_kernel(const i64* __restric
 void free_blocked_csc(BlockedCsc* b)
 {
     if (!b) return;
-    if (b->cp) (void)hipFree(b->cp);
-    if (b->ri) (void)hipFree(b->ri);
-    if (b->va) (void)hipFree(b->va);
+    if (b->cp) (void)smk::dev_free(b->cp);
+    if (b->ri) (void)smk::dev_free(b->ri);
+    if (b->va) (void)smk::dev_free(b->va);
     *b = BlockedCsc();
 }
 
@@ -171,11 +171,11 @@ int build_blocked_csc(i64 rows, i64 ncols, i64 nnz, const i64* colptr, const uns
     if (hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key, key_sorted, pos, perm, (int)nnz, 0, bits, st) != hipSuccess) fail("size query");
     unsigned** u32s[] = {&key, &key_sorted, &col_of, &pos, &perm, &col_b};
     for (unsigned** p : u32s)
-        if (!rc && hipMalloc((void**)p, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
-    if (!rc && hipMalloc(&temp, tb + 16) != hipSuccess) fail("hipMalloc");
-    if (!rc && hipMalloc((void**)&out->cp, (size_t)nb * (ncols + 1) * sizeof(i64)) != hipSuccess) fail("hipMalloc");
-    if (!rc && hipMalloc((void**)&out->ri, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
-    if (!rc && hipMalloc((void**)&out->va, (size_t)nnz * 8) != hipSuccess) fail("hipMalloc");
+        if (!rc && smk::dev_malloc((void**)p, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
+    if (!rc && smk::dev_malloc(&temp, tb + 16) != hipSuccess) fail("hipMalloc");
+    if (!rc && smk::dev_malloc((void**)&out->cp, (size_t)nb * (ncols + 1) * sizeof(i64)) != hipSuccess) fail("hipMalloc");
+    if (!rc && smk::dev_malloc((void**)&out->ri, (size_t)nnz * 4) != hipSuccess) fail("hipMalloc");
+    if (!rc && smk::dev_malloc((void**)&out->va, (size_t)nnz * 8) != hipSuccess) fail("hipMalloc");
     if (!rc) {
         const int g1 = (int)((ncols * 64 + 255) / 256 < 8192 ? (ncols * 64 + 255) / 256 : 8192);
         bl_keys_kernel<<<g1 > 0 ? g1 : 1, 256, 0, st>>>(colptr, rowidx, ncols, shift, key, col_of, pos);
@@ -190,7 +190,7 @@ int build_blocked_csc(i64 rows, i64 ncols, i64 nnz, const i64* colptr, const uns
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) fail("kernels");
     }
     void* ptrs[] = {key, key_sorted, col_of, pos, perm, col_b, temp};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (void* p : ptrs) if (p) (void)smk::dev_free(p);
     if (rc) { free_blocked_csc(out); return rc; }
     out->nb = nb; out->rb = (i64)1 << shift; out->ncols = ncols; out->nnz = nnz;
     return 0;
