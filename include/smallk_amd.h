@@ -150,6 +150,9 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
 void smk_solver_destroy(smk_solver* s);
 /* W0 (m x k) and the local H0 shard (k x ncols_local); runs solver.Init + progress_est->Init (:62-63) */
 int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const double* H0, int64_t ldH);
+/* the same with W0 / H0 = the counter-based uniform matrices of smk_uniform_fill_host(seed_w) / (seed_h), generated on the device
+ * (no host fill, no upload); unsharded solvers */
+int smk_solver_set_factors_uniform(smk_solver* s, uint64_t seed_w, uint64_t seed_h);
 /* the whole driver loop with stopping rule, final NormalizeAndScale, stats (:67-139) */
 int smk_solver_run(smk_solver* s, smk_stats* stats);
 /* enqueue `iters` solver iterations without convergence checks (the min_iter branch, :81-95);

@@ -97,6 +97,7 @@ SYMBOLS = {
     "smk_solver_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Options), _vp]),
     "smk_solver_destroy": (None, [_vp]),
     "smk_solver_set_factors": (C.c_int, [_vp, _dp, _i64, _dp, _i64]),
+    "smk_solver_set_factors_uniform": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "smk_solver_run": (C.c_int, [_vp, C.POINTER(Stats)]),
     "smk_solver_iterate": (C.c_int, [_vp, C.c_int]),
     "smk_solver_sync": (C.c_int, [_vp]),

@@ -89,6 +89,7 @@ int launch_convert_f64(const double* src, i64 ld_src, void* dst, int storage, i6
 int launch_transpose_store(const void* src, i64 ld_src, void* dst, i64 ld_dst, int storage, i64 rows, i64 cols,
                            hipStream_t st);
 // dst[:, j] = src[:, cols[j]] (whole padded columns; byte strides, multiples of 16)
+int launch_fill_factor_uniform(double* X, int k, i64 N, unsigned long long seed, int transposed, hipStream_t st);
 int launch_guard_compare(PartialView fast, const unsigned* cols, int ncols, const double* acc, int S_acc, i64 slab_acc, int kpp, int k,
                          double* out2, hipStream_t st);
 int launch_gather_cols(const void* src, i64 ld_src_bytes, const unsigned* cols_dev, i64 ncols, void* dst,

@@ -326,6 +326,7 @@ struct Run {
     smk_clust_stats stats = {0, 0};
     std::vector<unsigned> new_to_old;
     std::vector<double> Winit, Hinit;       // full-size initialisers from files
+    std::vector<double> Ws, Hs;             // factors of the node being split (actual_split), reused
 };
 
 int load_init_file(const std::string& path, std::vector<double>& buf, unsigned h, unsigned w)
@@ -343,8 +344,10 @@ int load_init_file(const std::string& path, std::vector<double>& buf, unsigned h
 int factor_node(Run& r, const smk_matrix* a, i64 h, i64 w, const unsigned* rows, const unsigned* cols,
                 std::vector<double>& W, std::vector<double>& H, const char* what)
 {
-    W.assign((size_t)h * 2, 0.0);
-    H.assign((size_t)w * 2, 0.0);
+    // results only (smk_solver_get_factors overwrites every entry): no zero fill -- a fresh 14 MB vector per node cost ~3 ms of
+    // page faults and memset at a million terms; callers that keep the buffers (actual_split) reuse them from node to node
+    if (W.size() < (size_t)h * 2) W.resize((size_t)h * 2);
+    if (H.size() < (size_t)w * 2) H.resize((size_t)w * 2);
     smk_options so = r.o->nmf;
     so.height = (int)h; so.width = (int)w; so.k = 2;
     so.algorithm = SMK_ALG_RANK2;
@@ -367,16 +370,17 @@ int factor_node(Run& r, const smk_matrix* a, i64 h, i64 w, const unsigned* rows,
                 H[(size_t)(2 * c)] = r.Hinit[(size_t)(2 * src)];
                 H[(size_t)(2 * c + 1)] = r.Hinit[(size_t)(2 * src + 1)];
             }
-        } else {
-            Stopwatch sw(&r.t_init);
-            smk_uniform_fill_host(W.data(), h, h, 2, 0, 0, h, r.seed + 0x9E37u * (++r.draws), 0);
-            smk_uniform_fill_host(H.data(), 2, 2, w, 0, 0, 2, r.seed + 0x9E37u * (++r.draws), 0);
         }
+        // random initialisers: the two counter-based uniform matrices of this attempt (W then H, as the reference draws them) are
+        // generated on the device by the solver itself -- the host copies were 24 ms of fills + uploads per C5-shaped run
+        const bool seeded = r.initdir.empty();
+        uint64_t seed_w = 0, seed_h = 0;
+        if (seeded) { seed_w = r.seed + 0x9E37u * (++r.draws); seed_h = r.seed + 0x9E37u * (++r.draws); }
         Stopwatch sw(&r.t_factor);
         smk_solver* s = nullptr;
         smk_stats st = {0, 0};
         int rc = smk_solver_create(&s, &so, a);
-        if (rc == SMK_OK) rc = smk_solver_set_factors(s, W.data(), h, H.data(), 2);
+        if (rc == SMK_OK) rc = seeded ? smk_solver_set_factors_uniform(s, seed_w, seed_h) : smk_solver_set_factors(s, W.data(), h, H.data(), 2);
         if (rc == SMK_OK) {
             rc = smk_solver_run(s, &st);
             if (rc == SMK_OK) rc = smk_solver_get_factors(s, 0, W.data(), h, H.data(), 2);
@@ -427,7 +431,7 @@ int actual_split(Run& r, const std::vector<unsigned>& subset, const double* w_pa
         rc = smk_matrix_gather_cols(r.full, subset.data(), (int64_t)subset.size(), &sub, r.new_to_old.data(), &nh);
     }
     if (rc != SMK_OK) return rc;
-    std::vector<double> Ws, Hs;
+    std::vector<double>&Ws = r.Ws, &Hs = r.Hs;              // reused from node to node (factor_node fills the first nh x 2 / 2 x |subset| entries)
     rc = factor_node(r, sub, nh, (i64)subset.size(), r.new_to_old.data(), subset.data(), Ws, Hs, "Node");
     { Stopwatch sw(&r.t_free); smk_matrix_destroy(sub); }
     if (rc != SMK_OK) return rc;
@@ -443,7 +447,7 @@ int actual_split(Run& r, const std::vector<unsigned>& subset, const double* w_pa
         W[(size_t)r.new_to_old[(size_t)i]] = Ws[(size_t)i];
         W[(size_t)(m + r.new_to_old[(size_t)i])] = Ws[(size_t)(nh + i)];
     }
-    H = Hs;
+    H.assign(Hs.begin(), Hs.begin() + (std::ptrdiff_t)(2 * subset.size()));       // Hs is a reused buffer: only this node's part
     }
     Stopwatch sw(&r.t_priority);
     *priority = (has0 && has1) ? priority_score(w_parent, W.data(), m) : -1.0;

@@ -757,6 +757,30 @@ int launch_colrange(const void* A, int storage, i64 ld, i64 rows, i64 cols, unsi
     return 0;
 }
 
+// the counter-based uniform start of a factor, generated where it is used: X is KP x N (ld KP, pad rows zero); entry (r, j) of
+// a k x N column-major host matrix has global index j * k + r (H), entry (i, c) of an N x k one has c * N + i (W kept transposed)
+__global__ __launch_bounds__(256) void fill_factor_uniform_kernel(double* __restrict__ X, int KP, int k, i64 N, unsigned long long seed, int transposed)
+{
+    const i64 total = N * KP;
+    for (i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (i64)gridDim.x * blockDim.x) {
+        const i64 j = idx / KP;
+        const int r = (int)(idx % KP);
+        double v = 0.0;
+        if (r < k) v = (double)uniform_value(seed, (uint64_t)(transposed ? (i64)r * N + j : j * k + r), 0);
+        X[idx] = v;
+    }
+}
+int launch_fill_factor_uniform(double* X, int k, i64 N, unsigned long long seed, int transposed, hipStream_t st)
+{
+    const int KP = kp_of(k);
+    i64 grid = (N * KP + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    fill_factor_uniform_kernel<<<(unsigned)grid, 256, 0, st>>>(X, KP, k, N, seed, transposed);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 // run-time guard of the product form (solver.cpp): sum of squared differences between the fast-form product (P1, all row
 // splits) and the accurate-form product of the same `ncols` sampled columns, and the accurate product's sum of squares
 __global__ __launch_bounds__(256) void guard_compare_kernel(PartialView fast, const unsigned* __restrict__ cols, int ncols,

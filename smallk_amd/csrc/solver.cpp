@@ -1283,6 +1283,39 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
     return SMK_OK;
 }
 
+// The same start as smk_solver_set_factors(W0, H0) with W0 = smk_uniform_fill_host(m x k, seed_w), H0 = smk_uniform_fill_host
+// (k x n, seed_h) -- the RandomMatrix stand-in of every caller in this library -- generated on the device: no host fill, no
+// upload.  (HierNMF2 draws two such matrices per node.)  Unsharded solvers only.
+int smk_solver_set_factors_uniform(smk_solver* s, uint64_t seed_w, uint64_t seed_h)
+{
+    if (!s) return SMK_BAD_PARAM;
+    if (is_dist(s) || s->comm) { set_error("set_factors_uniform: not for sharded solvers"); return SMK_UNSUPPORTED; }
+    if (s->nsplit == NSPLIT_F16X2 && (s->a->ascale == 0.f || s->a->ascale != s->pg1[0].ascale)) {
+        if (s->a->ascale == 0.f) { const int rc0 = matrix_measure_scale(s->a, s->st); if (rc0) return rc0; }
+        for (int g = 0; g < s->ng; ++g) s->pg1[g].ascale = s->pg2[g].ascale = s->a->ascale;
+        s->pl1.ascale = s->pl2.ascale = s->a->ascale;
+    }
+    int rc = launch_fill_factor_uniform(s->Wt, s->k, s->m, seed_w, 1, s->st);
+    if (!rc) rc = launch_fill_factor_uniform(s->H, s->k, s->n, seed_h, 0, s->st);
+    if (rc) return rc;
+    const int big = INT_MAX;
+    SMK_HIP(hipMemcpyAsync(s->fail_flag, &big, sizeof(int), hipMemcpyHostToDevice, s->st));
+    if (s->W0c) {
+        SMK_HIP(hipMemcpyAsync(s->W0c, s->Wt, (size_t)s->KP * s->m * sizeof(double), hipMemcpyDeviceToDevice, s->st));
+        SMK_HIP(hipMemcpyAsync(s->H0c, s->H, (size_t)s->KP * s->n * sizeof(double), hipMemcpyDeviceToDevice, s->st));
+    }
+    SMK_HIP(hipStreamSynchronize(s->st));
+    s->w_full = true;
+    s->wc_valid = false;
+    s->have_factors = true;
+    s->inited = false;
+    s->normalized = false;
+    s->iter = 0;
+    s->pg0 = 1.0;
+    s->last_metric = 1.0;
+    return SMK_OK;
+}
+
 // ---- collectives -------------------------------------------------------------------------------
 // callback hook: one host call per buffer, in stream order on the main stream
 static int dist_allreduce_cb(smk_solver* s, void* ptr, i64 count, int f64)

@@ -197,6 +197,10 @@ class NmfSolver:
         L.check(L.lib().smk_solver_set_factors(self._h, _p(W0), W0.shape[0], _p(H0), H0.shape[0]),
                 "smk_solver_set_factors")
 
+    def set_factors_uniform(self, seed_w, seed_h):
+        """W0 / H0 = uniform_host(m, k, seed_w) / uniform_host(k, n, seed_h), generated on the device"""
+        L.check(L.lib().smk_solver_set_factors_uniform(self._h, seed_w, seed_h), "smk_solver_set_factors_uniform")
+
     def run(self):
         st = L.Stats()
         rc = L.lib().smk_solver_run(self._h, C.byref(st))

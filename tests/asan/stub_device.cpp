@@ -191,6 +191,15 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
     for (int64_t c = 0; c < n; ++c) std::copy(H0 + c * ldH, H0 + c * ldH + k, s->H.begin() + c * k);
     return SMK_OK;
 }
+int smk_solver_set_factors_uniform(smk_solver* s, uint64_t seed_w, uint64_t seed_h)
+{
+    if (!s) return SMK_BAD_PARAM;
+    const int64_t m = s->a->m, n = s->a->n, k = s->o.k;
+    s->W.resize((size_t)m * k); s->H.resize((size_t)k * n);
+    orc_fill_uniform(s->W.data(), m, m, k, 0, 0, m, seed_w, 0);
+    orc_fill_uniform(s->H.data(), k, k, n, 0, 0, k, seed_h, 0);
+    return SMK_OK;
+}
 int smk_solver_run(smk_solver* s, smk_stats* st)
 {
     if (!s || s->W.empty()) return SMK_BAD_PARAM;

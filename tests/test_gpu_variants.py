@@ -151,3 +151,24 @@ def test_runtime_guard_of_the_product_form():
     assert well["guard_checks"] >= 5 and well["guard_fired"] == 0 and well["form_end"] == well["form_start"], well
     assert well["relW"] < 1e-4 and well["relH"] < 1e-4, well
     assert off["guard_checks"] == 0 and off["form_end"] == off["form_start"], off
+
+
+def test_set_factors_uniform_is_the_host_generator(gpu):
+    """smk_solver_set_factors_uniform: the start of a run generated on the device must be, bit for bit, the matrices
+    smk_uniform_fill_host gives (HierNMF2 draws its initialisers this way since round 4; the oracle replays the host ones)."""
+    m, n, k = 700, 333, 5
+    A = gpu.DenseMatrix(m, n)
+    A.fill_uniform(1)
+    s = gpu.NmfSolver(A, gpu.make_options(m, n, k, "MU", min_iter=1, max_iter=1))
+    s.set_factors_uniform(12345, 67890)
+    W, H = s.factors(normalize=False)
+    assert np.array_equal(W, gpu.uniform_host(m, k, 12345)) and np.array_equal(H, gpu.uniform_host(k, n, 67890))
+    s2 = gpu.NmfSolver(A, gpu.make_options(m, n, k, "MU", min_iter=3, max_iter=3))
+    s2.set_factors(gpu.uniform_host(m, k, 12345), gpu.uniform_host(k, n, 67890))
+    s.close()
+    s = gpu.NmfSolver(A, gpu.make_options(m, n, k, "MU", min_iter=3, max_iter=3))
+    s.set_factors_uniform(12345, 67890)
+    assert s.run()[0] == 0 and s2.run()[0] == 0
+    Wa, Ha = s.factors()
+    Wb, Hb = s2.factors()
+    assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
