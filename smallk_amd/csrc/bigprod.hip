@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(256) void bigprod_f64_kernel(const unsigned char* _
 // block b + 1 are issued before the multiply-adds of block b (register double buffer); the factor rows of a block travel
 // through a double-buffered LDS slab, one barrier per block.  Two accumulators per column per lane, joined at the end.
 // Measured on the C3 matrix (tools/r2_dense_rate.py): fp32 A 6.2 - 6.6 TB/s (the bf16x3 MFMA form: 5.9 - 6.1), bf16 A
-// 4.8 - 5.2 (6.1 - 6.2).  (The first version staged the factor rows through LDS with two barriers per block and loaded 8 of 16 columns at
+// 4.9 - 5.4 (6.1 - 6.2).  (The first version staged the factor rows through LDS with two barriers per block and loaded 8 of 16 columns at
 // a time: 4.4 / 3.6 TB/s.)
 template <int EBYTES>
 __global__ __launch_bounds__(256) void bigprod_f64_k2_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
@@ -1471,7 +1471,9 @@ __global__ __launch_bounds__(256) void bigprod_f64_k2_kernel(const unsigned char
                                                              double* __restrict__ P, i64 stages, i64 nst, i64 tiles, i64 ncols_pad,
                                                              int S, int pstride, int ktw, int accum)
 {
-    constexpr int CW = 8, NBW = 32;                       // columns per wave / per workgroup
+    constexpr int CW = EBYTES == 2 ? 16 : 8, NBW = 4 * CW;      // columns per wave / per workgroup: 128 bytes in flight per lane and buffer
+                                                            // either way (fp32: 8 x 16 B, a workgroup = half a plan tile; bf16: 16 x 8 B, a whole one)
+    constexpr int HALVES = 64 / NBW;                        // workgroups per 64-column plan tile
     constexpr int RPL = 4;                                // rows per lane and block: one 16-byte (fp32) / 8-byte (bf16) load per column
     constexpr int RB = 64 * RPL;                          // rows per block
     // 4 rows = 4 words (fp32) or 2 words (bf16: a register pair -- half the registers of the fp32 variant, so more waves cover
@@ -1481,9 +1483,9 @@ __global__ __launch_bounds__(256) void bigprod_f64_k2_kernel(const unsigned char
     typedef __attribute__((ext_vector_type(2))) unsigned words2_t;
     typedef typename std::conditional<EBYTES == 4, words4_t, words2_t>::type u32x4v;
     __shared__ double red[NBW][2];
-    const i64 half = blockIdx.x / S;                      // half a plan tile
+    const i64 half = blockIdx.x / S;                      // this workgroup's NBW columns
     const int split = (int)(blockIdx.x % S);
-    if (half >= 2 * tiles) return;
+    if (half >= HALVES * tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     i64 st0 = (i64)split * nst, st1 = st0 + nst;
     if (st1 > stages) st1 = stages;
@@ -1586,7 +1588,7 @@ static int launch_bigprod_f64(const BigProdPlan& pl, const void* B, i64 ldb, con
     const int ktw = 2 * kt_of(pl.kg);                      // 16-row tiles covering the group's 32-row k tiles
     if (kvalid <= 2) {                                     // rank 1 / 2: the vector-ALU kernel at the streaming rate
         if (pl.storage == STORE_BF16)
-            bigprod_f64_k2_kernel<2><<<(unsigned)(2 * grid), 256, 0, st>>>((const unsigned char*)B, ldb * 2, (const double*)X, pl.ldx, kvalid, len, P,
+            bigprod_f64_k2_kernel<2><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * 2, (const double*)X, pl.ldx, kvalid, len, P,
                                                                     pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum);
         else
             bigprod_f64_k2_kernel<4><<<(unsigned)(2 * grid), 256, 0, st>>>((const unsigned char*)B, ldb * 4, (const double*)X, pl.ldx, kvalid, len, P,

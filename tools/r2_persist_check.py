@@ -43,7 +43,9 @@ CASES_QUICK = [(3000, 6, 1, None, dict(min_iter=5, max_iter=400, tol=1e-4)),
                (50000, 16, 2, None, dict(min_iter=5, max_iter=60, tol=1e-9)),
                (20000, 5, 3, 61000, dict(min_iter=3, max_iter=300, tol=1e-3)),
                (700, 3, 4, None, dict(min_iter=1, max_iter=1, tol=1e-4)),
-               (900, 4, 5, None, dict(min_iter=2, max_iter=2, tol=0.9))]
+               (900, 4, 5, None, dict(min_iter=2, max_iter=2, tol=0.9)),
+               (4000, 8, 6, None, dict(min_iter=3, max_iter=400, tol=0.03, tolcount=3)),        # the rule must hold three checks in a row
+               (2500, 6, 11, 5000, dict(min_iter=40, max_iter=400, tol=0.05))]                  # min_iter beyond the point where the rule first holds
 CASES_TIME = [(62000, 16, 7, 192000, dict(min_iter=300, max_iter=300, tol=1e-9)),        # the C5 run's two long nodes
               (187000, 16, 8, 481000, dict(min_iter=100, max_iter=100, tol=1e-9)),
               (250000, 16, 9, 588000, dict(min_iter=100, max_iter=100, tol=1e-9)),
