@@ -110,4 +110,9 @@ l)  # HierNMF2 on 2 / 4 / 8 device contexts (all on this one GPU): identical tre
         SMK_CLUST_DEVICES=$d SMK_SHARDS_ON_ONE_GPU=1 SMK_CLUST_SERIALIZE=1 SMK_CLUST_TIMING=1 timeout 900 python3 tools/c5_hier.py 2>&1 | grep "subset\|hier_nmf2:\|purity" >> $OUT/c5_devices.txt
     done
     ;;
+m)  # last build of the round: whole GPU suite + smoke, then the judged artefacts (quick set) on it
+    python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error|^FAILED|^ERROR" | tail -20 > $OUT/gpu_suite.txt
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke >> $OUT/gpu_suite.txt
+    bash tools/profile.sh r04 quick > $OUT/profile.log 2>&1
+    ;;
 esac
