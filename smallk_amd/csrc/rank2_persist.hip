@@ -23,7 +23,7 @@
 // releases (buffer_wbl2 sc1: the XCD's L2 is written back once) and arrives at the top counter, the last XCD opens the
 // generation word; every workgroup acquires (buffer_inv sc1) before it reads what the others wrote.  Which XCD a workgroup
 // runs on is read from the hardware (HW_REG_XCC_ID), the membership counts come from one flat barrier at kernel start:
-// nothing depends on dispatch order or placement.  Polls are bounded by the wall clock (5 s); on expiry every workgroup
+// nothing depends on dispatch order or placement.  Every single wait is bounded by the wall clock (5 s); on expiry every workgroup
 // leaves through the abort word and the host runs the launch-per-kernel loop instead (the solver state was not touched).
 #include "devutil.h"
 #include "rank2_math.h"
@@ -48,12 +48,15 @@ __device__ __forceinline__ gu32_t* bar_word(const GridBar& b, int line) { return
 // one lane polls one word (relaxed, agent scope); false when the run has been aborted or the deadline passed
 __device__ __forceinline__ bool bar_wait(const GridBar& b, gu32_t* p, unsigned target)
 {
+    unsigned long long t_wait = 0;                     // when THIS wait began (a long factorisation is not a stall: the limit is per wait)
     for (unsigned spins = 0;; ++spins) {
         const unsigned v = __hip_atomic_load(p, R2P_RLX_AGENT);
         if ((int)(v - target) >= 0) return true;
         if ((spins & 63u) == 63u) {
             if (__hip_atomic_load(bar_word(b, R2P_ABORT), R2P_RLX_AGENT) != 0u) return false;
-            if (wall_clock64() > b.deadline) { __hip_atomic_store(bar_word(b, R2P_ABORT), 1u, R2P_RLX_AGENT); return false; }
+            const unsigned long long now = wall_clock64();
+            if (t_wait == 0) t_wait = now;
+            else if (now - t_wait > b.deadline) { __hip_atomic_store(bar_word(b, R2P_ABORT), 1u, R2P_RLX_AGENT); return false; }
         }
         __builtin_amdgcn_s_sleep(1);
     }
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(1024) void rank2_persist_kernel(R2PersistArgs A)
     GridBar bar;
     bar.w = (gu32_t*)A.sync;
     bar.epoch = 0;
-    bar.deadline = wall_clock64() + 500000000ull;           // 5 s of the 100 MHz constant clock
+    bar.deadline = 500000000ull;                            // longest single wait: 5 s of the 100 MHz constant clock
     if (tid == 0) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));

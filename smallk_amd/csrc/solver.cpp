@@ -2287,6 +2287,9 @@ static int rank2_persist_run(smk_solver* s, int* status, int* count)
 {
     const int nwg = rank2_persist_workgroups(s->m, s->n, s->a->nnz, g_cus);
     if (nwg < 1 || nwg > 1024) { *status = R2P_ABORTED; return 0; }
+    // TEST HOOK: behave as if the kernel's workgroups had not all become resident (the caller must then finish the run on the
+    // launch-per-kernel loop from the state solver.Init left)
+    if (const char* e = getenv("SMK_R2P_TEST_ABORT")) if (atoi(e) != 0) { *status = R2P_ABORTED; return 0; }
     if (!s->r2p_sync) {
         int rc = dev_alloc(&s->r2p_hc1, (size_t)2 * s->n);
         rc |= dev_alloc(&s->r2p_r2c, (size_t)2 * s->m);

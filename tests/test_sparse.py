@@ -182,3 +182,29 @@ def test_resident_rank2_kernel_matches_the_launch_per_kernel_loop():
     r = subprocess.run([sys.executable, "tools/r2_persist_check.py", "quick"], cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert "fell back" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_resident_rank2_kernel_falls_back_when_it_cannot_synchronise(tmp_path):
+    """If the resident kernel reports that its workgroups could not all synchronise (a bounded wait expired: somebody else
+    holds the CUs), the run continues on the launch-per-kernel loop from the state solver.Init left and the handle stays on
+    that path.  TEST HOOK SMK_R2P_TEST_ABORT=1 reports that outcome without launching; result = the oracle's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, scipy.sparse as sp\n"
+            "sys.path.insert(0, '.'); import oracle, smallk_amd as g\n"
+            "g.initialize(0)\n"
+            "rng = np.random.default_rng(3)\n"
+            "A = sp.random(900, 700, density=0.02, random_state=rng, data_rvs=lambda s: rng.random(s) + 0.1, format='csc') + 0.01 * sp.eye(900, 700, format='csc')\n"
+            "W0 = oracle.fill_uniform(900, 2, 5); H0 = oracle.fill_uniform(2, 700, 6)\n"
+            "r = g.nmf_sparse(A.tocsc(), W0, H0, 'RANK2', min_iter=3, max_iter=300, tol=1e-3)\n"
+            "ref = oracle.nmf(np.asfortranarray(A.toarray()), W0, H0, 'RANK2', min_iter=3, max_iter=300, tol=1e-3)\n"
+            "print('RES', r.result, r.iteration_count, ref.iteration_count, float(np.linalg.norm(r.W - ref.W) / np.linalg.norm(ref.W)))\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, SMK_R2P_TEST_ABORT="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = [l for l in out.stdout.splitlines() if l.startswith("RES")][0].split()
+    assert res[1] == "0" and res[2] == res[3] and float(res[4]) < 1e-8, res
+    assert "continuing on the launch-per-kernel path" in out.stderr
