@@ -82,10 +82,11 @@ def beat(stage, limit=None, rank=None):
         if limit is not None:
             _hb["limit"] = float(limit)
         r = _hb["rank"] if rank is None else rank
+        lim_now = _hb["limit"]
     if _hb["file"]:
-        try:
+        try:                                # rank <tab> limit of this stage <tab> stage: the parent applies the same limit (+ a margin)
             with open(_hb["file"], "a") as f:
-                f.write(f"{r} {stage} {time.time():.3f}\n")
+                f.write(f"{r}\t{lim_now:.0f}\t{stage}\n")
         except OSError:
             pass
     if os.environ.get("SMK_BENCH_VERBOSE"):
@@ -277,7 +278,7 @@ def run_plan(name, cmd, env, args, deadline):
     reader = threading.Thread(target=lambda: out_lines.extend(p.stdout.readlines()), daemon=True)
     reader.start()
     last_size, last_change, reason = 0, time.monotonic(), ""
-    startup = True                                       # until the first beat: imports of a cold image take minutes
+    stages, limits = {}, {}                              # per rank: the stage it is in and the time that stage may take
     while p.poll() is None:
         time.sleep(0.25)
         try:
@@ -286,21 +287,22 @@ def run_plan(name, cmd, env, args, deadline):
             size = last_size
         now = time.monotonic()
         if size != last_size:
-            last_size, last_change, startup = size, now, False
-        limit = (300.0 if startup else args.stall_s) + 15.0    # the ranks' own watchdogs fire first: they know more
+            last_size, last_change = size, now
+            try:
+                for l in open(hb.name):
+                    r, lm, st = l.rstrip("\n").split("\t", 2)
+                    stages[r], limits[r] = st, float(lm)
+            except Exception:
+                pass
+        # until the first beat: imports of a cold image take minutes.  Afterwards the longest limit among the stages the ranks
+        # are in, plus a margin: the ranks' own watchdogs fire first -- they know more
+        limit = (max(limits.values()) if limits else 300.0) + 15.0
         if now - last_change > limit:
             reason = f"no heartbeat from any rank for {now - last_change:.0f} s"
         elif now > deadline:
             reason = f"overall limit --watchdog-s {args.watchdog_s:.0f} s reached"
         if reason:
-            try:
-                stages = {}
-                for l in open(hb.name):
-                    r, st, _ = l.split(" ", 2)
-                    stages[r] = st
-                print(f"[bench] WATCHDOG ({name}): {reason}; last stage per rank: {stages}", file=sys.stderr, flush=True)
-            except Exception:
-                print(f"[bench] WATCHDOG ({name}): {reason}", file=sys.stderr, flush=True)
+            print(f"[bench] WATCHDOG ({name}): {reason}; last stage per rank: {stages}", file=sys.stderr, flush=True)
             rccl_log_excerpt()
             for sig, wait in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):      # OUR process group only
                 try:
