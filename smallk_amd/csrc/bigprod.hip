@@ -1275,6 +1275,8 @@ static const F3Variant kF3Variants[] = {
     {32, 2, 0, 8, 2},   // 125: as 108, folding into fp64 every 8 stages (256-row fp32 chains)
     {32, 3, 0, 4, 2},   // 126: as 108 with a 3-deep ring
     {32, 2, 0, 16, 2},  // 127: as 125, folding every 16 stages (512-row fp32 chains)
+    {32, 2, 0, 2, 2},   // 128: as 108, folding every 2 stages (64-row fp32 chains)
+    {32, 2, 0, 1, 2},   // 129: as 108, folding every stage (32-row fp32 chains: two roundings per accumulator and fold)
 };
 static const int kNumF3 = (int)(sizeof(kF3Variants) / sizeof(kF3Variants[0]));
 
@@ -1358,6 +1360,8 @@ static int launch_f3_f16(const BigProdPlan& pl, const void* B, i64 ldb, const vo
         case 25: return launch_f3_t<KT, 2, 32, 2, 0, 8, 2, 1>(pl, B, ldb, Xp, P, st);
         case 26: return launch_f3_t<KT, 2, 32, 3, 0, 4, 2, 1>(pl, B, ldb, Xp, P, st);
         case 27: return launch_f3_t<KT, 2, 32, 2, 0, 16, 2, 1>(pl, B, ldb, Xp, P, st);
+        case 28: return launch_f3_t<KT, 2, 32, 2, 0, 2, 2, 1>(pl, B, ldb, Xp, P, st);
+        case 29: return launch_f3_t<KT, 2, 32, 2, 0, 1, 2, 1>(pl, B, ldb, Xp, P, st);
         default: break;
     }
     set_error("unknown bigprod f16 variant");
@@ -1692,15 +1696,21 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     if (storage == STORE_F32 && pl.nsplit >= 2) v = (pl.kt == 2) ? 108 : 115;
     // fp16 two-term form: the two-workgroup kernel wins or ties at every shape measured (C2, 32768 x 8192 k = 32, both
     // passes of a C4 shard); the pipelined ones stay selectable (110, 111, 115)
-    // folding the fp32 accumulators into fp64 every 8 stages (variant 125) instead of 4 is worth 0.5 .. 6 % and keeps the
-    // product at 4e-8 of the exact one (2^-24 = 6e-8; measured by tools/mb/mb_bp_sweep against an fp64 host product)
-    if (storage == STORE_F32 && pl.nsplit == NSPLIT_F16X2) v = 125;
+    // The error of this form is the fp32 accumulation of the 22-bit hi * hi products (one rounding per MFMA), so it falls with
+    // the length of the fp32 chains (stages between two folds into fp64) and, relative to the result, with the number of
+    // folds: the fold interval follows the contraction length so that the product stays at 1e-8 .. 2e-8 of the exact one at
+    // every size (profiles/r04_fold_interval_sweep.txt, max over 512 entries against an fp64 host product: len 1500 9.2e-8
+    // with 8 stages per fold, 1.9e-8 with 1; len 8192 4.4e-8 -> 1.3e-8 with 2; len 65536 1.7e-8 and len 262144 1.0e-8 with 8).
+    // Short contractions are latency-bound, the extra folds cost nothing there; at C4 (len >= 65536) folding every 8 stages
+    // instead of 4 is worth 0 .. 2 %.
+    if (storage == STORE_F32 && pl.nsplit == NSPLIT_F16X2) v = len >= 65536 ? 125 : len >= 16384 ? 108 : len >= 4096 ? 128 : 129;
     const char* env = getenv("SMK_BP_VARIANT");
     if (env) v = atoi(env);
     const char* env2 = getenv("SMK_BP_VARIANT_K64");       // only for k in (32, 64]
     if (env2 && pl.kt == 2) v = atoi(env2);
     if (storage == STORE_F32 && pl.nsplit == 2 && v < 100) v = (pl.kt == 2) ? 108 : 115;   // the 2-term forms exist only there
-    if (pl.nsplit == NSPLIT_F16X2 && v != 108 && v != 110 && v != 111 && v != 115 && v != 125 && v != 126 && v != 127) v = 125;
+    if (pl.nsplit != NSPLIT_F16X2 && (v == 128 || v == 129)) v = 108;       // the short-chain variants exist for the fp16 form only
+    if (pl.nsplit == NSPLIT_F16X2 && v != 108 && v != 110 && v != 111 && v != 115 && v != 125 && v != 126 && v != 127 && v != 128 && v != 129) v = 125;
     if (v >= 100 && storage == STORE_F32 && pl.nsplit >= 2) {
         auto f3_fits = [&](int vv) {
             if (vv < 100 || vv >= 100 + kNumF3) return false;

@@ -941,6 +941,18 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     // (tools/wide_long_run.py: 1200 x 1000, k = 100, bf16x3: 1.2e-4 after 20 iterations, 1.1e-3 after 30; k = 160: 4e-5 after 25;
     // the accurate form: 8.5e-12 after 30).  At k <= 64 the same data stays below 2e-5 over 30 iterations with the fp16 form.
     if (opts->algorithm == SMK_ALG_BPP && opts->k > 64 && !a->sparse) nsplit_default = NSPLIT_F64;
+    // ... and at k in (32, 64] where the accurate form costs nothing measurable (A of at most 2^24 entries: the streaming pass
+    // is a 10 - 30 us launch next to a 100 us NNLS).  Block pivoting at these ranks amplifies the product error ~3000 x while
+    // the passive sets are still moving: on data with sparse planted factors (1500 x 1100, k = 64) the distance to the oracle's
+    // trajectory peaks at 0.4e-4 .. 2e-4 around iteration 100 with the fp16 form whatever its fold interval (3e-8 .. 9e-8
+    // products), 5e-6 with bf16x3, 2e-12 with the accurate form, and contracts to 4e-7 by iteration 500
+    // (profiles/r04_long_runs_500_iterations.txt).  Larger matrices keep the fp16 form (C4: 3 x the pass time otherwise);
+    // SMK_NSPLIT=8 / 3 select the other forms anywhere.
+    // (SMK_BPP_SMALL_ACCURATE=0 keeps the fp16 form: the test suite sets it, its small cases stand in for C4's path.)
+    const char* esa = getenv("SMK_BPP_SMALL_ACCURATE");             // read per solver, like SMK_NSPLIT
+    const bool small_accurate = !(esa && esa[0] == '0');
+    if (small_accurate && opts->algorithm == SMK_ALG_BPP && opts->k > 32 && !a->sparse && a->m * a->n_global <= ((i64)1 << 24))
+        nsplit_default = NSPLIT_F64;
     // Dense RANK2 (every node factorisation of HierNMF2 / flatclust on dense A runs 100 .. 1000 iterations to a tight
     // tolerance): the accurate form costs nothing at two factor rows -- bigprod_f64_k2_kernel does its 2 fp64 multiply-adds
     // per stored entry on the vector ALUs at the streaming rate -- and leaves only summation order between this path and

@@ -13,6 +13,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 # interface probing has been seen to stall for minutes on some boxes), no InfiniBand probing.  The caller's settings win.
 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 os.environ.setdefault("NCCL_IB_DISABLE", "1")
+# Block pivoting at k in (32, 64] on a matrix of at most 2^24 entries takes the accurate product form by default (solver.cpp).
+# The suite's small cases stand in for the fp16 two-term path that C4 takes and that cannot be compared with the oracle at
+# full size, so the suite keeps that form; test_gpu_variants.py::test_small_bpp_takes_the_accurate_form checks the default.
+os.environ.setdefault("SMK_BPP_SMALL_ACCURATE", "0")
 
 
 def pytest_configure(config):

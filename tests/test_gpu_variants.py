@@ -153,6 +153,43 @@ def test_runtime_guard_of_the_product_form():
     assert off["guard_checks"] == 0 and off["form_end"] == off["form_start"], off
 
 
+def test_small_bpp_takes_the_accurate_form(gpu, monkeypatch):
+    """Block pivoting at k in (32, 64] amplifies the product error ~3000 x while the passive sets still move: on data with sparse
+    planted factors the fp16 two-term form is 0.4e-4 .. 2e-4 away from the oracle's trajectory around iteration 100 (it contracts
+    to 4e-7 by iteration 500; profiles/r04_long_runs_500_iterations.txt).  Where the accurate form costs nothing measurable -- A of
+    at most 2^24 entries -- it is the default (the suite otherwise keeps the fp16 form, conftest.py): form 8, and the case that
+    peaks at 2e-4 stays at 1e-10 after the same 100 iterations.  Larger matrices, k <= 32 and MU keep the fp16 form."""
+    import oracle
+    monkeypatch.delenv("SMK_BPP_SMALL_ACCURATE", raising=False)
+    m, n, k = 1500, 1100, 64
+    rng = np.random.default_rng(17 + k)
+    r = k + 2
+    A = (rng.random((m, r)) * (rng.random((m, r)) > 0.7)) @ (rng.random((r, n)) * (rng.random((r, n)) > 0.7)) + 0.05 * rng.random((m, n))
+    A = oracle.quantize(A, 0)
+    W0, H0 = oracle.fill_uniform(m, k, 21), oracle.fill_uniform(k, n, 22)
+    D = gpu.DenseMatrix.from_host(A)
+    forms = {}
+    for alg, kk in (("BPP", 64), ("BPP", 33), ("BPP", 32), ("MU", 64)):
+        s = gpu.NmfSolver(D, gpu.make_options(m, n, kk, alg, min_iter=1, max_iter=1))
+        forms[(alg, kk)] = s.product_form()[0]
+        s.close()
+    assert forms == {("BPP", 64): 8, ("BPP", 33): 8, ("BPP", 32): 4, ("MU", 64): 4}, forms
+    big = gpu.DenseMatrix(8192, 4096)                     # 2^25 entries: the fp16 form
+    big.fill_uniform(1)
+    s = gpu.NmfSolver(big, gpu.make_options(8192, 4096, 64, "BPP", min_iter=1, max_iter=1))
+    assert s.product_form()[0] == 4
+    s.close()
+    kw = dict(min_iter=100, max_iter=100, tol=1e-14)
+    ref = oracle.nmf(A, W0, H0, "BPP", **kw)
+    got = gpu.nmf(A, W0, H0, "BPP", **kw)
+    assert got.result == ref.result == 0 and got.iteration_count == ref.iteration_count == 100
+    assert np.linalg.norm(got.W - ref.W) / np.linalg.norm(ref.W) < 1e-9
+    assert np.linalg.norm(got.H - ref.H) / np.linalg.norm(ref.H) < 1e-9
+    monkeypatch.setenv("SMK_BPP_SMALL_ACCURATE", "0")     # the fp16 form on the same case: inside 1e-3, not inside the 1e-4 bar
+    fast = gpu.nmf(A, W0, H0, "BPP", **kw)
+    assert np.linalg.norm(fast.W - ref.W) / np.linalg.norm(ref.W) < 1e-3
+
+
 def test_set_factors_uniform_is_the_host_generator(gpu):
     """smk_solver_set_factors_uniform: the start of a run generated on the device must be, bit for bit, the matrices
     smk_uniform_fill_host gives (HierNMF2 draws its initialisers this way since round 4; the oracle replays the host ones)."""

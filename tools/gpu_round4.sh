@@ -115,4 +115,7 @@ m)  # last build of the round: whole GPU suite + smoke, then the judged artefact
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke >> $OUT/gpu_suite.txt
     bash tools/profile.sh r04 quick > $OUT/profile.log 2>&1
     ;;
+n)  # drift of the product forms over long runs (up to 500 iterations) at k <= 64
+    timeout 3000 python3 tools/long_runs_500.py > $OUT/r04_long_runs_500_iterations.txt 2>&1
+    ;;
 esac
