@@ -9,6 +9,11 @@ import numpy as np
 
 CASES = [("BPP", 1500, 1100, 64), ("BPP", 1500, 1100, 32), ("HALS", 1200, 1000, 64), ("HALS", 1200, 1000, 32), ("MU", 1200, 1000, 64)]
 CHECKPOINTS = (50, 100, 200, 500)
+if os.environ.get("SMK_LONG_CASE"):              # e.g. SMK_LONG_CASE=BPP,8192,4096,64 SMK_LONG_AT=50,100
+    a, m_, n_, k_ = os.environ["SMK_LONG_CASE"].split(",")
+    CASES = [(a, int(m_), int(n_), int(k_))]
+if os.environ.get("SMK_LONG_AT"):
+    CHECKPOINTS = tuple(int(x) for x in os.environ["SMK_LONG_AT"].split(","))
 
 def child():
     import oracle, smallk_amd
