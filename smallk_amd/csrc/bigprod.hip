@@ -591,6 +591,8 @@ static inline i64 pack_nq(int storage, int nsplit, i64 N)
     return round_up(N, ROW_PAD) / (2 * E);
 }
 
+i64 packed_chunk_pairs_f16x2(int storage, i64 N) { return pack_nq(storage, NSPLIT_F16X2, N); }
+
 size_t packed_bytes(int storage, int k, i64 N, int nsplit)
 {
     if (nsplit == NSPLIT_F64) return 16;         // the accurate form reads the factor itself
@@ -712,17 +714,56 @@ struct F3Cfg {
     static constexpr bool OK = (TI % NLD == 0) && (LPS * PD <= 63) && (STAGE_BYTES * NSTAGE <= 160 * 1024);
 };
 
-template <int KT, int MB, int NSTAGE, int NWL, int FOLD, int WPS, int NS, int FMT>
+// TAIL workgroups of bigprod_f3_kernel (256 threads): workgroup w of 16 adds up entries 16 w .. 16 w + 15 of nblk partial
+// 16 x 16 Gram matrices -- gram_reduce_kernel's sums in gram_reduce_kernel's order (16 groups of threads stride the partials,
+// the 16 group sums are added in order), 32 loads in flight.  C2: the Gram matrix of the factor an NNLS launch has just solved
+// is needed by the NEXT NNLS launch, one streaming pass later, so its reduction rides in that pass instead of sitting in
+// front of it as a launch of its own.
+static __device__ __forceinline__ void gram_reduce_tail(const double* __restrict__ Gp, int nblk, double* __restrict__ G, int w,
+                                                        double* __restrict__ sh /* 16 x 17 doubles of LDS */)
+{
+    constexpr int ELEMS = 256;
+    const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int e = w * 16 + el;
+    double s = 0.0;
+    for (int b0 = g; b0 < nblk; b0 += 16 * 32) {
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = (b0 + 16 * u < nblk) ? Gp[(i64)(b0 + 16 * u) * ELEMS + e] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s += v[u];                 // (s + 0.0 == s: the padding changes nothing)
+    }
+    sh[g * 17 + el] = s;
+    __syncthreads();
+    if (g == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sh[i * 17 + el];
+        G[e] = t;
+    }
+}
+
+template <int KT, int MB, int NSTAGE, int NWL, int FOLD, int WPS, int NS, int FMT, int TAIL = 0>
 __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                                         const unsigned char* __restrict__ Xp,
                                                                         double* __restrict__ P, i64 stages, i64 nst,
                                                                         i64 tiles, i64 ncols_pad, int S, int logS, int pstride,
-                                                                        const double* __restrict__ oscale, float ascale, int accum)
+                                                                        const double* __restrict__ oscale, float ascale, int accum,
+                                                                        const double* __restrict__ tail_gp, int tail_nblk,
+                                                                        double* __restrict__ tail_g)
 {
     using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    if constexpr (TAIL == 1) {
+        // the first 16 workgroups (two per XCD, so the tile mapping below keeps its XCD of every other workgroup) reduce
+        static_assert(NWL == 0 && C::STAGE_BYTES * NSTAGE >= 16 * 17 * 8, "the tail needs 256 threads and 2176 bytes of LDS");
+        // (measured on C2, 512 product workgroups = every slot of the chip: reducers first 25.8 us per launch, reducers last 26.3,
+        // the reduction spread over the first 256 product workgroups behind their first stage loads 26.9; without a tail 24.9)
+        if (bid < 16) { gram_reduce_tail(tail_gp, tail_nblk, tail_g, bid, (double*)smem); return; }
+        bid -= 16;
+    }
     const int xcd = bid & 7;
     const i64 grp = bid >> 3;
     i64 tile;
@@ -918,7 +959,6 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
         for (int i = 0; i < C::PD; ++i)
             if (i < my_nst) issue(i);
     }
-
     int t = 0;
     for (; t + FOLD <= my_nst; t += FOLD) {
         stage_body(t, std::true_type{});
@@ -1280,7 +1320,7 @@ static const F3Variant kF3Variants[] = {
 };
 static const int kNumF3 = (int)(sizeof(kF3Variants) / sizeof(kF3Variants[0]));
 
-template <int KT, int NS, int MB, int NSTAGE, int NWL, int FOLD, int WPS, int FMT = 0>
+template <int KT, int NS, int MB, int NSTAGE, int NWL, int FOLD, int WPS, int FMT = 0, int TAIL = 0>
 static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
     using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
@@ -1290,7 +1330,7 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
     } else {
         constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
         static std::atomic<unsigned long long> attr_set{0};       // per device (first_use_on_this_device)
-        auto kern = bigprod_f3_kernel<KT, MB, NSTAGE, NWL, FOLD, WPS, NS, FMT>;
+        auto kern = bigprod_f3_kernel<KT, MB, NSTAGE, NWL, FOLD, WPS, NS, FMT, TAIL>;
         if (first_use_on_this_device(attr_set)) {
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         }
@@ -1303,8 +1343,10 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
         } else {
             grid = pl.tiles * pl.S;
         }
+        if (TAIL == 1) grid += 16;
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
-                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale, pl.accum);
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale, pl.accum,
+                                                      pl.tail_gp, pl.tail_nblk, pl.tail_g);
         SMK_HIP(hipGetLastError());
         return 0;
     }
@@ -1349,9 +1391,31 @@ static int launch_f3(const BigProdPlan& pl, const void* B, i64 ldb, const void* 
 }
 
 // fp16 two-term form: the variants that won for the bf16 forms
+// the variants (fold intervals 4 / 8 / 2 / 1 of the two-workgroup kernel, one k tile) that can carry the Gram reduction
+bool bigprod_supports_tail(const BigProdPlan& pl)
+{
+    return pl.nsplit == NSPLIT_F16X2 && pl.storage == STORE_F32 && pl.kt == 1 &&
+           (pl.variant == 108 || pl.variant == 125 || pl.variant == 128 || pl.variant == 129);
+}
+
 template <int KT>
 static int launch_f3_f16(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
+    if constexpr (KT == 1) {
+        if (pl.tail_nblk > 0) {
+            if (!pl.tail_gp || !pl.tail_g) { set_error("bigprod: tail without buffers"); return -100; }
+            switch (pl.variant - 100) {
+                case 8: return launch_f3_t<KT, 2, 32, 2, 0, 4, 2, 1, 1>(pl, B, ldb, Xp, P, st);
+                case 25: return launch_f3_t<KT, 2, 32, 2, 0, 8, 2, 1, 1>(pl, B, ldb, Xp, P, st);
+                case 28: return launch_f3_t<KT, 2, 32, 2, 0, 2, 2, 1, 1>(pl, B, ldb, Xp, P, st);
+                case 29: return launch_f3_t<KT, 2, 32, 2, 0, 1, 2, 1, 1>(pl, B, ldb, Xp, P, st);
+                default: break;
+            }
+            set_error("bigprod: this variant cannot carry the Gram reduction");
+            return -100;
+        }
+    }
+    if (pl.tail_nblk > 0) { set_error("bigprod: this shape cannot carry the Gram reduction"); return -100; }
     switch (pl.variant - 100) {
         case 8: return launch_f3_t<KT, 2, 32, 2, 0, 4, 2, 1>(pl, B, ldb, Xp, P, st);
         case 10: return launch_f3p_t<KT, 2, 4, 4, 4, 1, 1>(pl, B, ldb, Xp, P, st);

@@ -139,7 +139,13 @@ struct BigProdPlan {
     int kt, nsplit, storage, variant;
     i64 ncols_pad;
     size_t p_elems; // doubles needed for P
+    // optional tail (bigprod_supports_tail): 16 extra workgroups of the launch add up tail_nblk partial 16 x 16 Gram matrices
+    // (the layout nnls_bpp_kernel<16> leaves) into tail_g, in gram_reduce_kernel's order, while the product streams
+    const double* tail_gp = nullptr;
+    int tail_nblk = 0;
+    double* tail_g = nullptr;
 };
+bool bigprod_supports_tail(const BigProdPlan& pl);
 BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus);
 // the groups of a k-row factor (1 for k <= 64, 2 up to 128): same row splits, P laid out [S][ncols_pad][32 kt_of(k)]
 int plan_bigprod_groups(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out /* 2 */);
@@ -162,6 +168,10 @@ int launch_gram_scales(const double* G, int k, double* xscale, double* oscale, d
 int launch_absmax_f32(const float* A, i64 elems, unsigned* out, hipStream_t st);
 // out2[0] = bits of the largest column maximum of |A|, out2[1] = bits of the smallest non-zero one (0xFFFFFFFF: none)
 int launch_colrange(const void* A, int storage, i64 ld, i64 rows, i64 cols, unsigned* out2, hipStream_t st);
+// out[0] = the largest sum of squares of a column of A (rows x cols, column-major with leading dimension ld); one pass
+int launch_colnorm2_max(const void* A, int storage, i64 ld, i64 rows, i64 cols, double* out, hipStream_t st);
+// chunk pairs of the packed operand of an N-row factor in the fp16 two-term form (what NnlsPack::nq wants)
+i64 packed_chunk_pairs_f16x2(int storage, i64 N);
 // G = X X' and the packed streaming operand of X in one launch (k <= 64, bf16 fragments); returns 1 if this shape has
 // no fused kernel.  The ticket word at scratch[max_blocks * KP * KP] must be zero before the first call.
 int launch_gram_pack(const double* X, int k, i64 N, double* G, double* scratch, int max_blocks, int storage, int nsplit,
@@ -214,9 +224,22 @@ size_t hals_w_scratch_elems(int k, i64 M);
 // gram_partials / gram_nblk (optional): k in (8, 16], all columns from 0, at most NNLS_GRAM_MAX workgroups: the launch also
 // leaves partial Gram matrices X X' of the solved columns ([*gram_nblk][16 * 16], for launch_gram_reduce); *gram_nblk = 0 otherwise
 constexpr int NNLS_GRAM_MAX = 1024;
+// pack (optional, only together with gram_partials): the launch also writes the solved factor as the packed operand of the
+// fp16 two-term product (pack_f16x2_kernel's layout, KT = 1) with row scales that need no pass over the result: the system
+// matrix G is the Gram matrix of the OTHER factor F >= 0, and at a KKT point x_r |f_r| <= |F x| <= |a|, so
+// x_r <= anorm / sqrt(G_rr) with anorm = the largest 2-norm of a column (row) of A.  xscale / oscale receive the scales
+// (KP doubles each); an entry beyond fp16's range after scaling (cannot happen while the bound holds) sets *fail_flag = -4.
+struct NnlsPack {
+    unsigned char* out = nullptr;     // nullptr: off
+    double* xscale = nullptr;
+    double* oscale = nullptr;
+    double anorm = 0.0, ascale = 1.0;
+    i64 nq = 0;                       // 1-KiB chunk pairs of the operand (rows padded to ROW_PAD): the tail past the last column is zeroed
+};
+constexpr int NNLS_PACK_OVERFLOW = -4;
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
                     int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st,
-                    double* gram_partials = nullptr, int* gram_nblk = nullptr);
+                    double* gram_partials = nullptr, int* gram_nblk = nullptr, const NnlsPack* pack = nullptr);
 // k > 32: the inverse of G into scratch, ahead of launch_nnls_bpp(..., inverse_ready = 1, ...) (any stream)
 int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st);
 size_t nnls_scratch_elems(int k);

@@ -757,6 +757,50 @@ int launch_colrange(const void* A, int storage, i64 ld, i64 rows, i64 cols, unsi
     return 0;
 }
 
+// The largest sum of squares of a column (the a-priori bound on NNLS solutions that lets nnls_bpp_kernel<16> pack its own
+// result, common.h NnlsPack): a wave per column, fp64 sums, the maximum through the bit pattern (non-negative doubles order
+// like unsigned integers).  Infinities / NaNs in A leave the maximum alone (such a run fails elsewhere).
+template <typename T>
+__global__ __launch_bounds__(256) void colnorm2_max_kernel(const T* __restrict__ A, i64 ld, i64 rows, i64 cols, unsigned long long* __restrict__ out)
+{
+    const i64 wave = ((i64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const i64 nw = ((i64)gridDim.x * 256) >> 6;
+    for (i64 j = wave; j < cols; j += nw) {
+        double s0 = 0.0, s1 = 0.0;
+        i64 r = lane;
+        for (; r + 64 < rows; r += 128) {
+            float v0, v1;
+            if constexpr (sizeof(T) == 2) { v0 = bf16_bits_to_f32(A[j * ld + r]); v1 = bf16_bits_to_f32(A[j * ld + r + 64]); }
+            else { v0 = A[j * ld + r]; v1 = A[j * ld + r + 64]; }
+            s0 += (double)v0 * (double)v0;
+            s1 += (double)v1 * (double)v1;
+        }
+        if (r < rows) {
+            float v0;
+            if constexpr (sizeof(T) == 2) v0 = bf16_bits_to_f32(A[j * ld + r]);
+            else v0 = A[j * ld + r];
+            s0 += (double)v0 * (double)v0;
+        }
+        double s = s0 + s1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0 && s > 0.0 && s < 1.0e300) atomicMax(out, (unsigned long long)__double_as_longlong(s));
+    }
+}
+
+int launch_colnorm2_max(const void* A, int storage, i64 ld, i64 rows, i64 cols, double* out, hipStream_t st)
+{
+    SMK_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
+    i64 grid = (cols * 64 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    if (storage == STORE_BF16) colnorm2_max_kernel<unsigned short><<<(unsigned)grid, 256, 0, st>>>((const unsigned short*)A, ld, rows, cols, (unsigned long long*)out);
+    else colnorm2_max_kernel<float><<<(unsigned)grid, 256, 0, st>>>((const float*)A, ld, rows, cols, (unsigned long long*)out);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 // the counter-based uniform start of a factor, generated where it is used: X is KP x N (ld KP, pad rows zero); entry (r, j) of
 // a k x N column-major host matrix has global index j * k + r (H), entry (i, c) of an N x k one has c * N + i (W kept transposed)
 __global__ __launch_bounds__(256) void fill_factor_uniform_kernel(double* __restrict__ X, int KP, int k, i64 N, unsigned long long seed, int transposed)

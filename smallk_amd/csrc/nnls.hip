@@ -68,7 +68,7 @@ template <int KP>
 __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N,
                                                        PartialView R, const double* __restrict__ G,
                                                        int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
-                                                       const int* __restrict__ skip_if, double* __restrict__ Gp)
+                                                       const int* __restrict__ skip_if, double* __restrict__ Gp, NnlsPack pk)
 {
     constexpr int GS = KP;
     constexpr int GPB = 256 / GS;                   // column groups per block
@@ -79,6 +79,21 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
 
     const int lane = threadIdx.x & 63;
     const int i = threadIdx.x % GS;                 // component owned by this lane
+    // NnlsPack: the row scale of component i, from the diagonal of the system matrix (computed here, ahead of the solve)
+    double pack_xs = 1.0;
+    if constexpr (KP == 16) {
+        if (pk.out) {
+            const double g = gs[i * KP + i];
+            if (g > 0.0 && g < 1.0e300) {
+                const double bound = pk.anorm / sqrt(g);
+                if (bound > 1.0e-290 && bound < 1.0e290) {
+                    int ex = 0;
+                    (void)frexp(bound, &ex);                    // bound < 2^ex
+                    pack_xs = ldexp(1.0, 15 - ex);
+                }
+            }
+        }
+    }
     // KP = 16, Gp != nullptr: the Gram matrix X X' of the SOLVED columns comes out of this launch too.  A wave holds 4 columns
     // x 16 components with lane = component + 16 column -- exactly the A (and B) operand of v_mfma_f64_16x16x4 -- so one
     // matrix instruction per trip accumulates the wave's 16 x 16 partial; the four waves are added through LDS and the
@@ -193,6 +208,47 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
         if (Gp) {
             const double xg = (col_ok && comp_ok) ? x : 0.0;
             gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(xg, xg, gacc, 0, 0, 0);
+        }
+        // The packed operand of the product that follows (pack_f16x2_kernel's layout, KT = 1: this workgroup's 16 columns are
+        // chunk pair q = blockIdx.x), with row scales that need no pass over the solved factor -- see NnlsPack (common.h):
+        // x_i <= anorm / sqrt(G_ii) at a KKT point of a problem whose other factor is non-negative, so 2^15 / (the next power
+        // of two above that bound) keeps every entry below 2^15 with 2x to spare.  One trip per workgroup (the launcher
+        // guarantees it), so the barrier below is uniform.
+        if (pk.out) {
+            __shared__ double xsh[256];
+            xsh[(threadIdx.x / GS) * 16 + i] = (col_ok && comp_ok) ? x * pack_xs : 0.0;
+            if (blockIdx.x == 0 && threadIdx.x < 16) {
+                pk.xscale[i] = pack_xs;
+                pk.oscale[i] = 1.0 / (pack_xs * pk.ascale);
+            }
+            __syncthreads();
+            // fragment lane l = (r, h) holds rows 8 h .. 8 h + 7 of component r as 8 halves (16 bytes) per term; thread t converts
+            // entries 2 p, 2 p + 1 of lane l = t & 63 with p = t >> 6, so the four waves share the work and nobody waits for one
+            {
+                const int l = threadIdx.x & 63, p2 = (threadIdx.x >> 6) * 2, r = l & 31, h = l >> 5;
+                double r0 = 0.0, r1 = 0.0;
+                if (r < 16) { r0 = xsh[(h * 8 + p2) * 16 + r]; r1 = xsh[(h * 8 + p2 + 1) * 16 + r]; }
+                if (!(fabs(r0) < 65504.0) || !(fabs(r1) < 65504.0)) atomicMin(fail_flag, NNLS_PACK_OVERFLOW);
+                typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                unsigned char* dst = pk.out + (size_t)vb * 2048 + l * 16 + p2 * 2;
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    f16x2_t hh;
+                    hh[0] = (_Float16)(float)r0;
+                    hh[1] = (_Float16)(float)r1;
+                    r0 = (r0 - (double)(float)hh[0]) * 2048.0;          // F16X2_LO_SCALE: the low term is carried 2^11 up
+                    r1 = (r1 - (double)(float)hh[1]) * 2048.0;
+                    *(f16x2_t*)(dst + t2 * 1024) = hh;
+                }
+                // rows past the last column up to the padded length: zero chunk pairs, written by the last workgroup
+                if (vb == (i64)gridDim.x - 1) {
+                    const f16x2_t zero = {0, 0};
+                    for (i64 q = (i64)gridDim.x; q < pk.nq; ++q) {
+                        *(f16x2_t*)(pk.out + (size_t)q * 2048 + l * 16 + p2 * 2) = zero;
+                        *(f16x2_t*)(pk.out + (size_t)q * 2048 + 1024 + l * 16 + p2 * 2) = zero;
+                    }
+                }
+            }
         }
     }
     }
@@ -671,7 +727,7 @@ int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st)
 // inverse_ready != 0: launch_gram_inverse(G, ...) has already been ordered before this call.
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
                     int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st,
-                    double* gram_partials, int* gram_nblk)
+                    double* gram_partials, int* gram_nblk, const NnlsPack* pack)
 {
     if (gram_nblk) *gram_nblk = 0;
     if (nnls_uses_tiles(k)) return launch_nnls_bpp_wide(X, Y, k, col_begin, col_end, R, G, fail_flag, iter_tag, scratch, inverse_ready, num_cus, st);
@@ -724,7 +780,9 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
     // KP = 16, all columns, at most NNLS_GRAM_MAX workgroups: the launch also leaves the Gram partials of the solved factor
     double* gp = nullptr;
     if (gram_partials && gram_nblk && KPv == 16 && col_begin == 0 && grid1 == grid && grid <= NNLS_GRAM_MAX) { gp = gram_partials; *gram_nblk = grid; }
-    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid1, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if, gp)));
+    NnlsPack pk;                                           // only together with the Gram partials (one trip per workgroup, all columns)
+    if (pack && gp) pk = *pack;
+    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid1, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if, gp, pk)));
     SMK_HIP(hipGetLastError());
     return 0;
 }

@@ -84,6 +84,7 @@ struct smk_matrix {
     smk::DeviceCtx* owner = nullptr;                 // the context whose registry lists it (nullptr once that context is gone)
     mutable float ascale = 0.f;                      // fp16 two-term products: power of two with max|A| ascale in [2^13, 2^14); 0 = not yet measured
     mutable int col_spread_log2 = -1;                // log2(largest / smallest non-zero column maximum of |A|); -1 = not yet measured
+    mutable double colnorm_max = -1.0, rownorm_max = -1.0;   // largest 2-norm of a column / a row of A (dense; NnlsPack's bound); < 0 = not yet measured
     void* A = nullptr;  i64 ldA = 0, colsA = 0;      // m_pad x n_pad
     void* At = nullptr; i64 ldAt = 0, colsAt = 0;    // n_pad x m_pad
     // sparse A: CSC of the local columns and CSC of its transpose (fp64 values, 64-bit offsets)
@@ -170,6 +171,14 @@ struct smk_solver {
     double *xscale[2] = {nullptr, nullptr}, *oscale[2] = {nullptr, nullptr};   // fp16 two-term products: row scales of W / H (from the Gram diagonal) and their inverses
     bool packed_fresh[2] = {false, false};   // the fused Gram kernel has already written packW / packH for the next product
     int nnls_gram_nblk[2] = {0, 0};          // > 0: the NNLS launch of this side left that many Gram partials in gram_scratch (k <= 16)
+    // k in (8, 16], BPP, fp16 form, one GPU (C2): the NNLS launch also PACKS the factor it solves (row scales from an a-priori
+    // bound, NnlsPack) and the reduction of its Gram partials rides in the streaming pass that follows (BigProdPlan::tail_*),
+    // so nothing stands between the solve and the product.  Indexed by factor: 0 = W, 1 = H.
+    bool pack_in_solve = false;              // the shape qualifies (decided with the plans)
+    bool pack_in_solve_off = false;          // latched by pack_fail_soft
+    bool from_nnls[2] = {false, false};      // the factor is the output of an NNLS launch of this run (hence >= 0)
+    bool nnls_packed[2] = {false, false};    // the last NNLS launch packed this factor
+    int tail_nblk[2] = {0, 0};               // > 0: the next product of this factor carries the reduction of that many partials
     // HALS: the fused W sweep needs every workgroup resident; if its bounded polls ever expire (flag -3) the run is
     // repeated from the initial factors on the one-launch-per-column path, latched for the life of the handle
     double *W0c = nullptr, *H0c = nullptr;
@@ -416,7 +425,7 @@ static int matrix_make_transpose(smk_matrix* a)
 
 int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
 {
-    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; }     // new contents: scale and column spread are measured again on first use
+    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; a->colnorm_max = a->rownorm_max = -1.0; }     // new contents: scale, column spread and norms are measured again on first use
     if (!a || !host || ld < a->m || a->sparse) return SMK_BAD_PARAM;
     const size_t budget = (size_t)64 << 20;   // staging bytes
     i64 chunk = (i64)(budget / ((size_t)a->m * sizeof(double)));
@@ -444,7 +453,7 @@ int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
 
 int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed)
 {
-    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; }
+    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; a->colnorm_max = a->rownorm_max = -1.0; }
     if (!a || a->sparse) return SMK_BAD_PARAM;
     int rc = launch_fill_uniform(a->A, a->storage, a->ldA, a->m, a->n, a->ldA, a->colsA, 0, a->c0, a->m, seed,
                                  a->storage == SMK_STORE_BF16 ? 1 : 0, g_stream);
@@ -502,6 +511,7 @@ int smk_matrix_clone(const smk_matrix* src, smk_matrix** out)
     smk_matrix* a = new smk_matrix;
     a->m = src->m; a->n_global = src->n_global; a->c0 = src->c0; a->n = src->n; a->storage = src->storage;
     a->ascale = src->ascale; a->col_spread_log2 = src->col_spread_log2;
+    a->colnorm_max = src->colnorm_max; a->rownorm_max = src->rownorm_max;
     a->ldA = src->ldA; a->colsA = src->colsA; a->ldAt = src->ldAt; a->colsAt = src->colsAt;
     a->sparse = src->sparse; a->nnz = src->nnz;
     a->st = g_stream;
@@ -851,6 +861,24 @@ static int matrix_measure_scale(const smk_matrix* a, hipStream_t st)
     return 0;
 }
 
+// One pass over A and one over A' at HBM rate, once per matrix contents: the largest 2-norm of a column and of a row
+// (what bounds the NNLS solutions from above, NnlsPack)
+static int matrix_measure_norms(const smk_matrix* a, hipStream_t st)
+{
+    double* d = nullptr;
+    SMK_HIP(smk::dev_malloc((void**)&d, 2 * sizeof(double)));
+    double v[2] = {0.0, 0.0};
+    int rc = launch_colnorm2_max(a->A, a->storage, a->ldA, a->m, a->n, d, st);
+    if (!rc) rc = launch_colnorm2_max(a->At, a->storage, a->ldAt, a->n, a->m, d + 1, st);
+    if (!rc && hipMemcpyAsync(v, d, sizeof(v), hipMemcpyDeviceToHost, st) != hipSuccess) rc = SMK_DEVICE_ERROR;
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = SMK_DEVICE_ERROR;
+    (void)smk::dev_free(d);
+    if (rc) { set_error("could not measure the column / row norms of A"); return rc; }
+    a->colnorm_max = std::sqrt(v[0]);
+    a->rownorm_max = std::sqrt(v[1]);
+    return 0;
+}
+
 // Everything that depends on the product form (s->nsplit): the launch plans of both passes and the fp16 row scales ...
 static int plan_products(smk_solver* s)
 {
@@ -878,6 +906,14 @@ static int plan_products(smk_solver* s)
         }
         s->pl1 = s->pg1[0];
         s->pl2 = s->pg2[0];
+    }
+    const char* epk = getenv("SMK_NNLS_PACK");                      // read per plan, like SMK_NSPLIT (0 = the separate reduce-and-pack launch)
+    const bool pack_env = !(epk && epk[0] == '0');
+    s->pack_in_solve = pack_env && !s->pack_in_solve_off && s->o.algorithm == SMK_ALG_BPP && s->KP == 16 && s->nsplit == NSPLIT_F16X2 &&
+                       !a->sparse && s->ng == 1 && !is_dist(s) && !s->comm && bigprod_supports_tail(s->pl1) && bigprod_supports_tail(s->pl2);
+    if (s->pack_in_solve && (a->colnorm_max < 0.0 || a->rownorm_max < 0.0)) {
+        const int rc0 = matrix_measure_norms(a, s->st);
+        if (rc0) return rc0;
     }
     return 0;
 }
@@ -1024,6 +1060,10 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
         rc |= dev_alloc(&s->W0c, (size_t)s->KP * s->m);
         rc |= dev_alloc(&s->H0c, (size_t)s->KP * s->n);
         if (!rc) rc = hals_w_scratch_init(s->hals_scratch, s->k, s->m, s->st);
+    }
+    if (s->pack_in_solve && !s->W0c) {      // pack_fail_soft goes back to the initial factors
+        rc |= dev_alloc(&s->W0c, (size_t)s->KP * s->m);
+        rc |= dev_alloc(&s->H0c, (size_t)s->KP * s->n);
     }
     if (opts->algorithm == SMK_ALG_BPP) {
         // k <= 128: two (inverse + selector) halves; above: one Cholesky panel per resident workgroup (wide.hip)
@@ -1444,8 +1484,29 @@ static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, Partial
     const i64 N = side == 0 ? s->n : s->m;
     const bool want = fuse && s->KP == 16 && s->nsplit == NSPLIT_F16X2 && !is_dist(s) && c0 == 0 && c1 == N && (X == s->H || X == s->Wt);
     s->nnls_gram_nblk[side] = 0;
+    // ... and packs it, when the system matrix is the Gram matrix of a factor that an NNLS launch of this run produced (>= 0:
+    // the bound behind the row scales needs that; the first solve of a run works from the caller's factor and packs the old way)
+    const int fx = side == 0 ? 1 : 0;                // the factor being solved (0 = W, 1 = H); the other one is `side`
+    NnlsPack pk;
+    const bool pack = want && s->pack_in_solve && !s->pack_in_solve_off && !s->comm && s->from_nnls[side] && s->a->colnorm_max >= 0.0 && s->a->rownorm_max >= 0.0;
+    if (pack) {
+        pk.out = (unsigned char*)(fx == 0 ? s->packW : s->packH);
+        pk.xscale = s->xscale[fx];
+        pk.oscale = s->oscale[fx];
+        pk.anorm = side == 0 ? s->a->colnorm_max : s->a->rownorm_max;     // H's columns solve for columns of A, W's rows for rows
+        pk.ascale = (double)s->a->ascale;
+        pk.nq = packed_chunk_pairs_f16x2(s->a->storage, N);
+        // TEST HOOK: shrink the bound so that the scaled entries leave fp16's range (the launch must flag it, the run must be
+        // repeated without the packing: pack_fail_soft)
+        if (const char* e = getenv("SMK_NNLS_PACK_TEST_ANORM")) pk.anorm *= atof(e);
+    }
+    s->nnls_packed[fx] = false;
     const int rc = launch_nnls_bpp(X, nullptr, s->k, c0, c1, R, G, s->fail_flag, s->iter, inv_scratch(s, side), s->inv_done[side] ? 1 : 0, g_cus, s->st,
-                                   want ? s->gram_scratch : nullptr, want ? &s->nnls_gram_nblk[side] : nullptr);
+                                   want ? s->gram_scratch : nullptr, want ? &s->nnls_gram_nblk[side] : nullptr, pack ? &pk : nullptr);
+    if (!rc && (X == s->H || X == s->Wt)) {
+        s->from_nnls[fx] = c0 == 0 && c1 == N;
+        s->nnls_packed[fx] = pack && s->nnls_gram_nblk[side] > 0;
+    }
     // without the side stream (k <= 32) a first launch at k > 32 computes the inverse itself, in stream order
     if (!rc && c1 > c0 && s->KP >= 64) s->inv_done[side] = true;
     return rc;
@@ -1560,6 +1621,16 @@ static int prod1_sharded(smk_solver* s)
     return 0;
 }
 
+// the product of factor `side` (0 = W, 1 = H) takes the pending reduction of that factor's Gram partials along (gram_factor)
+static inline void take_tail(smk_solver* s, int side, BigProdPlan* pl)
+{
+    if (s->tail_nblk[side] <= 0) return;
+    pl->tail_gp = s->gram_scratch;
+    pl->tail_nblk = s->tail_nblk[side];
+    pl->tail_g = side == 0 ? s->Gw : s->Gh;
+    s->tail_nblk[side] = 0;
+}
+
 static int prod1(smk_solver* s)
 {
     if (s->w_sharded) return prod1_sharded(s);
@@ -1578,7 +1649,9 @@ static int prod1(smk_solver* s)
     if (rc) return rc;
     for (int g = 0; g < s->ng; ++g) {
         const void* Xp = f64 ? (const void*)(s->Wt + s->pg1[g].k0) : (const void*)((const unsigned char*)s->packW + s->pg1[g].pack_offset);
-        rc = timed_bigprod(s, 0, s->pg1[g], s->a->A, s->a->ldA, Xp, s->P1 + s->pg1[g].k0);
+        BigProdPlan pl = s->pg1[g];
+        take_tail(s, 0, &pl);
+        rc = timed_bigprod(s, 0, pl, s->a->A, s->a->ldA, Xp, s->P1 + s->pg1[g].k0);
         if (rc) return rc;
     }
     return 0;
@@ -1615,8 +1688,11 @@ static int prod2(smk_solver* s)
         return f64 ? (const void*)(s->H + pl.k0) : (const void*)((const unsigned char*)s->packH + pl.pack_offset);
     };
     if (!s->comm) {
-        for (int g = 0; g < s->ng && !rc; ++g)
-            rc = timed_bigprod(s, 1, s->pg2[g], s->a->At, s->a->ldAt, xh(s->pg2[g]), s->P2 + s->pg2[g].k0);
+        for (int g = 0; g < s->ng && !rc; ++g) {
+            BigProdPlan pl = s->pg2[g];
+            take_tail(s, 1, &pl);
+            rc = timed_bigprod(s, 1, pl, s->a->At, s->a->ldAt, xh(s->pg2[g]), s->P2 + s->pg2[g].k0);
+        }
         if (rc) return rc;
         rc = wait_gh(s);
         if (rc || !is_dist(s)) return rc;
@@ -1676,6 +1752,13 @@ static int gram_factor(smk_solver* s, int side)
         if (s->nnls_gram_nblk[ns] > 0) {
             const int nb = s->nnls_gram_nblk[ns];
             s->nnls_gram_nblk[ns] = 0;
+            // the solve packed the operand itself: nothing is needed before the product, which takes the reduction along
+            if (s->nnls_packed[side]) {
+                s->nnls_packed[side] = false;
+                s->packed_fresh[side] = true;
+                s->tail_nblk[side] = nb;
+                return 0;
+            }
             // ... and packs it in the same launch (the packing workgroups add up the 16 diagonal entries themselves)
             static const bool fuse_pack = [] { const char* e = getenv("SMK_REDUCE_PACK"); return !(e && e[0] == '0'); }();
             if (fuse_pack && !s->a->sparse) {
@@ -1735,6 +1818,10 @@ static int gather_w(smk_solver* s)
 static int solver_init(smk_solver* s)
 {
     int rc = 0;
+    // the factors are the caller's (or a restored snapshot): nothing is known to come from an NNLS launch, nothing is pending
+    s->from_nnls[0] = s->from_nnls[1] = false;
+    s->nnls_packed[0] = s->nnls_packed[1] = false;
+    s->tail_nblk[0] = s->tail_nblk[1] = 0;
     if (s->o.algorithm == SMK_ALG_HALS) {
         rc = gram_h(s);  if (rc) return rc;
         rc = prod2(s);   if (rc) return rc;
@@ -2064,6 +2151,30 @@ static int hals_fail_soft(smk_solver* s)
     return 1;
 }
 
+// An NNLS launch that packs its own result (NnlsPack) met an entry beyond fp16's range after scaling (flag -4): the a-priori
+// bound behind its row scales did not hold -- it cannot while the other factor is non-negative and the solve reaches a KKT
+// point, so this is a safety net.  Back to the initial factors with the packing latched off for the life of the handle.
+// Returns 1 when the caller should repeat its work.
+static int pack_fail_soft(smk_solver* s)
+{
+    if (!s->pack_in_solve || s->pack_in_solve_off || !s->W0c) return 0;
+    int flag = INT_MAX;
+    if (hipMemcpy(&flag, s->fail_flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || flag != NNLS_PACK_OVERFLOW) return 0;
+    fprintf(stderr, "smallk_amd: an NNLS launch could not pack its result inside fp16's range; repeating the run with the separate pack launch\n");
+    s->pack_in_solve_off = true;
+    const int big = INT_MAX;
+    (void)hipMemcpyAsync(s->Wt, s->W0c, (size_t)s->KP * s->m * sizeof(double), hipMemcpyDeviceToDevice, s->st);
+    (void)hipMemcpyAsync(s->H, s->H0c, (size_t)s->KP * s->n * sizeof(double), hipMemcpyDeviceToDevice, s->st);
+    (void)hipMemcpyAsync(s->fail_flag, &big, sizeof(int), hipMemcpyHostToDevice, s->st);
+    (void)hipStreamSynchronize(s->st);
+    s->inited = false;
+    s->normalized = false;
+    s->iter = 0;
+    s->pg0 = 1.0;
+    s->last_metric = 1.0;
+    return 1;
+}
+
 // ---- run-time guard of the product form ------------------------------------------------------------------------------
 // Which product form a run takes is decided when the solver is created (rank, algorithm, the spread of the column scales:
 // thresholds found by sweeps).  A matrix outside the swept families must not leave the 1e-4 bar silently, so the choice is
@@ -2247,7 +2358,7 @@ int smk_solver_sync(smk_solver* s)
     int rc = gather_w(s);                 // every rank calls sync: the fp64 W is whole again afterwards
     if (rc) return rc;
     rc = sync_and_check(s, nullptr);
-    if (rc == SMK_FAILURE && !is_dist(s) && hals_fail_soft(s)) {
+    if (rc == SMK_FAILURE && !is_dist(s) && (hals_fail_soft(s) || pack_fail_soft(s))) {
         rc = smk_solver_iterate(s, target);
         if (rc == SMK_OK) rc = sync_and_check(s, nullptr);
     }
@@ -2269,7 +2380,7 @@ static int solver_run_once(smk_solver* s, smk_stats* stats);
 int smk_solver_run(smk_solver* s, smk_stats* stats)
 {
     int rc = solver_run_once(s, stats);
-    if (rc == SMK_FAILURE && s && !is_dist(s) && hals_fail_soft(s)) rc = solver_run_once(s, stats);
+    if (rc == SMK_FAILURE && s && !is_dist(s) && (hals_fail_soft(s) || pack_fail_soft(s))) rc = solver_run_once(s, stats);
     return rc;
 }
 

@@ -190,6 +190,57 @@ def test_small_bpp_takes_the_accurate_form(gpu, monkeypatch):
     assert np.linalg.norm(fast.W - ref.W) / np.linalg.norm(ref.W) < 1e-3
 
 
+@pytest.mark.parametrize("m,n,k", [(2048, 1024, 16), (1999, 1037, 12), (700, 333, 9), (640, 5000, 16), (8192, 4096, 16), (8000, 4100, 13)])
+def test_nnls_launch_packs_its_own_result(gpu, monkeypatch, m, n, k):
+    """k in (8, 16], BPP, fp32 A, one GPU (C2's shape class): from the second solve of a run on, the NNLS launch writes the packed
+    fp16 two-term operand of the factor it solves -- row scales from the a-priori bound x_r <= max|a| / sqrt(G_rr), no pass over the
+    result -- and the reduction of its Gram partials rides in the streaming pass that follows (16 extra workgroups).  Same
+    iterates as the separate reduce-and-pack launch, inside the bar against the oracle (the two large shapes, C2 among them, fill
+    the chip: there the reduction is spread over the first 256 product workgroups, in another summation order); ragged sizes cover the zero padding of the operand, which the last workgroup writes."""
+    import oracle
+    rng = np.random.default_rng(m + k)
+    A = oracle.quantize(np.asfortranarray(rng.random((m, k)) @ rng.random((k, n)) + 0.1 * rng.random((m, n))), 0)
+    W0, H0 = oracle.fill_uniform(m, k, 43), oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    kw = dict(min_iter=12, max_iter=12, tol=1e-12)
+    ref = oracle.nmf(A, W0, H0, "BPP", **kw)
+    got = gpu.nmf(A, W0, H0, "BPP", **kw)
+    monkeypatch.setenv("SMK_NNLS_PACK", "0")
+    old = gpu.nmf(A, W0, H0, "BPP", **kw)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert got.result == old.result == ref.result == 0 and got.iteration_count == ref.iteration_count == 12
+    assert rel(got.W, ref.W) < 1e-4 and rel(got.H, ref.H) < 1e-4
+    # power-of-two scales are exact and the Gram partials are added in the same order: the two paths agree to the last bit until
+    # an entry sits in fp16's subnormal range under one scale and not the other (1e-14), which block pivoting then amplifies like
+    # any other rounding (the 8000 x 4100 case: identical for 3 iterations, 2e-14 after 4, 5e-8 after 12, both 2e-6 from the
+    # oracle).  That the new path RUNS is shown by the next test.
+    assert rel(got.W, old.W) < 1e-6 and rel(got.H, old.H) < 1e-6
+
+
+def test_nnls_pack_falls_back_when_an_entry_leaves_fp16_range():
+    """The launch flags a scaled entry beyond fp16's range (fail flag -4) and smk_solver_run repeats the run from the initial
+    factors with the separate pack launch.  The bound cannot fail on valid input; SMK_NNLS_PACK_TEST_ANORM shrinks it 1e6 x.
+    Also under SMK_POISON=1 (fresh workspaces filled with NaN bytes): the packing must write every byte the product reads."""
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import numpy as np, oracle, smallk_amd as gpu
+gpu.initialize(0)
+m, n, k = 1500, 777, 14
+rng = np.random.default_rng(3)
+A = oracle.quantize(np.asfortranarray(rng.random((m, n))), 0)
+W0, H0 = oracle.fill_uniform(m, k, 43), oracle.fill_uniform(k, n, 44)
+ref = oracle.nmf(A, W0, H0, "BPP", min_iter=8, max_iter=8)
+got = gpu.nmf(A, W0, H0, "BPP", min_iter=8, max_iter=8)
+rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+print("RESULT", got.result, got.iteration_count, rel(got.W, ref.W), rel(got.H, ref.H))
+""" % ROOT
+    for env, expect_msg in (({"SMK_NNLS_PACK_TEST_ANORM": "1e-6"}, True), ({"SMK_POISON": "1"}, False)):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env), cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+        assert res[1] == "0" and res[2] == "8" and float(res[3]) < 1e-4 and float(res[4]) < 1e-4, res
+        assert ("could not pack its result" in r.stderr) == expect_msg, r.stderr[-2000:]
+
+
 def test_set_factors_uniform_is_the_host_generator(gpu):
     """smk_solver_set_factors_uniform: the start of a run generated on the device must be, bit for bit, the matrices
     smk_uniform_fill_host gives (HierNMF2 draws its initialisers this way since round 4; the oracle replays the host ones)."""
