@@ -768,6 +768,9 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
     const i64 grp = bid >> 3;
     i64 tile;
     int split;
+    // (the other assignment -- every row split of a column tile on ONE XCD, so that a tile's pages of B are touched through one
+    // XCD only while the operand chunks go through every L2 -- measures the same within noise on five C4-sized shapes:
+    // profiles/r04_xcd_mapping_sweep.txt)
     if (S <= 8) {
         split = xcd & (S - 1);
         tile = grp * (8 >> logS) + (xcd >> logS);
