@@ -199,6 +199,12 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
         }
     }
 
+    // The reference zeroizes the WHOLE X and Y after every pivoting round (nnls.hpp:224-225), i.e. also the columns that never
+    // pivot -- as soon as ANY column of the solve does, which a workgroup cannot know.  Some column pivots in practically every
+    // solve of a run that has not converged, so the columns that never pivot are zeroized here as well (the columns that did
+    // pivot already are).  Differs from the reference only in solves where no column at all pivots, by entries below 1e-12.
+    if (fabs(x) < 1.0e-12) x = 0.0;
+    if (fabs(y) < 1.0e-12) y = 0.0;
     if (col_ok && comp_ok) {
         X[col * KP + i] = x;
         if (Y) Y[col * KP + i] = y;
@@ -228,7 +234,10 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
                 const int l = threadIdx.x & 63, p2 = (threadIdx.x >> 6) * 2, r = l & 31, h = l >> 5;
                 double r0 = 0.0, r1 = 0.0;
                 if (r < 16) { r0 = xsh[(h * 8 + p2) * 16 + r]; r1 = xsh[(h * 8 + p2 + 1) * 16 + r]; }
-                if (!(fabs(r0) < 65504.0) || !(fabs(r1) < 65504.0)) atomicMin(fail_flag, NNLS_PACK_OVERFLOW);
+                // (finite values only: a solve that met a non-positive pivot leaves inf / NaN behind and has raised the failure
+                // flag itself; that run fails as the reference's does and must not be repeated)
+                const double a0 = fabs(r0), a1 = fabs(r1);
+                if ((a0 >= 65504.0 && a0 < 1.0e300) || (a1 >= 65504.0 && a1 < 1.0e300)) atomicMin(fail_flag, NNLS_PACK_OVERFLOW);
                 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
                 unsigned char* dst = pk.out + (size_t)vb * 2048 + l * 16 + p2 * 2;
 #pragma unroll
@@ -527,6 +536,8 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
             ng = __popcll(nonopt) + __popcll(infeas);
             ++iter;
         }
+        if (fabs(x) < 1.0e-12) x = 0.0;              // columns that never pivot are zeroized too (nnls_bpp_kernel's note)
+        if (fabs(y) < 1.0e-12) y = 0.0;
         if (comp_ok) {
             X[col * KP + lane] = x;
             if (Y) Y[col * KP + lane] = y;
@@ -689,6 +700,10 @@ __global__ __launch_bounds__(NT) void nnls_bpp_inv128_kernel(double* __restrict_
             ng = __popcll(no0) + __popcll(no1) + __popcll(in0) + __popcll(in1);
             ++iter;
         }
+        if (fabs(x0) < 1.0e-12) x0 = 0.0;            // columns that never pivot are zeroized too (nnls_bpp_kernel's note)
+        if (fabs(x1) < 1.0e-12) x1 = 0.0;
+        if (fabs(y0) < 1.0e-12) y0 = 0.0;
+        if (fabs(y1) < 1.0e-12) y1 = 0.0;
         X[col * KP + lane] = x0;
         if (ok1) X[col * KP + 64 + lane] = x1;
         if (Y) {

@@ -1024,9 +1024,10 @@ __global__ __launch_bounds__(256) void nnls_wide_kernel(double* __restrict__ X, 
             ng = s_ng;
             ++iter;
         }
-        for (int e = tid; e < k; e += 256) {
-            X[col * KP + e] = xs[e];
-            if (Y) Y[col * KP + e] = ys[e];
+        for (int e = tid; e < k; e += 256) {          // columns that never pivot are zeroized too (nnls_bpp_kernel's note)
+            const double xo = xs[e], yo = ys[e];
+            X[col * KP + e] = fabs(xo) < 1.0e-12 ? 0.0 : xo;
+            if (Y) Y[col * KP + e] = fabs(yo) < 1.0e-12 ? 0.0 : yo;
         }
         failed_any |= failed ? 1 : 0;
         __syncthreads();
@@ -1526,9 +1527,10 @@ __global__ __launch_bounds__(256) void nnls_wide_tile_kernel(double* __restrict_
             failed = solve_and_classify(true);
             ++iter;
         }
-        for (int e = gt; e < k; e += GS) {
-            X[col * KP + e] = xs[e];
-            if (Y) Y[col * KP + e] = ys[e];
+        for (int e = gt; e < k; e += GS) {            // columns that never pivot are zeroized too (nnls_bpp_kernel's note)
+            const double xo = xs[e], yo = ys[e];
+            X[col * KP + e] = fabs(xo) < 1.0e-12 ? 0.0 : xo;
+            if (Y) Y[col * KP + e] = fabs(yo) < 1.0e-12 ? 0.0 : yo;
         }
         failed_any |= failed ? 1 : 0;
         group_sync<NW>();
