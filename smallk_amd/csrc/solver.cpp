@@ -1306,6 +1306,10 @@ int smk_solver_set_factors(smk_solver* s, const double* W0, int64_t ldW, const d
         for (int g = 0; g < s->ng; ++g) s->pg1[g].ascale = s->pg2[g].ascale = s->a->ascale;
         s->pl1.ascale = s->pl2.ascale = s->a->ascale;
     }
+    if (s->pack_in_solve && (s->a->colnorm_max < 0.0 || s->a->rownorm_max < 0.0)) {      // ... and so do the norms behind the packing NNLS launch
+        const int rc0 = matrix_measure_norms(s->a, s->st);
+        if (rc0) return rc0;
+    }
     // pad rows of the KP x N device layout must be (and stay) zero
     SMK_HIP(hipMemsetAsync(s->Wt, 0, (size_t)s->KP * s->m * sizeof(double), s->st));
     SMK_HIP(hipMemsetAsync(s->H, 0, (size_t)s->KP * s->n * sizeof(double), s->st));
@@ -1346,6 +1350,10 @@ int smk_solver_set_factors_uniform(smk_solver* s, uint64_t seed_w, uint64_t seed
         if (s->a->ascale == 0.f) { const int rc0 = matrix_measure_scale(s->a, s->st); if (rc0) return rc0; }
         for (int g = 0; g < s->ng; ++g) s->pg1[g].ascale = s->pg2[g].ascale = s->a->ascale;
         s->pl1.ascale = s->pl2.ascale = s->a->ascale;
+    }
+    if (s->pack_in_solve && (s->a->colnorm_max < 0.0 || s->a->rownorm_max < 0.0)) {      // ... and so do the norms behind the packing NNLS launch
+        const int rc0 = matrix_measure_norms(s->a, s->st);
+        if (rc0) return rc0;
     }
     int rc = launch_fill_factor_uniform(s->Wt, s->k, s->m, seed_w, 1, s->st);
     if (!rc) rc = launch_fill_factor_uniform(s->H, s->k, s->n, seed_h, 0, s->st);

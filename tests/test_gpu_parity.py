@@ -502,9 +502,12 @@ def test_fp32_product_forms_agree(gpu, monkeypatch):
     assert rel(out["2"].W, ref.W) < 1e-2
 
 
-def test_matrix_refilled_under_a_live_solver(gpu):
+@pytest.mark.parametrize("alg", ["HALS", "BPP"])
+def test_matrix_refilled_under_a_live_solver(gpu, alg):
     """smk_matrix_upload_f64 on a matrix that already has a solver: the power-of-two scale of the fp16 products is
-    measured again (the second matrix is 2^30 times larger than the first)"""
+    measured again (the second matrix is 2^30 times larger than the first) -- and, for block pivoting at k <= 16, the row /
+    column norms behind the packing NNLS launch (with the first matrix's norms the bound would be 2^30 too small: every entry
+    would leave fp16's range)"""
     from smallk_amd import DenseMatrix, NmfSolver, make_options
     m, n, k = 256, 192, 12
     A1 = mg.make_A(m, n, k, True, 0)
@@ -512,13 +515,13 @@ def test_matrix_refilled_under_a_live_solver(gpu):
     W0 = oracle.fill_uniform(m, k, 43)
     H0 = oracle.fill_uniform(k, n, 44)
     D = DenseMatrix.from_host(A1)
-    s = NmfSolver(D, make_options(m, n, k, "HALS", min_iter=4, max_iter=4))
+    s = NmfSolver(D, make_options(m, n, k, alg, min_iter=4, max_iter=4))
     for A, h0 in ((A1, H0), (A2, np.ldexp(H0, 30))):
         D.upload(A)
         s.set_factors(W0, h0)
         rc, it, _ = s.run()
         W, H = s.factors()
-        ref = oracle.nmf(A, W0, h0, "HALS", min_iter=4, max_iter=4)
+        ref = oracle.nmf(A, W0, h0, alg, min_iter=4, max_iter=4)
         assert rc == 0 and rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
     s.close()
     D.close()
