@@ -399,6 +399,16 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
     a->ldA = round_up(height, ROW_PAD);      a->colsA = round_up(ncols_local, COL_PAD);
     a->ldAt = round_up(ncols_local, ROW_PAD); a->colsAt = round_up(height, COL_PAD);
     const size_t es = (size_t)elem_size(storage);
+    // A column stride that is a multiple of 1 MiB gets ROW_PAD more (zero) rows: with the 128 columns of a workgroup's stage
+    // exactly 2^20 bytes apart the W'A pass of C4 runs 3 % slower (11.3 -> 10.95 ms) and that of a C4 shard 8 % (1.60 ->
+    // 1.47 ms; bench.py --emulate-world 8: 3.28 -> 3.15 ms per rank).  Smaller power-of-two strides are best left alone
+    // (C3: 128 KiB and 32 KiB strides, skewed: 1200 -> 1130 / 980 it/s); 256 and 384 rows more gain less than 128.
+    // SMK_LD_SKEW=0 turns it off, =n asks for n rows.  (profiles/r04_leading_dimension_skew.txt)
+    {
+        static const i64 skew = [] { const char* e = getenv("SMK_LD_SKEW"); return e ? (i64)atoll(e) / ROW_PAD * ROW_PAD : ROW_PAD; }();
+        if (skew > 0 && ((size_t)a->ldA * es) % ((size_t)1 << 20) == 0) a->ldA += skew;
+        if (skew > 0 && ((size_t)a->ldAt * es) % ((size_t)1 << 20) == 0) a->ldAt += skew;
+    }
     hipError_t e1 = smk::dev_malloc(&a->A, (size_t)a->ldA * a->colsA * es);
     hipError_t e2 = (e1 == hipSuccess) ? smk::dev_malloc(&a->At, (size_t)a->ldAt * a->colsAt * es) : e1;
     if (e1 != hipSuccess || e2 != hipSuccess) {

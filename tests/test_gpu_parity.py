@@ -502,6 +502,24 @@ def test_fp32_product_forms_agree(gpu, monkeypatch):
     assert rel(out["2"].W, ref.W) < 1e-2
 
 
+@pytest.mark.parametrize("alg,storage,quant,m", [("BPP", "f32", 0, 262144), ("MU", "bf16", 1, 524288), ("HALS", "f32", 0, 262144)])
+def test_column_stride_of_a_mebibyte_is_skewed(gpu, alg, storage, quant, m):
+    """A stored matrix whose column stride would be a multiple of 1 MiB (262144 fp32 rows: C4's height) is laid out with 128 more
+    zero rows per column (smk_matrix_create; the W'A pass of a C4 shard is 8 % faster that way).  Every consumer of the leading
+    dimension -- fill, upload, transpose, both passes, download -- must agree with it."""
+    n, k = 320, 8
+    A = oracle.quantize(np.asfortranarray(mg.make_A(m, n, k, True, 0)), quant)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=3, max_iter=3)
+    got = gpu.nmf(A, W0, H0, alg, min_iter=3, max_iter=3, storage=storage)
+    assert got.result == ref.result == 0
+    assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL
+    D = gpu.DenseMatrix.from_host(A, storage=storage)
+    assert np.array_equal(D.download(), A)
+    D.close()
+
+
 @pytest.mark.parametrize("alg", ["HALS", "BPP"])
 def test_matrix_refilled_under_a_live_solver(gpu, alg):
     """smk_matrix_upload_f64 on a matrix that already has a solver: the power-of-two scale of the fp16 products is
