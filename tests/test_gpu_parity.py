@@ -502,6 +502,41 @@ def test_fp32_product_forms_agree(gpu, monkeypatch):
     assert rel(out["2"].W, ref.W) < 1e-2
 
 
+ADVERSARIAL = [(alg, fam, k, storage) for alg, k, storage in (("MU", 12, "f32"), ("HALS", 20, "bf16"), ("BPP", 14, "f32"), ("BPP", 40, "bf16"), ("RANK2", 2, "f32"))
+               for fam in ("colscale", "rowscale", "zeros", "dupcols", "zerostart", "huge")]
+
+
+@pytest.mark.parametrize("alg,fam,k,storage", ADVERSARIAL)
+def test_scaled_and_degenerate_inputs(gpu, alg, fam, k, storage):
+    """Fixed members of the families tools/fuzz_adversarial.py sweeps at random: columns / rows scaled over 2^+-12 (the fp16 row
+    scales, the power-of-two scale of A and the a-priori bound of the packing NNLS launch all see them), zero rows and columns,
+    duplicated columns, starts with exact zeros, everything scaled by 2^40."""
+    m, n = 700, 520
+    rng = np.random.default_rng(len(fam) * 100 + k)
+    r = k + 2
+    A = (rng.random((m, r)) * (rng.random((m, r)) > 0.5)) @ (rng.random((r, n)) * (rng.random((r, n)) > 0.5)) + 0.02 * rng.random((m, n))
+    if fam == "colscale": A = A * np.ldexp(1.0, rng.integers(-12, 13, size=n))[None, :]
+    if fam == "rowscale": A = A * np.ldexp(1.0, rng.integers(-12, 13, size=m))[:, None]
+    if fam == "zeros":
+        A[rng.integers(0, m, size=14), :] = 0.0
+        A[:, rng.integers(0, n, size=10)] = 0.0
+    if fam == "dupcols": A[:, rng.integers(0, n, size=n // 4)] = A[:, rng.integers(0, n, size=n // 4)]
+    if fam == "huge": A = np.ldexp(A, 40)
+    quant = 1 if storage == "bf16" else 0
+    A = oracle.quantize(np.asfortranarray(A), quant)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 * A.mean() / (0.5 * k))
+    if fam == "zerostart":
+        W0[rng.random((m, k)) < 0.2] = 0.0
+        H0[rng.random((k, n)) < 0.2] = 0.0
+    kw = dict(min_iter=1, max_iter=8, tol=1e-14)
+    ref = oracle.nmf(A, W0, H0, alg, **kw)
+    got = gpu.nmf(A, W0, H0, alg, storage=storage, **kw)
+    assert got.result == ref.result and got.iteration_count == ref.iteration_count
+    if ref.result == 0:
+        assert rel(got.W, ref.W) < TOL and rel(got.H, ref.H) < TOL
+
+
 @pytest.mark.parametrize("alg,storage,quant,m", [("BPP", "f32", 0, 262144), ("MU", "bf16", 1, 524288), ("HALS", "f32", 0, 262144)])
 def test_column_stride_of_a_mebibyte_is_skewed(gpu, alg, storage, quant, m):
     """A stored matrix whose column stride would be a multiple of 1 MiB (262144 fp32 rows: C4's height) is laid out with 128 more
