@@ -74,11 +74,22 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
     constexpr int GPB = 256 / GS;                   // column groups per block
     if (skip_if && *skip_if != 0) return;           // the inverse-based kernel below took this launch
     __shared__ double gs[KP * KP];                  // gs[c*KP + i] = G[i][c] (symmetric)
+    const int lane = threadIdx.x & 63;
+    const int i = threadIdx.x % GS;                 // component owned by this lane
+    // the loads of the first trip -- right-hand side (one load per row split) and start -- are issued together with those of G,
+    // ahead of the barrier that publishes G: two dependent round trips to memory become one (a launch is ~12 us of such latencies)
+    double rhs_first = 0.0, x_first = 0.0;
+    {
+        const i64 col = col_begin + (i64)blockIdx.x * GPB + threadIdx.x / GS;
+        if ((i64)blockIdx.x * GPB < N - col_begin && i < k) {
+            const i64 cc = col < N ? col : (N - 1);
+            rhs_first = rhs_elem(R, cc, i);
+            x_first = X[cc * KP + i];
+        }
+    }
     for (int t = threadIdx.x; t < KP * KP; t += blockDim.x) gs[t] = G[t];
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    const int i = threadIdx.x % GS;                 // component owned by this lane
     // NnlsPack: the row scale of component i, from the diagonal of the system matrix (computed here, ahead of the solve)
     double pack_xs = 1.0;
     if constexpr (KP == 16) {
@@ -110,7 +121,10 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
     const i64 cc = col_ok ? col : (N - 1);
 
     double rhs = 0.0, x = 0.0, y = 0.0;
-    if (comp_ok) {
+    if (vb == (i64)blockIdx.x) {
+        rhs = rhs_first;
+        x = x_first;
+    } else if (comp_ok) {
         rhs = rhs_elem(R, cc, i);
         x = X[cc * KP + i];
     }
