@@ -425,6 +425,47 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
                                                         double* __restrict__ Gp)
 {
     constexpr int T = KP / 16;
+    if (KP == 64 && cols_per_wave <= 32) {
+        // KP = 64, short factors (<= 128 columns per workgroup: N <= 32768 with 256 partials; longer ones would re-read more than the
+        // L1 holds -- C4's W side 133 us against ~90): wave w owns tile ROW w of the result (4 of the 16 tiles) over ALL columns of the workgroup, instead of all 16
+        // tiles over a quarter of the columns: the same matrix instructions per wave, the loads four times (the four waves read
+        // the same lines at the same time), and no sum over the waves -- that sum (four turns of 4096 LDS read-modify-writes
+        // between barriers) was 8 of the 19 us this launch took on a 4096-column factor.
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const i64 c_begin = (i64)blockIdx.x * 4 * cols_per_wave;
+        i64 c_end = c_begin + 4 * cols_per_wave;
+        if (c_end > N) c_end = N;
+        f64x4_t acc[T];
+#pragma unroll
+        for (int b = 0; b < T; ++b) acc[b] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+        const int kc = lane >> 4, r16 = lane & 15;
+        for (i64 c0 = c_begin; c0 < c_end; c0 += 16) {
+            double f[4][T];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const i64 col = c0 + 4 * u + kc;
+                const bool ok = col < c_end;
+#pragma unroll
+                for (int t = 0; t < T; ++t) f[u][t] = ok ? X[col * KP + 16 * t + r16] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double fa = f[u][0];                            // the own tile row's operand (wave is uniform: a select, not an index)
+#pragma unroll
+                for (int t = 1; t < T; ++t) fa = (wave == t) ? f[u][t] : fa;
+#pragma unroll
+                for (int b = 0; b < T; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, f[u][b], acc[b], 0, 0, 0);
+            }
+        }
+        if constexpr (KP == 64) {
+            double* out = Gp + (i64)blockIdx.x * KP * KP;
+#pragma unroll
+            for (int b = 0; b < T; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(16 * b + r16) * KP + 16 * wave + kc + 4 * r] = acc[b][r];
+        }
+        return;
+    }
     __shared__ double red[KP * KP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const i64 wg = (i64)blockIdx.x * 4 + wave;
@@ -881,7 +922,9 @@ int launch_gram_partials(const double* X, int k, i64 N, double* scratch, int max
         const int rc = launch_gram_wide_partials(X, KP, N, scratch, max_blocks, &nblk, st);
         if (rc) return rc;
     } else if (KP >= 16) {
-        nblk = (int)((N + 255) / 256);               // >= 64 columns per wave
+        // one 16-column trip per wave while that keeps the partials within max_blocks (N <= 64 max_blocks), 64 and more columns
+        // per wave above: a factor of 4096 columns was 16 workgroups of 4 sequential trips, 26 us at KP = 64 on an idle chip
+        nblk = (int)((N + 63) / 64);
         if (nblk > max_blocks) nblk = max_blocks;
         if (nblk < 1) nblk = 1;
         i64 cpw = (N + (i64)nblk * 4 - 1) / ((i64)nblk * 4);
