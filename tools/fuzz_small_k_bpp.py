@@ -2,8 +2,9 @@
 row scales from the a-priori bound x_r <= max|a| / sqrt(G_rr) -- on data chosen to stress that bound and the
 fp16 range: well and ill conditioned planted factors, rows / columns scaled over 2^+-12, zero rows and columns, overall scales
 2^-30 / 2^+40, starts with negative entries (the first solve must then pack the old way), tolerance-based stopping (snapshot restore).
-Every case against the oracle at the 1e-4 bar (the nearly collinear family, cond(W'W) ~ 1e5: 1e-3 -- its distance comes from the
-conditioning and is the same on both paths), with the separate reduce-and-pack launch (SMK_NNLS_PACK=0) beside it.
+Every case against the oracle at the 1e-4 bar (the nearly collinear family, cond(W'W) ~ 1e5: as close as the separate launch --
+its 1e-4 .. 1e-3 comes from the conditioning and is the same on both paths), with the separate reduce-and-pack launch
+(SMK_NNLS_PACK=0) beside it.
 (Not swept: data scaled to ~1e-12, where the reference's absolute ZeroizeSmallValues threshold empties the factors of EVERY column
 once one column pivots and the run fails as not SPD; the device zeroizes the columns that pivot -- DESIGN 3.)
 The fallback message of pack_fail_soft must never appear (grep the stderr of this script).
@@ -67,7 +68,10 @@ for case in range(cases):
         continue
     e = max(rel(got.W, ref.W), rel(got.H, ref.H)); p = max(rel(got.W, old.W), rel(got.H, old.H))
     worst = max(worst, e); worst_pair = max(worst_pair, p)
-    if e > (1e-3 if fam == "collinear" else 1e-4) or p > 10 * max(e, 1e-7):
+    e_old = max(rel(old.W, ref.W), rel(old.H, ref.H))
+    # the nearly collinear family is where the fp16 product form itself leaves the bar (cond(W'W) ~ 1e5; 1e-4 .. 1e-3 on either
+    # path): there the packing launch only has to be as close as the separate launch
+    if (e > 2 * e_old + 1e-7 if fam == "collinear" else e > 1e-4) or p > 10 * max(e, 1e-7):
         bad.append(desc + f": {e:.2e} from the oracle (the separate launch: {max(rel(old.W, ref.W), rel(old.H, ref.H)):.2e})")
 print(f"{cases} cases in {time.time() - t0:.0f} s; families {fams}")
 print(f"worst distance to the oracle {worst:.2e}; worst distance between the packing launch and the separate launch {worst_pair:.2e}")
