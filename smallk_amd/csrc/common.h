@@ -243,6 +243,7 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
 // k > 32: the inverse of G into scratch, ahead of launch_nnls_bpp(..., inverse_ready = 1, ...) (any stream)
 int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st);
 size_t nnls_scratch_elems(int k);
+bool nnls_inverse_at_32();      // k in (16, 32] solves through the inverse of the Gram matrix too (SMK_NNLS_INV32=0: not)
 // normalisation: scale Wt rows by 1/nu_c, H rows by nu_c where nu_c^2 = G[c][c]
 int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int* fail_flag, hipStream_t st);
 // delta-fnorm: out[0] = sum (W - Wprev)^2, out[1] = sum W^2 ; then Wprev = W

@@ -411,10 +411,12 @@ __global__ __launch_bounds__(256) void gram_inverse_kernel(const double* __restr
 // profiles/r04_gram_inverse.txt).  The division is not what is left (rcp + Newton steps instead: 47.2 us): a step is an LDS
 // round trip, sixteen multiply-adds, the publication of the next row / column and a barrier.
 // Same operations in the same order as gram_inverse_kernel<64>: the result is bit-identical.
+template <int KP>
 __global__ __launch_bounds__(256) void gram_inverse64_kernel(const double* __restrict__ G, int k, double* __restrict__ Ginv,
                                                              int* __restrict__ status)
 {
-    constexpr int KP = 64, CQ = 4, EPT = 16;
+    static_assert(KP == 64 || KP == 32, "256 threads hold the matrix as KP rows x (256 / KP) segments");
+    constexpr int CQ = 256 / KP, EPT = KP / CQ;               // KP = 64: 4 segments of 16 entries; KP = 32: 8 segments of 4
     __shared__ __attribute__((aligned(16))) double rowj[2][KP];
     __shared__ double colj[2][KP];
     __shared__ double diag0[KP];
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256) void gram_inverse64_kernel(const double* __res
         __syncthreads();
     };
     for (int j0 = 0; j0 < k; j0 += EPT) {                       // k is uniform: every thread takes the same steps (barriers inside)
-#define SMK_GI_STEP(n) if (j0 + n < k) step(j0 + n, std::integral_constant<int, n>{});
+#define SMK_GI_STEP(n) if constexpr (n < EPT) { if (j0 + n < k) step(j0 + n, std::integral_constant<int, n>{}); }
         SMK_GI_STEP(0) SMK_GI_STEP(1) SMK_GI_STEP(2) SMK_GI_STEP(3) SMK_GI_STEP(4) SMK_GI_STEP(5) SMK_GI_STEP(6) SMK_GI_STEP(7)
         SMK_GI_STEP(8) SMK_GI_STEP(9) SMK_GI_STEP(10) SMK_GI_STEP(11) SMK_GI_STEP(12) SMK_GI_STEP(13) SMK_GI_STEP(14) SMK_GI_STEP(15)
 #undef SMK_GI_STEP
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
                                                           const int* __restrict__ status,
                                                           int* __restrict__ fail_flag, int iter_tag, i64 col_begin)
 {
-    static_assert(KP == 64, "one wave per column");
+    static_assert(KP == 64 || KP == 32, "one wave per column, one lane per component");
     constexpr int NW = NT / 64;
     if (*status == 0) return;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -508,9 +510,12 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
     double* gis = lds + KP * KP;                    // gis[c*KP + i] = Ginv[i][c]
     for (int t = threadIdx.x; t < KP * KP; t += NT) { gs[t] = G[t]; gis[t] = Ginv[t]; }
     const int lane = threadIdx.x & 63;
+    // KP = 32 (k in (16, 32], round 4): the upper half of the wave has no component; it runs along masked (comp_ok, the set
+    // masks) and reads the matrices at ln = lane mod KP so that it stays inside them
+    const int ln = lane & (KP - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* sv = lds + 2 * KP * KP + wave * (2 * KP);          // wave-private: 64 doubles of values
-    int* sidx = (int*)(sv + KP);                               //               64 ints of indices
+    double* sv = lds + 2 * KP * KP + wave * 128;               // wave-private: 64 doubles of values
+    int* sidx = (int*)(sv + 64);                               //               64 ints of indices
     __syncthreads();
 
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
@@ -534,8 +539,8 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
 #pragma unroll 8
             for (int c = 0; c < KP; c += 2) {
                 const f64x2_t rr = *(const f64x2_t*)(sv + c);              // broadcast read
-                v = __builtin_fma(gis[c * KP + lane], rr[0], v);
-                v1 = __builtin_fma(gis[(c + 1) * KP + lane], rr[1], v1);
+                v = __builtin_fma(gis[c * KP + ln], rr[0], v);
+                v1 = __builtin_fma(gis[(c + 1) * KP + ln], rr[1], v1);
             }
             v += v1;
         }
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
                 const int tb = __builtin_amdgcn_readlane(tl, b);
-                out = __builtin_fma(M[tb * KP + lane], readlane_f64(u, b), out);     // u = 0 beyond t
+                out = __builtin_fma(M[tb * KP + ln], readlane_f64(u, b), out);       // u = 0 beyond t
             }
             u_out = u;
             return out;
@@ -827,15 +832,23 @@ bool nnls_uses_tiles(int k)
 }
 
 size_t nnls_scratch_elems(int k) { return (size_t)kp_of(k) * kp_of(k) + 8; }     // k <= 128; above: nnls_wide_scratch_elems
+// k in (16, 32] also solves through the inverse of the Gram matrix (round 4; SMK_NNLS_INV32=0: the masked elimination, as before)
+bool nnls_inverse_at_32()
+{
+    static const bool on = [] { const char* e = getenv("SMK_NNLS_INV32"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 // k > 32: Ginv and the path selector into `scratch` (nnls_scratch_elems(k) doubles).  One workgroup, ~0.1 ms: the
 // solver runs it on a side stream beside the streaming product that separates the Gram matrix from its NNLS.
 int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st)
 {
     const int KPv = kp_of(k);
-    if (KPv < 64 || KPv > 128 || !scratch) return 0;
+    if (KPv < 32 || KPv > 128 || !scratch) return 0;
+    if (KPv == 32 && !nnls_inverse_at_32()) return 0;
     static const bool old64 = [] { const char* e = getenv("SMK_GRAM_INVERSE_OLD"); return e && atoi(e) != 0; }();
-    if (KPv == 64 && !old64) gram_inverse64_kernel<<<1, 256, 0, st>>>(G, k, scratch, (int*)(scratch + 64 * 64));
+    if (KPv == 32) gram_inverse64_kernel<32><<<1, 256, 0, st>>>(G, k, scratch, (int*)(scratch + 32 * 32));
+    else if (KPv == 64 && !old64) gram_inverse64_kernel<64><<<1, 256, 0, st>>>(G, k, scratch, (int*)(scratch + 64 * 64));
     else if (KPv == 64) gram_inverse_kernel<64><<<1, 256, 0, st>>>(G, k, scratch, (int*)(scratch + 64 * 64));
     else gram_inverse_kernel<128><<<1, 256, 0, st>>>(G, k, scratch, (int*)(scratch + 128 * 128));
     SMK_HIP(hipGetLastError());
@@ -873,12 +886,28 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
         SMK_HIP(hipGetLastError());
         return 0;
     }
+    if (KPv == 32 && inv_mode && scratch && nnls_inverse_at_32()) {
+        // k in (16, 32]: the same kernel, one wave per column with its upper half idle.  The masked elimination costs a full
+        // 32-step Gauss-Jordan per exchange and column (99 us per launch on 8192 x 4096 at k = 32, two thirds of the iteration);
+        // through the inverse an exchange is a t x t solve with t <= 16 (profiles/r04_gram_inverse.txt)
+        double* Ginv = scratch;
+        int* status = (int*)(scratch + 32 * 32);
+        if (!inverse_ready) { int irc = launch_gram_inverse(G, k, scratch, st); if (irc) return irc; }
+        constexpr int NT = 512;
+        const int lds = (2 * 32 * 32 + (NT / 64) * 128) * (int)sizeof(double);
+        i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
+        const i64 cap = (i64)num_cus * 2 * 4;
+        if (g2 > cap) g2 = cap;
+        nnls_bpp_inv_kernel<32, 512, 4><<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin);
+        SMK_HIP(hipGetLastError());
+        skip_if = status;
+    }
     if (KPv == 64 && inv_mode && scratch) {
         double* Ginv = scratch;
         int* status = (int*)(scratch + 64 * 64);
         if (!inverse_ready) { int irc = launch_gram_inverse(G, k, scratch, st); if (irc) return irc; }
         auto run = [&](auto kern, int NT, int wg_per_cu) -> int {
-            const int lds = (2 * 64 * 64 + (NT / 64) * 2 * 64) * (int)sizeof(double);
+            const int lds = (2 * 64 * 64 + (NT / 64) * 128) * (int)sizeof(double);
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
             const i64 cap = (i64)num_cus * wg_per_cu * 4;      // resident workgroups x a few rounds for balance

@@ -1080,7 +1080,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
         rc |= dev_alloc(&s->nnls_scratch, nnls_uses_tiles(s->k) ? nnls_wide_scratch_elems(s->k, g_cus, std::max(s->m, s->n)) : 2 * nnls_scratch_elems(s->k));
         // (above k = 128 the inverse stays in stream order: beside the product it gained 1-2 % -- measured -- and the two sides
         // share one scratch there)
-        if (s->KP >= 64 && !nnls_uses_tiles(s->k)) {
+        if ((s->KP >= 64 || (s->KP == 32 && nnls_inverse_at_32())) && !nnls_uses_tiles(s->k)) {
             if (hipStreamCreateWithFlags(&s->st_inv, hipStreamNonBlocking) != hipSuccess) rc |= 1;
             for (int i = 0; i < 2 && !rc; ++i) {
                 if (hipEventCreateWithFlags(&s->ev_g[i], hipEventDisableTiming) != hipSuccess) rc |= 1;
@@ -1526,7 +1526,7 @@ static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, Partial
         s->nnls_packed[fx] = pack && s->nnls_gram_nblk[side] > 0;
     }
     // without the side stream (k <= 32) a first launch at k > 32 computes the inverse itself, in stream order
-    if (!rc && c1 > c0 && s->KP >= 64) s->inv_done[side] = true;
+    if (!rc && c1 > c0 && (s->KP >= 64 || (s->KP == 32 && nnls_inverse_at_32()))) s->inv_done[side] = true;
     return rc;
 }
 
