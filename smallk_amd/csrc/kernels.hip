@@ -1001,7 +1001,7 @@ int launch_gram_pack(const double* X, int k, i64 N, double* G, double* scratch, 
     if (KP < 16 || KP > 64 || !bf16_frag || nsplit < 1 || nsplit > 3) return 1;     // (the fp16 form needs the finished Gram diagonal first)
     static const bool enabled = [] { const char* e = getenv("SMK_FUSED_GRAM"); return !(e && e[0] == '0'); }();
     if (!enabled) return 1;
-    int nblk = (int)((N + 255) / 256);                   // >= 64 columns per wave, as launch_gram
+    int nblk = (int)((N + 63) / 64);                     // one 16-column trip per wave while the partials stay within max_blocks, as launch_gram
     if (nblk > max_blocks) nblk = max_blocks;
     if (nblk < 1) nblk = 1;
     i64 cpw = (N + (i64)nblk * 4 - 1) / ((i64)nblk * 4);
