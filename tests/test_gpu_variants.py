@@ -44,6 +44,14 @@ def test_hals_w_multi_launch_fallback():
     run_quick_parity({"SMK_HALS_W": "multi"})
 
 
+@pytest.mark.parametrize("env", [{"SMK_NNLS_INV32": "0"}, {"SMK_GRAM_INVERSE_OLD": "1"}, {"SMK_NNLS_INV": "0"}, {"SMK_LD_SKEW": "0"}])
+def test_older_block_pivoting_routes_stay_selectable(env):
+    """k in (16, 32] by masked elimination (the default until late round 4: now through the inverse of the Gram matrix, like
+    k in (32, 64]); the 64 x 64 inversion kernel that kept its registers in scratch; no inverse at all; no column-stride skew.
+    quick_parity.py has block pivoting at k = 16, 20, 32, 33 and 64."""
+    run_quick_parity(env)
+
+
 def test_two_term_operand_split():
     # 16-bit operand: looser but still inside the bar on these shapes
     run_quick_parity({"SMK_NSPLIT": "2"})
