@@ -107,6 +107,11 @@ int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld);
 /* fill with the counter-based uniform [0,1) generator (matrixgen UNIFORM, matrixgen/src/main.cpp:64-72);
  * element (r, c) depends only on (seed, global index), so shards agree with the whole. */
 int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed);
+/* structured synthetic data (the planted-low-rank variant): A = Ws Hs + noise U, rounded to the storage type, with
+ * Ws (height x kstar) / Hs (kstar x width_global) the uniform matrices of seed + 1 / seed + 2 with entries <= threshold set to
+ * zero and U the uniform matrix of `seed`; keyed by the global element index like smk_matrix_fill_uniform, fp64 sums in
+ * increasing j (oracle twin: orc_fill_planted, same bits) */
+int smk_matrix_fill_planted(smk_matrix* a, uint64_t seed, int kstar, double threshold, double noise);
 /* read the shard back as fp64 (tests) */
 int smk_matrix_download_f64(const smk_matrix* a, double* host, int64_t ld);
 void smk_matrix_destroy(smk_matrix* a);

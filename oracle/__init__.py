@@ -72,6 +72,8 @@ def lib():
         _lib.orc_nnls_blockpivot.argtypes = [C.c_int, i64, dp, C.c_int, dp, i64, dp, i64, dp, i64, C.POINTER(C.c_int)]
         _lib.orc_fill_uniform.restype = None
         _lib.orc_fill_uniform.argtypes = [dp, i64, i64, i64, i64, i64, i64, C.c_uint64, C.c_int]
+        _lib.orc_fill_planted.restype = None
+        _lib.orc_fill_planted.argtypes = [dp, i64, i64, i64, i64, i64, i64, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_int]
         _lib.orc_quantize.restype = None
         _lib.orc_quantize.argtypes = [dp, i64, C.c_int]
         _lib.orc_projected_gradient_norm.restype = C.c_double
@@ -171,6 +173,15 @@ def fill_uniform(rows, cols, seed, *, quant=0, r0=0, c0=0, gheight=None) -> np.n
     out = np.empty((rows, cols), order="F")
     lib().orc_fill_uniform(_p(out), rows, rows, cols, r0, c0, rows if gheight is None else gheight,
                            seed, quant)
+    return out
+
+
+def fill_planted(rows, cols, seed, kstar, *, threshold=0.7, noise=0.05, quant=0, r0=0, c0=0, gheight=None) -> np.ndarray:
+    """Planted low-rank + noise block (orc_fill_planted); bit-identical to smk_matrix_fill_planted.  Rows r0.., columns c0..
+    of the matrix of global height `gheight`."""
+    out = np.empty((rows, cols), order="F")
+    lib().orc_fill_planted(_p(out), rows, rows, cols, r0, c0, rows if gheight is None else gheight, seed, kstar,
+                           threshold, noise, quant)
     return out
 
 

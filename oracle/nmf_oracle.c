@@ -107,6 +107,49 @@ void orc_fill_uniform(double* buf, i64 ld, i64 rows, i64 cols,
                 orc_uniform_value(seed, (uint64_t)((c0 + c) * gheight + (r0 + r)), quant);
 }
 
+/* Structured synthetic data ("planted-low-rank variant ... for convergence sanity"; the formula of
+ * tests/golden/make_golden.py:make_A with the order of operations fixed): element (r, c) of
+ *   A = Ws Hs + noise * U,  Ws = uniform(gheight x kstar, seed + 1) with entries <= thr dropped,
+ *   Hs = uniform(kstar x gwidth, seed + 2) likewise, U = uniform(gheight x gwidth, seed),
+ * fp64 sum in increasing j with one fma per term (a zero factor leaves the sum unchanged, so zero terms may be skipped),
+ * the noise term last with one more fma, then rounded to the storage type.  The device twin
+ * (smallk_amd/csrc/kernels.hip:fill_planted_kernel) does the same operations: identical bits. */
+void orc_fill_planted(double* buf, i64 ld, i64 rows, i64 cols, i64 r0, i64 c0, i64 gheight,
+                      uint64_t seed, int kstar, double thr, double noise, int quant)
+{
+    const float thrf = (float)thr;
+    float* ws = (float*)malloc((size_t)rows * kstar * sizeof(float));     /* [r][j] */
+#pragma omp parallel for schedule(static)
+    for (i64 r = 0; r < rows; ++r)
+        for (int j = 0; j < kstar; ++j) {
+            float w = (float)orc_uniform_value(seed + 1, (uint64_t)((i64)j * gheight + r0 + r), 0);
+            ws[r * kstar + j] = w > thrf ? w : 0.f;
+        }
+#pragma omp parallel
+    {
+        float* hs = (float*)malloc((size_t)kstar * sizeof(float));
+#pragma omp for schedule(static)
+        for (i64 c = 0; c < cols; ++c) {
+            for (int j = 0; j < kstar; ++j) {
+                float h = (float)orc_uniform_value(seed + 2, (uint64_t)((c0 + c) * (i64)kstar + j), 0);
+                hs[j] = h > thrf ? h : 0.f;
+            }
+            for (i64 r = 0; r < rows; ++r) {
+                double acc = 0.0;
+                const float* w = ws + r * kstar;
+                for (int j = 0; j < kstar; ++j)
+                    if (hs[j] != 0.f) acc = fma((double)w[j], (double)hs[j], acc);
+                float u = (float)orc_uniform_value(seed, (uint64_t)((c0 + c) * gheight + (r0 + r)), 0);
+                float v = (float)fma(noise, (double)u, acc);
+                if (quant == 1) v = orc_bf16_round(v);
+                AT(buf, ld, r, c) = (double)v;
+            }
+        }
+        free(hs);
+    }
+    free(ws);
+}
+
 /* Round a buffer in place to what the device stores (fp32 or bf16). */
 void orc_quantize(double* buf, i64 count, int quant)
 {

@@ -84,6 +84,9 @@ struct PartialView {
 
 int launch_fill_uniform(void* buf, int storage, i64 ld, i64 rows, i64 cols, i64 rows_pad, i64 cols_pad,
                         i64 r0, i64 c0, i64 gheight, uint64_t seed, int quant, hipStream_t st);
+// planted low-rank + noise, keyed by the global element index (kernels.hip: fill_planted_kernel)
+int launch_fill_planted(void* buf, int storage, i64 ld, i64 rows, i64 cols, i64 rows_pad, i64 cols_pad, i64 c0,
+                        i64 gheight, uint64_t seed, int kstar, double thr, double noise, int quant, hipStream_t st);
 int launch_convert_f64(const double* src, i64 ld_src, void* dst, int storage, i64 ld_dst, i64 rows, i64 cols,
                        hipStream_t st);
 int launch_transpose_store(const void* src, i64 ld_src, void* dst, i64 ld_dst, int storage, i64 rows, i64 cols,

@@ -56,6 +56,77 @@ int launch_fill_uniform(void* buf, int storage, i64 ld, i64 rows, i64 cols, i64 
     return 0;
 }
 
+// Structured synthetic data ("planted-low-rank variant for convergence sanity"): element (r, c) of
+//   A = Ws Hs + noise * U,   Ws = (m x kstar uniform, seed + 1, entries <= thr dropped), Hs = (kstar x n_global uniform,
+//   seed + 2, entries <= thr dropped), U = the uniform matrix of `seed`,
+// every factor keyed by its GLOBAL element index, the sum taken in fp64 with one fused multiply-add per j in increasing
+// j and the noise term added last with one more -- oracle/nmf_oracle.c:orc_fill_planted does the same operations in the same
+// order, so the stored fp32 / bf16 values are the oracle's bit for bit and shards agree with the whole.
+// A 64 x 64 tile per workgroup, 64 planted components at a time through LDS (the factors are generated in place: no
+// buffers), a row and 16 columns per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void fill_planted_kernel(T* __restrict__ buf, i64 ld, i64 rows, i64 cols, i64 rows_pad,
+                                                           i64 cols_pad, i64 c0, i64 gheight, uint64_t seed, int kstar,
+                                                           float thr, double noise, int quant)
+{
+    __shared__ float ws[64][65];     // [j][row]
+    __shared__ float hs[64][64];     // [j][col]
+    const i64 tr0 = (i64)blockIdx.x * 64, tc0 = (i64)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    for (int j0 = 0; j0 < kstar; j0 += 64) {
+        __syncthreads();
+        for (int jj = ty; jj < 64; jj += 4) {
+            const int j = j0 + jj;
+            float w = 0.f, h = 0.f;
+            if (j < kstar) {
+                if (tr0 + tx < rows) w = uniform_value(seed + 1, (uint64_t)((i64)j * gheight + tr0 + tx), 0);
+                if (tc0 + tx < cols) h = uniform_value(seed + 2, (uint64_t)((c0 + tc0 + tx) * (i64)kstar + j), 0);
+            }
+            ws[jj][tx] = w > thr ? w : 0.f;
+            hs[jj][tx] = h > thr ? h : 0.f;
+        }
+        __syncthreads();
+        const int jn = kstar - j0 < 64 ? kstar - j0 : 64;
+        for (int jj = 0; jj < jn; ++jj) {
+            const double w = (double)ws[jj][tx];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_fma(w, (double)hs[jj][ty * 16 + i], acc[i]);
+        }
+    }
+    const i64 r = tr0 + tx;
+    if (r >= rows_pad) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const i64 c = tc0 + ty * 16 + i;
+        if (c >= cols_pad) continue;
+        float v = 0.f;
+        if (r < rows && c < cols) {
+            const float u = uniform_value(seed, (uint64_t)((c0 + c) * gheight + r), 0);
+            v = (float)__builtin_fma(noise, (double)u, acc[i]);
+            if (quant == 1) v = bf16_bits_to_f32(f32_to_bf16_rne(v));
+        }
+        buf[c * ld + r] = store_cast<T>(v);
+    }
+}
+
+int launch_fill_planted(void* buf, int storage, i64 ld, i64 rows, i64 cols, i64 rows_pad, i64 cols_pad, i64 c0,
+                        i64 gheight, uint64_t seed, int kstar, double thr, double noise, int quant, hipStream_t st)
+{
+    dim3 grid((unsigned)((rows_pad + 63) / 64), (unsigned)((cols_pad + 63) / 64));
+    if (grid.y > 65535u) return -101; /* SMK_UNSUPPORTED: more than 4 M columns */
+    if (storage == STORE_BF16)
+        fill_planted_kernel<unsigned short><<<grid, 256, 0, st>>>((unsigned short*)buf, ld, rows, cols, rows_pad, cols_pad,
+                                                                  c0, gheight, seed, kstar, (float)thr, noise, quant);
+    else
+        fill_planted_kernel<float><<<grid, 256, 0, st>>>((float*)buf, ld, rows, cols, rows_pad, cols_pad, c0, gheight,
+                                                         seed, kstar, (float)thr, noise, quant);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
 // fp64 (host layout, staged on device) -> storage dtype
 template <typename T>
 __global__ __launch_bounds__(256) void convert_f64_kernel(const double* __restrict__ src, i64 ld_src,

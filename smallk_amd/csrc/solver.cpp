@@ -474,6 +474,19 @@ int smk_matrix_fill_uniform(smk_matrix* a, uint64_t seed)
     return SMK_OK;
 }
 
+int smk_matrix_fill_planted(smk_matrix* a, uint64_t seed, int kstar, double threshold, double noise)
+{
+    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; a->colnorm_max = a->rownorm_max = -1.0; }
+    if (!a || a->sparse || kstar < 1 || kstar > 4096 || !(threshold >= 0.0 && threshold < 1.0) || !(noise >= 0.0)) return SMK_BAD_PARAM;
+    int rc = launch_fill_planted(a->A, a->storage, a->ldA, a->m, a->n, a->ldA, a->colsA, a->c0, a->m, seed, kstar, threshold,
+                                 noise, a->storage == SMK_STORE_BF16 ? 1 : 0, g_stream);
+    if (rc) return rc;
+    rc = matrix_make_transpose(a);
+    if (rc) return rc;
+    SMK_HIP(hipStreamSynchronize(g_stream));
+    return SMK_OK;
+}
+
 int smk_matrix_download_f64(const smk_matrix* a, double* host, int64_t ld)
 {
     if (!a || !host || ld < a->m || a->sparse) return SMK_BAD_PARAM;

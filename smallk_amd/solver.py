@@ -95,6 +95,10 @@ class DenseMatrix:
     def fill_uniform(self, seed):
         L.check(L.lib().smk_matrix_fill_uniform(self._h, seed), "smk_matrix_fill_uniform")
 
+    def fill_planted(self, seed, kstar, threshold=0.7, noise=0.05):
+        """A = Ws Hs + noise U with sparse planted factors (entries <= threshold dropped), SURVEY 8(d)."""
+        L.check(L.lib().smk_matrix_fill_planted(self._h, seed, kstar, threshold, noise), "smk_matrix_fill_planted")
+
     def download(self) -> np.ndarray:
         out = np.empty((self.height, self.ncols), order="F")
         L.check(L.lib().smk_matrix_download_f64(self._h, _p(out), self.height), "smk_matrix_download_f64")
