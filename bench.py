@@ -146,7 +146,7 @@ def start_rank_watchdog(stall_s):
     threading.Thread(target=watch, name="bench-watchdog", daemon=True).start()
 
 
-def cpu_baseline(m, n, k, alg, quant, budget_s=20.0):
+def cpu_baseline(m, n, k, alg, quant, budget_s=20.0, data="uniform"):
     """The CPU oracle on a bounded sample (same k, algorithm, dtype rounding; fewer rows/cols), timed on this
     host's cores, priced so that the parts add up:
 
@@ -161,7 +161,7 @@ def cpu_baseline(m, n, k, alg, quant, budget_s=20.0):
     import numpy as np
     import oracle
     ms, ns = min(m, 8192), min(n, 4096)
-    A = oracle.fill_uniform(ms, ns, 42, quant=quant)
+    A = oracle.fill_uniform(ms, ns, 42, quant=quant) if data == "uniform" else oracle.fill_planted(ms, ns, 42, k, quant=quant)
     W0 = oracle.fill_uniform(ms, k, 43)
     H0 = oracle.fill_uniform(k, ns, 44) * (2.0 / k)          # same start as the GPU leg: E[W0 H0] = E[A]
     oracle.nmf(A, W0, H0, alg, min_iter=1, max_iter=1)        # warm up threads/pages
@@ -236,7 +236,11 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS) + ["s_reuters", "s_reuters_hals", "s_1m"],
+                    help="c1..c4: BASELINE.json's dense configurations; s_*: sparse A, one GPU (bench_sparse.py)")
+    ap.add_argument("--data", default="uniform", choices=["uniform", "planted"],
+                    help="dense workloads: i.i.d. uniform A, or A = Ws Hs + 0.05 U with sparse planted factors of rank k "
+                         "(smk_matrix_fill_planted: block pivoting keeps exchanging variables for many iterations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without torch.distributed: one process, one host thread per device, communicators from "
@@ -345,7 +349,7 @@ def launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL across processes)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     common = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload,
-              "--stall-s", str(args.stall_s)]
+              "--data", args.data, "--stall-s", str(args.stall_s)]
     if args.no_cpu_baseline:
         common.append("--no-cpu-baseline")
     me = os.path.join(ROOT, "bench.py")
@@ -396,7 +400,7 @@ def build_report(args, world, elapsed, windows, rank0, ranks_report, collectives
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": storage if storage == "bf16" else "f32",
-        "data": "synthetic",
+        "data": "synthetic" if args.data == "uniform" else "synthetic (planted sparse factors of rank k + 0.05 uniform noise)",
         "config": {"workload": desc, "m": m, "n": n, "k": k, "algorithm": alg, "A_storage": storage,
                    "state": "W,H,Gram fp64; big products: MFMA with fp32 accumulation folded into fp64",
                    "parallelism": parallelism, "collectives": collectives},
@@ -578,7 +582,10 @@ def run_rank(args):
     total_iters = args.warmup + args.steps
     beat("matrix fill", limit=lim(args, 180.0))
     A = smallk_amd.DenseMatrix(m, n, col0=col0, ncols=ncols, storage=storage)
-    A.fill_uniform(42)
+    if args.data == "planted":
+        A.fill_planted(42, k, 0.7, 0.05)
+    else:
+        A.fill_uniform(42)
     W0 = smallk_amd.uniform_host(m, k, 43)
     # E[A] = 1/2: scale H0 so that W0 H0 has the same mean.  (An unscaled uniform start makes the first HALS
     # W update clamp every entry to zero and the run would iterate on the all-eps guard columns.)
@@ -655,7 +662,7 @@ def run_rank(args):
                            {"ms0": ms0, "c0": c0, "ms1": ms1, "c1": c1, "bytes": bytes_per_launch, "flops": flops_per_launch},
                            ranks_report, collectives, parallelism)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(m, n, k, alg, 1 if storage == "bf16" else 0)
+            out["cpu_baseline"] = cpu_baseline(m, n, k, alg, 1 if storage == "bf16" else 0, data=args.data)
         guard.restore()
         print(json.dumps(out), flush=True)
     if rank == 0 and world > 1:
@@ -716,7 +723,10 @@ def run_single_process(args):
             comms[r].selftest()             # known sums through the communicator before the run is trusted to it
             col0, ncols = sdist.shard_columns(n, N, r)
             A = smallk_amd.DenseMatrix(m, n, col0=col0, ncols=ncols, storage=storage)
-            A.fill_uniform(42)
+            if args.data == "planted":
+                A.fill_planted(42, k, 0.7, 0.05)
+            else:
+                A.fill_uniform(42)
             W0 = smallk_amd.uniform_host(m, k, 43)
             H0 = smallk_amd.uniform_host(k, ncols, 44, c0=col0, gheight=k) * (2.0 / k)
             opts = smallk_amd.make_options(m, n, k, alg, min_iter=total_iters, max_iter=total_iters)
@@ -807,6 +817,9 @@ def main():
     args_list = [a for a in sys.argv[1:] if a != "--in-child"]
     in_child = len(args_list) != len(sys.argv) - 1
     args = parse_args(args_list)
+    if args.workload.startswith("s_"):
+        import bench_sparse
+        sys.exit(bench_sparse.run_sparse(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not in_child:
         # plain invocation: this process starts the ranks and makes no GPU call itself
         sys.exit(launch(args))

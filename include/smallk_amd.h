@@ -124,6 +124,10 @@ void smk_thread_context_end(void);
 int smk_device_count(void);
 int smk_current_device(void);
 int smk_device_synchronize(void);   /* hipDeviceSynchronize on the calling thread's current device */
+/* The library keeps freed device workspaces of up to 512 MB each (at most 4 GB per device, SMK_DEVMEM_CACHE_MB) for reuse; they are
+ * invisible to other allocators in the process (torch, RCCL).  smk_device_trim returns those of the current device to the HIP
+ * runtime (call it before creating communicators or large torch tensors); the return value is the number of bytes that were cached. */
+size_t smk_device_trim(void);
 /* sparse A in CSC (replaces SparseMatrix<double>, common/include/sparse_matrix_decl.hpp:21-132): the local
  * columns [col0, col0+ncols_local); 32-bit indices as in the reference, duplicates allowed (they add up).
  * The transpose is built here too (the reference does it in Solver_Generic_BPP::Init, nmf_solver_bpp.hpp:319). */
@@ -144,6 +148,12 @@ int smk_csc_subset_cols_compact(int64_t height, int64_t width, const unsigned* c
                                 int64_t* new_height, int64_t* out_nnz);
 int smk_matrix_download_csc(const smk_matrix* a, int transposed, unsigned* col_offsets, unsigned* row_indices,
                             double* data);
+/* The reference's sparse Gemm by itself (common/include/sparse_gemm_ab_impl.hpp:24-100, :480-582; sparse_gemm_ba_impl.hpp:25-99),
+ * in the gather form the solver uses: out (k x ncols(B), ld ldo) = X (k x rows(B), ld ldx) * B, B = A (transposed == 0, i.e. W'A
+ * from X = W') or B = A' (transposed != 0, i.e. (AH')' from X = H), on the kernel the solver takes at rank k.  reps > 0 and
+ * avg_ms != NULL: that many more launches timed with HIP events. */
+int smk_matrix_sparse_product(const smk_matrix* a, int transposed, int k, const double* X, int64_t ldx, double* out,
+                              int64_t ldo, int reps, double* avg_ms);
 int64_t smk_matrix_nnz(const smk_matrix* a);
 int64_t smk_matrix_height(const smk_matrix* a);
 /* same generator on the host, for W0/H0 (RandomMatrix stand-in, smallk.cpp:533,554) */

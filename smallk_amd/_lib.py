@@ -92,7 +92,9 @@ SYMBOLS = {
                                               C.POINTER(C.c_uint), _i64, C.POINTER(C.c_uint), C.POINTER(C.c_uint), _dp,
                                               C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(_i64), C.POINTER(_i64)]),
     "smk_matrix_download_csc": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), _dp]),
+    "smk_device_trim": (C.c_size_t, []),
     "smk_matrix_nnz": (_i64, [_vp]),
+    "smk_matrix_sparse_product": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _i64, _dp, _i64, C.c_int, C.POINTER(C.c_double)]),
     "smk_matrix_height": (_i64, [_vp]),
     "smk_uniform_fill_host": (None, [_dp, _i64, _i64, _i64, _i64, _i64, _i64, C.c_uint64, C.c_int]),
     "smk_solver_create": (C.c_int, [C.POINTER(_vp), C.POINTER(Options), _vp]),

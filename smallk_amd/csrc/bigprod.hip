@@ -1266,10 +1266,11 @@ static int launch_f3p_t(const BigProdPlan& pl, const void* B, i64 ldb, const voi
         return -100;
     } else {
         constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
-        static std::atomic<unsigned long long> attr_set{0};       // per device (first_use_on_this_device)
+        static std::atomic<unsigned long long> attr_set{0};       // per device (DeviceOnce)
         auto kern = bigprod_f3p_kernel<KT, NSTAGE, NWL, FOLD, PIN, NS, FMT>;
-        if (first_use_on_this_device(attr_set)) {
+        if (DeviceOnce once{attr_set}) {
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            once.done();
         }
         int logS = 0;
         while ((1 << logS) < pl.S) ++logS;
@@ -1332,10 +1333,11 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
         return -100;
     } else {
         constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
-        static std::atomic<unsigned long long> attr_set{0};       // per device (first_use_on_this_device)
+        static std::atomic<unsigned long long> attr_set{0};       // per device (DeviceOnce)
         auto kern = bigprod_f3_kernel<KT, MB, NSTAGE, NWL, FOLD, WPS, NS, FMT, TAIL>;
-        if (first_use_on_this_device(attr_set)) {
+        if (DeviceOnce once{attr_set}) {
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            once.done();
         }
         int logS = 0;
         while ((1 << logS) < pl.S) ++logS;
@@ -1837,10 +1839,11 @@ static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const
 {
     using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
     constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
-    static std::atomic<unsigned long long> attr_set{0};       // per device (first_use_on_this_device)
+    static std::atomic<unsigned long long> attr_set{0};       // per device (DeviceOnce)
     auto kern = bigprod_kernel<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
-    if (first_use_on_this_device(attr_set)) {
+    if (DeviceOnce once{attr_set}) {
         SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        once.done();
     }
     int logS = 0;
     while ((1 << logS) < pl.S) ++logS;

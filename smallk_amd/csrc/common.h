@@ -1,6 +1,7 @@
 // smallk_amd/csrc/common.h -- shared host-side declarations for the MI355X NMF library.
 #pragma once
 #include <atomic>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstddef>
@@ -43,16 +44,30 @@ void dev_cache_stats(unsigned long long* hits, unsigned long long* misses, size_
 inline int kt_of(int k) { return (k + 31) / 32; }
 // "do this once" for things that are per DEVICE (hipFuncSetAttribute applies to the function on the current device): one
 // process may drive several devices (smk_nmf_dense_sharded, bench.py --single-process, HierNMF2 with SMK_CLUST_DEVICES), and a
-// process-wide flag would opt the kernel in on the first device only.  Two threads on one device may both return true: harmless.
-inline bool first_use_on_this_device(std::atomic<unsigned long long>& mask)
-{
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (mask.load(std::memory_order_relaxed) & bit) return false;
-    mask.fetch_or(bit, std::memory_order_relaxed);
-    return true;
-}
+// process-wide flag would opt the kernel in on the first device only.  Usage:
+//     static std::atomic<unsigned long long> attr_set{0};
+//     if (DeviceOnce once{attr_set}) { SMK_HIP(hipFuncSetAttribute(...)); once.done(); }
+// The device's bit is set by done(), i.e. only after the set-up has succeeded (an early return leaves it clear and the next
+// call tries again), and the first caller holds a lock until then: a second host thread on the same device (shards on one GPU,
+// HierNMF2 workers) waits instead of launching with > 64 KB of dynamic LDS before the opt-in has taken effect.
+inline std::mutex& device_once_mutex() { static std::mutex mu; return mu; }
+struct DeviceOnce {
+    std::atomic<unsigned long long>& mask;
+    unsigned long long bit = 0;
+    std::unique_lock<std::mutex> lk;
+    bool first = false;
+    explicit DeviceOnce(std::atomic<unsigned long long>& m) : mask(m)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        bit = 1ull << (dev & 63);
+        if (mask.load(std::memory_order_acquire) & bit) return;
+        lk = std::unique_lock<std::mutex>(device_once_mutex());
+        first = !(mask.load(std::memory_order_acquire) & bit);
+    }
+    explicit operator bool() const { return first; }
+    void done() { mask.fetch_or(bit, std::memory_order_release); }
+};
 // doubles per column of the partial products of a dense pass: the k tiles of 32 rows -- but 8 / 16 for k <= 8 / 16 (half or a
 // quarter of the bytes written by the streaming pass and read by the update kernel behind it: C2 is k = 16)
 inline int kpp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : kt_of(k) * 32; }
@@ -309,6 +324,28 @@ int launch_rank2_persist(const R2PersistArgs& a, int workgroups, hipStream_t st)
 // nnz_hint: number of stored entries (picks the lanes per column of the rank-2 kernel; <= 0: unknown)
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, i64 nnz_hint, const double* X,
                        int ldx, int k, double* P, int kpp, hipStream_t st);
+
+// spmm_seg.hip: the gather product at ranks 3 .. 128, work cut by stored entries.  The plan of one CSC (A or A'): segments of
+// <= spmm_seg_len() consecutive entries = whole columns, or pieces of one long column (summed by a fix-up launch)
+struct SegPlan {
+    i64 nseg = 0, nlong = 0, npieces = 0, ncols = 0, nnz = 0;
+    bool has_empty = false;          // some column has no stored entry (P is cleared first, the column walk skips them)
+    bool uniform = false;            // column lengths within 4 x the mean: the column-per-lane-group kernel is the faster one
+    i64 longest = 0;
+    i64* seg_p0 = nullptr;           // first entry
+    unsigned* seg_len = nullptr;     // entries
+    unsigned* seg_col = nullptr;     // column of the first entry
+    unsigned* seg_piece = nullptr;   // 0xFFFFFFFF: whole columns; else the slot of this piece in `pieces`
+    unsigned* rowflag = nullptr;     // row indices, bit 31 set on the last entry of a column
+    unsigned* long_col = nullptr;    // columns longer than a segment ...
+    i64* long_piece0 = nullptr;      // ... and their first piece (nlong + 1 entries)
+    double* pieces = nullptr;        // npieces x 128 doubles
+};
+int spmm_seg_len();
+int build_seg_plan(i64 ncols, i64 nnz, const i64* colptr, const unsigned* rowidx, SegPlan* out, hipStream_t st);
+void free_seg_plan(SegPlan* s);
+int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, const double* X, int k, double* P, int kpp,
+                    hipStream_t st);
 
 // spmm_blocked.hip: the rank-2 gather product with the gathered factor cut into row blocks that stay in one XCD's L2.
 // A matrix regrouped by row block: block b is a CSC of its own (cp[b * (ncols + 1) + j] .. are absolute positions in ri / va)

@@ -3,7 +3,7 @@
 // HierNMF2, flat clustering and repeated Nmf() calls create and destroy a solver (~35 device buffers), a column subset
 // (6 - 12) and sort workspaces per node; hipMalloc maps fresh pages and hipFree synchronises the device and unmaps them,
 // ~0.1 - 0.3 ms each: on the C5-shaped run (15 node factorisations) that was ~0.1 s of a 0.9 s run.  Freed blocks of up to
-// 512 MB are kept per device (at most 16 GB of them) and handed out again to requests that fit (the smallest cached block
+// 512 MB are kept per device (at most 4 GB of them; SMK_DEVMEM_CACHE_MB) and handed out again to requests that fit (the smallest cached block
 // that is large enough and not more than 4 x the request).  Everything larger -- the resident matrices of the big
 // workloads -- goes straight to the runtime.
 //   * dev_free() synchronises the block's device before the block can be reused: the same guarantee hipFree gives
@@ -11,7 +11,7 @@
 //   * a failed hipMalloc empties the device's cache and tries once more;
 //   * SMK_DEVMEM_CACHE=0 turns the cache off (every call goes to the runtime), SMK_POISON=1 still poisons every block a
 //     caller receives (dev_alloc in solver.cpp), reused or fresh;
-//   * smk_finalize / smk_thread_context_end return the cached blocks of their device (dev_trim).
+//   * smk_finalize / smk_thread_context_end / smk_device_trim return the cached blocks of their device (dev_trim).
 #include "common.h"
 
 #include <map>
@@ -22,7 +22,15 @@ namespace smk {
 
 namespace {
 constexpr size_t MAX_CACHED_BLOCK = (size_t)512 << 20;
-constexpr size_t MAX_CACHED_TOTAL = (size_t)16 << 30;
+// per device.  4 GB covers the per-node workspaces this cache exists for (a solver's ~35 buffers, a subset's 6 - 12, the
+// sort workspaces: < 1 GB on the C5-shaped run); what is parked here is invisible to the other allocators of the process
+// (torch, RCCL's channel buffers), so the cap is modest and adjustable (SMK_DEVMEM_CACHE_MB), and smk_device_trim() hands
+// everything back before a caller creates communicators or large torch tensors
+size_t max_cached_total()
+{
+    static const size_t cap = [] { const char* e = getenv("SMK_DEVMEM_CACHE_MB"); return e ? (size_t)atoll(e) << 20 : (size_t)4 << 30; }();
+    return cap;
+}
 constexpr int MAX_DEVICES = 64;
 
 struct Rec { int dev; size_t bytes; };
@@ -107,7 +115,7 @@ hipError_t dev_free(void* p)
     (void)hipDeviceSynchronize();
     if (cur != rec.dev) (void)hipSetDevice(cur);
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_cached[rec.dev] + rec.bytes > MAX_CACHED_TOTAL) return hipFree(p);
+    if (g_cached[rec.dev] + rec.bytes > max_cached_total()) return hipFree(p);
     g_free[rec.dev].emplace(rec.bytes, p);
     g_cached[rec.dev] += rec.bytes;
     return hipSuccess;

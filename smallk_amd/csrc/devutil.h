@@ -138,16 +138,56 @@ __device__ __forceinline__ void load_rhs4(const PartialView& R, i64 j, int e0, d
     }
 }
 
-// one element (row i of column j) of the summed partial product
-__device__ __forceinline__ double rhs_elem(const PartialView& R, i64 j, int i)
+// one element (row i of column j) of the summed partial product.
+// The slabs are read in batches whose loads are all in flight together: a loop of `v += p[s * slab]` waits for every load
+// before it issues the next (the adds are ordered), i.e. S dependent round trips to memory per element -- 16 on the H side of
+// a 1/8 column shard of C4, where that chain WAS the NNLS launch (51 us for 2 columns per wave, profiles/r05_c4_planted_rank0_of_8_*).
+// Indices are clamped instead of predicated so that a batch is branch-free; the adds are predicated (sum in slab order).
+struct RhsPending { double t[4]; double tail; };
+
+// issue the loads of element (i, j): the first four slabs stay un-summed in registers (no arithmetic, hence no wait: the caller
+// can compute on something else until rhs_finish), slabs 4 .. S-1 are summed here, eight loads at a time
+__device__ __forceinline__ void rhs_issue(const PartialView& R, i64 j, int i, RhsPending& q)
 {
-    double v = 0.0;
+    q.tail = 0.0;
+    const i64 off = j * R.kpp + i;
     if (R.f64) {
-        for (int s = 0; s < R.S; ++s) v += ((const double*)R.p)[s * R.slab + j * R.kpp + i];
-    } else {
-        for (int s = 0; s < R.S; ++s) v += (double)((const float*)R.p)[s * R.slab + j * R.kpp + i];
+        const double* p = (const double*)R.p + off;
+        q.t[0] = p[0];
+        if (R.S == 1) { q.t[1] = q.t[2] = q.t[3] = 0.0; return; }
+#pragma unroll
+        for (int u = 1; u < 4; ++u) q.t[u] = p[(i64)(u < R.S ? u : 0) * R.slab];
+        for (int s0 = 4; s0 < R.S; s0 += 8) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p[(i64)(s0 + u < R.S ? s0 + u : R.S - 1) * R.slab];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (s0 + u < R.S) q.tail += t[u];
+        }
+    } else {            // fp32 on the wire (SMK_COMM_F64=0): summed at once
+        const float* p = (const float*)R.p + off;
+        double v = 0.0;
+        for (int s = 0; s < R.S; ++s) v += (double)p[(i64)s * R.slab];
+        q.t[0] = v;
+        q.t[1] = q.t[2] = q.t[3] = 0.0;
+    }
+}
+__device__ __forceinline__ double rhs_finish(const PartialView& R, const RhsPending& q)
+{
+    double v = q.t[0];
+    if (R.f64 && R.S > 1) {
+        v += q.t[1];
+        if (R.S > 2) v += q.t[2];
+        if (R.S > 3) v += q.t[3];
+        if (R.S > 4) v += q.tail;
     }
     return v;
+}
+__device__ __forceinline__ double rhs_elem(const PartialView& R, i64 j, int i)
+{
+    RhsPending q;
+    rhs_issue(R, j, i, q);
+    return rhs_finish(R, q);
 }
 
 // block-wide sum of one double; result valid in thread 0

@@ -523,27 +523,47 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
     const int max_iter = 5 * k;
     int failed_any = 0;
 
-    for (i64 col = col_begin + (i64)blockIdx.x * NW + wave; col < N; col += (i64)gridDim.x * NW) {
-        double rhs = 0.0, x = 0.0, y = 0.0;
-        if (comp_ok) {
-            rhs = rhs_elem(R, col, lane);
-            x = X[col * KP + lane];
+    // A wave works through its columns one after the other, and a column is load -> ~0.3 us of arithmetic -> store: without
+    // the loads of column c + 1 in flight during the arithmetic of column c every column costs a round trip to memory on top
+    // (1 M columns at k = 32, 256 columns per wave: 1.19 ms per launch, 4.6 us per column and wave, of which the arithmetic
+    // is a tenth; profiles/r05_s_1m_kernel_stats.md).  The right-hand side and the start of the NEXT column are requested
+    // before the current one is touched.
+    const i64 col_stride = (i64)gridDim.x * NW;
+    i64 col = col_begin + (i64)blockIdx.x * NW + wave;
+    RhsPending rq;
+    rq.t[0] = rq.t[1] = rq.t[2] = rq.t[3] = rq.tail = 0.0;
+    double x_next = 0.0;
+    if (col < N && comp_ok) {
+        rhs_issue(R, col, lane, rq);
+        x_next = X[col * KP + lane];
+    }
+    for (; col < N; col += col_stride) {
+        double rhs = comp_ok ? rhs_finish(R, rq) : 0.0, x = x_next, y = 0.0;
+        if (col + col_stride < N && comp_ok) {
+            rhs_issue(R, col + col_stride, lane, rq);
+            x_next = X[(col + col_stride) * KP + lane];
         }
         unsigned long long F = __ballot(comp_ok && x > 0.0) & kmask;       // passive_set = (X > 0), nnls.hpp:157
 
-        // v = Ginv r
-        sv[lane] = rhs;
+        // v = Ginv r, the unconstrained solution: needed by the complement form only (and when every variable is passive).
+        // A column whose passive sets stay small -- sparse factors: a document in two or three topics, a node in one community
+        // -- never takes that form, and the KP-step product was a third of its time (s_1m: 1.19 ms per launch of 1 M columns,
+        // profiles/r05_s_1m_kernel_stats.md), so it is computed when the first solve of the column asks for it.
         double v = 0.0;
-        {
-            double v1 = 0.0;
+        bool have_v = false;
+        auto need_v = [&]() {
+            if (have_v) return;
+            have_v = true;
+            sv[lane] = rhs;
+            double v0 = 0.0, v1 = 0.0;
 #pragma unroll 8
             for (int c = 0; c < KP; c += 2) {
                 const f64x2_t rr = *(const f64x2_t*)(sv + c);              // broadcast read
-                v = __builtin_fma(gis[c * KP + ln], rr[0], v);
+                v0 = __builtin_fma(gis[c * KP + ln], rr[0], v0);
                 v1 = __builtin_fma(gis[(c + 1) * KP + ln], rr[1], v1);
             }
-            v += v1;
-        }
+            v = v0 + v1;
+        };
 
         int failed = 0;
         // compact solve of M[T,T] u = s_T on the first TB lanes (rows >= t are identity rows), then
@@ -585,9 +605,10 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
             const unsigned long long Zs = ~Fs & kmask;
             const int p = __popcll(Fs), q = __popcll(Zs);
             const bool inF = (Fs >> lane) & 1ull;
-            if (q == 0) { x = v; y = 0.0; return; }
+            if (q == 0) { need_v(); x = v; y = 0.0; return; }
             if (p == 0) { x = 0.0; y = comp_ok ? -rhs : 0.0; return; }
             const bool comp = q <= p;                                       // complement form on Ginv
+            if (comp) need_v();
             const unsigned long long T = comp ? Zs : Fs;
             const int t = comp ? q : p;
             const double* M = comp ? gis : gs;
@@ -925,7 +946,9 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
         skip_if = status;
     }
     int grid1 = grid;
-    if (skip_if && grid1 > num_cus * 12) grid1 = num_cus * 12;      // 3 resident workgroups per CU x 4 trips when it does run
+    // the fallback behind the inverse-based kernel almost always exits on its first load: two workgroups per CU (6.1 -> ~3 us
+    // of launch at 1500 workgroups, profiles/r05_s_reuters_kernel_stats.md) and more trips on the rare launch that does run
+    if (skip_if && grid1 > num_cus * 2) grid1 = num_cus * 2;
     // KP = 16, all columns, at most NNLS_GRAM_MAX workgroups: the launch also leaves the Gram partials of the solved factor
     double* gp = nullptr;
     if (gram_partials && gram_nblk && KPv == 16 && col_begin == 0 && grid1 == grid && grid <= NNLS_GRAM_MAX) { gp = gram_partials; *gram_nblk = grid; }

@@ -51,7 +51,7 @@ __device__ __forceinline__ bool bar_wait(const GridBar& b, gu32_t* p, unsigned t
     unsigned long long t_wait = 0;                     // when THIS wait began (a long factorisation is not a stall: the limit is per wait)
     for (unsigned spins = 0;; ++spins) {
         const unsigned v = __hip_atomic_load(p, R2P_RLX_AGENT);
-        if ((int)(v - target) >= 0) return true;
+        if ((int)(v - target) >= 0) return __hip_atomic_load(bar_word(b, R2P_ABORT), R2P_RLX_AGENT) == 0u;   // a late arrival of an abandoned run must not go on
         if ((spins & 63u) == 63u) {
             if (__hip_atomic_load(bar_word(b, R2P_ABORT), R2P_RLX_AGENT) != 0u) return false;
             const unsigned long long now = wall_clock64();
@@ -78,7 +78,9 @@ __device__ __forceinline__ bool grid_barrier(GridBar& b, int* sh_ok)
             const unsigned t = __hip_atomic_fetch_add(bar_word(b, R2P_TOP), 1u, R2P_RLX_AGENT) + 1u;
             if (t == e * b.nx) __hip_atomic_store(bar_word(b, R2P_TOPGEN), e, R2P_RLX_AGENT);
             else ok = bar_wait(b, bar_word(b, R2P_TOPGEN), e);
-            __hip_atomic_store(bar_word(b, R2P_XGEN + b.xcc), e, R2P_RLX_AGENT);
+            // the members are released only by a barrier that completed; after an abort or a timeout they find the ABORT word
+            // themselves (the leader's own wait has set it) instead of running on beside workgroups that have left
+            if (ok) __hip_atomic_store(bar_word(b, R2P_XGEN + b.xcc), e, R2P_RLX_AGENT);
         } else {
             ok = bar_wait(b, bar_word(b, R2P_XGEN + b.xcc), e);
         }
@@ -196,7 +198,10 @@ __global__ __launch_bounds__(1024) void rank2_persist_kernel(R2PersistArgs A)
     GridBar bar;
     bar.w = (gu32_t*)A.sync;
     bar.epoch = 0;
-    bar.deadline = 500000000ull;                            // longest single wait: 5 s of the 100 MHz constant clock
+    // longest single wait, in ticks of the 100 MHz constant clock: 0.25 s for the start-up barrier (whether every workgroup
+    // is resident is decided within microseconds of the launch; a grid that does not fit, e.g. under a CU mask, gives up
+    // quickly), 5 s afterwards (a wait inside the loop covers a whole phase of the slowest workgroup)
+    bar.deadline = 25000000ull;
     if (tid == 0) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -214,6 +219,7 @@ __global__ __launch_bounds__(1024) void rank2_persist_kernel(R2PersistArgs A)
     }
     __syncthreads();
     bar.xcc = sh_u[0]; bar.xtot = sh_u[1]; bar.nx = sh_u[2];
+    bar.deadline = 500000000ull;
     if (!sh_ok) { if (gtid == 0) A.out[0] = (double)R2P_ABORTED; return; }
 
     // ---- this workgroup's blocks of the two sides; LDS: products | offsets of A | offsets of A' | row-index copies ----
@@ -444,6 +450,10 @@ __global__ __launch_bounds__(1024) void rank2_persist_kernel(R2PersistArgs A)
         A.out[4] = metric;
         A.out[5] = (double)fail_tag;
         for (int q = 0; q < 4; ++q) A.out[8 + q] = (double)tk[q] * 0.01;     // us
+        // a run that any workgroup abandoned is ABORTED whatever this workgroup saw at its last barrier: the others never
+        // wrote their rows of Wt / H (the host then repeats the run on the launch-per-kernel path from the state Init left)
+        if ((status == R2P_CONVERGED || status == R2P_EXHAUSTED) && __hip_atomic_load(bar_word(bar, R2P_ABORT), R2P_RLX_AGENT) != 0u)
+            status = R2P_ABORTED;
         A.out[0] = (double)status;
     }
 }
@@ -475,9 +485,18 @@ int launch_rank2_persist(const R2PersistArgs& a, int workgroups, hipStream_t st)
 {
     SMK_HIP(hipMemsetAsync(a.sync, 0, rank2_persist_sync_bytes(), st));
     SMK_HIP(hipMemsetAsync(a.out, 0, 16 * sizeof(double), st));
-    static std::atomic<unsigned long long> attr_set{0};       // per device (first_use_on_this_device)
-    if (first_use_on_this_device(attr_set)) {
+    static std::atomic<unsigned long long> attr_set{0};       // per device (DeviceOnce)
+    if (DeviceOnce once{attr_set}) {
         SMK_HIP(hipFuncSetAttribute((const void*)rank2_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R2P_LDS_BYTES));
+        once.done();
+    }
+    {   // every workgroup has to be resident at once (two grid barriers per iteration): a grid the occupancy calculator does
+        // not place is refused here (the caller takes the launch-per-kernel path) rather than after the start-up deadline
+        int per_cu = 0, dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)rank2_persist_kernel, 1024, a.lds_bytes) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && (i64)per_cu * cus < workgroups)
+            return 1;      // not an error: "does not fit"
     }
     rank2_persist_kernel<<<workgroups, 1024, a.lds_bytes, st>>>(a);
     SMK_HIP(hipGetLastError());

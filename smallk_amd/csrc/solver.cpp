@@ -97,6 +97,9 @@ struct smk_matrix {
     // RANK2 on a factor larger than an L2: the entries regrouped by row block (spmm_blocked.hip), built on first use
     mutable BlockedCsc bA, bAt;
     mutable bool blocked_tried = false;
+    // ranks 3 .. 128 on sparse A: the entry-balanced segments of CSC(A) / CSC(A') (spmm_seg.hip), built on first use
+    mutable SegPlan segA, segAt;
+    mutable bool seg_tried = false;
     mutable std::vector<unsigned> h_colptr, h_rowidx;     // fetched on first use (ensure_host_csc)
     mutable std::vector<double> h_val;
 };
@@ -304,6 +307,14 @@ int smk_current_device(void)
 {
     int d = 0;
     return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
+
+size_t smk_device_trim(void)
+{
+    size_t cached = 0;
+    smk::dev_cache_stats(nullptr, nullptr, &cached);
+    smk::dev_trim();
+    return cached;
 }
 
 int smk_device_synchronize(void)
@@ -518,6 +529,8 @@ void smk_matrix_destroy(smk_matrix* a)
     unregister_matrix(a);
     free_blocked_csc(&a->bA);
     free_blocked_csc(&a->bAt);
+    free_seg_plan(&a->segA);
+    free_seg_plan(&a->segAt);
     void* ptrs[] = {a->A, a->At, a->colptr, a->colptr_t, a->rowidx, a->rowidx_t, a->val, a->val_t};
     for (void* p : ptrs)
         if (p) (void)smk::dev_free(p);
@@ -647,6 +660,73 @@ int smk_matrix_download_csc(const smk_matrix* a, int transposed, unsigned* col_o
         SMK_HIP(hipMemcpy(row_indices, transposed ? a->rowidx_t : a->rowidx, (size_t)a->nnz * sizeof(unsigned), hipMemcpyDeviceToHost));
         SMK_HIP(hipMemcpy(data, transposed ? a->val_t : a->val, (size_t)a->nnz * sizeof(double), hipMemcpyDeviceToHost));
     }
+    return SMK_OK;
+}
+static int ensure_seg_plans(const smk_matrix* a)
+{
+    if (a->seg_tried) return 0;
+    a->seg_tried = true;
+    static const bool seg_on = [] { const char* e = getenv("SMK_SPMM_SEG"); return !(e && e[0] == '0'); }();
+    hipStream_t bst = a->st ? a->st : g_stream;
+    if (seg_on && (build_seg_plan(a->n, a->nnz, a->colptr, a->rowidx, &a->segA, bst) ||
+                   build_seg_plan(a->m, a->nnz, a->colptr_t, a->rowidx_t, &a->segAt, bst))) {
+        free_seg_plan(&a->segA);
+        free_seg_plan(&a->segAt);
+    }
+    return 0;
+}
+
+// The sparse Gemm of the reference by itself (common/include/sparse_gemm_ab_impl.hpp / sparse_gemm_ba_impl.hpp in gather
+// form): out (k x ncols(B)) = X (k x rows(B)) * B with B = A (transposed == 0: W'A from X = W') or B = A' (transposed != 0:
+// (AH')' from X = H), on the kernel the solver would take at rank k.  `reps` launches are timed with HIP events (avg_ms, may be NULL).
+int smk_matrix_sparse_product(const smk_matrix* a, int transposed, int k, const double* X, int64_t ldx, double* out,
+                              int64_t ldo, int reps, double* avg_ms)
+{
+    if (!a || !a->sparse || k < 1 || k > MAX_K || !X || !out || ldx < k || ldo < k) return SMK_BAD_PARAM;
+    const i64 rows = transposed ? a->n : a->m, ncols = transposed ? a->m : a->n;
+    const int KP = kp_of(k);
+    const int kpp = (k <= 2) ? 2 : KP;
+    const int ldx_dev = (k <= 2) ? 2 : KP;
+    hipStream_t st = a->st ? a->st : g_stream;
+    if (k > 2 && !is_wide(k)) ensure_seg_plans(a);
+    std::vector<double> xp((size_t)rows * ldx_dev, 0.0), pp((size_t)ncols * kpp);
+    for (i64 r = 0; r < rows; ++r)
+        for (int c = 0; c < k; ++c) xp[(size_t)r * ldx_dev + c] = X[r * ldx + c];
+    double *dX = nullptr, *dP = nullptr;
+    int rc = dev_alloc(&dX, xp.size());
+    if (!rc) rc = dev_alloc(&dP, pp.size());
+    struct Free { double *&a, *&b; ~Free() { if (a) (void)smk::dev_free(a); if (b) (void)smk::dev_free(b); } } guard{dX, dP};
+    if (rc) return rc;
+    SMK_HIP(hipMemcpyAsync(dX, xp.data(), xp.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    const i64* cp = transposed ? a->colptr_t : a->colptr;
+    const unsigned* ri = transposed ? a->rowidx_t : a->rowidx;
+    const double* va = transposed ? a->val_t : a->val;
+    const SegPlan& seg = transposed ? a->segAt : a->segA;
+    auto once = [&]() -> int {
+        if (k > 2 && !is_wide(k) && seg.rowflag && seg.ncols == ncols && !seg.uniform) return launch_spmm_seg(seg, cp, va, dX, k, dP, kpp, st);
+        return launch_spmm_gather(cp, ri, va, ncols, a->nnz, dX, ldx_dev, k, dP, kpp, st);
+    };
+    rc = once();
+    if (rc) return rc;
+    if (reps > 0 && avg_ms) {
+        hipEvent_t e0, e1;
+        SMK_HIP(hipEventCreate(&e0));
+        SMK_HIP(hipEventCreate(&e1));
+        SMK_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < reps && !rc; ++i) rc = once();
+        SMK_HIP(hipEventRecord(e1, st));
+        SMK_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = (double)ms / reps;
+        if (rc) return rc;
+    }
+    SMK_HIP(hipMemcpyAsync(pp.data(), dP, pp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    SMK_HIP(hipStreamSynchronize(st));
+    for (i64 j = 0; j < ncols; ++j)
+        for (int c = 0; c < k; ++c) out[j * ldo + c] = pp[(size_t)j * kpp + c];
     return SMK_OK;
 }
 int64_t smk_matrix_nnz(const smk_matrix* a) { return a ? a->nnz : 0; }
@@ -1044,6 +1124,10 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
             }
             nb1 = a->bA.nb > 1 ? a->bA.nb : 1;
             nb2 = a->bAt.nb > 1 ? a->bAt.nb : 1;
+        } else if (!is_wide(opts->k)) {
+            // MU / HALS / BPP at ranks up to 128: the gather products work on entry-balanced segments (spmm_seg.hip);
+            // SMK_SPMM_SEG=0 keeps the column-per-lane-group kernel of round 4
+            ensure_seg_plans(a);
         }
         s->pl1.S = nb1; s->pl1.p_elems = (size_t)nb1 * s->pl1.ncols_pad * s->kpp;
         s->pl2.S = nb2; s->pl2.p_elems = (size_t)nb2 * s->pl2.ncols_pad * s->kpp;
@@ -1584,7 +1668,9 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
     }
     int rc;
     const BlockedCsc& blk = (which == 0) ? s->a->bA : s->a->bAt;
+    const SegPlan& seg = (which == 0) ? s->a->segA : s->a->segAt;
     if (ldx == 2 && blk.nb > 1) rc = launch_spmm_blocked2(blk, X, P, which == 0 ? s->pl1.ncols_pad : s->pl2.ncols_pad, s->st);
+    else if (ldx == s->KP && s->k > 2 && !is_wide(s->k) && seg.ncols == ncols && seg.rowflag && !seg.uniform) rc = launch_spmm_seg(seg, colptr, val, X, s->k, P, s->kpp, s->st);
     else rc = launch_spmm_gather(colptr, rowidx, val, ncols, s->a->nnz, X, ldx, s->k, P, s->kpp, s->st);
     if (timed) {
         if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
@@ -2424,11 +2510,16 @@ int smk_solver_run(smk_solver* s, smk_stats* stats)
 // 16 M-entry root 645 -> 556 us) because its entry-parallel products issue exactly one gather per stored entry with all of
 // a chunk's gathers in flight -- so there is no size limit by default (SMK_R2_PERSIST_NNZ sets one, SMK_R2_PERSIST=0 turns
 // the kernel off).
+// devices on which a resident launch could not synchronise its workgroups (a CU mask, another process holding CUs): latched
+// for the PROCESS, not per solver handle -- HierNMF2 and flatclust create a solver per node and per trial, and each would pay the
+// start-up deadline again and print the warning again
+static std::atomic<unsigned long long> g_r2p_off_devices{0};
 static bool rank2_persist_eligible(const smk_solver* s)
 {
     static const int mode = [] { const char* e = getenv("SMK_R2_PERSIST"); return e ? atoi(e) : 1; }();
     static const i64 max_nnz = [] { const char* e = getenv("SMK_R2_PERSIST_NNZ"); return e ? (i64)atoll(e) : (i64)1 << 40; }();
     if (!mode || s->r2p_off) return false;
+    if (g_r2p_off_devices.load(std::memory_order_relaxed) & (1ull << (smk_current_device() & 63))) return false;
     if (s->o.algorithm != SMK_ALG_RANK2 || !s->a->sparse || s->o.prog_est_algorithm != SMK_PROG_PG_RATIO) return false;
     if (is_dist(s) || s->comm || s->o.verbose || s->timing || !s->Hc || !s->Wc) return false;
     if (rank2_persist_workgroups(s->m, s->n, s->a->nnz, g_cus) < 1) return false;      // more than 4096 rows per workgroup
@@ -2468,6 +2559,7 @@ static int rank2_persist_run(smk_solver* s, int* status, int* count)
     a.lds_bytes = (unsigned)rank2_persist_lds_bytes();
     a.out = s->r2p_out;
     int rc = launch_rank2_persist(a, nwg, s->st);
+    if (rc == 1) { *status = R2P_ABORTED; return 0; }       // the grid does not fit the device as it is now
     if (rc) return rc;
     SMK_HIP(hipMemcpyAsync(s->r2p_pin, s->r2p_out, 16 * sizeof(double), hipMemcpyDeviceToHost, s->st));
     SMK_HIP(hipStreamSynchronize(s->st));
@@ -2532,7 +2624,9 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
         // left, so the launch-per-kernel loop below takes over, latched for the life of the handle
         s->r2p_off = true;
         s->wc_valid = false;           // the compact copy of W served as the kernel's work array
-        fprintf(stderr, "smallk_amd: the resident RANK2 kernel could not synchronise its workgroups; continuing on the launch-per-kernel path\n");
+        const unsigned long long bit = 1ull << (smk_current_device() & 63);
+        if (!(g_r2p_off_devices.fetch_or(bit, std::memory_order_relaxed) & bit))       // once per device and process
+            fprintf(stderr, "smallk_amd: the resident RANK2 kernel could not synchronise its workgroups on device %d; this process continues on the launch-per-kernel path there\n", smk_current_device());
     }
 
     // The stopping rule of iteration i (NmfSolve, nmf_solve_generic.hpp:81-121) is evaluated AFTER

@@ -1616,9 +1616,10 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
         SMK_HIP(hipGetLastError());
     }
     const int lds = nnls_wide_lds_bytes(k);
-    static std::atomic<unsigned long long> attr_set{0};       // per device (first_use_on_this_device)
-    if (first_use_on_this_device(attr_set)) {
+    static std::atomic<unsigned long long> attr_set{0};       // per device (DeviceOnce)
+    if (DeviceOnce once{attr_set}) {
         SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        once.done();
     }
     // G invertible: the tile kernel -- a wave per column with the block's tiles in LDS where four values per lane cover a
     // column (k <= 256) and SMK_WIDE_NW=1 asks for it, else the workgroup on one column with as many tile rows in LDS as fit
@@ -1632,10 +1633,11 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
         // against 5.0 with the workgroup on one; k = 192 6.2 against 5.8; k = 256 13.7 against 11.0
         const bool fits3 = k <= 256 && tile_slice_bytes(k, tp_full) * 3 <= 156 * 1024;
         const bool one_wave = (nw_env == 1 && k <= 256) || (nw_env == 0 && fits3);
-        static std::atomic<unsigned long long> attr_tile{0};       // per device (first_use_on_this_device)
-        if (first_use_on_this_device(attr_tile)) {
+        static std::atomic<unsigned long long> attr_tile{0};       // per device (DeviceOnce)
+        if (DeviceOnce once{attr_tile}) {
             SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
             SMK_HIP(hipFuncSetAttribute((const void*)nnls_wide_tile_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            once.done();
         }
         if (one_wave) {
             const size_t slice = tile_slice_bytes(k, tp_full);

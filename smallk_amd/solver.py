@@ -47,6 +47,11 @@ def thread_context_end():
     L.lib().smk_thread_context_end()
 
 
+def trim_device_cache() -> int:
+    """Return the library's cached (freed) device workspaces of the current device to the HIP runtime; bytes that were cached."""
+    return int(L.lib().smk_device_trim())
+
+
 def set_stream(stream_ptr: int):
     L.check(L.lib().smk_set_stream(C.c_void_p(stream_ptr)), "smk_set_stream")
 
@@ -140,6 +145,18 @@ class SparseMatrix(DenseMatrix):
     def from_scipy(cls, A):
         A = A.tocsc()
         return cls(A.data, A.indices, A.indptr, A.shape)
+
+    def product(self, X, *, transposed=False, reps=0):
+        """The sparse Gemm by itself: X (k x height) * A, or with ``transposed`` X (k x width) * A'; returns the k x ncols
+        result and, for reps > 0, the average launch time in ms (smk_matrix_sparse_product)."""
+        X = _f(X)
+        k = X.shape[0]
+        assert X.shape[1] == (self.ncols if transposed else self.height)
+        out = np.zeros((k, self.height if transposed else self.ncols), order="F")
+        ms = C.c_double(0)
+        L.check(L.lib().smk_matrix_sparse_product(self._h, int(transposed), k, _p(X), k, _p(out), k, int(reps),
+                                                  C.byref(ms) if reps > 0 else None), "smk_matrix_sparse_product")
+        return (out, ms.value) if reps > 0 else out
 
 
 def load_matrix_market(path):

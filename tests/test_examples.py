@@ -36,3 +36,16 @@ def test_python_example_runs():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "documents per flat cluster" in r.stdout and "NMF: W (2000, 8)" in r.stdout
+
+
+def test_pysmallk_clustering_classes_import_from_the_package():
+    """pysmallk's Hierclust / Flatclust (smallk_lib.pyx:924-1420) stay importable where rounds 1-3 had them."""
+    import smallk_amd
+    from smallk_amd import Flatclust, Hierclust
+    import smallk_amd.pyclust as pc
+    assert pc.Hierclust is Hierclust and pc.Flatclust is Flatclust and smallk_amd.pyclust is pc
+    for cls in (Hierclust, Flatclust):
+        for name in ("load_matrix", "load_dictionary", "cluster", "get_top_indices", "get_assignments", "write_output", "finalize"):
+            assert callable(getattr(cls, name)), (cls.__name__, name)
+    with pytest.raises(AttributeError):
+        smallk_amd.no_such_thing

@@ -207,4 +207,4 @@ def test_resident_rank2_kernel_falls_back_when_it_cannot_synchronise(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     res = [l for l in out.stdout.splitlines() if l.startswith("RES")][0].split()
     assert res[1] == "0" and res[2] == res[3] and float(res[4]) < 1e-8, res
-    assert "continuing on the launch-per-kernel path" in out.stderr
+    assert "continues on the launch-per-kernel path" in out.stderr
