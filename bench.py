@@ -60,6 +60,7 @@ WORKLOADS = {
     "c4s": (262144, 8192, 64, "BPP", "f32", "EXPERIMENT one 1/8 column shard of C4: 262144x8192 k=64 BPP fp32"),
     "c4b": (262144, 65536, 64, "BPP", "bf16", "EXPERIMENT C4 with A held as bf16"),
     "b32": (32768, 8192, 32, "BPP", "f32", "EXPERIMENT 32768x8192 k=32 BPP fp32"),
+    "c4mu": (262144, 65536, 64, "MU", "f32", "EXPERIMENT C4's matrix under MU (replicated W update, all-reduce of (AH')')"),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "f32": 157.3}
@@ -117,6 +118,29 @@ def rccl_log_excerpt(max_lines=60, out=sys.stderr):
     if not files:
         print("[bench] no RCCL log files (/tmp/smk_rccl_*.log)", file=out)
     out.flush()
+
+
+def rccl_choices(max_items=40):
+    """What RCCL chose per collective and size -- its own TUNING lines ("AllReduce: 33554432 Bytes -> Algo 1 proto 2 time ...",
+    NCCL_DEBUG_SUBSYS=TUNING) from this run's per-rank log files, de-duplicated; algorithm / protocol numbers are RCCL's enums
+    (algo 0 tree, 1 ring, ...; proto 0 LL, 1 LL128, 2 simple).  Empty when RCCL printed none (one rank, or another log format)."""
+    import glob
+    import re
+    pat = re.compile(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)")
+    seen, out = set(), []
+    try:
+        files = sorted(glob.glob(os.environ.get("SMK_BENCH_RCCL_LOG_GLOB", "/tmp/smk_rccl_*.log")), key=os.path.getmtime, reverse=True)
+        for fn in files[:1]:
+            for l in open(fn, errors="replace"):
+                m = pat.search(l)
+                if m and m.groups() not in seen:
+                    seen.add(m.groups())
+                    out.append({"collective": m.group(1), "bytes": int(m.group(2)), "algo": int(m.group(3)), "proto": int(m.group(4))})
+                    if len(out) >= max_items:
+                        return out
+    except Exception:
+        pass
+    return out
 
 
 def start_rank_watchdog(stall_s):
@@ -411,6 +435,7 @@ def build_report(args, world, elapsed, windows, rank0, ranks_report, collectives
         "useful_tflops_vs_native_mfma_peak": mfma_tf / MFMA_PEAK_TF[storage],
         "whole_iteration_tflops": 4.0 * m * n * k / (elapsed / args.steps) / 1e12,
         "collectives_ms_per_step_rank0": ranks_report[0]["collectives_ms_per_step"] if sharded else None,
+        "exposed_comm_ms_per_step_rank0": ranks_report[0].get("exposed_comm_ms") if sharded else None,
         "per_rank": ranks_report if sharded else None,
         "windows": len(windows), "windows_ms": [round(w * 1e3, 4) for w in windows],
         "timed_region_s": sum(windows),
@@ -441,10 +466,25 @@ def build_report(args, world, elapsed, windows, rank0, ranks_report, collectives
                                                         "smallk_amd/csrc/bigprod.hip; rerun tools/profile.sh")
         except Exception:
             pass
+    # MFMA utilisation from counters (north_star asks for it by name): a separate rocprofv3 --pmc pass (tools/pmc_mfma.py ->
+    # profiles/mfma_util.json), tied to the kernel source like the traffic figure
+    prof = os.path.join(ROOT, "profiles", "mfma_util.json")
+    if os.path.exists(prof) and args.emulate_world <= 1:
+        try:
+            pj = json.load(open(prof))
+            key = f"{args.workload}_n{world}"
+            if key in pj:
+                if pj[key].get("kernel_source_sha16") == kernel_source_sha16():
+                    out["roofline"]["mfma_busy_frac"] = pj[key]["mfma_busy_frac"]
+                    out["roofline"]["mfma_busy_source"] = pj[key].get("source", "profiles/")
+                else:
+                    out["roofline"]["mfma_busy_stale"] = "profiles/mfma_util.json was measured on another version of bigprod.hip"
+        except Exception:
+            pass
     return out
 
 
-def per_rank_report(rank, args, k, windows, ms0, c0, ms1, c1, msc, cc):
+def per_rank_report(rank, args, k, windows, ms0, c0, ms1, c1, msc, cc, msx=0.0, cx=0, mscal=0.0, ccal=0):
     """per rank and per step: both streaming passes, the collectives' own spans, and what the step spends outside the
     passes.  If the collectives take longer than that remainder, the difference was hidden behind the products:
     overlap_lower_bound = max(0, 1 - outside / collectives)."""
@@ -453,6 +493,14 @@ def per_rank_report(rank, args, k, windows, ms0, c0, ms1, c1, msc, cc):
     pr = {"rank": rank, "ms_per_step": sum(windows) / timed_steps * 1e3,
           "products_ms_per_step": (ms0 + ms1) / timed_steps, "collectives_ms_per_step": msc / timed_steps,
           "collective_calls_per_step": cc / timed_steps, "passes_per_step": (c0 + c1) / ngroups / timed_steps}
+    # MEASURED exposure: the main stream's waits for events of the collective stream, each bracketed by two events on the main
+    # stream (slot 3 of smk_solver_kernel_time); ~5 us per wait is the bracket itself
+    # and the same bracket around a wait for an event that completed long ago (slot 4) is what a bracket costs by itself
+    null_ms = mscal / ccal if ccal > 0 else 0.0
+    pr["exposed_comm_ms_raw"] = msx / timed_steps
+    pr["exposed_comm_waits_per_step"] = cx / timed_steps
+    pr["wait_bracket_cost_ms"] = null_ms
+    pr["exposed_comm_ms"] = max(0.0, (msx - cx * null_ms) / timed_steps)
     pr["outside_products_ms_per_step"] = pr["ms_per_step"] - pr["products_ms_per_step"]
     pr["overlap_lower_bound"] = (max(0.0, 1.0 - pr["outside_products_ms_per_step"] / pr["collectives_ms_per_step"])
                                  if pr["collectives_ms_per_step"] > 0 else None)
@@ -465,7 +513,7 @@ def rccl_env_defaults(set_keys):
     resolve) and no InfiniBand probing -- the data path is xGMI either way.  The caller's settings win."""
     if "NCCL_DEBUG" not in os.environ:
         os.environ["NCCL_DEBUG"] = "INFO"
-        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH" + (",TUNING" if os.environ.get("SMK_BENCH_RCCL_TUNING") else ""))
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH" + ("" if os.environ.get("SMK_BENCH_RCCL_TUNING") == "0" else ",TUNING"))
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/smk_rccl_%h_%p.log")
     if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
         for key, val in (("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1")):
@@ -647,8 +695,10 @@ def run_rank(args):
     ms1, c1 = solver.kernel_time(1)
     sharded = world > 1 or args.emulate_world > 1
     msc, cc = solver.kernel_time(2) if sharded else (0.0, 0)    # spans of the collectives on the second stream, this rank
+    msx, cx = solver.kernel_time(3) if sharded else (0.0, 0)    # the main stream's waits for them (measured exposure)
+    mscal, ccal = solver.kernel_time(4) if sharded else (0.0, 0)
     bytes_per_launch, flops_per_launch = solver.kernel_work(0)
-    per_rank = per_rank_report(rank, args, k, windows, ms0, c0, ms1, c1, msc, cc)
+    per_rank = per_rank_report(rank, args, k, windows, ms0, c0, ms1, c1, msc, cc, msx, cx, mscal, ccal)
     ranks_report = [per_rank]
     if world > 1:
         ranks_report = [None] * world
@@ -661,6 +711,8 @@ def run_rank(args):
         out = build_report(args, world, elapsed, windows,
                            {"ms0": ms0, "c0": c0, "ms1": ms1, "c1": c1, "bytes": bytes_per_launch, "flops": flops_per_launch},
                            ranks_report, collectives, parallelism)
+        if world > 1:
+            out["rccl_choices"] = rccl_choices()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, n, k, alg, 1 if storage == "bf16" else 0, data=args.data)
         guard.restore()
@@ -768,7 +820,9 @@ def run_single_process(args):
             ms0, c0 = solver.kernel_time(0)
             ms1, c1 = solver.kernel_time(1)
             msc, cc = solver.kernel_time(2)
-            shared["reports"][r] = per_rank_report(r, args, k, windows, ms0, c0, ms1, c1, msc, cc)
+            msx, cx = solver.kernel_time(3)
+            mscal, ccal = solver.kernel_time(4)
+            shared["reports"][r] = per_rank_report(r, args, k, windows, ms0, c0, ms1, c1, msc, cc, msx, cx, mscal, ccal)
             if r == 0:
                 b, f = solver.kernel_work(0)
                 shared["rank0"] = {"ms0": ms0, "c0": c0, "ms1": ms1, "c1": c1, "bytes": b, "flops": f}
@@ -803,6 +857,7 @@ def run_single_process(args):
         np.save(os.environ["SMK_BENCH_DUMP_W"], shared["W"])
     out = build_report(args, N, elapsed, windows, shared["rank0"], shared["reports"], collectives,
                        f"column-shard x{N}, ONE process, one host thread per device")
+    out["rccl_choices"] = rccl_choices()
     guard.restore()
     print(json.dumps(out), flush=True)
     if not share:

@@ -198,7 +198,10 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
 int smk_solver_enable_timing(smk_solver* s, int on);
 /* which: 0 = W'A pass, 1 = H*At pass (a pass that the multi-GPU schedule cuts into chunks counts as ONE launch per group of
  * 64 factor rows; its time is the sum of its chunk launches), 2 = the per-chunk collectives of a sharded run, timed on the
- * collective stream (the sums of (AH')' and, BPP, the all-gathers of the packed W).  Total ms and count since enable. */
+ * collective stream (the sums of (AH')' and, BPP, the all-gathers of the packed W); 3 = the time the MAIN stream stood waiting
+ * for events of the collective stream (each wait bracketed by two events on the main stream: the measured, not inferred, exposed
+ * part of the exchange); 4 = the same bracket around a wait for an event that completed long ago (what a bracket costs by itself,
+ * ~15 us: subtract brackets x its average from slot 3).  Total ms and count since enable. */
 int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* launches);
 /* algorithmic bytes / flops one launch of pass `which` moves (len*ncols*sizeof(elt), 2*k*len*ncols) */
 int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double* flops);

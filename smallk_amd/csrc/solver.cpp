@@ -242,9 +242,15 @@ struct smk_solver {
     unsigned pass_counter[2] = {0, 0}, pass_sampled[2] = {0, 0};     // passes seen / passes that carried events since enable_timing
     bool pass_timed[2] = {false, false};     // this W'A / H*At pass (all of its launches, and the collectives behind it) is a timed sample
     struct TimedSpan { hipEvent_t e0, e1; int counts; };     // counts: this span completes one launch (a pass cut into chunks is ONE launch)
-    std::vector<TimedSpan> ev[3];         // 0: W'A passes, 1: H*At passes, 2: the big collectives of a sharded run (on st2)
-    double acc_ms[3] = {0, 0, 0};
-    int launches[3] = {0, 0, 0};
+    // 0: W'A passes, 1: H*At passes, 2: the big collectives of a sharded run (on st2), 3: what the MAIN stream spends waiting
+    // for events of the collective stream (the exposed part of the exchange: the bracket holds nothing but the wait)
+    // 4: the same bracket around a wait for an event that completed long ago -- what a bracket costs by itself (three packets
+    // through the command processor, ~15 us): exposure = slot 3 - brackets x the average of slot 4
+    std::vector<TimedSpan> ev[5];
+    double acc_ms[5] = {0, 0, 0, 0, 0};
+    int launches[5] = {0, 0, 0, 0, 0};
+    hipEvent_t ev_cal = nullptr;          // recorded once on the collective stream
+    unsigned cal_counter = 0;
 };
 
 static const int GRAM_BLOCKS = 256;
@@ -1204,8 +1210,9 @@ void smk_solver_destroy(smk_solver* s)
                     s->xscale[0], s->xscale[1], s->oscale[0], s->oscale[1], s->r2_scratch, s->r2_prog, s->Graw, s->Hc, s->Wc, s->wide_tmp};
     for (void* p : ptrs)
         if (p) (void)smk::dev_free(p);
-    for (int w = 0; w < 3; ++w)
+    for (int w = 0; w < 5; ++w)
         for (auto& e : s->ev[w]) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    if (s->ev_cal) (void)hipEventDestroy(s->ev_cal);
     for (int b = 0; b < 2; ++b) {
         if (s->snap[b]) (void)smk::dev_free(s->snap[b]);
         if (s->pev[b]) (void)hipEventDestroy(s->pev[b]);
@@ -1498,12 +1505,50 @@ static int comm_fork(smk_solver* s, hipEvent_t ev)
     SMK_HIP(hipStreamWaitEvent(s->st2, ev, 0));
     return 0;
 }
+// The main stream waits for `n` events of the collective stream.  On a timed pass the wait is bracketed by two events on the
+// main stream: their distance is the time the main stream stood still for the exchange -- measured exposure instead of the
+// "step time minus products" subtraction (slot 3 of smk_solver_kernel_time; the two records themselves cost a few us of idle
+// time, so an exchange that is hidden completely still reads ~5 us per wait).
+static int main_waits_for_comm(smk_solver* s, const hipEvent_t* evs, int n)
+{
+    const bool timed = s->timing && (s->pass_timed[0] || s->pass_timed[1]);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed && (s->cal_counter++ & 3u) == 0 && s->st2) {        // every fourth bracket is preceded by a calibration bracket
+        if (!s->ev_cal) {
+            SMK_HIP(hipEventCreateWithFlags(&s->ev_cal, hipEventDisableTiming));
+            SMK_HIP(hipEventRecord(s->ev_cal, s->st2));
+        } else {
+            hipEvent_t c0 = nullptr, c1 = nullptr;
+            SMK_HIP(hipEventCreate(&c0));
+            if (hipEventCreate(&c1) != hipSuccess) { (void)hipEventDestroy(c0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
+            (void)hipEventRecord(c0, s->st);
+            (void)hipStreamWaitEvent(s->st, s->ev_cal, 0);
+            (void)hipEventRecord(c1, s->st);
+            s->ev[4].push_back({c0, c1, 1});
+        }
+    }
+    if (timed) {
+        SMK_HIP(hipEventCreate(&e0));
+        if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("hipEventCreate failed"); return SMK_DEVICE_ERROR; }
+        (void)hipEventRecord(e0, s->st);
+    }
+    for (int i = 0; i < n; ++i)
+        if (hipStreamWaitEvent(s->st, evs[i], 0) != hipSuccess) {
+            if (timed) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+            set_error("hipStreamWaitEvent failed");
+            return SMK_DEVICE_ERROR;
+        }
+    if (timed) {
+        (void)hipEventRecord(e1, s->st);
+        s->ev[3].push_back({e0, e1, 1});
+    }
+    return 0;
+}
 // ... and the main stream waits for what st2 has been given so far
 static int comm_join(smk_solver* s, hipEvent_t ev)
 {
     SMK_HIP(hipEventRecord(ev, s->st2));
-    SMK_HIP(hipStreamWaitEvent(s->st, ev, 0));
-    return 0;
+    return main_waits_for_comm(s, &ev, 1);
 }
 
 // a collective on st2 bracketed by events when timing is on (slot 2 of smk_solver_kernel_time)
@@ -1549,7 +1594,8 @@ static int allreduce_gh(smk_solver* s)
 static int wait_gh(smk_solver* s)
 {
     if (!s->gh_pending) return 0;
-    SMK_HIP(hipStreamWaitEvent(s->st, s->ev_gh, 0));
+    const int rc = main_waits_for_comm(s, &s->ev_gh, 1);
+    if (rc) return rc;
     s->gh_pending = false;
     return 0;
 }
@@ -1557,7 +1603,8 @@ static int wait_gh(smk_solver* s)
 static int wait_r2(smk_solver* s)
 {
     if (!s->r2_pending) return 0;
-    for (int j = 0; j < s->nchunk; ++j) SMK_HIP(hipStreamWaitEvent(s->st, s->ev_r[j], 0));
+    const int rc = main_waits_for_comm(s, s->ev_r, s->nchunk);
+    if (rc) return rc;
     s->r2_pending = false;
     return 0;
 }
@@ -1718,7 +1765,7 @@ static int prod1_sharded(smk_solver* s)
     for (int j = 0; j < s->nchunk; ++j) {
         i64 r0, r1;
         chunk_rows(s, j, &r0, &r1);
-        SMK_HIP(hipStreamWaitEvent(s->st, s->ev_a[j], 0));
+        { const int wrc = main_waits_for_comm(s, &s->ev_a[j], 1); if (wrc) return wrc; }
         const i64 rows = std::min<i64>(r1, s->m) - r0;
         if (rows <= 0) continue;
         const bool last = (j == s->nchunk - 1) || (std::min<i64>(r1, s->m) >= s->m);
@@ -2039,7 +2086,7 @@ static int solver_iteration(smk_solver* s)
 
 static int resolve_events(smk_solver* s)
 {
-    for (int w = 0; w < 3; ++w) {
+    for (int w = 0; w < 5; ++w) {
         for (auto& e : s->ev[w]) {
             float ms = 0.f;
             SMK_HIP(hipEventElapsedTime(&ms, e.e0, e.e1));
@@ -2876,14 +2923,18 @@ int smk_solver_enable_timing(smk_solver* s, int on)
     if (const char* e = getenv("SMK_TIMING_STRIDE")) s->timing_stride = std::max(1, atoi(e));
     s->pass_counter[0] = s->pass_counter[1] = 0;
     s->pass_sampled[0] = s->pass_sampled[1] = 0;
-    s->acc_ms[0] = s->acc_ms[1] = s->acc_ms[2] = 0.0;
-    s->launches[0] = s->launches[1] = s->launches[2] = 0;
+    for (int w = 0; w < 5; ++w) { s->acc_ms[w] = 0.0; s->launches[w] = 0; }
     return SMK_OK;
 }
 
 int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* launches)
 {
-    if (!s || which < 0 || which > 2) return SMK_BAD_PARAM;      // 2: the (AH')' sum and the W all-gather of a sharded run
+    if (!s || which < 0 || which > 4) return SMK_BAD_PARAM;      // 2: the (AH')' sum and the W all-gather of a sharded run; 3: main-stream waits for them
+    if (which == 4) {       // calibration brackets: unscaled (their average is what matters)
+        if (total_ms) *total_ms = s->acc_ms[4];
+        if (launches) *launches = s->launches[4];
+        return SMK_OK;
+    }
     // one pass in `timing_stride` carries events: totals are scaled by the TRUE ratio passes seen / passes sampled (100 passes
     // at stride 8 are 13 samples standing for 100, not for 104); the collectives (slot 2) are sampled with either pass
     const unsigned seen = which < 2 ? s->pass_counter[which] : s->pass_counter[0] + s->pass_counter[1];
