@@ -60,6 +60,7 @@ WORKLOADS = {
     "c4s": (262144, 8192, 64, "BPP", "f32", "EXPERIMENT one 1/8 column shard of C4: 262144x8192 k=64 BPP fp32"),
     "c4b": (262144, 65536, 64, "BPP", "bf16", "EXPERIMENT C4 with A held as bf16"),
     "b32": (32768, 8192, 32, "BPP", "f32", "EXPERIMENT 32768x8192 k=32 BPP fp32"),
+    "c3t": (16384, 65536, 32, "HALS", "bf16", "EXPERIMENT C3 transposed: 16384x65536 k=32 HALS bf16"),
     "c4mu": (262144, 65536, 64, "MU", "f32", "EXPERIMENT C4's matrix under MU (replicated W update, all-reduce of (AH')')"),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -265,6 +266,8 @@ def parse_args(argv=None):
     ap.add_argument("--data", default="uniform", choices=["uniform", "planted"],
                     help="dense workloads: i.i.d. uniform A, or A = Ws Hs + 0.05 U with sparse planted factors of rank k "
                          "(smk_matrix_fill_planted: block pivoting keeps exchanging variables for many iterations)")
+    ap.add_argument("--single-copy", action="store_true",
+                    help="bf16 workloads under MU / HALS: A without its stored transpose (smk_matrix_create_single_copy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without torch.distributed: one process, one host thread per device, communicators from "
@@ -373,7 +376,7 @@ def launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL across processes)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     common = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload,
-              "--data", args.data, "--stall-s", str(args.stall_s)]
+              "--data", args.data, "--stall-s", str(args.stall_s)] + (["--single-copy"] if args.single_copy else [])
     if args.no_cpu_baseline:
         common.append("--no-cpu-baseline")
     me = os.path.join(ROOT, "bench.py")
@@ -425,7 +428,7 @@ def build_report(args, world, elapsed, windows, rank0, ranks_report, collectives
         "vs_baseline": None,
         "dtype": storage if storage == "bf16" else "f32",
         "data": "synthetic" if args.data == "uniform" else "synthetic (planted sparse factors of rank k + 0.05 uniform noise)",
-        "config": {"workload": desc, "m": m, "n": n, "k": k, "algorithm": alg, "A_storage": storage,
+        "config": {"workload": desc + (" [single copy of A: no stored transpose]" if args.single_copy else ""), "m": m, "n": n, "k": k, "algorithm": alg, "A_storage": storage,
                    "state": "W,H,Gram fp64; big products: MFMA with fp32 accumulation folded into fp64",
                    "parallelism": parallelism, "collectives": collectives},
         # useful flops (2 k per matrix entry) of the streaming products.  fp32 storage computes them as three fp16
@@ -629,7 +632,7 @@ def run_rank(args):
 
     total_iters = args.warmup + args.steps
     beat("matrix fill", limit=lim(args, 180.0))
-    A = smallk_amd.DenseMatrix(m, n, col0=col0, ncols=ncols, storage=storage)
+    A = smallk_amd.DenseMatrix(m, n, col0=col0, ncols=ncols, storage=storage, single_copy=args.single_copy)
     if args.data == "planted":
         A.fill_planted(42, k, 0.7, 0.05)
     else:

@@ -70,6 +70,9 @@ SYMBOLS = {
     "smk_nmf_dense": (C.c_int, [C.POINTER(Options), _dp, _i64, _dp, _i64, _dp, _i64, C.POINTER(Stats), C.c_int]),
     "smk_matrix_create": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _i64, C.c_int]),
     "smk_matrix_upload_f64": (C.c_int, [_vp, _dp, _i64]),
+    "smk_matrix_create_single_copy": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _i64, C.c_int]),
+    "smk_matrix_is_single_copy": (C.c_int, [_vp]),
+    "smk_matrix_device_bytes": (_i64, [_vp]),
     "smk_matrix_fill_uniform": (C.c_int, [_vp, C.c_uint64]),
     "smk_matrix_fill_planted": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_double, C.c_double]),
     "smk_matrix_download_f64": (C.c_int, [_vp, _dp, _i64]),

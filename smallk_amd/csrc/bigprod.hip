@@ -82,7 +82,16 @@ template <int LPS, int PD> __device__ __forceinline__ void wait_stage(int ahead)
     wait_vmcnt<0>();
 }
 
-template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK, int NWL>
+// TRB ("transposed source", bf16 only): the SAME product with B = A' taken from A itself, so that MU and HALS need no stored
+// transpose (the reference's MU / HALS call Gemm(NORMAL, TRANSPOSE) on A, nmf_solver_mu.hpp:121-164, nmf_solver_hals.hpp:166-199;
+// only its BPP keeps At).  B then points at A (m x n column-major), the tile's 128 "columns" are 128 consecutive ROWS of A (the
+// contiguous direction) and a stage is 64 COLUMNS of A: the contraction runs down the strided direction.  A stage is fetched as
+// 1-KiB pieces of [8 columns][64 rows] -- 128 contiguous bytes per column, full lines, fetched by 8 adjacent lanes -- and the
+// MFMA operand (8 contraction-consecutive values per lane) comes out of LDS through ds_read_b64_tr_b16, the gfx950
+// transposing read: the 16 lanes of a group hand in the four quarters of four 32-byte rows and each receives one column of
+// that 4 x 16 block.  A half-wave reads 4 rows x 64 bytes, laid out (half-swapped rows) on one whole bank row: no conflicts.
+// Everything else (X operand, ring, splits, epilogue) is unchanged.
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK, int NWL, bool TRB = false>
 __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                          const unsigned char* __restrict__ Xp,
                                                          double* __restrict__ P, i64 stages, i64 nst,
@@ -90,6 +99,7 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
 {
     using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
     constexpr int KTW = C::KTW;
+    static_assert(!TRB || (EBYTES == 2 && CW == 1 && MB % 16 == 0), "transposed source: bf16, 128-row tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // ---- XCD-aware block -> (tile, split): all blocks of one split share an XCD's L2
@@ -129,12 +139,22 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
     for (int i = 0; i < C::LPS; ++i) {
         const int t = lw + C::NLD * i;             // wave-level load index within the stage
         if (t * 1024 < C::B_BYTES) {
+            if constexpr (TRB) {
+                // piece t: columns 8 (t / 2) .. + 7 of the stage, rows 64 (t % 2) .. + 63 of the tile.  Eight ADJACENT lanes fetch the
+                // 128 contiguous bytes of one column (lane = 8 jj + y: with the two 64-byte halves on lanes 32 apart the pass ran
+                // 11 - 18 % below the stored-transpose pass); the LDS row of column jj holds its eight 16-byte chunks x = y ^ 4 (jj / 2 % 2):
+                // the 64-byte halves of rows 2, 3, 6, 7 are swapped so that the four rows a transposing read touches (pitch 128 B)
+                // fall on four different quarters of the 256-byte bank row
+                const int jj = lane >> 3, x = (lane & 7) ^ (((jj >> 1) & 1) << 2);
+                src_off[i] = (i64)((t >> 1) * 8 + jj) * ldb_bytes + (col0 + (t & 1) * 64 + x * 8) * 2;
+            } else {
             const int p = t * 64 + lane;           // chunk position inside the LDS B tile
             const int j = p / C::CPC;
             const int pc = p % C::CPC;
             const int swz = (j >> C::SWZ_SH) & C::SWZ_MASK;
             const int lc = pc ^ swz;
             src_off[i] = (col0 + j) * ldb_bytes + (i64)lc * 16;
+            }
             is_b[i] = 1;
         } else {
             src_off[i] = (i64)(t * 1024 - C::B_BYTES) + lane * 16;   // offset inside the X stage block
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
 #pragma unroll
         for (int i = 0; i < C::LPS; ++i) {
             const int t = lw + C::NLD * i;
-            const unsigned char* g = is_b[i] ? (B + src_off[i] + stage * (C::MB * EBYTES))
+            const unsigned char* g = is_b[i] ? (B + src_off[i] + (TRB ? stage * C::MB * ldb_bytes : stage * (C::MB * EBYTES)))
                                              : (Xp + stage * C::X_BYTES + src_off[i]);
             // B is streamed once: non-temporal policy (aux = 2) keeps it from displacing the X slice in L2
             if (is_b[i])
@@ -191,6 +211,22 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
         swz_r[c] = (jl >> C::SWZ_SH) & C::SWZ_MASK;
         bfrag_base[c] = jl * C::CPC * 16;
     }
+    // transposed source: this wave's 32 rows are sub-tile (cwv & 1) of the pieces with t % 2 == cwv / 2; lane half h takes the
+    // columns 8 h .. 8 h + 7 of a 16-column MFMA step = piece pair 2 q + h; inside a 16-lane group lane p hands in row p / 4,
+    // quarter p % 4 of the group's 4 x 16 block and receives column p
+    const int tr_row = (lane & 15) >> 2;                                           // row of the 4 x 16 block this lane hands in (+ 4 in the second read)
+    const int tr_chunk = ((cwv & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1)) ^ (((tr_row >> 1) & 1) << 2);
+    const int tr_base = (h * 2 + (cwv >> 1)) * 1024 + tr_row * 128 + tr_chunk * 16 + (lane & 1) * 8;
+    auto tr_frag = [&](const unsigned char* sb, int q) -> u32x4_t {
+        typedef short s16x4_t __attribute__((ext_vector_type(4)));
+        const unsigned char* a = sb + tr_base + q * 4096;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4_t*)(a));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4_t*)(a + 512));     // rows 4 .. 7: the same swap pattern
+        typedef short s16x8_t __attribute__((ext_vector_type(8)));
+        const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(u32x4_t, v);
+    };
+    (void)tr_base;
 
     auto flush = [&](f32x16_t (&a)[NT]) {
 #pragma unroll
@@ -266,7 +302,10 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
                 // MFMAs of step q so that LDS latency hides behind the matrix pipe
                 if (q == 0) {
 #pragma unroll
-                    for (int c = 0; c < CW; ++c) bq[0][c] = *(const u32x4_t*)(sb + bfrag_base[c] + ((lc ^ swz_r[c]) << 4));
+                    for (int c = 0; c < CW; ++c) {
+                        if constexpr (TRB) bq[0][c] = tr_frag(sb, 0);
+                        else bq[0][c] = *(const u32x4_t*)(sb + bfrag_base[c] + ((lc ^ swz_r[c]) << 4));
+                    }
 #pragma unroll
                     for (int s = 0; s < NSPLIT; ++s)
 #pragma unroll
@@ -276,8 +315,10 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
                 if (q + 1 < C::QS) {
                     const int lcn = 2 * (q + 1) + h;
 #pragma unroll
-                    for (int c = 0; c < CW; ++c)
-                        bq[(q + 1) & 1][c] = *(const u32x4_t*)(sb + bfrag_base[c] + ((lcn ^ swz_r[c]) << 4));
+                    for (int c = 0; c < CW; ++c) {
+                        if constexpr (TRB) bq[(q + 1) & 1][c] = tr_frag(sb, q + 1);
+                        else bq[(q + 1) & 1][c] = *(const u32x4_t*)(sb + bfrag_base[c] + ((lcn ^ swz_r[c]) << 4));
+                    }
 #pragma unroll
                     for (int s = 0; s < NSPLIT; ++s)
 #pragma unroll
@@ -1734,6 +1775,43 @@ int plan_bigprod_groups(int storage, int k, i64 len, i64 ncols, int nsplit, int 
     return ng;
 }
 
+// the H*A' pass of a single-copy (bf16) matrix: same geometry as the stored-transpose pass -- 128 rows of A per tile, 64 columns
+// of A per stage -- on the two kernel shapes that exist for the transposed source (k <= 32: 4 waves, 2-deep ring, two workgroups
+// per CU; k in (32, 64]: 8 compute + 4 loader waves, 3-deep)
+int plan_bigprod_groups_tr(int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out)
+{
+    int ng = 0;
+    size_t off = 0;
+    const int pstride = kpp_of(k);
+    if (nsplit < 1 || nsplit > 3) nsplit = 3;
+    for (int k0 = 0; k0 < k; k0 += 64, ++ng) {
+        const int kg = k - k0 < 64 ? k - k0 : 64;
+        BigProdPlan pl;
+        pl.storage = STORE_BF16;
+        pl.kt = kt_of(kg);
+        pl.k0 = k0; pl.kg = kg; pl.pstride = pstride; pl.pack_offset = off;
+        pl.nsplit = nsplit;
+        pl.tr = 1;
+        pl.variant = pl.kt == 2 ? 18 : 6;
+        pl.mb = 64; pl.nb = 128;
+        pl.len = len;
+        pl.stages = (len + 63) / 64;
+        pl.tiles = (ncols + 127) / 128;
+        pl.ncols_pad = round_up(ncols, COL_PAD);
+        int S = 1;
+        while (pl.tiles * S < 2 * (i64)num_cus && S < 64 && pl.stages / (2 * S) >= 8) S *= 2;
+        const char* envS = getenv("SMK_BP_SPLITS");
+        if (envS && atoi(envS) > 0) { S = 1; while (S < atoi(envS) && S < 64) S *= 2; }
+        if (ng > 0) S = out[0].S;
+        pl.S = S;
+        pl.nst = (pl.stages + S - 1) / S;
+        off += packed_bytes(STORE_BF16, kg, len, nsplit);
+        out[ng] = pl;
+    }
+    for (int g = 0; g < ng; ++g) out[g].p_elems = (size_t)out[0].S * out[0].ncols_pad * pstride;
+    return ng;
+}
+
 BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus)
 {
     BigProdPlan pl;
@@ -1834,13 +1912,13 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
     return pl;
 }
 
-template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK, int NWL>
+template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK, int NWL, bool TRB = false>
 static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
     using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
     constexpr int lds = C::STAGE_BYTES * C::NSTAGE;
     static std::atomic<unsigned long long> attr_set{0};       // per device (DeviceOnce)
-    auto kern = bigprod_kernel<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
+    auto kern = bigprod_kernel<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL, TRB>;
     if (DeviceOnce once{attr_set}) {
         SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         once.done();
@@ -1915,8 +1993,64 @@ static int launch_bigprod_v(const BigProdPlan& pl, const void* B, i64 ldb, const
     return launch_bigprod_if<EBYTES, KT, NSPLIT, 64, 3, 1, 1>(pl, B, ldb, Xp, P, st);
 }
 
+// transposed source: B = A (bf16), ldb = its column stride
+template <int KT, int NSPLIT, int MB, int NSTAGE, int WK, int NWL>
+static int launch_bigprod_if_tr(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
+{
+    if constexpr (bp_fits(2, KT, NSPLIT, MB, NSTAGE, 1, WK, NWL)) {
+        BigProdPlan q = pl;                    // the plan was made for 64-column stages
+        q.mb = MB;
+        q.stages = (pl.len + MB - 1) / MB;
+        q.nst = (q.stages + q.S - 1) / q.S;
+        return launch_bigprod_t<2, KT, NSPLIT, MB, NSTAGE, 1, WK, NWL, true>(q, B, ldb, Xp, P, st);
+    } else {
+        set_error("bigprod (transposed source): this shape does not fit");
+        return -100;
+    }
+}
+template <int KT, int NSPLIT>
+static int launch_bigprod_tr_v(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
+{
+    // the kernel shapes built for the transposed source (numbers = the variants of kVariants; SMK_BP_TR_VARIANT picks one)
+    static const int v = [] { const char* e = getenv("SMK_BP_TR_VARIANT"); return e ? atoi(e) : -1; }();
+    if constexpr (KT == 1) {
+        switch (v) {
+            case 0: return launch_bigprod_t<2, 1, NSPLIT, 64, 3, 1, 1, 0, true>(pl, B, ldb, Xp, P, st);
+            case 1: return launch_bigprod_t<2, 1, NSPLIT, 64, 4, 1, 1, 0, true>(pl, B, ldb, Xp, P, st);
+            case 15: return launch_bigprod_t<2, 1, NSPLIT, 64, 3, 1, 1, 4, true>(pl, B, ldb, Xp, P, st);
+            case 6: return launch_bigprod_t<2, 1, NSPLIT, 64, 2, 1, 1, 0, true>(pl, B, ldb, Xp, P, st);
+            case 17: return launch_bigprod_t<2, 1, NSPLIT, 64, 5, 1, 1, 4, true>(pl, B, ldb, Xp, P, st);
+            case 23: return launch_bigprod_t<2, 1, NSPLIT, 64, 2, 1, 1, 4, true>(pl, B, ldb, Xp, P, st);
+            case 20: return launch_bigprod_if_tr<1, NSPLIT, 32, 4, 1, 2>(pl, B, ldb, Xp, P, st);
+            case 24: return launch_bigprod_if_tr<1, NSPLIT, 32, 5, 1, 2>(pl, B, ldb, Xp, P, st);
+            case 25: return launch_bigprod_if_tr<1, NSPLIT, 32, 6, 1, 2>(pl, B, ldb, Xp, P, st);
+            case 26: return launch_bigprod_if_tr<1, NSPLIT, 32, 3, 1, 2>(pl, B, ldb, Xp, P, st);
+            // 16: four loader waves and a 4-deep ring, one workgroup per CU.  The shape of the stored-transpose pass (6: 2-deep, two
+            // workgroups per CU) runs 400 us on C3 against 339; with loader waves 354 - 363 (profiles/r05_single_copy_c3.txt)
+            default: return launch_bigprod_t<2, 1, NSPLIT, 64, 4, 1, 1, 4, true>(pl, B, ldb, Xp, P, st);
+        }
+    } else {
+        switch (v) {
+            case 11: return launch_bigprod_t<2, 2, NSPLIT, 64, 3, 1, 2, 0, true>(pl, B, ldb, Xp, P, st);
+            case 19: return launch_bigprod_t<2, 2, NSPLIT, 64, 4, 1, 2, 4, true>(pl, B, ldb, Xp, P, st);
+            default: return launch_bigprod_t<2, 2, NSPLIT, 64, 3, 1, 2, 4, true>(pl, B, ldb, Xp, P, st);      // 18
+        }
+    }
+}
+template <int KT>
+static int launch_bigprod_tr(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
+{
+    if (pl.nsplit == 3) return launch_bigprod_tr_v<KT, 3>(pl, B, ldb, Xp, P, st);
+    if (pl.nsplit == 2) return launch_bigprod_tr_v<KT, 2>(pl, B, ldb, Xp, P, st);
+    return launch_bigprod_tr_v<KT, 1>(pl, B, ldb, Xp, P, st);
+}
+
 int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
+    if (pl.tr) {
+        if (pl.storage != STORE_BF16 || pl.nsplit < 1 || pl.nsplit > 3) { set_error("bigprod: the transposed source exists for bf16 storage with 1 .. 3 operand terms"); return -100; }
+        return pl.kt == 1 ? launch_bigprod_tr<1>(pl, B, ldb, Xp, P, st) : launch_bigprod_tr<2>(pl, B, ldb, Xp, P, st);
+    }
     if (pl.nsplit == NSPLIT_F64) return launch_bigprod_f64(pl, B, ldb, Xp, P, pl.len, st);
     if (pl.storage == STORE_BF16) {
         if (pl.kt == 1) {

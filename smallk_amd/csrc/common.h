@@ -148,6 +148,9 @@ struct BigProdPlan {
     float ascale = 1.0f;
     int ldx = 0;    // NSPLIT_F64: doubles per column of the factor (its padded rank KP)
     int accum = 0;  // != 0: the launch adds to P instead of overwriting it (a later row chunk of the same product)
+    // transposed source (bf16 storage, single-copy matrices): B is A itself for the H*A' pass -- the tile's columns are rows of A,
+    // a stage is 64 columns of A, ldb the column stride of A (bigprod.hip: TRB); plan_bigprod_tr fills the plan
+    int tr = 0;
     int mb = 0, nb = 0;   // rows per stage / columns per workgroup tile of the chosen kernel variant
     int S;          // row splits
     i64 len = 0;    // NSPLIT_F64: contraction length (rows past it read as zero from the factor)
@@ -168,6 +171,8 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
 // the groups of a k-row factor (1 for k <= 64, 2 up to 128): same row splits, P laid out [S][ncols_pad][32 kt_of(k)]
 int plan_bigprod_groups(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out /* 2 */);
 int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st);
+// the groups of the H*A' pass taken from A itself: len = columns of A (the contraction), ncols = rows of A; bf16 storage, nsplit 1..3
+int plan_bigprod_groups_tr(int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out);
 
 int launch_reduce_partials(PartialView pv, int k, i64 c0, i64 N, void* out /* [.][kpp] */, int out_f64, hipStream_t st);
 

@@ -87,6 +87,10 @@ struct smk_matrix {
     mutable double colnorm_max = -1.0, rownorm_max = -1.0;   // largest 2-norm of a column / a row of A (dense; NnlsPack's bound); < 0 = not yet measured
     void* A = nullptr;  i64 ldA = 0, colsA = 0;      // m_pad x n_pad
     void* At = nullptr; i64 ldAt = 0, colsAt = 0;    // n_pad x m_pad
+    // single copy (bf16 storage, MU / HALS): no stored transpose -- the H*A' pass contracts down the strided direction of A itself
+    // (bigprod.hip, TRB), as the reference's MU / HALS do (Gemm(NORMAL, TRANSPOSE) on A, nmf_solver_mu.hpp:121-164,
+    // nmf_solver_hals.hpp:166-199); half the footprint, no transpose pass at load time
+    bool single = false;
     // sparse A: CSC of the local columns and CSC of its transpose (fp64 values, 64-bit offsets)
     bool sparse = false;
     i64 nnz = 0;
@@ -400,6 +404,7 @@ void smk_uniform_fill_host(double* buf, int64_t ld, int64_t rows, int64_t cols, 
 // ------------------------------------------------------------------------------------------
 // matrix
 // ------------------------------------------------------------------------------------------
+static thread_local bool g_create_single = false;
 int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0, int64_t ncols_local,
                       int storage)
 {
@@ -426,8 +431,12 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
         if (skew > 0 && ((size_t)a->ldA * es) % ((size_t)1 << 20) == 0) a->ldA += skew;
         if (skew > 0 && ((size_t)a->ldAt * es) % ((size_t)1 << 20) == 0) a->ldAt += skew;
     }
+    {   // SMK_SINGLE_COPY=1: bf16 matrices are created without the stored transpose (smk_matrix_create_single_copy asks for it explicitly)
+        const char* esc = getenv("SMK_SINGLE_COPY");
+        a->single = g_create_single || (esc && esc[0] == '1' && storage == SMK_STORE_BF16);
+    }
     hipError_t e1 = smk::dev_malloc(&a->A, (size_t)a->ldA * a->colsA * es);
-    hipError_t e2 = (e1 == hipSuccess) ? smk::dev_malloc(&a->At, (size_t)a->ldAt * a->colsAt * es) : e1;
+    hipError_t e2 = (e1 == hipSuccess && !a->single) ? smk::dev_malloc(&a->At, (size_t)a->ldAt * a->colsAt * es) : e1;
     if (e1 != hipSuccess || e2 != hipSuccess) {
         set_error(std::string("smk::dev_malloc(A): ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         if (a->A) (void)smk::dev_free(a->A);
@@ -435,7 +444,7 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
         return SMK_DEVICE_ERROR;
     }
     e1 = hipMemsetAsync(a->A, 0, (size_t)a->ldA * a->colsA * es, g_stream);
-    if (e1 == hipSuccess) e1 = hipMemsetAsync(a->At, 0, (size_t)a->ldAt * a->colsAt * es, g_stream);
+    if (e1 == hipSuccess && a->At) e1 = hipMemsetAsync(a->At, 0, (size_t)a->ldAt * a->colsAt * es, g_stream);
     if (e1 != hipSuccess) {
         set_error(std::string("hipMemsetAsync(A): ") + hipGetErrorString(e1));
         smk_matrix_destroy(a);
@@ -445,8 +454,47 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
     return SMK_OK;
 }
 
+int smk_matrix_create_single_copy(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0, int64_t ncols_local,
+                                  int storage)
+{
+    if (storage != SMK_STORE_BF16) { set_error("single-copy matrices exist for bf16 storage (the transposing LDS read is a 16-bit instruction)"); return SMK_UNSUPPORTED; }
+    g_create_single = true;
+    const int rc = smk_matrix_create(out, height, width_global, col0, ncols_local, storage);
+    g_create_single = false;
+    return rc;
+}
+int smk_matrix_is_single_copy(const smk_matrix* a) { return a && a->single ? 1 : 0; }
+// bytes of HBM the resident matrix occupies (A, the stored transpose when there is one, the CSC arrays of a sparse matrix)
+int64_t smk_matrix_device_bytes(const smk_matrix* a)
+{
+    if (!a) return 0;
+    if (a->sparse) return (int64_t)((size_t)(a->n + 1 + a->m + 1) * sizeof(i64) + 2 * (size_t)a->nnz * (sizeof(unsigned) + sizeof(double)));
+    const size_t es = (size_t)elem_size(a->storage);
+    return (int64_t)((size_t)a->ldA * a->colsA * es + (a->At ? (size_t)a->ldAt * a->colsAt * es : 0));
+}
+
+// a single-copy matrix meets a consumer of the stored transpose (BPP, RANK2, the accurate form, column subsets): allocate and fill
+// it now; solvers already planned on the transposed source keep reading A (their plans say so)
+static int matrix_materialize_transpose(const smk_matrix* ca)
+{
+    smk_matrix* a = const_cast<smk_matrix*>(ca);       // the lazily built parts of a matrix (scales, blocked CSC, segment plans) are filled the same way
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!a->single || a->At) return 0;
+    const size_t es = (size_t)elem_size(a->storage);
+    hipStream_t st = a->st ? a->st : g_stream;
+    if (smk::dev_malloc(&a->At, (size_t)a->ldAt * a->colsAt * es) != hipSuccess) { a->At = nullptr; set_error("no memory for the stored transpose of a single-copy matrix"); return SMK_DEVICE_ERROR; }
+    SMK_HIP(hipMemsetAsync(a->At, 0, (size_t)a->ldAt * a->colsAt * es, st));
+    const int rc = launch_transpose_store(a->A, a->ldA, a->At, a->ldAt, a->storage, a->m, a->n, st);
+    if (rc) return rc;
+    SMK_HIP(hipStreamSynchronize(st));
+    a->single = false;
+    return 0;
+}
+
 static int matrix_make_transpose(smk_matrix* a)
 {
+    if (a->single) return 0;
     return launch_transpose_store(a->A, a->ldA, a->At, a->ldAt, a->storage, a->m, a->n, g_stream);
 }
 
@@ -555,7 +603,7 @@ int smk_matrix_clone(const smk_matrix* src, smk_matrix** out)
     a->ascale = src->ascale; a->col_spread_log2 = src->col_spread_log2;
     a->colnorm_max = src->colnorm_max; a->rownorm_max = src->rownorm_max;
     a->ldA = src->ldA; a->colsA = src->colsA; a->ldAt = src->ldAt; a->colsAt = src->colsAt;
-    a->sparse = src->sparse; a->nnz = src->nnz;
+    a->sparse = src->sparse; a->nnz = src->nnz; a->single = src->single;
     a->st = g_stream;
     register_matrix(a);
     bool ok = true;
@@ -997,7 +1045,8 @@ static int plan_products(smk_solver* s)
         if (rc0) return rc0;
     }
     s->ng = plan_bigprod_groups(a->storage, s->k, s->m, s->n, s->nsplit, g_cus, s->pg1);
-    (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
+    if (a->single) (void)plan_bigprod_groups_tr(s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);      // H*A' from A itself
+    else (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
     if (s->nsplit == NSPLIT_F64)
         for (int g = 0; g < s->ng; ++g) { s->pg1[g].ldx = s->KP; s->pg2[g].ldx = s->KP; }
     s->pl1 = s->pg1[0];
@@ -1114,6 +1163,16 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if (s->nsplit == NSPLIT_F64 && a->sparse) s->nsplit = 3;      // sparse A: gather products in fp64 already
     // the fp16 two-term form applies to fp32 storage; RANK2 keeps its Gram matrices inside its own solve kernel
     if (s->nsplit == NSPLIT_F16X2 && (a->storage != SMK_STORE_F32 || a->sparse || opts->algorithm == SMK_ALG_RANK2)) s->nsplit = 3;
+    if (a->single && !a->sparse) {
+        // what the transposed-source kernel covers: MU and HALS with the 16-bit product forms (the reference's BPP keeps a transpose
+        // itself, nmf_solver_bpp.hpp:319; RANK2 and the accurate form contract down the contiguous direction of A' on the vector
+        // ALUs / fp64 matrix cores).  Anything else gets the stored transpose now, once (the matrix is an ordinary one afterwards).
+        const bool ok_alg = opts->algorithm == SMK_ALG_MU || opts->algorithm == SMK_ALG_HALS;
+        if (!ok_alg || s->nsplit < 1 || s->nsplit > 3) {
+            const int trc = matrix_materialize_transpose(a);
+            if (trc) { smk_solver_destroy(s); return trc; }
+        }
+    }
     int rc = plan_products(s);
     if (rc) { smk_solver_destroy(s); return rc; }
     if (a->sparse) {   // gather products write one slab, as dense as the factor layout (KP values per column; RANK2: the 2 live ones)
@@ -1855,7 +1914,8 @@ static int prod2(smk_solver* s)
         for (int g = 0; g < s->ng && !rc; ++g) {
             BigProdPlan pl = s->pg2[g];
             take_tail(s, 1, &pl);
-            rc = timed_bigprod(s, 1, pl, s->a->At, s->a->ldAt, xh(s->pg2[g]), s->P2 + s->pg2[g].k0);
+            rc = pl.tr ? timed_bigprod(s, 1, pl, s->a->A, s->a->ldA, xh(s->pg2[g]), s->P2 + s->pg2[g].k0)
+                       : timed_bigprod(s, 1, pl, s->a->At, s->a->ldAt, xh(s->pg2[g]), s->P2 + s->pg2[g].k0);
         }
         if (rc) return rc;
         rc = wait_gh(s);
@@ -1871,7 +1931,10 @@ static int prod2(smk_solver* s)
         for (int g = 0; g < s->ng; ++g) {
             BigProdPlan pl = s->pg2[g];
             pl.tiles = (r1 - r0 + pl.nb - 1) / pl.nb;
-            rc = timed_bigprod(s, 1, pl, (const unsigned char*)s->a->At + (size_t)r0 * s->a->ldAt * es, s->a->ldAt,
+            // rows [r0, r1) of A: columns of the stored transpose, or -- single copy -- a row offset into A itself
+            const unsigned char* Bsrc = pl.tr ? (const unsigned char*)s->a->A + (size_t)r0 * es
+                                              : (const unsigned char*)s->a->At + (size_t)r0 * s->a->ldAt * es;
+            rc = timed_bigprod(s, 1, pl, Bsrc, pl.tr ? s->a->ldA : s->a->ldAt,
                                xh(pl), s->P2 + pl.k0 + r0 * pl.pstride, j == s->nchunk - 1 ? 1 : 0);
             if (rc) return rc;
         }

@@ -75,20 +75,30 @@ def make_options(m, n, k, algorithm, *, min_iter=5, max_iter=5000, tol=0.005, to
 class DenseMatrix:
     """A (or the column shard [col0, col0+ncols) of it) resident in HBM with its transpose."""
 
-    def __init__(self, height, width_global, *, col0=0, ncols=None, storage="f32"):
+    def __init__(self, height, width_global, *, col0=0, ncols=None, storage="f32", single_copy=False):
+        """single_copy: no stored transpose (bf16 storage; serves MU and HALS -- smk_matrix_create_single_copy)"""
         self.height = int(height)
         self.width_global = int(width_global)
         self.col0 = int(col0)
         self.ncols = int(width_global - col0 if ncols is None else ncols)
         self.storage = STORAGE[storage] if isinstance(storage, str) else int(storage)
         self._h = C.c_void_p()
-        L.check(L.lib().smk_matrix_create(C.byref(self._h), self.height, self.width_global, self.col0,
-                                          self.ncols, self.storage), "smk_matrix_create")
+        create = L.lib().smk_matrix_create_single_copy if single_copy else L.lib().smk_matrix_create
+        L.check(create(C.byref(self._h), self.height, self.width_global, self.col0, self.ncols, self.storage),
+                "smk_matrix_create_single_copy" if single_copy else "smk_matrix_create")
+
+    @property
+    def single_copy(self) -> bool:
+        return bool(L.lib().smk_matrix_is_single_copy(self._h))
+
+    @property
+    def device_bytes(self) -> int:
+        return int(L.lib().smk_matrix_device_bytes(self._h))
 
     @classmethod
-    def from_host(cls, A, *, storage="f32"):
+    def from_host(cls, A, *, storage="f32", single_copy=False):
         A = _f(A)
-        mat = cls(A.shape[0], A.shape[1], storage=storage)
+        mat = cls(A.shape[0], A.shape[1], storage=storage, single_copy=single_copy)
         mat.upload(A)
         return mat
 

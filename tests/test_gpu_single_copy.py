@@ -1,0 +1,95 @@
+"""Single-copy matrices (no stored transpose): MU and HALS with the H*A' pass taken from A itself (bigprod.hip, transposed
+source) -- the reference's MU / HALS call Gemm(NORMAL, TRANSPOSE) on A (nmf_solver_mu.hpp:121-164, nmf_solver_hals.hpp:166-199).
+Same results as with the stored transpose (the same products, the usual bars against the oracle), half the footprint; a consumer of
+the transpose (BPP, RANK2, the accurate form) makes the matrix build it on demand."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(gpu, A, W0, H0, alg, iters, single, storage="bf16"):
+    from smallk_amd import DenseMatrix, NmfSolver, make_options
+    D = DenseMatrix.from_host(A, storage=storage, single_copy=single)
+    assert D.single_copy == single
+    s = NmfSolver(D, make_options(A.shape[0], A.shape[1], W0.shape[1], alg, normalize=False))
+    s.set_factors(W0, H0)
+    s.iterate(iters)
+    assert s.sync() == 0
+    W, H = s.factors(normalize=False)
+    nbytes = D.device_bytes
+    s.close()
+    D.close()
+    return W, H, nbytes
+
+
+@pytest.mark.parametrize("alg", ["MU", "HALS"])
+@pytest.mark.parametrize("m,n,k", [(512, 256, 8), (700, 1100, 17), (1000, 333, 32), (2051, 1500, 33), (640, 4100, 64), (900, 800, 100)])
+def test_single_copy_equals_stored_transpose_and_oracle(gpu, alg, m, n, k):
+    import oracle
+    if alg == "HALS" and k > 64:
+        pytest.skip("HALS above k = 64 takes the accurate form, which builds the stored transpose (tested below)")
+    A = oracle.fill_uniform(m, n, 7, quant=1)
+    W0 = oracle.fill_uniform(m, k, 8)
+    H0 = oracle.fill_uniform(k, n, 9) * (2.0 / k)
+    iters = 6
+    W1, H1, b1 = _run(gpu, A, W0, H0, alg, iters, single=True)
+    W2, H2, b2 = _run(gpu, A, W0, H0, alg, iters, single=False)
+    fro = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    assert fro(W1, W2) < 1e-6 and fro(H1, H2) < 1e-6, (fro(W1, W2), fro(H1, H2))
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, normalize=False)
+    assert fro(W1, ref.W) < 1e-4 and fro(H1, ref.H) < 1e-4, (fro(W1, ref.W), fro(H1, ref.H))
+    assert b1 < 0.62 * b2                       # the footprint the ABI reports: no second copy
+
+
+def test_single_copy_builds_the_transpose_when_something_needs_it(gpu):
+    """BPP, RANK2 and the accurate form read the stored transpose: the first such solver on a single-copy matrix allocates and
+    fills it (the matrix is an ordinary one afterwards); MU / HALS solvers created before keep reading A.  fp32 storage has no
+    single-copy form (the transposing LDS read is a 16-bit instruction)."""
+    import ctypes as C
+    import oracle
+    from smallk_amd import DenseMatrix, NmfSolver, make_options
+    from smallk_amd import _lib as L
+    m, n, k = 600, 400, 8
+    A = oracle.fill_uniform(m, n, 3, quant=1)
+    W0, H0 = oracle.fill_uniform(m, k, 4), oracle.fill_uniform(k, n, 5) * (2.0 / k)
+    D = DenseMatrix.from_host(A, storage="bf16", single_copy=True)
+    b0 = D.device_bytes
+    mu = NmfSolver(D, make_options(m, n, k, "MU", normalize=False))       # planned on the transposed source
+    mu.set_factors(W0, H0)
+    assert D.single_copy
+    bpp = NmfSolver(D, make_options(m, n, k, "BPP", normalize=False))     # needs A': built now
+    assert not D.single_copy and D.device_bytes > 1.6 * b0
+    bpp.set_factors(W0, H0)
+    for s, alg in ((mu, "MU"), (bpp, "BPP")):
+        s.iterate(4)
+        assert s.sync() == 0
+        W, H = s.factors(normalize=False)
+        ref = oracle.nmf(A, W0, H0, alg, min_iter=4, max_iter=4, normalize=False)
+        assert np.linalg.norm(W - ref.W) / np.linalg.norm(ref.W) < 1e-4 and np.linalg.norm(H - ref.H) / np.linalg.norm(ref.H) < 1e-4
+        s.close()
+    D.close()
+    h = C.c_void_p()
+    assert L.lib().smk_matrix_create_single_copy(C.byref(h), 600, 400, 0, 400, L.STORE_F32) == -101      # SMK_UNSUPPORTED: fp32 storage
+
+
+def test_single_copy_full_size_c3(gpu):
+    """configs[2] (65536 x 16384, k = 32, HALS, bf16) on a single-copy matrix: three iterations against the stored-transpose run
+    on the same generated data."""
+    from smallk_amd import DenseMatrix, NmfSolver, make_options, uniform_host
+    m, n, k = 65536, 16384, 32
+    W0, H0 = uniform_host(m, k, 102), uniform_host(k, n, 103) * (2.0 / k)
+    out = []
+    for single in (True, False):
+        D = DenseMatrix(m, n, storage="bf16", single_copy=single)
+        D.fill_uniform(101)
+        s = NmfSolver(D, make_options(m, n, k, "HALS", normalize=False))
+        s.set_factors(W0, H0)
+        s.iterate(3)
+        assert s.sync() == 0
+        out.append(s.factors(normalize=False) + (D.device_bytes,))
+        s.close()
+        D.close()
+    fro = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert fro(out[0][0], out[1][0]) < 1e-6 and fro(out[0][1], out[1][1]) < 1e-6
+    assert out[0][2] * 2 <= out[1][2] * 1.01
