@@ -60,6 +60,31 @@ def test_nmf_matches_oracle_and_golden(gpu, golden, m, n, k, planted, quant, alg
     assert np.allclose(np.linalg.norm(got.W, axis=0), 1.0, atol=1e-9)
 
 
+DEFAULT_PATH_CASES = [c for c in CASES if c[5] == "BPP" and c[2] > 32 and c[4] == 0]
+
+
+@pytest.mark.parametrize("m,n,k,planted,quant,alg,iters", DEFAULT_PATH_CASES)
+def test_bpp_above_k32_on_the_shipped_default_path(gpu, golden, monkeypatch, m, n, k, planted, quant, alg, iters):
+    """conftest.py keeps the fp16 two-term form for small block-pivoting problems (they stand in for C4's path); the SHIPPED
+    default for A of at most 2^24 entries at k in (32, 64] is the accurate form (solver.cpp).  The same golden cases on that
+    default: one selection rule, more than one tripwire."""
+    monkeypatch.delenv("SMK_BPP_SMALL_ACCURATE", raising=False)
+    A = mg.make_A(m, n, k, planted, quant)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44)
+    D = gpu.DenseMatrix.from_host(A)
+    s = gpu.NmfSolver(D, gpu.make_options(m, n, k, alg, min_iter=iters, max_iter=iters))
+    assert s.product_form()[0] == 8
+    s.set_factors(W0, H0)
+    rc, it, _ = s.run()
+    W, H = s.factors()
+    s.close()
+    D.close()
+    assert rc == 0 and it == iters
+    key = f"{alg}_{m}x{n}_k{k}_it{iters}_q{quant}"
+    assert rel(W, golden[key + "_W"]) < 1e-7 and rel(H, golden[key + "_H"]) < 1e-7       # the accurate form: summation order only
+
+
 R2CASES = [(m, n, q, it) for (m, n) in mg.RANK2_CASES for q in (0, 1) for it in ((1, 5, 20) if q == 0 else (5,))]
 
 
