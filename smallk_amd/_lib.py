@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsmallk_amd.so")
+LIB_PATH = os.environ.get("SMK_LIB_PATH") or os.path.join(_HERE, "lib", "libsmallk_amd.so")      # SMK_LIB_PATH: an A/B build of the library (tools/)
 
 # Result codes (include/smallk_amd.h)
 OK, NOTINITIALIZED, INITIALIZED, BAD_PARAM, FAILURE, SIZE_TOO_LARGE = 0, -1, -2, -3, -4, -5

@@ -172,9 +172,10 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
             const unsigned char* g = is_b[i] ? (B + src_off[i] + (TRB ? stage * C::MB * ldb_bytes : stage * (C::MB * EBYTES)))
                                              : (Xp + stage * C::X_BYTES + src_off[i]);
             // B is streamed once: non-temporal policy (aux = 2) keeps it from displacing the X slice in L2
-            if (is_b[i])
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
-            else
+            if (is_b[i]) {
+                if (accum & 2) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);        // a matrix that fits the Infinity Cache: keep it there
+                else __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
+            } else
                 __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
         }
     };
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
                         v[u] = tsum;
                     }
                     if (kw * KTW * 32 + kt * 32 + 8 * g >= prows) continue;      // k <= 16: a column of P holds 8 / 16 rows, not 32 (kpp_of)
-                    if (accum) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);   // a later row chunk of the same product
+                    if (accum & 1) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);   // a later row chunk of the same product
                     *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
                 }
             }
@@ -860,7 +861,8 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
         for (int i = 0; i < C::LPS; ++i) {
             const int t = lw + C::NLD * i;
             if (is_b[i]) {
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
+                if (accum & 2) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);        // a matrix that fits the Infinity Cache: keep it there
+                else __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
                 gsrc[i] += C::MB * 4;
             } else {
                 __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
@@ -1042,7 +1044,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
                     v[1] *= os[1];
                 }
                 if (pstride < 32 && kt * 32 + 8 * g >= pstride) continue;      // k <= 16: a column of P holds 8 / 16 rows, not 32 (kpp_of)
-                if (accum) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);
+                if (accum & 1) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);
                 *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
             }
 }
@@ -1127,7 +1129,8 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
         for (int i = 0; i < C::LPS; ++i) {
             const int t = lw + C::NLD * i;
             if (is_b[i]) {
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
+                if (accum & 2) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);        // a matrix that fits the Infinity Cache: keep it there
+                else __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
                 gsrc[i] += C::MB * 4;
             } else {
                 if constexpr ((PIN & 16) == 0)      // experiment bit 16: the X fragments are not fetched at all
@@ -1293,7 +1296,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), 2) void bigprod_f3p_kernel(const un
                     v[1] *= os[1];
                 }
                 if (pstride < 32 && kt * 32 + 8 * g >= pstride) continue;      // k <= 16: a column of P holds 8 / 16 rows, not 32 (kpp_of)
-                if (accum) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);
+                if (accum & 1) v += *(const f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i);
                 *(f64x2_t*)(pout + kt * 32 + 8 * g + 4 * h + i) = v;
             }
 }
@@ -1323,7 +1326,7 @@ static int launch_f3p_t(const BigProdPlan& pl, const void* B, i64 ldb, const voi
             grid = pl.tiles * pl.S;
         }
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
-                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale, pl.accum);
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale, pl.accum | (pl.temporal ? 2 : 0));
         SMK_HIP(hipGetLastError());
         return 0;
     }
@@ -1391,7 +1394,7 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
         }
         if (TAIL == 1) grid += 16;
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
-                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale, pl.accum,
+                                                      pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale, pl.accum | (pl.temporal ? 2 : 0),
                                                       pl.tail_gp, pl.tail_nblk, pl.tail_g);
         SMK_HIP(hipGetLastError());
         return 0;
@@ -1933,7 +1936,7 @@ static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const
         grid = pl.tiles * pl.S;
     }
     kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * EBYTES, (const unsigned char*)Xp, P,
-                                           pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.accum);
+                                           pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.accum | (pl.temporal ? 2 : 0));
     SMK_HIP(hipGetLastError());
     return 0;
 }

@@ -148,6 +148,11 @@ struct BigProdPlan {
     float ascale = 1.0f;
     int ldx = 0;    // NSPLIT_F64: doubles per column of the factor (its padded rank KP)
     int accum = 0;  // != 0: the launch adds to P instead of overwriting it (a later row chunk of the same product)
+    // cache policy of the streamed loads of A: 0 = non-temporal (A is read once per pass and must not displace the operand slices:
+    // right whenever A and A' together exceed the 256 MB Infinity Cache -- C3 7 %, a 1 GB matrix 20 % faster than with the default
+    // policy), 1 = default policy (both copies stay cache resident between the passes: C2, 268 MB of A + A', 8 % faster);
+    // the solver decides by the bytes an iteration streams (profiles/r05_cache_policy_ab.txt)
+    int temporal = 0;
     // transposed source (bf16 storage, single-copy matrices): B is A itself for the H*A' pass -- the tile's columns are rows of A,
     // a stage is 64 columns of A, ldb the column stride of A (bigprod.hip: TRB); plan_bigprod_tr fills the plan
     int tr = 0;

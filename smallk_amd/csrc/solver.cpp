@@ -1049,6 +1049,15 @@ static int plan_products(smk_solver* s)
     else (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
     if (s->nsplit == NSPLIT_F64)
         for (int g = 0; g < s->ng; ++g) { s->pg1[g].ldx = s->KP; s->pg2[g].ldx = s->KP; }
+    {
+        // Cache policy of the streamed loads (BigProdPlan::temporal): what one iteration streams -- A and, unless the matrix is a
+        // single copy, A' -- either stays in the 256 MB Infinity Cache between the passes or it does not.  Measured crossover:
+        // profiles/r05_cache_policy_ab.txt.  SMK_BP_TEMPORAL=0/1 forces a policy.
+        const double streamed = (double)s->m * (double)s->n * elem_size(a->storage) * (a->single ? 1.0 : 2.0) * s->ng;
+        static const int forced = [] { const char* e = getenv("SMK_BP_TEMPORAL"); return e ? atoi(e) : -1; }();
+        const int temporal = forced >= 0 ? (forced ? 1 : 0) : (streamed <= 300.0e6 ? 1 : 0);
+        for (int g = 0; g < s->ng; ++g) { s->pg1[g].temporal = temporal; s->pg2[g].temporal = temporal; }
+    }
     s->pl1 = s->pg1[0];
     s->pl2 = s->pg2[0];
     if (s->nsplit == NSPLIT_F16X2) {
