@@ -61,6 +61,8 @@ WORKLOADS = {
     "c4b": (262144, 65536, 64, "BPP", "bf16", "EXPERIMENT C4 with A held as bf16"),
     "b32": (32768, 8192, 32, "BPP", "f32", "EXPERIMENT 32768x8192 k=32 BPP fp32"),
     "c3t": (16384, 65536, 32, "HALS", "bf16", "EXPERIMENT C3 transposed: 16384x65536 k=32 HALS bf16"),
+    "mall": (65536, 1024, 32, "HALS", "bf16", "EXPERIMENT 65536x1024 k=32 HALS bf16: 134 MB of A, both passes from the Infinity Cache with --single-copy"),
+    "mall2": (65536, 2048, 32, "HALS", "bf16", "EXPERIMENT 65536x2048 k=32 HALS bf16: 268 MB of A"),
     "c4mu": (262144, 65536, 64, "MU", "f32", "EXPERIMENT C4's matrix under MU (replicated W update, all-reduce of (AH')')"),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

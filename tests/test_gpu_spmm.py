@@ -86,3 +86,56 @@ def test_segment_kernel_equals_round4_kernel_in_a_run(gpu, monkeypatch):
     got = gpu.nmf_sparse(A, W0, H0, "MU", min_iter=8, max_iter=8)
     assert ref.result == 0 and got.result == 0
     assert np.linalg.norm(got.W - ref.W) < 1e-8 and np.linalg.norm(got.H - ref.H) < 1e-8
+
+
+@pytest.mark.parametrize("alg,k", [("MU", 8), ("BPP", 24), ("HALS", 16)])
+def test_column_sharded_sparse_run_on_the_segment_kernel(gpu, alg, k):
+    """Sparse A column-sharded over two ranks (in-process stand-in communicator, both on this GPU): every rank's shard gets its
+    own segment plans (CSC of the local columns and of their transpose); factors against the dense oracle on the whole matrix."""
+    import threading
+    import oracle
+    from smallk_amd import Comm, NmfSolver, SparseMatrix, make_options, thread_context_begin, thread_context_end
+    from smallk_amd import dist as sdist
+    from smallk_amd.synthetic import term_document
+    m, n, iters, world = 1200, 900, 6, 2
+    A = term_document(m, n, 30_000, seed=4).tocsc()
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 * A.mean() / (0.5 * k) + 0.05)
+    ref = oracle.nmf(A.toarray(), W0, H0, alg, min_iter=iters, max_iter=iters, normalize=False)
+    assert ref.result == 0
+    comms = Comm.init_local(world)
+    out, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            thread_context_begin(0)
+            c0, nc = sdist.shard_columns(n, world, rank)
+            sub = A[:, c0:c0 + nc].tocsc()
+            S = SparseMatrix(sub.data, sub.indices, sub.indptr, (m, nc), col0=c0, width_global=n)
+            sv = NmfSolver(S, make_options(m, n, k, alg, min_iter=iters, max_iter=iters, normalize=False))
+            sv.attach_comm(comms[rank])
+            sv.set_factors(W0, H0[:, c0:c0 + nc])
+            sv.iterate(iters)
+            rc = sv.sync()
+            W, H = sv.factors(normalize=False)
+            out[rank] = (rc, W, H)
+            sv.close()
+            S.close()
+        except Exception as e:          # pragma: no cover
+            errors.append((rank, repr(e)))
+        finally:
+            thread_context_end()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    for c in comms:
+        c.close()
+    assert not errors, errors
+    assert all(o is not None and o[0] == 0 for o in out)
+    H = np.concatenate([o[2] for o in out], axis=1)
+    fro = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert fro(out[0][1], ref.W) < 1e-8 and fro(H, ref.H) < 1e-8, (fro(out[0][1], ref.W), fro(H, ref.H))
+    assert np.array_equal(out[0][1], out[1][1])
