@@ -102,13 +102,12 @@ int smk_nmf_sparse(const smk_options* opts, unsigned height, unsigned width, uns
  * matrix, plus its transpose (the reference's BPP solver keeps At too, nmf_solver_bpp.hpp:319). */
 int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0,
                       int64_t ncols_local, int storage);
-/* The same without the stored transpose ("single copy"; bf16 storage only): the reference's MU and HALS call Gemm(NORMAL, TRANSPOSE)
+/* The same without the stored transpose ("single copy"): the reference's MU and HALS call Gemm(NORMAL, TRANSPOSE)
  * on A itself (nmf_solver_mu.hpp:121-164, nmf_solver_hals.hpp:166-199) -- only its BPP keeps A' -- and so does this matrix: the
- * H*A' pass contracts down the strided direction of A (transposing LDS reads).  Half the footprint (twice the problem per GPU) and
+ * H*A' pass contracts down the strided direction of A (bf16: transposing LDS reads; fp32: strided 4-byte reads).  Half the footprint (twice the problem per GPU) and
  * no transpose pass at load time.  Solvers on it: MU and HALS with the 16-bit product forms read A only; the first solver that needs
  * the transpose (BPP, RANK2, the accurate form) makes the matrix allocate and fill it, after which it is an ordinary matrix
- * (smk_matrix_is_single_copy / smk_matrix_device_bytes tell).  fp32 storage: SMK_UNSUPPORTED (the transposing LDS read is a 16-bit
- * instruction).  SMK_SINGLE_COPY=1 makes smk_matrix_create do this for every bf16 matrix. */
+ * (smk_matrix_is_single_copy / smk_matrix_device_bytes tell).  SMK_SINGLE_COPY=1 makes smk_matrix_create do this for every dense matrix. */
 int smk_matrix_create_single_copy(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0,
                                   int64_t ncols_local, int storage);
 int smk_matrix_is_single_copy(const smk_matrix* a);

@@ -82,7 +82,7 @@ template <int LPS, int PD> __device__ __forceinline__ void wait_stage(int ahead)
     wait_vmcnt<0>();
 }
 
-// TRB ("transposed source", bf16 only): the SAME product with B = A' taken from A itself, so that MU and HALS need no stored
+// TRB ("transposed source", bf16; the fp32 counterpart is bigprod_f3_kernel with TAIL = 2): the SAME product with B = A' taken from A itself, so that MU and HALS need no stored
 // transpose (the reference's MU / HALS call Gemm(NORMAL, TRANSPOSE) on A, nmf_solver_mu.hpp:121-164, nmf_solver_hals.hpp:166-199;
 // only its BPP keeps At).  B then points at A (m x n column-major), the tile's 128 "columns" are 128 consecutive ROWS of A (the
 // contiguous direction) and a stage is 64 COLUMNS of A: the contraction runs down the strided direction.  A stage is fetched as
@@ -797,6 +797,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
     using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+    static_assert(TAIL != 2 || MB == 32, "transposed source (TAIL == 2): 32-column stages, pieces of two columns");
     int bid = blockIdx.x;
     if constexpr (TAIL == 1) {
         // the first 16 workgroups (two per XCD, so the tile mapping below keeps its XCD of every other workgroup) reduce
@@ -844,11 +845,18 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
     for (int i = 0; i < C::LPS; ++i) {
         const int t = lw + C::NLD * i;
         if (t * 1024 < C::B_BYTES) {
+            if constexpr (TAIL == 2) {
+                // transposed source (fp32): B = A, the tile's columns are 128 consecutive ROWS of A, a stage is MB COLUMNS of A.
+                // Piece t = columns 2 t, 2 t + 1 of the stage, 512 contiguous bytes (four lines) each, fetched by 32 adjacent
+                // lanes; the LDS image is the natural [column][row] one with a 512-byte pitch
+                gsrc[i] = B + (st0 * C::MB + 2 * t + (lane >> 5)) * ldb_bytes + (col0 + (lane & 31) * 4) * 4;
+            } else {
             const int p = t * 64 + lane;
             const int j = p / C::CPC;
             const int pc = p % C::CPC;
             const int swz = (j >> C::SWZ_SH) & C::SWZ_MASK;
             gsrc[i] = B + (col0 + j) * ldb_bytes + (i64)(pc ^ swz) * 16 + st0 * (C::MB * 4);
+            }
             is_b[i] = 1;
         } else {
             gsrc[i] = Xp + st0 * C::X_BYTES + (i64)(t * 1024 - C::B_BYTES) + lane * 16;
@@ -863,7 +871,8 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
             if (is_b[i]) {
                 if (accum & 2) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);        // a matrix that fits the Infinity Cache: keep it there
                 else __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, NT_AUX);
-                gsrc[i] += C::MB * 4;
+                if constexpr (TAIL == 2) gsrc[i] += C::MB * ldb_bytes;
+                else gsrc[i] += C::MB * 4;
             } else {
                 __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc[i], (LDS_AS void*)(lbase + t * 1024), 16, 0, 0);
                 gsrc[i] += C::X_BYTES;
@@ -915,11 +924,19 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
         for (int q = 0; q < C::QS; ++q) {
             // rows 16q + 8h .. +7 of this lane's column = fp32 chunks 4q + 2h, 4q + 2h + 1
             const int lc0 = 4 * q + 2 * h;
+            (void)lc0;
+            f32x8_t x;
+            if constexpr (TAIL == 2) {
+                // the lane's row of A in the 8 columns 16 q + 8 h .. + 7 of the stage: eight 4-byte reads 512 bytes apart (a half-wave
+                // reads 32 consecutive words per instruction: conflict-free)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = *(const float*)(sb + (16 * q + 8 * h + e) * 512 + jl * 4);
+            } else {
             const f32x4_t f0 = *(const f32x4_t*)(sb + bfrag_base + (((lc0) ^ swz_r) << 4));
             const f32x4_t f1 = *(const f32x4_t*)(sb + bfrag_base + (((lc0 + 1) ^ swz_r) << 4));
-            f32x8_t x;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { x[e] = f0[e]; x[4 + e] = f1[e]; }
+            }
             if constexpr (FMT == 1) {
                 // fp16 two-term form: hi = fp16(a s), lo = fp16(a s - hi); products hi*hi | hi*lo + lo*hi
                 f16x8_t a[KT][2];
@@ -1781,24 +1798,34 @@ int plan_bigprod_groups(int storage, int k, i64 len, i64 ncols, int nsplit, int 
 // the H*A' pass of a single-copy (bf16) matrix: same geometry as the stored-transpose pass -- 128 rows of A per tile, 64 columns
 // of A per stage -- on the two kernel shapes that exist for the transposed source (k <= 32: 4 waves, 2-deep ring, two workgroups
 // per CU; k in (32, 64]: 8 compute + 4 loader waves, 3-deep)
-int plan_bigprod_groups_tr(int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out)
+int plan_bigprod_groups_tr(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out)
 {
     int ng = 0;
     size_t off = 0;
     const int pstride = kpp_of(k);
-    if (nsplit < 1 || nsplit > 3) nsplit = 3;
+    const bool f32 = storage == STORE_F32;
+    if (f32) { if (nsplit != NSPLIT_F16X2 && nsplit != 3) nsplit = 3; }       // fp32 A: the fp16 two-term form or bf16x3
+    else if (nsplit < 1 || nsplit > 3) nsplit = 3;
     for (int k0 = 0; k0 < k; k0 += 64, ++ng) {
         const int kg = k - k0 < 64 ? k - k0 : 64;
         BigProdPlan pl;
-        pl.storage = STORE_BF16;
+        pl.storage = storage;
         pl.kt = kt_of(kg);
         pl.k0 = k0; pl.kg = kg; pl.pstride = pstride; pl.pack_offset = off;
         pl.nsplit = nsplit;
         pl.tr = 1;
-        pl.variant = pl.kt == 2 ? 18 : 6;
-        pl.mb = 64; pl.nb = 128;
+        if (f32) {
+            // the two-workgroup shape of bigprod_f3_kernel (32-column stages, 2-deep ring); the fold interval follows the
+            // contraction length as in plan_bigprod
+            pl.variant = len >= 65536 ? 125 : len >= 16384 ? 108 : len >= 4096 ? 128 : 129;
+            pl.mb = 32;
+        } else {
+            pl.variant = pl.kt == 2 ? 18 : 6;
+            pl.mb = 64;
+        }
+        pl.nb = 128;
         pl.len = len;
-        pl.stages = (len + 63) / 64;
+        pl.stages = (len + pl.mb - 1) / pl.mb;
         pl.tiles = (ncols + 127) / 128;
         pl.ncols_pad = round_up(ncols, COL_PAD);
         int S = 1;
@@ -1808,7 +1835,7 @@ int plan_bigprod_groups_tr(int k, i64 len, i64 ncols, int nsplit, int num_cus, B
         if (ng > 0) S = out[0].S;
         pl.S = S;
         pl.nst = (pl.stages + S - 1) / S;
-        off += packed_bytes(STORE_BF16, kg, len, nsplit);
+        off += packed_bytes(storage, kg, len, nsplit);
         out[ng] = pl;
     }
     for (int g = 0; g < ng; ++g) out[g].p_elems = (size_t)out[0].S * out[0].ncols_pad * pstride;
@@ -2048,10 +2075,38 @@ static int launch_bigprod_tr(const BigProdPlan& pl, const void* B, i64 ldb, cons
     return launch_bigprod_tr_v<KT, 1>(pl, B, ldb, Xp, P, st);
 }
 
+// transposed source, fp32 storage: bigprod_f3_kernel<..., TAIL = 2> in its two-workgroup shape, fold interval by variant
+template <int KT>
+static int launch_f3_tr(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
+{
+    if (pl.nsplit == NSPLIT_F16X2) {
+        if (!pl.oscale) { set_error("bigprod: the fp16 two-term form needs the output scales"); return -100; }
+        switch (pl.variant) {
+            case 125: return launch_f3_t<KT, 2, 32, 2, 0, 8, 2, 1, 2>(pl, B, ldb, Xp, P, st);
+            case 128: return launch_f3_t<KT, 2, 32, 2, 0, 2, 2, 1, 2>(pl, B, ldb, Xp, P, st);
+            case 129: return launch_f3_t<KT, 2, 32, 2, 0, 1, 2, 1, 2>(pl, B, ldb, Xp, P, st);
+            default: return launch_f3_t<KT, 2, 32, 2, 0, 4, 2, 1, 2>(pl, B, ldb, Xp, P, st);
+        }
+    }
+    // bf16x3: a stage is 16 KB of A + 6 KB (k <= 32) or 12 KB of operand fragments; 22 pieces do not split over four loading
+    // waves, so k <= 32 takes the shape with two loader waves (variant 104's), k in (32, 64] the plain one
+    constexpr int NWL = KT == 1 ? 2 : 0, WPS = KT == 1 ? 3 : 2;
+    switch (pl.variant) {
+        case 125: return launch_f3_t<KT, 3, 32, 2, NWL, 8, WPS, 0, 2>(pl, B, ldb, Xp, P, st);
+        case 128: return launch_f3_t<KT, 3, 32, 2, NWL, 2, WPS, 0, 2>(pl, B, ldb, Xp, P, st);
+        case 129: return launch_f3_t<KT, 3, 32, 2, NWL, 1, WPS, 0, 2>(pl, B, ldb, Xp, P, st);
+        default: return launch_f3_t<KT, 3, 32, 2, NWL, 4, WPS, 0, 2>(pl, B, ldb, Xp, P, st);
+    }
+}
+
 int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st)
 {
     if (pl.tr) {
-        if (pl.storage != STORE_BF16 || pl.nsplit < 1 || pl.nsplit > 3) { set_error("bigprod: the transposed source exists for bf16 storage with 1 .. 3 operand terms"); return -100; }
+        if (pl.storage == STORE_F32) {
+            if (pl.nsplit != 3 && pl.nsplit != NSPLIT_F16X2) { set_error("bigprod: the transposed source of fp32 storage takes the fp16 two-term form or bf16x3"); return -100; }
+            return pl.kt == 1 ? launch_f3_tr<1>(pl, B, ldb, Xp, P, st) : launch_f3_tr<2>(pl, B, ldb, Xp, P, st);
+        }
+        if (pl.nsplit < 1 || pl.nsplit > 3) { set_error("bigprod: the transposed source of bf16 storage takes 1 .. 3 operand terms"); return -100; }
         return pl.kt == 1 ? launch_bigprod_tr<1>(pl, B, ldb, Xp, P, st) : launch_bigprod_tr<2>(pl, B, ldb, Xp, P, st);
     }
     if (pl.nsplit == NSPLIT_F64) return launch_bigprod_f64(pl, B, ldb, Xp, P, pl.len, st);

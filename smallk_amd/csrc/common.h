@@ -176,8 +176,9 @@ BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int
 // the groups of a k-row factor (1 for k <= 64, 2 up to 128): same row splits, P laid out [S][ncols_pad][32 kt_of(k)]
 int plan_bigprod_groups(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out /* 2 */);
 int launch_bigprod(const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp, double* P, hipStream_t st);
-// the groups of the H*A' pass taken from A itself: len = columns of A (the contraction), ncols = rows of A; bf16 storage, nsplit 1..3
-int plan_bigprod_groups_tr(int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out);
+// the groups of the H*A' pass taken from A itself: len = columns of A (the contraction), ncols = rows of A; bf16 storage with
+// nsplit 1..3, or fp32 storage with the fp16 two-term form / bf16x3
+int plan_bigprod_groups_tr(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out);
 
 int launch_reduce_partials(PartialView pv, int k, i64 c0, i64 N, void* out /* [.][kpp] */, int out_f64, hipStream_t st);
 

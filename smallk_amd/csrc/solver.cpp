@@ -87,8 +87,8 @@ struct smk_matrix {
     mutable double colnorm_max = -1.0, rownorm_max = -1.0;   // largest 2-norm of a column / a row of A (dense; NnlsPack's bound); < 0 = not yet measured
     void* A = nullptr;  i64 ldA = 0, colsA = 0;      // m_pad x n_pad
     void* At = nullptr; i64 ldAt = 0, colsAt = 0;    // n_pad x m_pad
-    // single copy (bf16 storage, MU / HALS): no stored transpose -- the H*A' pass contracts down the strided direction of A itself
-    // (bigprod.hip, TRB), as the reference's MU / HALS do (Gemm(NORMAL, TRANSPOSE) on A, nmf_solver_mu.hpp:121-164,
+    // single copy (MU / HALS): no stored transpose -- the H*A' pass contracts down the strided direction of A itself
+    // (bigprod.hip: TRB for bf16, TAIL = 2 for fp32), as the reference's MU / HALS do (Gemm(NORMAL, TRANSPOSE) on A, nmf_solver_mu.hpp:121-164,
     // nmf_solver_hals.hpp:166-199); half the footprint, no transpose pass at load time
     bool single = false;
     // sparse A: CSC of the local columns and CSC of its transpose (fp64 values, 64-bit offsets)
@@ -431,9 +431,9 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
         if (skew > 0 && ((size_t)a->ldA * es) % ((size_t)1 << 20) == 0) a->ldA += skew;
         if (skew > 0 && ((size_t)a->ldAt * es) % ((size_t)1 << 20) == 0) a->ldAt += skew;
     }
-    {   // SMK_SINGLE_COPY=1: bf16 matrices are created without the stored transpose (smk_matrix_create_single_copy asks for it explicitly)
+    {   // SMK_SINGLE_COPY=1: dense matrices are created without the stored transpose (smk_matrix_create_single_copy asks for it explicitly)
         const char* esc = getenv("SMK_SINGLE_COPY");
-        a->single = g_create_single || (esc && esc[0] == '1' && storage == SMK_STORE_BF16);
+        a->single = g_create_single || (esc && esc[0] == '1');
     }
     hipError_t e1 = smk::dev_malloc(&a->A, (size_t)a->ldA * a->colsA * es);
     hipError_t e2 = (e1 == hipSuccess && !a->single) ? smk::dev_malloc(&a->At, (size_t)a->ldAt * a->colsAt * es) : e1;
@@ -457,7 +457,6 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
 int smk_matrix_create_single_copy(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0, int64_t ncols_local,
                                   int storage)
 {
-    if (storage != SMK_STORE_BF16) { set_error("single-copy matrices exist for bf16 storage (the transposing LDS read is a 16-bit instruction)"); return SMK_UNSUPPORTED; }
     g_create_single = true;
     const int rc = smk_matrix_create(out, height, width_global, col0, ncols_local, storage);
     g_create_single = false;
@@ -1045,7 +1044,7 @@ static int plan_products(smk_solver* s)
         if (rc0) return rc0;
     }
     s->ng = plan_bigprod_groups(a->storage, s->k, s->m, s->n, s->nsplit, g_cus, s->pg1);
-    if (a->single) (void)plan_bigprod_groups_tr(s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);      // H*A' from A itself
+    if (a->single) (void)plan_bigprod_groups_tr(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);      // H*A' from A itself
     else (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
     if (s->nsplit == NSPLIT_F64)
         for (int g = 0; g < s->ng; ++g) { s->pg1[g].ldx = s->KP; s->pg2[g].ldx = s->KP; }
@@ -1177,7 +1176,8 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
         // itself, nmf_solver_bpp.hpp:319; RANK2 and the accurate form contract down the contiguous direction of A' on the vector
         // ALUs / fp64 matrix cores).  Anything else gets the stored transpose now, once (the matrix is an ordinary one afterwards).
         const bool ok_alg = opts->algorithm == SMK_ALG_MU || opts->algorithm == SMK_ALG_HALS;
-        if (!ok_alg || s->nsplit < 1 || s->nsplit > 3) {
+        const bool ok_form = a->storage == SMK_STORE_BF16 ? (s->nsplit >= 1 && s->nsplit <= 3) : (s->nsplit == 3 || s->nsplit == NSPLIT_F16X2);
+        if (!ok_alg || !ok_form) {
             const int trc = matrix_materialize_transpose(a);
             if (trc) { smk_solver_destroy(s); return trc; }
         }

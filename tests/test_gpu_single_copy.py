@@ -23,20 +23,27 @@ def _run(gpu, A, W0, H0, alg, iters, single, storage="bf16"):
     return W, H, nbytes
 
 
+@pytest.mark.parametrize("storage,quant", [("bf16", 1), ("f32", 0)])
 @pytest.mark.parametrize("alg", ["MU", "HALS"])
-@pytest.mark.parametrize("m,n,k", [(512, 256, 8), (700, 1100, 17), (1000, 333, 32), (2051, 1500, 33), (640, 4100, 64), (900, 800, 100)])
-def test_single_copy_equals_stored_transpose_and_oracle(gpu, alg, m, n, k):
+@pytest.mark.parametrize("m,n,k", [(512, 256, 8), (700, 1100, 17), (1000, 333, 32), (2051, 1500, 33), (640, 4100, 64), (900, 800, 100),
+                                   (300, 17000, 16)])
+def test_single_copy_equals_stored_transpose_and_oracle(gpu, alg, m, n, k, storage, quant):
+    """bf16: the transposing LDS read; fp32: eight strided 4-byte reads per operand, fp16 two-term form (MU) / bf16x3 (HALS); the last
+    shape has a contraction long enough for the 4-stage fold interval."""
     import oracle
     if alg == "HALS" and k > 64:
         pytest.skip("HALS above k = 64 takes the accurate form, which builds the stored transpose (tested below)")
-    A = oracle.fill_uniform(m, n, 7, quant=1)
+    A = oracle.fill_uniform(m, n, 7, quant=quant)
     W0 = oracle.fill_uniform(m, k, 8)
     H0 = oracle.fill_uniform(k, n, 9) * (2.0 / k)
     iters = 6
-    W1, H1, b1 = _run(gpu, A, W0, H0, alg, iters, single=True)
-    W2, H2, b2 = _run(gpu, A, W0, H0, alg, iters, single=False)
+    W1, H1, b1 = _run(gpu, A, W0, H0, alg, iters, single=True, storage=storage)
+    W2, H2, b2 = _run(gpu, A, W0, H0, alg, iters, single=False, storage=storage)
     fro = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
-    assert fro(W1, W2) < 1e-6 and fro(H1, H2) < 1e-6, (fro(W1, W2), fro(H1, H2))
+    # the same products with other fp32 accumulation chains (fold intervals, kernel shapes); HALS amplifies product-level
+    # differences several thousand times (solver.cpp): measured 2e-6 .. 3.3e-6 on fp32 A, below 1e-6 everywhere else
+    bar = 2e-5 if alg == "HALS" else 1e-6
+    assert fro(W1, W2) < bar and fro(H1, H2) < bar, (fro(W1, W2), fro(H1, H2))
     ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, normalize=False)
     assert fro(W1, ref.W) < 1e-4 and fro(H1, ref.H) < 1e-4, (fro(W1, ref.W), fro(H1, ref.H))
     assert b1 < 0.62 * b2                       # the footprint the ABI reports: no second copy
@@ -44,12 +51,9 @@ def test_single_copy_equals_stored_transpose_and_oracle(gpu, alg, m, n, k):
 
 def test_single_copy_builds_the_transpose_when_something_needs_it(gpu):
     """BPP, RANK2 and the accurate form read the stored transpose: the first such solver on a single-copy matrix allocates and
-    fills it (the matrix is an ordinary one afterwards); MU / HALS solvers created before keep reading A.  fp32 storage has no
-    single-copy form (the transposing LDS read is a 16-bit instruction)."""
-    import ctypes as C
+    fills it (the matrix is an ordinary one afterwards); MU / HALS solvers created before keep reading A."""
     import oracle
     from smallk_amd import DenseMatrix, NmfSolver, make_options
-    from smallk_amd import _lib as L
     m, n, k = 600, 400, 8
     A = oracle.fill_uniform(m, n, 3, quant=1)
     W0, H0 = oracle.fill_uniform(m, k, 4), oracle.fill_uniform(k, n, 5) * (2.0 / k)
@@ -69,8 +73,6 @@ def test_single_copy_builds_the_transpose_when_something_needs_it(gpu):
         assert np.linalg.norm(W - ref.W) / np.linalg.norm(ref.W) < 1e-4 and np.linalg.norm(H - ref.H) / np.linalg.norm(ref.H) < 1e-4
         s.close()
     D.close()
-    h = C.c_void_p()
-    assert L.lib().smk_matrix_create_single_copy(C.byref(h), 600, 400, 0, 400, L.STORE_F32) == -101      # SMK_UNSUPPORTED: fp32 storage
 
 
 def test_single_copy_full_size_c3(gpu):
