@@ -63,6 +63,7 @@ WORKLOADS = {
     "c3t": (16384, 65536, 32, "HALS", "bf16", "EXPERIMENT C3 transposed: 16384x65536 k=32 HALS bf16"),
     "mall": (65536, 1024, 32, "HALS", "bf16", "EXPERIMENT 65536x1024 k=32 HALS bf16: 134 MB of A, both passes from the Infinity Cache with --single-copy"),
     "mall2": (65536, 2048, 32, "HALS", "bf16", "EXPERIMENT 65536x2048 k=32 HALS bf16: 268 MB of A"),
+    "c4x2": (262144, 131072, 64, "BPP", "f32", "EXPERIMENT twice C4: 262144x131072 k=64 BPP fp32 -- 137 GB as a single copy (--single-copy)"),
     "c2mu": (8192, 4096, 16, "MU", "f32", "EXPERIMENT C2's matrix under MU"),
     "c3f": (65536, 16384, 32, "HALS", "f32", "EXPERIMENT C3's shape with fp32 A (HALS, bf16x3 products)"),
     "c4mu": (262144, 65536, 64, "MU", "f32", "EXPERIMENT C4's matrix under MU (replicated W update, all-reduce of (AH')')"),

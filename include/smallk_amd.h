@@ -105,9 +105,10 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
 /* The same without the stored transpose ("single copy"): the reference's MU and HALS call Gemm(NORMAL, TRANSPOSE)
  * on A itself (nmf_solver_mu.hpp:121-164, nmf_solver_hals.hpp:166-199) -- only its BPP keeps A' -- and so does this matrix: the
  * H*A' pass contracts down the strided direction of A (bf16: transposing LDS reads; fp32: strided 4-byte reads).  Half the footprint (twice the problem per GPU) and
- * no transpose pass at load time.  Solvers on it: MU and HALS with the 16-bit product forms read A only; the first solver that needs
- * the transpose (BPP, RANK2, the accurate form) makes the matrix allocate and fill it, after which it is an ordinary matrix
- * (smk_matrix_is_single_copy / smk_matrix_device_bytes tell).  SMK_SINGLE_COPY=1 makes smk_matrix_create do this for every dense matrix. */
+ * no transpose pass at load time.  Solvers on it: MU, HALS and BPP with the 16-bit product forms read A only; the first solver that needs
+ * the transpose (RANK2, the accurate form) makes the matrix allocate and fill it, after which it is an ordinary matrix
+ * (smk_matrix_is_single_copy / smk_matrix_device_bytes tell).  SMK_SINGLE_COPY=1 makes smk_matrix_create do this for every dense matrix,
+ * and smk_matrix_create does it by itself when A fits the device memory and A + A' do not. */
 int smk_matrix_create_single_copy(smk_matrix** out, int64_t height, int64_t width_global, int64_t col0,
                                   int64_t ncols_local, int storage);
 int smk_matrix_is_single_copy(const smk_matrix* a);

@@ -437,6 +437,14 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
     }
     hipError_t e1 = smk::dev_malloc(&a->A, (size_t)a->ldA * a->colsA * es);
     hipError_t e2 = (e1 == hipSuccess && !a->single) ? smk::dev_malloc(&a->At, (size_t)a->ldAt * a->colsAt * es) : e1;
+    if (e1 == hipSuccess && e2 != hipSuccess && !a->single) {
+        // A fits, A and A' together do not: the matrix becomes a single copy (MU, HALS and BPP with the 16-bit product forms run
+        // on it as they are; RANK2 and the accurate form will ask for the transpose and report the allocation failure then)
+        (void)hipGetLastError();
+        a->At = nullptr;
+        a->single = true;
+        e2 = hipSuccess;
+    }
     if (e1 != hipSuccess || e2 != hipSuccess) {
         set_error(std::string("smk::dev_malloc(A): ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         if (a->A) (void)smk::dev_free(a->A);
@@ -1076,7 +1084,7 @@ static int plan_products(smk_solver* s)
     const char* epk = getenv("SMK_NNLS_PACK");                      // read per plan, like SMK_NSPLIT (0 = the separate reduce-and-pack launch)
     const bool pack_env = !(epk && epk[0] == '0');
     s->pack_in_solve = pack_env && !s->pack_in_solve_off && s->o.algorithm == SMK_ALG_BPP && s->KP == 16 && s->nsplit == NSPLIT_F16X2 &&
-                       !a->sparse && s->ng == 1 && !is_dist(s) && !s->comm && bigprod_supports_tail(s->pl1) && bigprod_supports_tail(s->pl2);
+                       !a->sparse && !a->single && s->ng == 1 && !is_dist(s) && !s->comm && bigprod_supports_tail(s->pl1) && bigprod_supports_tail(s->pl2);
     if (s->pack_in_solve && (a->colnorm_max < 0.0 || a->rownorm_max < 0.0)) {
         const int rc0 = matrix_measure_norms(a, s->st);
         if (rc0) return rc0;
@@ -1172,10 +1180,11 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     // the fp16 two-term form applies to fp32 storage; RANK2 keeps its Gram matrices inside its own solve kernel
     if (s->nsplit == NSPLIT_F16X2 && (a->storage != SMK_STORE_F32 || a->sparse || opts->algorithm == SMK_ALG_RANK2)) s->nsplit = 3;
     if (a->single && !a->sparse) {
-        // what the transposed-source kernel covers: MU and HALS with the 16-bit product forms (the reference's BPP keeps a transpose
-        // itself, nmf_solver_bpp.hpp:319; RANK2 and the accurate form contract down the contiguous direction of A' on the vector
-        // ALUs / fp64 matrix cores).  Anything else gets the stored transpose now, once (the matrix is an ordinary one afterwards).
-        const bool ok_alg = opts->algorithm == SMK_ALG_MU || opts->algorithm == SMK_ALG_HALS;
+        // what the transposed-source kernels cover: MU, HALS and BPP with the 16-bit product forms (the reference's BPP keeps a
+        // transpose itself, nmf_solver_bpp.hpp:319 -- its W-side right-hand side H A' is the same product as MU's and HALS's, so it
+        // does not have to; RANK2 and the accurate form contract down the contiguous direction of A' on the vector ALUs / fp64
+        // matrix cores).  Anything else gets the stored transpose now, once (the matrix is an ordinary one afterwards).
+        const bool ok_alg = opts->algorithm == SMK_ALG_MU || opts->algorithm == SMK_ALG_HALS || opts->algorithm == SMK_ALG_BPP;
         const bool ok_form = a->storage == SMK_STORE_BF16 ? (s->nsplit >= 1 && s->nsplit <= 3) : (s->nsplit == 3 || s->nsplit == NSPLIT_F16X2);
         if (!ok_alg || !ok_form) {
             const int trc = matrix_materialize_transpose(a);

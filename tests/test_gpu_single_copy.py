@@ -2,6 +2,8 @@
 source) -- the reference's MU / HALS call Gemm(NORMAL, TRANSPOSE) on A (nmf_solver_mu.hpp:121-164, nmf_solver_hals.hpp:166-199).
 Same results as with the stored transpose (the same products, the usual bars against the oracle), half the footprint; a consumer of
 the transpose (BPP, RANK2, the accurate form) makes the matrix build it on demand."""
+import os
+
 import numpy as np
 import pytest
 
@@ -24,15 +26,15 @@ def _run(gpu, A, W0, H0, alg, iters, single, storage="bf16"):
 
 
 @pytest.mark.parametrize("storage,quant", [("bf16", 1), ("f32", 0)])
-@pytest.mark.parametrize("alg", ["MU", "HALS"])
+@pytest.mark.parametrize("alg", ["MU", "HALS", "BPP"])
 @pytest.mark.parametrize("m,n,k", [(512, 256, 8), (700, 1100, 17), (1000, 333, 32), (2051, 1500, 33), (640, 4100, 64), (900, 800, 100),
                                    (300, 17000, 16)])
 def test_single_copy_equals_stored_transpose_and_oracle(gpu, alg, m, n, k, storage, quant):
     """bf16: the transposing LDS read; fp32: eight strided 4-byte reads per operand, fp16 two-term form (MU) / bf16x3 (HALS); the last
     shape has a contraction long enough for the 4-stage fold interval."""
     import oracle
-    if alg == "HALS" and k > 64:
-        pytest.skip("HALS above k = 64 takes the accurate form, which builds the stored transpose (tested below)")
+    if alg in ("HALS", "BPP") and k > 64:
+        pytest.skip("HALS and BPP above k = 64 take the accurate form, which builds the stored transpose (tested below)")
     A = oracle.fill_uniform(m, n, 7, quant=quant)
     W0 = oracle.fill_uniform(m, k, 8)
     H0 = oracle.fill_uniform(k, n, 9) * (2.0 / k)
@@ -42,7 +44,7 @@ def test_single_copy_equals_stored_transpose_and_oracle(gpu, alg, m, n, k, stora
     fro = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
     # the same products with other fp32 accumulation chains (fold intervals, kernel shapes); HALS amplifies product-level
     # differences several thousand times (solver.cpp): measured 2e-6 .. 3.3e-6 on fp32 A, below 1e-6 everywhere else
-    bar = 2e-5 if alg == "HALS" else 1e-6
+    bar = 2e-5 if alg in ("HALS", "BPP") else 1e-6
     assert fro(W1, W2) < bar and fro(H1, H2) < bar, (fro(W1, W2), fro(H1, H2))
     ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, normalize=False)
     assert fro(W1, ref.W) < 1e-4 and fro(H1, ref.H) < 1e-4, (fro(W1, ref.W), fro(H1, ref.H))
@@ -50,7 +52,7 @@ def test_single_copy_equals_stored_transpose_and_oracle(gpu, alg, m, n, k, stora
 
 
 def test_single_copy_builds_the_transpose_when_something_needs_it(gpu):
-    """BPP, RANK2 and the accurate form read the stored transpose: the first such solver on a single-copy matrix allocates and
+    """RANK2 and the accurate form read the stored transpose: the first such solver on a single-copy matrix allocates and
     fills it (the matrix is an ordinary one afterwards); MU / HALS solvers created before keep reading A."""
     import oracle
     from smallk_amd import DenseMatrix, NmfSolver, make_options
@@ -62,7 +64,11 @@ def test_single_copy_builds_the_transpose_when_something_needs_it(gpu):
     mu = NmfSolver(D, make_options(m, n, k, "MU", normalize=False))       # planned on the transposed source
     mu.set_factors(W0, H0)
     assert D.single_copy
-    bpp = NmfSolver(D, make_options(m, n, k, "BPP", normalize=False))     # needs A': built now
+    os.environ["SMK_NSPLIT"] = "8"
+    try:
+        bpp = NmfSolver(D, make_options(m, n, k, "BPP", normalize=False)) # the accurate form needs A': built now
+    finally:
+        del os.environ["SMK_NSPLIT"]
     assert not D.single_copy and D.device_bytes > 1.6 * b0
     bpp.set_factors(W0, H0)
     for s, alg in ((mu, "MU"), (bpp, "BPP")):
@@ -95,3 +101,38 @@ def test_single_copy_full_size_c3(gpu):
     fro = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     assert fro(out[0][0], out[1][0]) < 1e-6 and fro(out[0][1], out[1][1]) < 1e-6
     assert out[0][2] * 2 <= out[1][2] * 1.01
+
+
+def test_matrix_beyond_half_of_hbm_falls_back_to_a_single_copy(gpu):
+    """262144 x 196608 fp32 = 206 GB: A fits the 288 GB of one MI355X, A and A' together do not.  smk_matrix_create then makes the
+    matrix a single copy by itself; one BPP iteration at k = 64 (the fp16 two-term form, both products from A) is checked on sampled
+    columns and rows against the oracle exactly as the C4 test does -- 1.5 x C4's matrix on one GPU."""
+    import oracle
+    from smallk_amd import DenseMatrix, NmfSolver, make_options, uniform_host
+    m, n, k, seed = 262144, 196608, 64, 601
+    A = DenseMatrix(m, n)                                  # asks for both copies
+    try:
+        assert A.single_copy and A.device_bytes < 215e9
+        A.fill_uniform(seed)
+        W0, H0 = uniform_host(m, k, 602), uniform_host(k, n, 603) * (2.0 / k)
+        s = NmfSolver(A, make_options(m, n, k, "BPP", normalize=False))
+        assert s.product_form()[0] == 4
+        s.set_factors(W0, H0)
+        s.iterate(1)
+        assert s.sync() == 0
+        W1, H1 = s.factors(normalize=False)
+        s.close()
+        assert A.single_copy
+    finally:
+        A.close()
+    relerr = lambda a, b: float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+    rng = np.random.default_rng(6)
+    cols = np.sort(rng.choice(n, size=k + 8, replace=False))
+    Ac = np.asfortranarray(np.concatenate([oracle.fill_uniform(m, 1, seed, c0=int(c), gheight=m) for c in cols], axis=1))
+    ref = oracle.nmf(Ac, W0, H0[:, cols], "BPP", min_iter=1, max_iter=1, normalize=False)
+    assert ref.result == 0 and relerr(H1[:, cols], ref.H) < 1e-4
+    rows = np.sort(rng.choice(m, size=k + 8, replace=False))
+    Ar = np.asfortranarray(np.concatenate([oracle.fill_uniform(1, n, seed, r0=int(r), gheight=m) for r in rows], axis=0))
+    ref = oracle.nmf(np.asfortranarray(Ar.T), np.asfortranarray(H1.T), np.asfortranarray(W0[rows, :].T), "BPP",
+                     min_iter=1, max_iter=1, normalize=False)
+    assert ref.result == 0 and relerr(W1[rows, :], ref.H.T) < 1e-4
