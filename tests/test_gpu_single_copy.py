@@ -136,3 +136,54 @@ def test_matrix_beyond_half_of_hbm_falls_back_to_a_single_copy(gpu):
     ref = oracle.nmf(np.asfortranarray(Ar.T), np.asfortranarray(H1.T), np.asfortranarray(W0[rows, :].T), "BPP",
                      min_iter=1, max_iter=1, normalize=False)
     assert ref.result == 0 and relerr(W1[rows, :], ref.H.T) < 1e-4
+
+
+@pytest.mark.parametrize("alg,storage,quant", [("BPP", "f32", 0), ("MU", "f32", 0), ("HALS", "bf16", 1), ("BPP", "bf16", 1)])
+def test_column_sharded_run_on_single_copy_shards(gpu, alg, storage, quant):
+    """Three column shards through the in-process stand-in communicator, every shard a single copy: the chunked H*A' pass
+    (reduce-scatter / all-reduce per row chunk) reads row ranges of A itself.  Against the oracle on the whole matrix."""
+    import threading
+    import oracle
+    from smallk_amd import Comm, DenseMatrix, NmfSolver, make_options, thread_context_begin, thread_context_end
+    from smallk_amd import dist as sdist
+    m, n, k, iters, world = 20000, 3000, 24, 4, 3
+    A = oracle.fill_uniform(m, n, 31, quant=quant)
+    W0 = oracle.fill_uniform(m, k, 32)
+    H0 = oracle.fill_uniform(k, n, 33) * (2.0 / k)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=iters, max_iter=iters, normalize=False)
+    comms = Comm.init_local(world)
+    out, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            thread_context_begin(0)
+            c0, nc = sdist.shard_columns(n, world, rank)
+            D = DenseMatrix(m, n, col0=c0, ncols=nc, storage=storage, single_copy=True)
+            D.upload(A[:, c0:c0 + nc])
+            sv = NmfSolver(D, make_options(m, n, k, alg, min_iter=iters, max_iter=iters, normalize=False))
+            sv.attach_comm(comms[rank])
+            sv.set_factors(W0, H0[:, c0:c0 + nc])
+            sv.iterate(iters)
+            rc = sv.sync()
+            W, H = sv.factors(normalize=False)
+            out[rank] = (rc, W, H, D.single_copy)
+            sv.close()
+            D.close()
+        except Exception as e:          # pragma: no cover
+            errors.append((rank, repr(e)))
+        finally:
+            thread_context_end()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    for c in comms:
+        c.close()
+    assert not errors, errors
+    assert all(o is not None and o[0] == 0 and o[3] for o in out)          # still single copies after the run
+    H = np.concatenate([o[2] for o in out], axis=1)
+    fro = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert fro(out[0][1], ref.W) < 1e-4 and fro(H, ref.H) < 1e-4, (fro(out[0][1], ref.W), fro(H, ref.H))
+    assert np.array_equal(out[0][1], out[world - 1][1])
