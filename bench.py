@@ -461,7 +461,7 @@ def build_report(args, world, elapsed, windows, rank0, ranks_report, collectives
     # HBM traffic comes from separate rocprofv3 --pmc passes (tools/profile.sh -> profiles/hbm_traffic.json).  The
     # entry records the hash of the kernel source it was measured on: a figure from an older kernel is not printed.
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(prof) and args.emulate_world <= 1:
+    if os.path.exists(prof) and args.emulate_world <= 1 and not args.single_copy and args.data == "uniform":     # the passes they were taken on
         try:
             pj = json.load(open(prof))
             key = f"{args.workload}_n{world}"
@@ -477,7 +477,7 @@ def build_report(args, world, elapsed, windows, rank0, ranks_report, collectives
     # MFMA utilisation from counters (north_star asks for it by name): a separate rocprofv3 --pmc pass (tools/pmc_mfma.py ->
     # profiles/mfma_util.json), tied to the kernel source like the traffic figure
     prof = os.path.join(ROOT, "profiles", "mfma_util.json")
-    if os.path.exists(prof) and args.emulate_world <= 1:
+    if os.path.exists(prof) and args.emulate_world <= 1 and not args.single_copy:
         try:
             pj = json.load(open(prof))
             key = f"{args.workload}_n{world}"
