@@ -109,7 +109,11 @@ def test_matrix_beyond_half_of_hbm_falls_back_to_a_single_copy(gpu):
     columns and rows against the oracle exactly as the C4 test does -- 1.5 x C4's matrix on one GPU."""
     import oracle
     from smallk_amd import DenseMatrix, NmfSolver, make_options, uniform_host
+    import gc
+    from smallk_amd import trim_device_cache
     m, n, k, seed = 262144, 196608, 64, 601
+    gc.collect()                                           # matrices of earlier tests that were left to the collector
+    trim_device_cache()
     A = DenseMatrix(m, n)                                  # asks for both copies
     try:
         assert A.single_copy and A.device_bytes < 215e9
