@@ -129,7 +129,8 @@ def rccl_log_excerpt(max_lines=60, out=sys.stderr):
 def rccl_choices(max_items=40):
     """What RCCL chose per collective and size -- its own TUNING lines ("AllReduce: 33554432 Bytes -> Algo 1 proto 2 time ...",
     NCCL_DEBUG_SUBSYS=TUNING) from this run's per-rank log files, de-duplicated; algorithm / protocol numbers are RCCL's enums
-    (algo 0 tree, 1 ring, ...; proto 0 LL, 1 LL128, 2 simple).  Empty when RCCL printed none (one rank, or another log format)."""
+    (algo 0 tree, 1 ring, ...; proto 0 LL, 1 LL128, 2 simple).  Empty unless the run was started with SMK_BENCH_RCCL_TUNING=1 (RCCL
+    then logs every collective call: a diagnostic run, not a measurement), with one rank, or with another log format."""
     import glob
     import re
     pat = re.compile(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)")
@@ -521,7 +522,9 @@ def rccl_env_defaults(set_keys):
     resolve) and no InfiniBand probing -- the data path is xGMI either way.  The caller's settings win."""
     if "NCCL_DEBUG" not in os.environ:
         os.environ["NCCL_DEBUG"] = "INFO"
-        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH" + ("" if os.environ.get("SMK_BENCH_RCCL_TUNING") == "0" else ",TUNING"))
+        # TUNING makes RCCL print one line per collective CALL (algorithm / protocol for that size): wanted once, for rccl_choices,
+        # but it is host work inside the timed region -- opt-in (SMK_BENCH_RCCL_TUNING=1), never in a run whose number is quoted
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH" + (",TUNING" if os.environ.get("SMK_BENCH_RCCL_TUNING") == "1" else ""))
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/smk_rccl_%h_%p.log")
     if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
         for key, val in (("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1")):
