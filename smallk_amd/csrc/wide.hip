@@ -2,7 +2,7 @@
 //
 // The kernels of kernels.hip / nnls.hip keep a column's k values in a few lanes and the k x k Gram matrix in LDS or in
 // registers; neither survives k > 128 (512 KB of Gram matrix at k = 256).  This file is the general path: KP = k rounded
-// up to a multiple of 64 (up to 1024), one WAVE per column with V = KP / 64 values per lane (element e of a column lives
+// up to a multiple of 64 (up to 2048), one WAVE per column with V = KP / 64 values per lane (element e of a column lives
 // in lane e % 64, slot e / 64, so every load of a column or of a Gram row is one coalesced 512-byte line per slot), the
 // Gram matrix read through the caches.  Block principal pivoting: k <= 256 a wave per column with the block of an exchange
 // as 16 x 16 tiles in LDS (blocked Cholesky on the f64 matrix cores), above that a workgroup per column (Cholesky of the
@@ -273,7 +273,23 @@ __global__ __launch_bounds__(256) void grad_pg_wide_kernel(const double* __restr
         case 14: { constexpr int V = 14; CALL; } break;            \
         case 15: { constexpr int V = 15; CALL; } break;            \
         case 16: { constexpr int V = 16; CALL; } break;            \
-        default: set_error("wide kernels: KP must be 192 .. 1024"); return -100; \
+        case 17: { constexpr int V = 17; CALL; } break;            \
+        case 18: { constexpr int V = 18; CALL; } break;            \
+        case 19: { constexpr int V = 19; CALL; } break;            \
+        case 20: { constexpr int V = 20; CALL; } break;            \
+        case 21: { constexpr int V = 21; CALL; } break;            \
+        case 22: { constexpr int V = 22; CALL; } break;            \
+        case 23: { constexpr int V = 23; CALL; } break;            \
+        case 24: { constexpr int V = 24; CALL; } break;            \
+        case 25: { constexpr int V = 25; CALL; } break;            \
+        case 26: { constexpr int V = 26; CALL; } break;            \
+        case 27: { constexpr int V = 27; CALL; } break;            \
+        case 28: { constexpr int V = 28; CALL; } break;            \
+        case 29: { constexpr int V = 29; CALL; } break;            \
+        case 30: { constexpr int V = 30; CALL; } break;            \
+        case 31: { constexpr int V = 31; CALL; } break;            \
+        case 32: { constexpr int V = 32; CALL; } break;            \
+        default: set_error("wide kernels: KP must be 192 .. 2048"); return -100; \
     }
 
 // x <- x .* R ./ (y + 1e-13) with y = (X G) of the same column from rows_times_sym_wide_kernel; a thread per entry

@@ -199,7 +199,7 @@ def test_failure_and_bad_params(gpu):
     assert gpu.nmf(A, np.ones((12, 3)), np.ones((3, 6)), "MU", tol=2.0).result == L.BAD_PARAM
     assert gpu.nmf(A[:, :2], np.ones((12, 3)), np.ones((3, 2)), "MU").result == L.BAD_PARAM   # k > n
     with pytest.raises(L.SmallkError):
-        gpu.nmf(np.ones((1100, 1030)), np.ones((1100, 1025)), np.ones((1025, 1030)), "MU")   # k > 1024
+        gpu.nmf(np.ones((1100, 1030)), np.ones((1100, 1025)), np.ones((1025, 1030)), "BPP")   # k > 1024 under block pivoting
 
 
 @pytest.mark.parametrize("alg,storage,quant,m,n,k,iters", [
@@ -380,15 +380,43 @@ def test_rank_above_512(gpu, alg, m, n, k, iters):
         assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
 
 
-def test_rank_above_1024_is_refused_loudly(gpu):
-    """k > 1024 is valid for the reference and not built on the device path: SMK_UNSUPPORTED with a message,
-    never a silent fallback."""
+def test_rank_caps_are_refused_loudly(gpu):
+    """The reference bounds k only by n (common/src/nmf_options.cpp:47-52).  Here MU and HALS run to k = 2048, block pivoting to
+    k = 1024 (the widest instantiations of wide.hip); above: SMK_UNSUPPORTED with a message, never a silent fallback."""
     import oracle
     from smallk_amd import _lib as L
     A = oracle.fill_uniform(1100, 1030, 1)
     with pytest.raises(L.SmallkError) as e:
-        gpu.nmf(A, oracle.fill_uniform(1100, 1025, 2), oracle.fill_uniform(1025, 1030, 3), "MU", min_iter=1, max_iter=1)
+        gpu.nmf(A, oracle.fill_uniform(1100, 1025, 2), oracle.fill_uniform(1025, 1030, 3), "BPP", min_iter=1, max_iter=1)
     assert e.value.code == L.UNSUPPORTED and "k <= 1024" in str(e.value)
+    B = oracle.fill_uniform(2100, 2060, 1)
+    with pytest.raises(L.SmallkError) as e:
+        gpu.nmf(B, oracle.fill_uniform(2100, 2049, 2), oracle.fill_uniform(2049, 2060, 3), "MU", min_iter=1, max_iter=1)
+    assert e.value.code == L.UNSUPPORTED and "k <= 2048" in str(e.value)
+    G = np.eye(1025)
+    with pytest.raises(L.SmallkError):
+        gpu.nnls_blockpivot(G, np.ones((1025, 2)), np.zeros((1025, 2)))
+
+
+@pytest.mark.parametrize("alg,k", [("MU", 1100), ("HALS", 1100), ("MU", 2048), ("HALS", 2048)])
+def test_ranks_between_1024_and_2048(gpu, alg, k):
+    """MU and HALS above k = 1024 (round 5: the wide kernels instantiated to 32 values per lane, the streaming products as up to 32
+    groups of 64 factor rows), dense and sparse A, against the oracle."""
+    import oracle
+    import scipy.sparse as sp
+    m, n = 2300, 2100
+    A = oracle.fill_uniform(m, n, 42)
+    W0 = oracle.fill_uniform(m, k, 43)
+    H0 = oracle.fill_uniform(k, n, 44) * (2.0 / k)
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=2, max_iter=2)
+    got = gpu.nmf(A, W0, H0, alg, min_iter=2, max_iter=2)
+    assert got.result == 0 and rel(got.W, ref.W) < 1e-6 and rel(got.H, ref.H) < 1e-6, (rel(got.W, ref.W), rel(got.H, ref.H))
+    if alg == "MU":
+        rng = np.random.default_rng(3)
+        S = sp.random(m, n, density=0.05, random_state=rng, data_rvs=lambda s: rng.random(s) + 0.05, format="csc")
+        refs = oracle.nmf(S.toarray(), W0, H0, alg, min_iter=2, max_iter=2)
+        gots = gpu.nmf_sparse(S, W0, H0, alg, min_iter=2, max_iter=2)
+        assert gots.result == 0 and np.linalg.norm(gots.W - refs.W) < 1e-8 and np.linalg.norm(gots.H - refs.H) < 1e-8
 
 
 @pytest.mark.parametrize("alg", ["MU", "HALS", "BPP"])
