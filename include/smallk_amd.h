@@ -35,7 +35,7 @@ enum {
     SMK_FLATCLUST_FAILURE = -6,
     /* extensions (never produced by the reference) */
     SMK_DEVICE_ERROR = -100, /* HIP runtime error, see smk_last_error() */
-    SMK_UNSUPPORTED = -101   /* valid for the reference, not built here (k > 2048; block pivoting: k > 1024) */
+    SMK_UNSUPPORTED = -101   /* valid for the reference, not built here (k > 2048) */
 };
 
 /* enum NmfAlgorithm, common/include/nmf.hpp:28-34 (NOT smallk::Algorithm's order) */

@@ -28,7 +28,7 @@ inline i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
 // padded rank: the narrow kernels are built for 8 / 16 / 32 / 64 / 128; above that ("wide", wide.hip) a multiple of 64
 inline int kp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : k <= 128 ? 128 : (k + 63) / 64 * 64; }
 constexpr int MAX_K = 2048;                    // larger ranks: SMK_UNSUPPORTED (the widest instantiation of wide.hip: 32 values per lane)
-constexpr int MAX_K_BPP = 1024;                // block pivoting: the tile kernels of wide.hip are built to 16 tile columns of 64
+constexpr int MAX_K_BPP = MAX_K;               // block pivoting: above k = 1024 through the direct form only (wide.hip: wide_use_inverse)
 constexpr int MAX_GROUPS = MAX_K / 64;         // the streaming product takes 64 factor rows per pass over A
 inline bool is_wide(int k) { return k > 128; }
 // block pivoting takes the tile kernels of wide.hip (and their scratch layout) from this rank on: everything above 128, and

@@ -851,7 +851,7 @@ int clust_flat(Run& r, smk_tree& t)
         set_error("Insufficient number of leaf nodes for flat clustering.");
         return SMK_FLATCLUST_FAILURE;
     }
-    if (k > smk::MAX_K_BPP) { set_error("flat clustering: more than 1024 clusters is not built on the device path"); return SMK_UNSUPPORTED; }
+    if (k > 1024) { set_error("flat clustering: more than 1024 clusters is not built on the device path"); return SMK_UNSUPPORTED; }
     std::vector<double> W((size_t)m * k), H((size_t)k * n);
     int c = 0;
     for (size_t q = 0; q < t.nodes.size(); ++q)
@@ -896,7 +896,7 @@ int run_clust(const smk_clust_options* opts, smk_matrix* full, uint64_t seed, ui
               smk_tree** tree_out, smk_clust_stats* stats)
 {
     // the flat step factors with k = number of clusters: refuse before the tree search, not after it
-    if (opts->flat && opts->num_clusters > smk::MAX_K_BPP) {
+    if (opts->flat && opts->num_clusters > 1024) {
         set_error("flat clustering: more than 1024 clusters is not built on the device path");
         return SMK_UNSUPPORTED;
     }

@@ -1115,7 +1115,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if (!opts || !a) return SMK_BAD_PARAM;
     if (!smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
     if (opts->height != a->m || opts->width != a->n_global) { set_error("options/matrix dimension mismatch"); return SMK_BAD_PARAM; }
-    if (opts->k > MAX_K || (opts->algorithm == SMK_ALG_BPP && opts->k > MAX_K_BPP)) { set_error("device path supports k <= 2048 (MU, HALS) / k <= 1024 (BPP)"); return SMK_UNSUPPORTED; }
+    if (opts->k > MAX_K || (opts->algorithm == SMK_ALG_BPP && opts->k > MAX_K_BPP)) { set_error("device path supports k <= 2048"); return SMK_UNSUPPORTED; }
     // W and H element counts must fit the reference's 32-bit index (nmf.cpp:194-210)
     if ((uint64_t)a->m * (uint64_t)opts->k > 0x7FFFFFFFull) { fprintf(stderr, "W matrix size too large\n"); return SMK_SIZE_TOO_LARGE; }
     if ((uint64_t)a->n_global * (uint64_t)opts->k > 0x7FFFFFFFull) { fprintf(stderr, "H matrix size too large\n"); return SMK_SIZE_TOO_LARGE; }
@@ -2911,7 +2911,7 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
 {
     if (!g_init) { set_error("smk_initialize() has not been called"); return SMK_NOTINITIALIZED; }
     if (k <= 0 || ncols <= 0 || !LHS || !RHS || !X || ldL < k || ldR < k || ldX < k || (Y && ldY < k)) return SMK_BAD_PARAM;
-    if (k > MAX_K_BPP) { set_error("device path supports k <= 1024 for block pivoting"); return SMK_UNSUPPORTED; }
+    if (k > MAX_K_BPP) { set_error("device path supports k <= 2048"); return SMK_UNSUPPORTED; }
     const int KP = kp_of(k);
     std::vector<double> hg((size_t)KP * KP, 0.0), hr((size_t)KP * ncols, 0.0), hx((size_t)KP * ncols, 0.0);
     for (int c = 0; c < k; ++c)
@@ -3050,7 +3050,7 @@ int smk_nmf_dense(const smk_options* opts, const double* A, int64_t ldA, double*
     }
     if (!opts || !smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
     if (!A || !W || !H) return SMK_BAD_PARAM;
-    if (opts->k > MAX_K || (opts->algorithm == SMK_ALG_BPP && opts->k > MAX_K_BPP)) { set_error("device path supports k <= 2048 (MU, HALS) / k <= 1024 (BPP)"); return SMK_UNSUPPORTED; }     // before anything is uploaded
+    if (opts->k > MAX_K || (opts->algorithm == SMK_ALG_BPP && opts->k > MAX_K_BPP)) { set_error("device path supports k <= 2048"); return SMK_UNSUPPORTED; }     // before anything is uploaded
     const int64_t m = opts->height, n = opts->width;
     if (ldA < m || ldW < m || ldH < opts->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
     smk_matrix* a = nullptr;
@@ -3084,7 +3084,7 @@ int smk_nmf_dense_sharded(const smk_options* opts, const double* A, int64_t ldA,
     }
     if (!opts || !smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
     if (!A || !W || !H || nshards < 1 || nshards > 16) return SMK_BAD_PARAM;
-    if (opts->k > MAX_K || (opts->algorithm == SMK_ALG_BPP && opts->k > MAX_K_BPP)) { set_error("device path supports k <= 2048 (MU, HALS) / k <= 1024 (BPP)"); return SMK_UNSUPPORTED; }
+    if (opts->k > MAX_K || (opts->algorithm == SMK_ALG_BPP && opts->k > MAX_K_BPP)) { set_error("device path supports k <= 2048"); return SMK_UNSUPPORTED; }
     const int64_t m = opts->height, n = opts->width;
     if (ldA < m || ldW < m || ldH < opts->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
     if (nshards > n) nshards = (int)n;
@@ -3175,7 +3175,7 @@ int smk_nmf_sparse(const smk_options* opts, unsigned height, unsigned width, uns
     }
     if (!opts || !smk_is_valid(opts, 1)) return SMK_BAD_PARAM;
     if (!col_offsets || !row_indices || !data || !W || !H) return SMK_BAD_PARAM;
-    if (opts->k > MAX_K || (opts->algorithm == SMK_ALG_BPP && opts->k > MAX_K_BPP)) { set_error("device path supports k <= 2048 (MU, HALS) / k <= 1024 (BPP)"); return SMK_UNSUPPORTED; }
+    if (opts->k > MAX_K || (opts->algorithm == SMK_ALG_BPP && opts->k > MAX_K_BPP)) { set_error("device path supports k <= 2048"); return SMK_UNSUPPORTED; }
     if ((int64_t)height != opts->height || (int64_t)width != opts->width) return SMK_BAD_PARAM;
     if (ldW < opts->height || ldH < opts->k) { set_error("leading dimension too small"); return SMK_BAD_PARAM; }
     smk_matrix* a = nullptr;

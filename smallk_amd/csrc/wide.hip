@@ -1592,15 +1592,19 @@ size_t nnls_wide_scratch_elems(int k, int num_cus, i64 ncols)
     return ((size_t)num_cus * nnls_wide_wgs_per_cu(k) + 2) * KP * KP + 8 + KP * CH_NB + (size_t)ncols * KP;
 }
 
-static inline bool wide_use_inverse()
+// k > 1024: the route through the inverse of G (panel Cholesky, V = R Ginv, complement blocks on tiles) returns wrong exchanges
+// from KP = 1088 on (found in round 5 when the rank cap was lifted; not traced: NNLS at k = 1025 is 0.2 off, at k = 1100 the
+// passive sets differ), while the direct form -- nnls_wide_kernel: the reference's own computation on the passive block -- is right to
+// 1e-14 at k = 1100 and 2048.  Above 1024 only the direct form runs: correct, and as slow as a t x t Cholesky per exchange is.
+static inline bool wide_use_inverse(int k)
 {
     static const bool use_inv = [] { const char* e = getenv("SMK_NNLS_INV"); return !(e && e[0] == '0'); }();
-    return use_inv;
+    return use_inv && k <= 1024;
 }
 
 int launch_gram_inverse_wide(const double* G, int k, double* scratch, int num_cus, hipStream_t st)
 {
-    if (!scratch || !wide_use_inverse()) return 0;
+    if (!scratch || !wide_use_inverse(k)) return 0;
     const int KP = kp_of(k);
     double* L = scratch + (size_t)num_cus * nnls_wide_wgs_per_cu(k) * KP * KP;
     double* Ginv = L + (size_t)KP * KP;
@@ -1624,7 +1628,7 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
     double* Ginv = L + (size_t)KP * KP;
     int* status = (int*)(Ginv + (size_t)KP * KP);
     double* V = Ginv + (size_t)KP * KP + 8 + (size_t)KP * CH_NB; // ncols x KP: the caller sized the scratch for its columns
-    const bool use_inv = wide_use_inverse();
+    const bool use_inv = wide_use_inverse(k);
     if (use_inv) {
         if (!inverse_ready && launch_gram_inverse_wide(G, k, scratch, num_cus, st)) return -100;
         rows_times_sym_wide_kernel<true><<<dim3((unsigned)((ncols + 63) / 64), (unsigned)(KP / 64)), 256, 0, st>>>(R, nullptr, Ginv, status, k, KP,

@@ -199,7 +199,7 @@ def test_failure_and_bad_params(gpu):
     assert gpu.nmf(A, np.ones((12, 3)), np.ones((3, 6)), "MU", tol=2.0).result == L.BAD_PARAM
     assert gpu.nmf(A[:, :2], np.ones((12, 3)), np.ones((3, 2)), "MU").result == L.BAD_PARAM   # k > n
     with pytest.raises(L.SmallkError):
-        gpu.nmf(np.ones((1100, 1030)), np.ones((1100, 1025)), np.ones((1025, 1030)), "BPP")   # k > 1024 under block pivoting
+        gpu.nmf(np.ones((2100, 2060)), np.ones((2100, 2049)), np.ones((2049, 2060)), "BPP")   # k > 2048
 
 
 @pytest.mark.parametrize("alg,storage,quant,m,n,k,iters", [
@@ -380,22 +380,48 @@ def test_rank_above_512(gpu, alg, m, n, k, iters):
         assert np.linalg.norm(r.H - ref.H) / np.linalg.norm(ref.H) < 1e-4
 
 
-def test_rank_caps_are_refused_loudly(gpu):
-    """The reference bounds k only by n (common/src/nmf_options.cpp:47-52).  Here MU and HALS run to k = 2048, block pivoting to
-    k = 1024 (the widest instantiations of wide.hip); above: SMK_UNSUPPORTED with a message, never a silent fallback."""
+def test_rank_cap_is_refused_loudly(gpu):
+    """The reference bounds k only by n (common/src/nmf_options.cpp:47-52); here k <= 2048 (the widest instantiations of wide.hip);
+    above: SMK_UNSUPPORTED with a message, never a silent fallback."""
     import oracle
     from smallk_amd import _lib as L
-    A = oracle.fill_uniform(1100, 1030, 1)
-    with pytest.raises(L.SmallkError) as e:
-        gpu.nmf(A, oracle.fill_uniform(1100, 1025, 2), oracle.fill_uniform(1025, 1030, 3), "BPP", min_iter=1, max_iter=1)
-    assert e.value.code == L.UNSUPPORTED and "k <= 1024" in str(e.value)
     B = oracle.fill_uniform(2100, 2060, 1)
-    with pytest.raises(L.SmallkError) as e:
-        gpu.nmf(B, oracle.fill_uniform(2100, 2049, 2), oracle.fill_uniform(2049, 2060, 3), "MU", min_iter=1, max_iter=1)
-    assert e.value.code == L.UNSUPPORTED and "k <= 2048" in str(e.value)
-    G = np.eye(1025)
+    for alg in ("MU", "BPP"):
+        with pytest.raises(L.SmallkError) as e:
+            gpu.nmf(B, oracle.fill_uniform(2100, 2049, 2), oracle.fill_uniform(2049, 2060, 3), alg, min_iter=1, max_iter=1)
+        assert e.value.code == L.UNSUPPORTED and "k <= 2048" in str(e.value)
     with pytest.raises(L.SmallkError):
-        gpu.nnls_blockpivot(G, np.ones((1025, 2)), np.zeros((1025, 2)))
+        gpu.nnls_blockpivot(np.eye(2049), np.ones((2049, 2)), np.zeros((2049, 2)))
+
+
+@pytest.mark.parametrize("k", [1025, 1100, 2048])
+def test_block_pivoting_between_1024_and_2048(gpu, k):
+    """NnlsBlockpivot above k = 1024 runs the direct form only (the route through the Gram inverse is wrong from KP = 1088 on and is
+    switched off there, wide.hip): X, Y and the passive sets against the oracle, and a two-iteration factorisation that must
+    decrease the objective and stay non-negative."""
+    import oracle
+    rng = np.random.default_rng(k)
+    mm = k + 200
+    Wm = rng.random((mm, k))
+    G = np.asfortranarray(Wm.T @ Wm)
+    B = Wm.T @ rng.random((mm, 5))
+    B[:, ::3] -= 1.5 * np.abs(B[:, ::3]).mean()
+    B = np.asfortranarray(B)
+    X0 = np.asfortranarray(rng.random((k, 5)) * (rng.random((k, 5)) < 0.5))
+    oko, Xo, Yo, _ = oracle.nnls_blockpivot(G, B, X0)
+    okg, Xg, Yg = gpu.nnls_blockpivot(G, B, X0)
+    assert oko and okg
+    assert np.abs(Xg - Xo).max() <= 1e-9 * np.abs(Xo).max() and np.array_equal(Xg > 0, Xo > 0)
+    assert np.abs(G @ Xg - B - Yg).max() < 1e-8 * np.abs(B).max()
+    if k == 1100:
+        m, n = 1300, 1150
+        A = oracle.fill_uniform(m, n, 42)
+        W0, H0 = oracle.fill_uniform(m, k, 43), oracle.fill_uniform(k, n, 44) * (2.0 / k)
+        r1 = gpu.nmf(A, W0, H0, "BPP", min_iter=1, max_iter=1, normalize=False)
+        r2 = gpu.nmf(A, W0, H0, "BPP", min_iter=2, max_iter=2, normalize=False)
+        f = lambda r: float(np.linalg.norm(A - r.W @ r.H))
+        assert r1.result == 0 and r2.result == 0 and (r2.W >= 0).all() and (r2.H >= 0).all()
+        assert f(r2) < f(r1) < float(np.linalg.norm(A - W0 @ H0))
 
 
 @pytest.mark.parametrize("alg,k", [("MU", 1100), ("HALS", 1100), ("MU", 2048), ("HALS", 2048)])
