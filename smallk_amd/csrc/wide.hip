@@ -1593,13 +1593,13 @@ size_t nnls_wide_scratch_elems(int k, int num_cus, i64 ncols)
 }
 
 // k > 1024: the route through the inverse of G (panel Cholesky, V = R Ginv, complement blocks on tiles) returns wrong exchanges
-// from KP = 1088 on (found in round 5 when the rank cap was lifted; not traced: NNLS at k = 1025 is 0.2 off, at k = 1100 the
-// passive sets differ), while the direct form -- nnls_wide_kernel: the reference's own computation on the passive block -- is right to
+// from KP = 1088 on (found in round 5 when the rank cap was lifted; not traced further than this: with every variable passive the
+// components e >= 1024 of x = Ginv r come out wrong, e < 1024 right -- SMK_NNLS_INV=2 forces the route there to reproduce it), while the direct form -- nnls_wide_kernel: the reference's own computation on the passive block -- is right to
 // 1e-14 at k = 1100 and 2048.  Above 1024 only the direct form runs: correct, and as slow as a t x t Cholesky per exchange is.
 static inline bool wide_use_inverse(int k)
 {
-    static const bool use_inv = [] { const char* e = getenv("SMK_NNLS_INV"); return !(e && e[0] == '0'); }();
-    return use_inv && k <= 1024;
+    static const int mode = [] { const char* e = getenv("SMK_NNLS_INV"); return e ? atoi(e) : 1; }();      // 2: also above 1024 (to trace the defect)
+    return mode == 2 || (mode != 0 && k <= 1024);
 }
 
 int launch_gram_inverse_wide(const double* G, int k, double* scratch, int num_cus, hipStream_t st)
