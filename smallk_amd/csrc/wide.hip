@@ -1426,19 +1426,22 @@ __global__ __launch_bounds__(256) void nnls_wide_tile_kernel(double* __restrict_
             if (tpx <= tp_lds) bad = tiles_exchange<NW>(Tl, Msrc, KP, idx, t, zs, lane, wave, sc + 4);
             else bad = tiles_exchange<NW>(Tg, Msrc, KP, idx, t, zs, lane, wave, sc + 4);
 #endif
-            // out = base + Msrc[:, T] u  with base = v (complement) or -r (direct); up to four entries per thread
-            {
+            // out = base + Msrc[:, T] u  with base = v (complement) or -r (direct); four entries per thread and trip: one trip up to
+            // kq = 4 GS (a wave per column: k <= 256; the workgroup on a column: k <= 1024), more above (round 5: the single trip left
+            // the entries e >= 1024 of a column untouched -- the defect that capped block pivoting at k = 1024)
+            for (int eo = 0; eo < kq; eo += 4 * GS) {
+                const int gte = gt + eo;                        // this thread's first entry of the trip
                 double acc[4][2] = {};
                 if (!bad) {
                     int a = 0;
-                    if (kq <= 2 * GS) {                         // at most two entries per thread: 16 rows' loads in flight
+                    if (kq <= 2 * GS) {        // (eo == 0 here)                         // at most two entries per thread: 16 rows' loads in flight
                         for (; a + 16 <= t; a += 16) {
                             double g[2][16];
 #pragma unroll
                             for (int u = 0; u < 16; ++u) {
-                                const size_t row = (size_t)idx[a + u] * KP + gt;
+                                const size_t row = (size_t)idx[a + u] * KP + gte;
 #pragma unroll
-                                for (int v = 0; v < 2; ++v) g[v][u] = (gt + GS * v < kq) ? Msrc[row + GS * v] : 0.0;
+                                for (int v = 0; v < 2; ++v) g[v][u] = (gte + GS * v < kq) ? Msrc[row + GS * v] : 0.0;
                             }
 #pragma unroll
                             for (int u = 0; u < 16; ++u) {
@@ -1452,9 +1455,9 @@ __global__ __launch_bounds__(256) void nnls_wide_tile_kernel(double* __restrict_
                         double g[4][8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            const size_t row = (size_t)idx[a + u] * KP + gt;
+                            const size_t row = (size_t)idx[a + u] * KP + gte;
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) g[v][u] = (gt + GS * v < kq) ? Msrc[row + GS * v] : 0.0;
+                            for (int v = 0; v < 4; ++v) g[v][u] = (gte + GS * v < kq) ? Msrc[row + GS * v] : 0.0;
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
@@ -1464,16 +1467,16 @@ __global__ __launch_bounds__(256) void nnls_wide_tile_kernel(double* __restrict_
                         }
                     }
                     for (; a < t; ++a) {
-                        const size_t row = (size_t)idx[a] * KP + gt;
+                        const size_t row = (size_t)idx[a] * KP + gte;
                         const double za = zs[a];
 #pragma unroll
                         for (int v = 0; v < 4; ++v)
-                            if (gt + GS * v < kq) acc[v][0] = __builtin_fma(Msrc[row + GS * v], za, acc[v][0]);
+                            if (gte + GS * v < kq) acc[v][0] = __builtin_fma(Msrc[row + GS * v], za, acc[v][0]);
                     }
                 }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const int e = gt + GS * v;
+                    const int e = gte + GS * v;
                     if (e < kq) {
                         const double o = (comp ? vs[e] : -rs[e]) + (acc[v][0] + acc[v][1]);
                         const bool pe = pas[e] != 0;
@@ -1592,14 +1595,12 @@ size_t nnls_wide_scratch_elems(int k, int num_cus, i64 ncols)
     return ((size_t)num_cus * nnls_wide_wgs_per_cu(k) + 2) * KP * KP + 8 + KP * CH_NB + (size_t)ncols * KP;
 }
 
-// k > 1024: the route through the inverse of G (panel Cholesky, V = R Ginv, complement blocks on tiles) returns wrong exchanges
-// from KP = 1088 on (found in round 5 when the rank cap was lifted; not traced further than this: with every variable passive the
-// components e >= 1024 of x = Ginv r come out wrong, e < 1024 right -- SMK_NNLS_INV=2 forces the route there to reproduce it), while the direct form -- nnls_wide_kernel: the reference's own computation on the passive block -- is right to
-// 1e-14 at k = 1100 and 2048.  Above 1024 only the direct form runs: correct, and as slow as a t x t Cholesky per exchange is.
+// SMK_NNLS_INV=0: the direct form only (nnls_wide_kernel: the reference's own computation on the passive block)
 static inline bool wide_use_inverse(int k)
 {
-    static const int mode = [] { const char* e = getenv("SMK_NNLS_INV"); return e ? atoi(e) : 1; }();      // 2: also above 1024 (to trace the defect)
-    return mode == 2 || (mode != 0 && k <= 1024);
+    static const int mode = [] { const char* e = getenv("SMK_NNLS_INV"); return e ? atoi(e) : 1; }();
+    (void)k;
+    return mode != 0;
 }
 
 int launch_gram_inverse_wide(const double* G, int k, double* scratch, int num_cus, hipStream_t st)

@@ -396,9 +396,9 @@ def test_rank_cap_is_refused_loudly(gpu):
 
 @pytest.mark.parametrize("k", [1025, 1100, 2048])
 def test_block_pivoting_between_1024_and_2048(gpu, k):
-    """NnlsBlockpivot above k = 1024 runs the direct form only (the route through the Gram inverse is wrong from KP = 1088 on and is
-    switched off there, wide.hip): X, Y and the passive sets against the oracle, and a two-iteration factorisation that must
-    decrease the objective and stay non-negative."""
+    """NnlsBlockpivot above k = 1024 (round 5: the last step of the tile kernel covered only the first 1024 entries of a column):
+    X, Y and the passive sets against the oracle, and a two-iteration factorisation that must decrease the objective and stay
+    non-negative."""
     import oracle
     rng = np.random.default_rng(k)
     mm = k + 200
