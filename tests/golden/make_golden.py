@@ -210,3 +210,12 @@ def main():
 
 if __name__ == "__main__":
     sys.exit(main())
+
+
+def make_planted_fixture(path):
+    """tests/golden/planted_generator.npz: a 48 x 40 block of the planted-data generator (orc_fill_planted, seed 2024, rank 19,
+    threshold 0.7, noise 0.05) in fp32 and bf16 storage -- pins the generator's bits (tests/test_round5_cpu.py).  Needs the
+    oracle library: python -c "import sys; sys.path.insert(0, 'tests/golden'); import make_golden as m; m.make_planted_fixture('tests/golden/planted_generator.npz')" """
+    import oracle
+    np.savez_compressed(path, f32=oracle.fill_planted(48, 40, 2024, 19), bf16=oracle.fill_planted(48, 40, 2024, 19, quant=1),
+                        params=np.array([48, 40, 2024, 19]))

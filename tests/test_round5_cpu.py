@@ -61,3 +61,12 @@ def test_bench_knows_the_sparse_workloads_without_touching_a_gpu():
     import bench_sparse
     A = bench_sparse.make_matrix("s_reuters")
     assert A.shape == (12411, 7984) and 4.0e5 < A.nnz < 6.0e5
+
+
+def test_planted_generator_bits_are_pinned():
+    """the committed block (tests/golden/planted_generator.npz, make_golden.make_planted_fixture): a change of the generator's
+    formula or order of operations would silently change every planted-data measurement"""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "planted_generator.npz"))
+    m, n, seed, ks = (int(v) for v in fx["params"])
+    assert np.array_equal(oracle.fill_planted(m, n, seed, ks), fx["f32"])
+    assert np.array_equal(oracle.fill_planted(m, n, seed, ks, quant=1), fx["bf16"])
