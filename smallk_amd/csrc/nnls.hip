@@ -854,6 +854,16 @@ bool nnls_uses_tiles(int k)
 
 size_t nnls_scratch_elems(int k) { return (size_t)kp_of(k) * kp_of(k) + 8; }     // k <= 128; above: nnls_wide_scratch_elems
 // k in (16, 32] also solves through the inverse of the Gram matrix (round 4; SMK_NNLS_INV32=0: the masked elimination, as before)
+// Workgroups of the inverse-based kernels = resident workgroups x rounds.  Every workgroup first copies G and Ginv into LDS (16 /
+// 64 KB) and a wave prefetches its next column, so few columns per wave waste both: one round up to 65536 columns (s_reuters 159 ->
+// 154 us per iteration, 32768 x 8192 at k = 32 466 -> 453), four above, where more workgroups in flight hide more latency (10^6
+// columns: 3.39 against 3.56 ms per iteration; C4 whole: no difference).  SMK_NNLS_ROUNDS overrides.
+static inline int nnls_rounds(i64 ncols)
+{
+    static const int forced = [] { const char* e = getenv("SMK_NNLS_ROUNDS"); return e ? atoi(e) : 0; }();
+    return forced > 0 ? forced : (ncols <= 65536 ? 1 : 4);
+}
+
 bool nnls_inverse_at_32()
 {
     static const bool on = [] { const char* e = getenv("SMK_NNLS_INV32"); return !(e && e[0] == '0'); }();
@@ -917,7 +927,7 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
         constexpr int NT = 512;
         const int lds = (2 * 32 * 32 + (NT / 64) * 128) * (int)sizeof(double);
         i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
-        const i64 cap = (i64)num_cus * 2 * 4;
+        const i64 cap = (i64)num_cus * 2 * nnls_rounds(ncols);
         if (g2 > cap) g2 = cap;
         nnls_bpp_inv_kernel<32, 512, 4><<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin);
         SMK_HIP(hipGetLastError());
@@ -931,7 +941,7 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
             const int lds = (2 * 64 * 64 + (NT / 64) * 128) * (int)sizeof(double);
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
-            const i64 cap = (i64)num_cus * wg_per_cu * 4;      // resident workgroups x a few rounds for balance
+            const i64 cap = (i64)num_cus * wg_per_cu * nnls_rounds(ncols);
             if (g2 > cap) g2 = cap;
             kern<<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin);
             SMK_HIP(hipGetLastError());
