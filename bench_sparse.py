@@ -7,10 +7,14 @@ in 1.560 s = 56 it/s; hardware not stated, 8 threads).  That file (smallk_data/r
 entries = 0.48 % dense, Zipf term frequencies), so the numbers stand beside the reference's, not against them.  `s_1m` is
 C5's matrix (10^6-node community graph, 16 M entries) under BPP at k = 32.
 
-A step = one NMF iteration: the two gather products (spmm_seg.hip) + Gram matrices + the factor updates.
-roofline: the gather product, algorithmic bytes per launch = nnz (12 + 8 KP) [value + row index + one gathered factor row per
-stored entry] + ncols 8 KP [the result], against the 8 TB/s HBM peak (on the Reuters shape the factor sits in L2, so the
-fraction can exceed what HBM could deliver: the bound is stated, not re-chosen)."""
+A step = one NMF iteration: the two gather products (spmm_seg.hip / spmm_gather) + Gram matrices + the factor updates.
+roofline (round 6): the gather product is bound by the rate at which 8 KP-byte factor rows can be GATHERED, not by HBM -- the factor
+(256 MB at 10^6 x 32) is served by L2 / the Infinity Cache.  `bound: "gather"`, algorithmic bytes per launch = nnz (12 + 8 KP)
+[value + row index + one gathered factor row per stored entry] + ncols 8 KP [the result]; `peak` = the rate a pure row-gather
+kernel reaches on this chip for rows of that size from a table of the factor's size (tools/mb/mb_gather.hip gatherrow<RB>,
+profiles/r06_row_gather_ceiling.txt), plus the stream of values and indices at the same time.  Beside it `hbm_min_bytes` =
+nnz 12 + (rows + cols) 8 KP (every array touched once) with its own fraction of the 8 TB/s HBM peak, the share of the step the
+block-pivoting launches take, and the counter-based `traffic` (profiles/hbm_traffic.json, key s_1m_n1)."""
 import json
 import os
 import sys
@@ -28,6 +32,28 @@ SPARSE_WORKLOADS = {
              "sparse 10^6 x 10^6 community graph (C5's matrix), 16 M entries, k=32 BPP"),
 }
 HBM_PEAK_GBS = 8000.0
+# measured ceiling of a pure row gather (tools/mb/mb_gather.hip, profiles/r06_row_gather_ceiling.txt): TB/s of gathered bytes for
+# rows of 8 KP bytes -- {row bytes: (table in L2, table of 256 MB = Infinity Cache, table of 1 GB = HBM)}; filled from the profile
+# file when it is present (bench lines say which figure they used)
+GATHER_CEILING_FILE = os.path.join(ROOT, "profiles", "r06_row_gather_ceiling.json")
+
+
+def gather_peak(row_bytes, table_bytes):
+    """GB/s of gathered bytes a pure row-gather reaches for rows of `row_bytes` from a table of `table_bytes` (measured; None
+    when the profile has not been taken)"""
+    try:
+        j = json.load(open(GATHER_CEILING_FILE))
+    except Exception:
+        return None, None
+    rows = j.get(str(int(row_bytes)))
+    if not rows:
+        return None, None
+    # rows: list of [table MB, GB/s]; take the smallest table that holds ours
+    rows = sorted(rows)
+    for mb, gbs in rows:
+        if table_bytes <= mb * (1 << 20):
+            return gbs, f"gatherrow{int(row_bytes)} from a {mb} MB table"
+    return rows[-1][1], f"gatherrow{int(row_bytes)} from a {rows[-1][0]} MB table"
 
 
 def make_matrix(name):
@@ -110,11 +136,23 @@ def run_sparse(args):
     elapsed = sorted(windows)[len(windows) // 2]
     ms0, c0 = solver.kernel_time(0)
     ms1, c1 = solver.kernel_time(1)
+    msn, cn = solver.kernel_time(5) if alg == "BPP" else (0.0, 0)        # the block-pivoting launches (both sides)
     KP = 8 if k <= 8 else 16 if k <= 16 else 32 if k <= 32 else 64 if k <= 64 else 128
     bytes0 = A.nnz * (12.0 + 8.0 * KP) + n * 8.0 * KP
     bytes1 = A.nnz * (12.0 + 8.0 * KP) + m * 8.0 * KP
     avg_ms = (ms0 + ms1) / max(c0 + c1, 1)
     achieved = 0.5 * (bytes0 + bytes1) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    kernels = sorted({solver.kernel_name(0), solver.kernel_name(1)})
+    hbm_min = A.nnz * 12.0 + (m + n) * 8.0 * KP                 # every array touched once per launch (average of the two passes)
+    peak_g, peak_src = gather_peak(8 * KP, max(m, n) * 8 * KP)
+    # the stream of values + indices rides along at 12 B per gathered row: scale the pure-gather ceiling to algorithmic bytes
+    peak = peak_g * (12.0 + 8.0 * KP) / (8.0 * KP) if peak_g else None
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        traffic = tj.get(f"{name}_n1", {}).get("bytes_per_launch")
+    except Exception:
+        pass
     out = {
         "metric": "NMF iterations/sec", "value": args.steps / elapsed, "unit": "iterations/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -124,12 +162,18 @@ def run_sparse(args):
                    "generator": f"smallk_amd/synthetic.py:{gen}", "generate_s": round(t_gen, 2),
                    "longest_column": int(np.diff(A.indptr).max()), "longest_row": int(np.diff(A.tocsr().indptr).max())},
         "windows": len(windows), "windows_ms": [round(w * 1e3, 4) for w in windows], "timed_region_s": sum(windows),
-        "roofline": {"bound": "hbm", "kernel": "smk::spmm_seg_kernel",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "avg_launch_ms": avg_ms, "launches": c0 + c1,
+        "roofline": {"bound": "gather", "kernel": " + ".join(kernels),
+                     "achieved": achieved, "peak": peak if peak else HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / (peak if peak else HBM_PEAK_GBS),
+                     "peak_source": (f"measured pure row gather ({peak_src}), scaled by (12 + row) / row for the value + index stream"
+                                     if peak else "no gather ceiling on file: HBM peak"),
+                     "traffic": traffic, "avg_launch_ms": avg_ms, "launches": c0 + c1,
                      "pass_WtA_ms": ms0 / max(c0, 1), "pass_HAt_ms": ms1 / max(c1, 1),
                      "algorithmic_bytes_per_launch": 0.5 * (bytes0 + bytes1),
-                     "products_share_of_step": (ms0 + ms1) / max(len(windows) * args.steps, 1) / (elapsed / args.steps * 1e3)},
+                     "hbm_min_bytes": hbm_min, "hbm_min_frac": hbm_min / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
+                     "products_share_of_step": (ms0 + ms1) / max(len(windows) * args.steps, 1) / (elapsed / args.steps * 1e3),
+                     "nnls_share_of_step": msn / max(len(windows) * args.steps, 1) / (elapsed / args.steps * 1e3),
+                     "nnls_avg_launch_ms": msn / max(cn, 1)},
         "reference_published": {"s_reuters": "BPP k=32: 39 iterations in 4.354 s = 9.0 it/s (pages_smallkAPI.rst:58-92; its own "
                                              "reuters.mtx, hardware not stated)",
                                 "s_reuters_hals": "HALS k=16: 88 iterations in 1.560 s = 56 it/s (pages_smallkAPI.rst:110-143)",

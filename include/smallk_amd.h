@@ -213,8 +213,18 @@ int smk_solver_enable_timing(smk_solver* s, int on);
  * collective stream (the sums of (AH')' and, BPP, the all-gathers of the packed W); 3 = the time the MAIN stream stood waiting
  * for events of the collective stream (each wait bracketed by two events on the main stream: the measured, not inferred, exposed
  * part of the exchange); 4 = the same bracket around a wait for an event that completed long ago (what a bracket costs by itself,
- * ~15 us: subtract brackets x its average from slot 3).  Total ms and count since enable. */
+ * ~15 us: subtract brackets x its average from slot 3); 5 = the block-pivoting (NNLS) launches of BPP, sampled with the passes.
+ * Total ms and count since enable. */
 int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* launches);
+/* name of the kernel pass `which` (0 = W'A, 1 = H*At) launches for this solver -- the streaming product and its variant, or which of the
+ * sparse gather products the plan chose (spmm_seg_kernel on ragged columns, spmm_gather_kernel on fixed-degree graphs, ...): what
+ * bench.py attributes `roofline.achieved` to */
+int smk_solver_kernel_name(const smk_solver* s, int which, char* out, int cap);
+/* diagnostics of the block-pivoting kernels (csrc/nnls.hip), live only in a process started with SMK_NNLS_STATS=1 (else
+ * SMK_UNSUPPORTED): 256 counters -- [0..15] exchanges per column (nnls.hpp:192-241 trips), [16..80] size of a column's first
+ * compact solve, [96..160] of its later ones, [176] / [177] solves in the complement / direct form, [178] columns, [179] / [180]
+ * solves with all / no variables passive.  Synchronises the device.  reset != 0 clears the counters after the read. */
+int smk_debug_nnls_stats(unsigned long long* out256, int reset);
 /* algorithmic bytes / flops one launch of pass `which` moves (len*ncols*sizeof(elt), 2*k*len*ncols) */
 int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double* flops);
 

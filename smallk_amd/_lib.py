@@ -115,6 +115,8 @@ SYMBOLS = {
     "smk_solver_enable_timing": (C.c_int, [_vp, C.c_int]),
     "smk_solver_kernel_time": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int)]),
     "smk_solver_kernel_work": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "smk_debug_nnls_stats": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
+    "smk_solver_kernel_name": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int]),
     "smk_solver_comm_workspace_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     "smk_comm_unique_id": (C.c_int, [_vp]),
     "smk_comm_init_rank": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),

@@ -1804,8 +1804,10 @@ int plan_bigprod_groups_tr(int storage, int k, i64 len, i64 ncols, int nsplit, i
     size_t off = 0;
     const int pstride = kpp_of(k);
     const bool f32 = storage == STORE_F32;
-    if (f32) { if (nsplit != NSPLIT_F16X2 && nsplit != 3) nsplit = 3; }       // fp32 A: the fp16 two-term form or bf16x3
-    else if (nsplit < 1 || nsplit > 3) nsplit = 3;
+    // forms the transposed-source kernels exist for (fp32 A: the fp16 two-term form or bf16x3; bf16 A: 1 .. 3 bf16 terms).  Anything
+    // else -- the accurate form above all -- must not be re-labelled here: the caller would then hand an fp64 factor to a kernel
+    // that reads packed 16-bit fragments (plan_products materialises the stored transpose instead)
+    if (f32 ? (nsplit != NSPLIT_F16X2 && nsplit != 3) : (nsplit < 1 || nsplit > 3)) return -1;
     for (int k0 = 0; k0 < k; k0 += 64, ++ng) {
         const int kg = k - k0 < 64 ? k - k0 : 64;
         BigProdPlan pl;

@@ -28,7 +28,8 @@ inline i64 round_up(i64 x, i64 m) { return (x + m - 1) / m * m; }
 // padded rank: the narrow kernels are built for 8 / 16 / 32 / 64 / 128; above that ("wide", wide.hip) a multiple of 64
 inline int kp_of(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : k <= 128 ? 128 : (k + 63) / 64 * 64; }
 constexpr int MAX_K = 2048;                    // larger ranks: SMK_UNSUPPORTED (the widest instantiation of wide.hip: 32 values per lane)
-constexpr int MAX_K_BPP = MAX_K;               // block pivoting: above k = 1024 through the direct form only (wide.hip: wide_use_inverse)
+constexpr int MAX_K_BPP = MAX_K;               // block pivoting: the Gram-inverse route at every rank (SMK_NNLS_INV=0: the direct form only); scratch at
+                                               // KP = 2048: (num_cus x workgroups per CU + 2) x KP^2 doubles = about 8.6 GB per solver (nnls_wide_scratch_elems)
 constexpr int MAX_GROUPS = MAX_K / 64;         // the streaming product takes 64 factor rows per pass over A
 inline bool is_wide(int k) { return k > 128; }
 // block pivoting takes the tile kernels of wide.hip (and their scratch layout) from this rank on: everything above 128, and
@@ -269,10 +270,20 @@ struct NnlsPack {
 constexpr int NNLS_PACK_OVERFLOW = -4;
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
                     int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st,
-                    double* gram_partials = nullptr, int* gram_nblk = nullptr, const NnlsPack* pack = nullptr);
+                    double* gram_partials = nullptr, int* gram_nblk = nullptr, const NnlsPack* pack = nullptr,
+                    unsigned* defer_ws = nullptr);
+// k in (32, 64]: work list of the four-columns-per-wave kernel (nnls_g16.hip), nnls_defer_elems(ncols) unsigneds per launch
+// in flight; without it launch_nnls_bpp keeps the wave-per-column kernel for every column
+inline size_t nnls_defer_elems(i64 ncols) { return (size_t)ncols + 4; }
+int launch_nnls_bpp_g16(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G, const double* Ginv,
+                        const int* status, int* fail_flag, int iter_tag, unsigned* defer, int num_cus, hipStream_t st,
+                        unsigned long long* stats);
+unsigned long long* nnls_stats_ptr();
 // k > 32: the inverse of G into scratch, ahead of launch_nnls_bpp(..., inverse_ready = 1, ...) (any stream)
 int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st);
 size_t nnls_scratch_elems(int k);
+// diagnostics: the 256 counters of nnls.hip (SMK_NNLS_STATS=1), -1 when the counters are off
+int nnls_stats_read(unsigned long long* out256, int reset);
 bool nnls_inverse_at_32();      // k in (16, 32] solves through the inverse of the Gram matrix too (SMK_NNLS_INV32=0: not)
 // normalisation: scale Wt rows by 1/nu_c, H rows by nu_c where nu_c^2 = G[c][c]
 int launch_scale_rows(double* X, int k, i64 N, const double* G, int invert, int* fail_flag, hipStream_t st);
@@ -356,8 +367,10 @@ struct SegPlan {
 int spmm_seg_len();
 int build_seg_plan(i64 ncols, i64 nnz, const i64* colptr, const unsigned* rowidx, SegPlan* out, hipStream_t st);
 void free_seg_plan(SegPlan* s);
+// `pieces`: the caller's own npieces x 128 doubles for the partial sums of long columns (a solver owns one per pass, so that two
+// solvers on one matrix and different streams do not share it); nullptr: the plan's buffer (one stream at a time)
 int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, const double* X, int k, double* P, int kpp,
-                    hipStream_t st);
+                    hipStream_t st, double* pieces = nullptr);
 
 // spmm_blocked.hip: the rank-2 gather product with the gathered factor cut into row blocks that stay in one XCD's L2.
 // A matrix regrouped by row block: block b is a CSC of its own (cp[b * (ncols + 1) + j] .. are absolute positions in ri / va)

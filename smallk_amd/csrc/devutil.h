@@ -190,6 +190,18 @@ __device__ __forceinline__ double rhs_elem(const PartialView& R, i64 j, int i)
     return rhs_finish(R, q);
 }
 
+// 1 / x to full precision: v_rcp_f64 + two Newton steps (the block-pivoting kernels divide by pivots)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+// diagnostics of the block-pivoting kernels (nnls.hip: nnls_stats_ptr)
+__device__ __forceinline__ void nnls_stat(unsigned long long* stats, int slot) { atomicAdd(&stats[slot], 1ull); }
+
 // block-wide sum of one double; result valid in thread 0
 __device__ __forceinline__ double block_sum(double v, double* sh /* >= 4 doubles */)
 {

@@ -5,6 +5,33 @@
 
 namespace smk {
 
+// --------------------------------------------------------------------------
+// Diagnostics (SMK_NNLS_STATS=1; tools/nnls_sets.py, smk_debug_nnls_stats): histograms of the work block pivoting does, kept in
+// 256 device counters -- [0..15] exchanges per column (15 = 15 or more), [16..80] size t of the FIRST compact solve of a column
+// (16 + t), [96..160] size of every later solve, [176] solves in the complement form, [177] in the direct form, [178] columns,
+// [179] solves with every variable passive, [180] with none.  nullptr (the default) costs one uniform branch per column.
+// --------------------------------------------------------------------------
+unsigned long long* nnls_stats_ptr()
+{
+    static unsigned long long* buf = [] {
+        const char* e = getenv("SMK_NNLS_STATS");
+        unsigned long long* p = nullptr;
+        if (e && atoi(e) != 0 && hipMalloc((void**)&p, 256 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(p, 0, 256 * sizeof(unsigned long long));
+        else p = nullptr;
+        return p;
+    }();
+    return buf;
+}
+int nnls_stats_read(unsigned long long* out256, int reset)
+{
+    unsigned long long* p = nnls_stats_ptr();
+    if (!p) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (out256 && hipMemcpy(out256, p, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    if (reset) (void)hipMemset(p, 0, 256 * sizeof(unsigned long long));
+    return 0;
+}
+
 // ==========================================================================
 // NNLS by block principal pivoting, one column per GS-lane group (GS = KP).
 // Lane i of a group owns component i of the column: x_i, y_i, rhs_i, its
@@ -68,7 +95,8 @@ template <int KP>
 __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N,
                                                        PartialView R, const double* __restrict__ G,
                                                        int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
-                                                       const int* __restrict__ skip_if, double* __restrict__ Gp, NnlsPack pk)
+                                                       const int* __restrict__ skip_if, double* __restrict__ Gp, NnlsPack pk,
+                                                       unsigned long long* __restrict__ stats)
 {
     constexpr int GS = KP;
     constexpr int GPB = 256 / GS;                   // column groups per block
@@ -168,6 +196,7 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
     };
 
     unsigned long long F = group_ballot<GS>(passive, lane) & kmask;
+    if (stats && i == 0 && col_ok) { nnls_stat(stats, 16 + __popcll(F)); nnls_stat(stats, 178); }
     solve(F);
     residual();
 
@@ -212,6 +241,7 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
             if (ng == 0) active = false;
         }
     }
+    if (stats && i == 0 && col_ok) nnls_stat(stats, iter < 15 ? iter : 15);
 
     // The reference zeroizes the WHOLE X and Y after every pivoting round (nnls.hpp:224-225), i.e. also the columns that never
     // pivot -- as soon as ANY column of the solve does, which a workgroup cannot know.  Some column pivots in practically every
@@ -313,15 +343,6 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
 // The inverse is taken only when every Gauss-Jordan pivot of G is positive and not tiny (gram_inverse_kernel
 // sets status = 1); otherwise nnls_bpp_kernel<64> above runs and reproduces the reference's non-SPD failure.
 // --------------------------------------------------------------------------
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
-
 // Ginv = G^-1 (k x k live, 64 x 64 storage, pads zero) by in-place Gauss-Jordan, one workgroup of 256 threads:
 // thread (r, cq) keeps the 16 entries a[r][16 cq .. 16 cq + 15] in registers; per pivot only the pivot row and
 // column travel through LDS (double buffered: one barrier per step).  (KP = 64 runs gram_inverse64_kernel below: in this
@@ -500,11 +521,17 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
                                                           PartialView R, const double* __restrict__ G,
                                                           const double* __restrict__ Ginv,
                                                           const int* __restrict__ status,
-                                                          int* __restrict__ fail_flag, int iter_tag, i64 col_begin)
+                                                          int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
+                                                          unsigned long long* __restrict__ stats,
+                                                          const unsigned* __restrict__ worklist)
 {
     static_assert(KP == 64 || KP == 32, "one wave per column, one lane per component");
     constexpr int NW = NT / 64;
     if (*status == 0) return;
+    // worklist != nullptr: only the columns nnls_bpp_g16_kernel handed over (worklist[0] of them, col_begin + worklist[1 + i]);
+    // usually few or none, so the count is read before the matrices are copied
+    const i64 nwork = worklist ? (i64)worklist[0] : 0;
+    if (worklist && (i64)blockIdx.x * NW >= nwork) return;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* gs = lds;                               // gs[c*KP + i]  = G[i][c]
     double* gis = lds + KP * KP;                    // gis[c*KP + i] = Ginv[i][c]
@@ -528,20 +555,28 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
     // (1 M columns at k = 32, 256 columns per wave: 1.19 ms per launch, 4.6 us per column and wave, of which the arithmetic
     // is a tenth; profiles/r05_s_1m_kernel_stats.md).  The right-hand side and the start of the NEXT column are requested
     // before the current one is touched.
+    // positions idx walk the columns [col_begin, N) or the work list
     const i64 col_stride = (i64)gridDim.x * NW;
-    i64 col = col_begin + (i64)blockIdx.x * NW + wave;
+    const i64 nidx = worklist ? nwork : (N - col_begin);
+    auto col_of = [&](i64 idx) -> i64 { return col_begin + (worklist ? (i64)worklist[1 + idx] : idx); };
+    i64 idx = (i64)blockIdx.x * NW + wave;
     RhsPending rq;
     rq.t[0] = rq.t[1] = rq.t[2] = rq.t[3] = rq.tail = 0.0;
     double x_next = 0.0;
-    if (col < N && comp_ok) {
-        rhs_issue(R, col, lane, rq);
-        x_next = X[col * KP + lane];
+    i64 col_nx = idx < nidx ? col_of(idx) : 0;
+    if (idx < nidx && comp_ok) {
+        rhs_issue(R, col_nx, lane, rq);
+        x_next = X[col_nx * KP + lane];
     }
-    for (; col < N; col += col_stride) {
+    for (; idx < nidx; idx += col_stride) {
+        const i64 col = col_nx;
         double rhs = comp_ok ? rhs_finish(R, rq) : 0.0, x = x_next, y = 0.0;
-        if (col + col_stride < N && comp_ok) {
-            rhs_issue(R, col + col_stride, lane, rq);
-            x_next = X[(col + col_stride) * KP + lane];
+        if (idx + col_stride < nidx) {
+            col_nx = col_of(idx + col_stride);
+            if (comp_ok) {
+                rhs_issue(R, col_nx, lane, rq);
+                x_next = X[col_nx * KP + lane];
+            }
         }
         unsigned long long F = __ballot(comp_ok && x > 0.0) & kmask;       // passive_set = (X > 0), nnls.hpp:157
 
@@ -566,6 +601,7 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
         };
 
         int failed = 0;
+        int nsolve = 0;                                                     // diagnostics only
         // compact solve of M[T,T] u = s_T on the first TB lanes (rows >= t are identity rows), then
         // out = base + M[:,T] u.  TB is a compile-time bound: no branch inside the elimination.
         auto compact = [&](auto tb_tag, const double* M, int t, int tl, double sc, double base, double& u_out) -> double {
@@ -605,6 +641,12 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
             const unsigned long long Zs = ~Fs & kmask;
             const int p = __popcll(Fs), q = __popcll(Zs);
             const bool inF = (Fs >> lane) & 1ull;
+            if (stats && lane == 0) {
+                const int tt = q <= p ? q : p;
+                nnls_stat(stats, (nsolve == 0 ? 16 : 96) + tt);
+                nnls_stat(stats, q == 0 ? 179 : p == 0 ? 180 : q <= p ? 176 : 177);
+            }
+            ++nsolve;
             if (q == 0) { need_v(); x = v; y = 0.0; return; }
             if (p == 0) { x = 0.0; y = comp_ok ? -rhs : 0.0; return; }
             const bool comp = q <= p;                                       // complement form on Ginv
@@ -671,6 +713,7 @@ __global__ __launch_bounds__(NT, WPS) void nnls_bpp_inv_kernel(double* __restric
             X[col * KP + lane] = x;
             if (Y) Y[col * KP + lane] = y;
         }
+        if (stats && lane == 0) { nnls_stat(stats, iter < 15 ? iter : 15); nnls_stat(stats, 178); }
         failed_any |= failed;
     }
     if (failed_any && lane == 0) atomicMin(fail_flag, iter_tag);
@@ -891,7 +934,7 @@ int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st)
 // inverse_ready != 0: launch_gram_inverse(G, ...) has already been ordered before this call.
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
                     int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st,
-                    double* gram_partials, int* gram_nblk, const NnlsPack* pack)
+                    double* gram_partials, int* gram_nblk, const NnlsPack* pack, unsigned* defer_ws)
 {
     if (gram_nblk) *gram_nblk = 0;
     if (nnls_uses_tiles(k)) return launch_nnls_bpp_wide(X, Y, k, col_begin, col_end, R, G, fail_flag, iter_tag, scratch, inverse_ready, num_cus, st);
@@ -929,7 +972,10 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
         i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
         const i64 cap = (i64)num_cus * 2 * nnls_rounds(ncols);
         if (g2 > cap) g2 = cap;
-        nnls_bpp_inv_kernel<32, 512, 4><<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin);
+        // round 6: four columns per wave (nnls_g16.hip); SMK_NNLS_G16=0 keeps the wave-per-column kernel
+        const int g16 = launch_nnls_bpp_g16(X, Y, k, col_begin, col_end, R, G, Ginv, status, fail_flag, iter_tag, nullptr, num_cus, st, nnls_stats_ptr());
+        if (g16 < 0) return g16;
+        if (g16 == 0) nnls_bpp_inv_kernel<32, 512, 4><<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin, nnls_stats_ptr(), nullptr);
         SMK_HIP(hipGetLastError());
         skip_if = status;
     }
@@ -937,13 +983,21 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
         double* Ginv = scratch;
         int* status = (int*)(scratch + 64 * 64);
         if (!inverse_ready) { int irc = launch_gram_inverse(G, k, scratch, st); if (irc) return irc; }
+        // round 6: the columns whose exchanges stay at t <= 16 are solved four per wave (nnls_g16.hip); the others arrive here
+        // through the work list
+        const unsigned* worklist = nullptr;
+        if (defer_ws && inv_mode == 1) {
+            const int g16 = launch_nnls_bpp_g16(X, Y, k, col_begin, col_end, R, G, Ginv, status, fail_flag, iter_tag, defer_ws, num_cus, st, nnls_stats_ptr());
+            if (g16 < 0) return g16;
+            if (g16 > 0) worklist = defer_ws;
+        }
         auto run = [&](auto kern, int NT, int wg_per_cu) -> int {
             const int lds = (2 * 64 * 64 + (NT / 64) * 128) * (int)sizeof(double);
             SMK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             i64 g2 = (ncols + NT / 64 - 1) / (NT / 64);
             const i64 cap = (i64)num_cus * wg_per_cu * nnls_rounds(ncols);
             if (g2 > cap) g2 = cap;
-            kern<<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin);
+            kern<<<(unsigned)g2, NT, lds, st>>>(X, Y, k, N, R, G, Ginv, status, fail_flag, iter_tag, col_begin, nnls_stats_ptr(), worklist);
             SMK_HIP(hipGetLastError());
             return 0;
         };
@@ -964,7 +1018,7 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
     if (gram_partials && gram_nblk && KPv == 16 && col_begin == 0 && grid1 == grid && grid <= NNLS_GRAM_MAX) { gp = gram_partials; *gram_nblk = grid; }
     NnlsPack pk;                                           // only together with the Gram partials (one trip per workgroup, all columns)
     if (pack && gp) pk = *pack;
-    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid1, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if, gp, pk)));
+    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid1, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if, gp, pk, skip_if ? nullptr : nnls_stats_ptr())));
     SMK_HIP(hipGetLastError());
     return 0;
 }

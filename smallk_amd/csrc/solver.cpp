@@ -148,6 +148,7 @@ struct smk_solver {
     i64 m = 0, n = 0;
     hipStream_t st = nullptr;
     double *H = nullptr, *Wt = nullptr, *Gw = nullptr, *Gh = nullptr, *gram_scratch = nullptr;
+    double* seg_pieces[2] = {nullptr, nullptr};     // sparse A, spmm_seg.hip: partial sums of the long columns of pass 0 / 1
     double *Wprev = nullptr, *hals_scratch = nullptr, *pg_partials = nullptr, *scal = nullptr, *tmpW = nullptr;
     double* wide_tmp = nullptr;           // k > 128: max(m, n) x KP, the product X G of the MU rule and of the gradients
     double* tmpH = nullptr;               // k x n compact copy of H for the host (get_factors)
@@ -172,6 +173,7 @@ struct smk_solver {
     double guard_last = 0.0;               // cond * delta of the last check
     bool wc_valid = false;
     double* nnls_scratch = nullptr;       // BPP: inverses of W'W and HH' + path selectors (k > 32), two halves
+    unsigned* nnls_defer = nullptr;       // BPP, k in (32, 64]: work list between nnls_bpp_g16_kernel and the wave-per-column kernel
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
     bool inv_pending[2] = {false, false};
@@ -250,9 +252,9 @@ struct smk_solver {
     // for events of the collective stream (the exposed part of the exchange: the bracket holds nothing but the wait)
     // 4: the same bracket around a wait for an event that completed long ago -- what a bracket costs by itself (three packets
     // through the command processor, ~15 us): exposure = slot 3 - brackets x the average of slot 4
-    std::vector<TimedSpan> ev[5];
-    double acc_ms[5] = {0, 0, 0, 0, 0};
-    int launches[5] = {0, 0, 0, 0, 0};
+    std::vector<TimedSpan> ev[6];       // 0 / 1: the passes, 2 - 4: collectives, waits, calibration, 5: the block-pivoting launches
+    double acc_ms[6] = {0, 0, 0, 0, 0, 0};
+    int launches[6] = {0, 0, 0, 0, 0, 0};
     hipEvent_t ev_cal = nullptr;          // recorded once on the collective stream
     unsigned cal_counter = 0;
 };
@@ -418,7 +420,11 @@ int smk_matrix_create(smk_matrix** out, int64_t height, int64_t width_global, in
     a->m = height; a->n_global = width_global; a->c0 = col0; a->n = ncols_local; a->storage = storage;
     a->st = g_stream;
     register_matrix(a);
-    a->ldA = round_up(height, ROW_PAD);      a->colsA = round_up(ncols_local, COL_PAD);
+    // rows of A padded to COL_PAD, not ROW_PAD: a single-copy matrix is also read through the transposed source, whose tiles are
+    // 128 ROWS of A and whose chunked passes (sharded runs, chunk_rows) run to round_up(m, COL_PAD) -- with 128-row padding a
+    // height with 0 < m mod 256 <= 128 let the last tile read 128 rows past the column (the next column's data; past the
+    // allocation in the last column).  The pad rows are zero like every other pad.
+    a->ldA = round_up(height, COL_PAD);      a->colsA = round_up(ncols_local, COL_PAD);
     a->ldAt = round_up(ncols_local, ROW_PAD); a->colsAt = round_up(height, COL_PAD);
     const size_t es = (size_t)elem_size(storage);
     // A column stride that is a multiple of 1 MiB gets ROW_PAD more (zero) rows: with the 128 columns of a workgroup's stage
@@ -725,6 +731,9 @@ int smk_matrix_download_csc(const smk_matrix* a, int transposed, unsigned* col_o
 }
 static int ensure_seg_plans(const smk_matrix* a)
 {
+    // lazily built part of a shared, nominally const matrix: same lock discipline as matrix_materialize_transpose
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     if (a->seg_tried) return 0;
     a->seg_tried = true;
     static const bool seg_on = [] { const char* e = getenv("SMK_SPMM_SEG"); return !(e && e[0] == '0'); }();
@@ -1043,6 +1052,17 @@ static int matrix_measure_norms(const smk_matrix* a, hipStream_t st)
     return 0;
 }
 
+// What the transposed-source kernels cover: MU, HALS and BPP with the 16-bit product forms (the reference's BPP keeps a transpose
+// itself, nmf_solver_bpp.hpp:319 -- its W-side right-hand side H A' is the same product as MU's and HALS's, so it does not have
+// to; RANK2 and the accurate form contract down the contiguous direction of A' on the vector ALUs / fp64 matrix cores).
+static bool single_copy_serves(const smk_solver* s)
+{
+    const int alg = s->o.algorithm;
+    const bool ok_alg = alg == SMK_ALG_MU || alg == SMK_ALG_HALS || alg == SMK_ALG_BPP;
+    const bool ok_form = s->a->storage == SMK_STORE_BF16 ? (s->nsplit >= 1 && s->nsplit <= 3) : (s->nsplit == 3 || s->nsplit == NSPLIT_F16X2);
+    return ok_alg && ok_form;
+}
+
 // Everything that depends on the product form (s->nsplit): the launch plans of both passes and the fp16 row scales ...
 static int plan_products(smk_solver* s)
 {
@@ -1051,9 +1071,20 @@ static int plan_products(smk_solver* s)
         const int rc0 = matrix_measure_scale(a, s->st);
         if (rc0) return rc0;
     }
+    if (a->single && !a->sparse && !single_copy_serves(s)) {
+        // every (re-)plan passes here -- smk_solver_create, the form agreement of attach_comm, guard_resolve, smk_solver_nnls_hals:
+        // a single-copy matrix whose run leaves what the transposed-source kernels cover gets its stored transpose NOW, once
+        // (the matrix is an ordinary one afterwards; solvers already planned on the transposed source keep reading A)
+        const int trc = matrix_materialize_transpose(a);
+        if (trc) return trc;
+    }
     s->ng = plan_bigprod_groups(a->storage, s->k, s->m, s->n, s->nsplit, g_cus, s->pg1);
-    if (a->single) (void)plan_bigprod_groups_tr(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);      // H*A' from A itself
-    else (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
+    if (a->single) {                                                                                        // H*A' from A itself
+        if (plan_bigprod_groups_tr(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2) < 0) {
+            set_error("no transposed-source kernel for this product form");
+            return SMK_UNSUPPORTED;
+        }
+    } else (void)plan_bigprod_groups(a->storage, s->k, s->n, s->m, s->nsplit, g_cus, s->pg2);
     if (s->nsplit == NSPLIT_F64)
         for (int g = 0; g < s->ng; ++g) { s->pg1[g].ldx = s->KP; s->pg2[g].ldx = s->KP; }
     {
@@ -1179,18 +1210,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if (s->nsplit == NSPLIT_F64 && a->sparse) s->nsplit = 3;      // sparse A: gather products in fp64 already
     // the fp16 two-term form applies to fp32 storage; RANK2 keeps its Gram matrices inside its own solve kernel
     if (s->nsplit == NSPLIT_F16X2 && (a->storage != SMK_STORE_F32 || a->sparse || opts->algorithm == SMK_ALG_RANK2)) s->nsplit = 3;
-    if (a->single && !a->sparse) {
-        // what the transposed-source kernels cover: MU, HALS and BPP with the 16-bit product forms (the reference's BPP keeps a
-        // transpose itself, nmf_solver_bpp.hpp:319 -- its W-side right-hand side H A' is the same product as MU's and HALS's, so it
-        // does not have to; RANK2 and the accurate form contract down the contiguous direction of A' on the vector ALUs / fp64
-        // matrix cores).  Anything else gets the stored transpose now, once (the matrix is an ordinary one afterwards).
-        const bool ok_alg = opts->algorithm == SMK_ALG_MU || opts->algorithm == SMK_ALG_HALS || opts->algorithm == SMK_ALG_BPP;
-        const bool ok_form = a->storage == SMK_STORE_BF16 ? (s->nsplit >= 1 && s->nsplit <= 3) : (s->nsplit == 3 || s->nsplit == NSPLIT_F16X2);
-        if (!ok_alg || !ok_form) {
-            const int trc = matrix_materialize_transpose(a);
-            if (trc) { smk_solver_destroy(s); return trc; }
-        }
-    }
+    // (a single-copy matrix outside what the transposed-source kernels cover gets its stored transpose inside plan_products)
     int rc = plan_products(s);
     if (rc) { smk_solver_destroy(s); return rc; }
     if (a->sparse) {   // gather products write one slab, as dense as the factor layout (KP values per column; RANK2: the 2 live ones)
@@ -1258,6 +1278,7 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     if (opts->algorithm == SMK_ALG_BPP) {
         // k <= 128: two (inverse + selector) halves; above: one Cholesky panel per resident workgroup (wide.hip)
         rc |= dev_alloc(&s->nnls_scratch, nnls_uses_tiles(s->k) ? nnls_wide_scratch_elems(s->k, g_cus, std::max(s->m, s->n)) : 2 * nnls_scratch_elems(s->k));
+        if (s->KP == 64 && !nnls_uses_tiles(s->k)) rc |= dev_alloc(&s->nnls_defer, nnls_defer_elems(std::max(s->m, s->n)));
         // (above k = 128 the inverse stays in stream order: beside the product it gained 1-2 % -- measured -- and the two sides
         // share one scratch there)
         if ((s->KP >= 64 || (s->KP == 32 && nnls_inverse_at_32())) && !nnls_uses_tiles(s->k)) {
@@ -1287,7 +1308,7 @@ void smk_solver_destroy(smk_solver* s)
                     s->xscale[0], s->xscale[1], s->oscale[0], s->oscale[1], s->r2_scratch, s->r2_prog, s->Graw, s->Hc, s->Wc, s->wide_tmp};
     for (void* p : ptrs)
         if (p) (void)smk::dev_free(p);
-    for (int w = 0; w < 5; ++w)
+    for (int w = 0; w < 6; ++w)
         for (auto& e : s->ev[w]) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     if (s->ev_cal) (void)hipEventDestroy(s->ev_cal);
     for (int b = 0; b < 2; ++b) {
@@ -1301,6 +1322,8 @@ void smk_solver_destroy(smk_solver* s)
     { void* r2p[] = {s->r2p_hc1, s->r2p_r2c, s->r2p_part, s->r2p_out, s->r2p_sync}; for (void* q : r2p) if (q) (void)smk::dev_free(q); }
     if (s->r2p_pin) (void)hipHostFree(s->r2p_pin);
     for (int b = 0; b < 2; ++b) if (s->pin_r2[b]) (void)hipHostFree(s->pin_r2[b]);
+    for (int b = 0; b < 2; ++b) if (s->seg_pieces[b]) (void)smk::dev_free(s->seg_pieces[b]);
+    if (s->nnls_defer) (void)smk::dev_free(s->nnls_defer);
     if (s->comm_ws) (void)smk::dev_free(s->comm_ws);
     if (s->Wown) (void)smk::dev_free(s->Wown);
     if (s->R2own) (void)smk::dev_free(s->R2own);
@@ -1740,8 +1763,15 @@ static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, Partial
         if (const char* e = getenv("SMK_NNLS_PACK_TEST_ANORM")) pk.anorm *= atof(e);
     }
     s->nnls_packed[fx] = false;
+    // slot 5 of smk_solver_kernel_time: the block-pivoting launches (both kernels of a k > 16 solve), sampled with the pass that fed them
+    hipEvent_t te0 = nullptr, te1 = nullptr;
+    if (s->timing && s->pass_timed[side] && c1 > c0) {
+        if (hipEventCreate(&te0) == hipSuccess && hipEventCreate(&te1) == hipSuccess) (void)hipEventRecord(te0, s->st);
+        else { if (te0) (void)hipEventDestroy(te0); te0 = te1 = nullptr; }
+    }
+    struct Stamp { smk_solver* s; hipEvent_t a, b; ~Stamp() { if (a) { (void)hipEventRecord(b, s->st); s->ev[5].push_back({a, b, 1}); } } } stamp{s, te0, te1};
     const int rc = launch_nnls_bpp(X, nullptr, s->k, c0, c1, R, G, s->fail_flag, s->iter, inv_scratch(s, side), s->inv_done[side] ? 1 : 0, g_cus, s->st,
-                                   want ? s->gram_scratch : nullptr, want ? &s->nnls_gram_nblk[side] : nullptr, pack ? &pk : nullptr);
+                                   want ? s->gram_scratch : nullptr, want ? &s->nnls_gram_nblk[side] : nullptr, pack ? &pk : nullptr, s->nnls_defer);
     if (!rc && (X == s->H || X == s->Wt)) {
         s->from_nnls[fx] = c0 == 0 && c1 == N;
         s->nnls_packed[fx] = pack && s->nnls_gram_nblk[side] > 0;
@@ -1794,7 +1824,15 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
     const BlockedCsc& blk = (which == 0) ? s->a->bA : s->a->bAt;
     const SegPlan& seg = (which == 0) ? s->a->segA : s->a->segAt;
     if (ldx == 2 && blk.nb > 1) rc = launch_spmm_blocked2(blk, X, P, which == 0 ? s->pl1.ncols_pad : s->pl2.ncols_pad, s->st);
-    else if (ldx == s->KP && s->k > 2 && !is_wide(s->k) && seg.ncols == ncols && seg.rowflag && !seg.uniform) rc = launch_spmm_seg(seg, colptr, val, X, s->k, P, s->kpp, s->st);
+    else if (ldx == s->KP && s->k > 2 && !is_wide(s->k) && seg.ncols == ncols && seg.rowflag && !seg.uniform) {
+        // the partial sums of long columns live in the SOLVER (two solvers on one sparse matrix run on their own streams)
+        if (seg.npieces > 0 && !s->seg_pieces[which] && smk::dev_malloc((void**)&s->seg_pieces[which], (size_t)seg.npieces * 128 * sizeof(double)) != hipSuccess) {
+            s->seg_pieces[which] = nullptr;
+            set_error("no memory for the long-column partial sums");
+            return SMK_DEVICE_ERROR;
+        }
+        rc = launch_spmm_seg(seg, colptr, val, X, s->k, P, s->kpp, s->st, s->seg_pieces[which]);
+    }
     else rc = launch_spmm_gather(colptr, rowidx, val, ncols, s->a->nnz, X, ldx, s->k, P, s->kpp, s->st);
     if (timed) {
         if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
@@ -1949,6 +1987,7 @@ static int prod2(smk_solver* s)
         for (int g = 0; g < s->ng; ++g) {
             BigProdPlan pl = s->pg2[g];
             pl.tiles = (r1 - r0 + pl.nb - 1) / pl.nb;
+            if (pl.tr && r0 + pl.tiles * pl.nb > s->a->ldA) { set_error("transposed-source chunk runs past the padded rows of A"); return SMK_FAILURE; }
             // rows [r0, r1) of A: columns of the stored transpose, or -- single copy -- a row offset into A itself
             const unsigned char* Bsrc = pl.tr ? (const unsigned char*)s->a->A + (size_t)r0 * es
                                               : (const unsigned char*)s->a->At + (size_t)r0 * s->a->ldAt * es;
@@ -2167,7 +2206,7 @@ static int solver_iteration(smk_solver* s)
 
 static int resolve_events(smk_solver* s)
 {
-    for (int w = 0; w < 5; ++w) {
+    for (int w = 0; w < 6; ++w) {
         for (auto& e : s->ev[w]) {
             float ms = 0.f;
             SMK_HIP(hipEventElapsedTime(&ms, e.e0, e.e1));
@@ -2930,7 +2969,9 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
     rc |= dev_alloc(&dy, hx.size());
     rc |= dev_alloc(&dscratch, nnls_uses_tiles(k) ? nnls_wide_scratch_elems(k, g_cus, ncols) : nnls_scratch_elems(k));
     rc |= dev_alloc(&dflag, (size_t)1);
-    struct Free { std::vector<void*> p; ~Free() { for (void* q : p) if (q) (void)smk::dev_free(q); } } guard{{dg, dr, dx, dy, dscratch, dflag}};
+    unsigned* ddefer = nullptr;
+    if (KP == 64 && !nnls_uses_tiles(k)) rc |= dev_alloc(&ddefer, nnls_defer_elems(ncols));
+    struct Free { std::vector<void*> p; ~Free() { for (void* q : p) if (q) (void)smk::dev_free(q); } } guard{{dg, dr, dx, dy, dscratch, dflag, ddefer}};
     if (rc) return SMK_DEVICE_ERROR;
     const int big = INT_MAX;
     SMK_HIP(hipMemcpyAsync(dg, hg.data(), hg.size() * sizeof(double), hipMemcpyHostToDevice, g_stream));
@@ -2939,7 +2980,7 @@ int smk_nnls_blockpivot(int k, int64_t ncols, const double* LHS, int64_t ldL, co
     SMK_HIP(hipMemsetAsync(dy, 0, hx.size() * sizeof(double), g_stream));
     SMK_HIP(hipMemcpyAsync(dflag, &big, sizeof(int), hipMemcpyHostToDevice, g_stream));
     const PartialView pv{dr, 1, 0, KP, 1};
-    rc = launch_nnls_bpp(dx, dy, k, 0, ncols, pv, dg, dflag, 0, dscratch, 0, g_cus, g_stream);
+    rc = launch_nnls_bpp(dx, dy, k, 0, ncols, pv, dg, dflag, 0, dscratch, 0, g_cus, g_stream, nullptr, nullptr, nullptr, ddefer);
     if (rc) return rc;
     int flag = INT_MAX;
     SMK_HIP(hipMemcpyAsync(hx.data(), dx, hx.size() * sizeof(double), hipMemcpyDeviceToHost, g_stream));
@@ -3004,13 +3045,13 @@ int smk_solver_enable_timing(smk_solver* s, int on)
     if (const char* e = getenv("SMK_TIMING_STRIDE")) s->timing_stride = std::max(1, atoi(e));
     s->pass_counter[0] = s->pass_counter[1] = 0;
     s->pass_sampled[0] = s->pass_sampled[1] = 0;
-    for (int w = 0; w < 5; ++w) { s->acc_ms[w] = 0.0; s->launches[w] = 0; }
+    for (int w = 0; w < 6; ++w) { s->acc_ms[w] = 0.0; s->launches[w] = 0; }
     return SMK_OK;
 }
 
 int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* launches)
 {
-    if (!s || which < 0 || which > 4) return SMK_BAD_PARAM;      // 2: the (AH')' sum and the W all-gather of a sharded run; 3: main-stream waits for them
+    if (!s || which < 0 || which > 5) return SMK_BAD_PARAM;      // 2: the (AH')' sum and the W all-gather of a sharded run; 3: main-stream waits for them; 5: block pivoting
     if (which == 4) {       // calibration brackets: unscaled (their average is what matters)
         if (total_ms) *total_ms = s->acc_ms[4];
         if (launches) *launches = s->launches[4];
@@ -3024,6 +3065,38 @@ int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* laun
     if (total_ms) *total_ms = s->acc_ms[which] * f;
     if (launches) *launches = (int)llround((double)s->launches[which] * f);
     return SMK_OK;
+}
+
+// the kernel pass `which` launches (what the bench lines and profiles attribute their time to); same decision as timed_spmm /
+// launch_bigprod
+int smk_solver_kernel_name(const smk_solver* s, int which, char* out, int cap)
+{
+    if (!s || which < 0 || which > 1 || !out || cap < 8) return SMK_BAD_PARAM;
+    std::string name;
+    if (s->a->sparse) {
+        const BlockedCsc& blk = (which == 0) ? s->a->bA : s->a->bAt;
+        const SegPlan& seg = (which == 0) ? s->a->segA : s->a->segAt;
+        const i64 ncols = which == 0 ? s->n : s->m;
+        const int ldx = s->Wc ? 2 : s->KP;
+        if (s->r2p_sync && s->o.algorithm == SMK_ALG_RANK2) name = "smk::rank2_persist_kernel";
+        else if (ldx == 2 && blk.nb > 1) name = "smk::spmm_blocked2_kernel";
+        else if (ldx == s->KP && s->k > 2 && !is_wide(s->k) && seg.ncols == ncols && seg.rowflag && !seg.uniform) name = "smk::spmm_seg_kernel";
+        else name = "smk::spmm_gather_kernel";
+    } else {
+        const BigProdPlan& pl = which == 0 ? s->pl1 : s->pl2;
+        name = s->nsplit == NSPLIT_F64 ? (s->k <= 2 ? "smk::bigprod_f64_k2_kernel" : "smk::bigprod_f64_kernel")
+             : s->a->storage == SMK_STORE_F32 ? "smk::bigprod_f3_kernel" : "smk::bigprod_kernel";
+        name += " variant " + std::to_string(pl.variant) + (pl.tr ? " (transposed source)" : "");
+    }
+    snprintf(out, (size_t)cap, "%s", name.c_str());
+    return SMK_OK;
+}
+
+int smk_debug_nnls_stats(unsigned long long* out256, int reset)
+{
+    if (!g_init) return SMK_NOTINITIALIZED;
+    const int rc = nnls_stats_read(out256, reset);
+    return rc == 0 ? SMK_OK : rc == -1 ? SMK_UNSUPPORTED : SMK_DEVICE_ERROR;
 }
 
 int smk_solver_kernel_work(const smk_solver* s, int which, double* bytes, double* flops)

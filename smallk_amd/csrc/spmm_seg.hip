@@ -233,9 +233,10 @@ int build_seg_plan(i64 ncols, i64 nnz, const i64* colptr, const unsigned* rowidx
 }
 
 int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, const double* X, int k, double* P, int kpp,
-                    hipStream_t st)
+                    hipStream_t st, double* pieces)
 {
     const int KPv = kp_of(k);
+    if (!pieces) pieces = sp.pieces;
     if (sp.ncols <= 0) return 0;
     if (sp.has_empty) SMK_HIP(hipMemsetAsync(P, 0, (size_t)sp.ncols * kpp * sizeof(double), st));
     if (sp.nseg == 0) return 0;
@@ -244,14 +245,14 @@ int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, con
     const double* v = val;
     static const int ufix = [] { const char* e = getenv("SMK_SPMM_SEG_U"); return e ? atoi(e) : 0; }();
 #define SMK_SEG(U)                                                                                                                  \
-    KP_DISPATCH128(KPv, (sp.has_empty ? spmm_seg_kernel<KP, U, true><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, sp.pieces) \
-                                      : spmm_seg_kernel<KP, U, false><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, sp.pieces)))
+    KP_DISPATCH128(KPv, (sp.has_empty ? spmm_seg_kernel<KP, U, true><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, pieces) \
+                                      : spmm_seg_kernel<KP, U, false><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, pieces)))
     if (ufix == 4) { SMK_SEG(4); } else if (ufix == 16) { SMK_SEG(16); } else { SMK_SEG(8); }
 #undef SMK_SEG
     SMK_HIP(hipGetLastError());
     if (sp.nlong > 0) {
         const unsigned g2 = (unsigned)((sp.nlong + 3) / 4);
-        KP_DISPATCH128(KPv, (spmm_seg_fixup_kernel<KP><<<g2, 256, 0, st>>>(sp.long_col, sp.long_piece0, sp.nlong, sp.pieces, P, kpp)));
+        KP_DISPATCH128(KPv, (spmm_seg_fixup_kernel<KP><<<g2, 256, 0, st>>>(sp.long_col, sp.long_piece0, sp.nlong, pieces, P, kpp)));
         SMK_HIP(hipGetLastError());
     }
     return 0;

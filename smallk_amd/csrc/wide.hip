@@ -1596,16 +1596,15 @@ size_t nnls_wide_scratch_elems(int k, int num_cus, i64 ncols)
 }
 
 // SMK_NNLS_INV=0: the direct form only (nnls_wide_kernel: the reference's own computation on the passive block)
-static inline bool wide_use_inverse(int k)
+static inline bool wide_use_inverse()
 {
     static const int mode = [] { const char* e = getenv("SMK_NNLS_INV"); return e ? atoi(e) : 1; }();
-    (void)k;
     return mode != 0;
 }
 
 int launch_gram_inverse_wide(const double* G, int k, double* scratch, int num_cus, hipStream_t st)
 {
-    if (!scratch || !wide_use_inverse(k)) return 0;
+    if (!scratch || !wide_use_inverse()) return 0;
     const int KP = kp_of(k);
     double* L = scratch + (size_t)num_cus * nnls_wide_wgs_per_cu(k) * KP * KP;
     double* Ginv = L + (size_t)KP * KP;
@@ -1629,7 +1628,7 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
     double* Ginv = L + (size_t)KP * KP;
     int* status = (int*)(Ginv + (size_t)KP * KP);
     double* V = Ginv + (size_t)KP * KP + 8 + (size_t)KP * CH_NB; // ncols x KP: the caller sized the scratch for its columns
-    const bool use_inv = wide_use_inverse(k);
+    const bool use_inv = wide_use_inverse();
     if (use_inv) {
         if (!inverse_ready && launch_gram_inverse_wide(G, k, scratch, num_cus, st)) return -100;
         rows_times_sym_wide_kernel<true><<<dim3((unsigned)((ncols + 63) / 64), (unsigned)(KP / 64)), 256, 0, st>>>(R, nullptr, Ginv, status, k, KP,

@@ -76,7 +76,8 @@ class DenseMatrix:
     """A (or the column shard [col0, col0+ncols) of it) resident in HBM with its transpose."""
 
     def __init__(self, height, width_global, *, col0=0, ncols=None, storage="f32", single_copy=False):
-        """single_copy: no stored transpose (bf16 storage; serves MU and HALS -- smk_matrix_create_single_copy)"""
+        """single_copy: no stored transpose (bf16 or fp32 storage; serves MU, HALS and BPP with the 16-bit product forms; RANK2 and the
+        accurate form build the transpose on demand -- smk_matrix_create_single_copy)"""
         self.height = int(height)
         self.width_global = int(width_global)
         self.col0 = int(col0)
@@ -269,6 +270,12 @@ class NmfSolver:
         ms, cnt = C.c_double(0), C.c_int(0)
         L.check(L.lib().smk_solver_kernel_time(self._h, which, C.byref(ms), C.byref(cnt)), "smk_solver_kernel_time")
         return ms.value, cnt.value
+
+    def kernel_name(self, which) -> str:
+        """the kernel pass `which` (0 = W'A, 1 = H*At) launches"""
+        buf = C.create_string_buffer(160)
+        L.check(L.lib().smk_solver_kernel_name(self._h, which, buf, 160), "smk_solver_kernel_name")
+        return buf.value.decode()
 
     def kernel_work(self, which):
         b, f = C.c_double(0), C.c_double(0)

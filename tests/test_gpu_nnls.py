@@ -147,3 +147,23 @@ def test_hard_problems_use_backup_rule(gpu, k):
     B = np.asfortranarray(W.T @ (rng.random((3 * k, 200)) - 0.45))
     X0 = np.asfortranarray((rng.random((k, 200)) < 0.5) * 1.0)
     compare(gpu, G, B, X0, tol=1e-7)
+
+
+def test_four_columns_per_wave_is_bit_identical_to_a_wave_per_column(tmp_path):
+    """nnls_g16.hip (round 6: a column per 16-lane row, four per wave; columns of k > 32 whose exchange needs more than 16 rows go
+    to the wave-per-column kernel through a work list) against nnls.hip's wave-per-column kernel on 63 problems: same operations in
+    the same order, so the same bits -- and tools/nnls_g16_check.py's family covers both forms, t = 0 .. 32 and ragged column counts."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, env in (("wave", {"SMK_NNLS_G16": "0"}), ("g16", {}), ("g16_shape1", {"SMK_NNLS_G16_SHAPE": "1"})):
+        f = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "nnls_g16_check.py"), f], capture_output=True, text=True,
+                           env=dict(os.environ, **env), cwd=root, timeout=600)
+        assert r.returncode == 0 and "cases OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append(np.load(f))
+    ref = outs[0]
+    for other in outs[1:]:
+        assert sorted(ref.files) == sorted(other.files)
+        for name in ref.files:
+            assert np.array_equal(ref[name], other[name], equal_nan=True), name

@@ -7,7 +7,7 @@
 // Run each under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and read tools/pmc_dump.py: FETCH_SIZE (KiB) per launch against the
 // known numbers gives the factor to apply to the rank-2 gather products.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mb/mb_gather.hip -o tools/mb/mb_gather
-//   tools/mb/mb_gather <stream|gather16|gather16L2> [MB of table, default 1024] [gathers in millions, default 16]
+//   tools/mb/mb_gather <stream|gather16|gather16L2|gatherrow64|gatherrow128|gatherrow256|gatherrow512> [MB of table, default 1024] [gathers in millions, default 16]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +35,19 @@ __global__ __launch_bounds__(256) void gather16_kernel(const f4* __restrict__ x,
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = 1.f;
 }
 
+// gatherrow: `count` reads of one ROW of RB bytes (a factor row of the sparse products: 8 KP bytes, spmm_seg.hip / spmm_gather) at
+// pseudo-random row positions, RB / 16 adjacent lanes per row: the ceiling of the gather products at ranks 3 .. 128
+template <int RB>
+__global__ __launch_bounds__(256) void gatherrow_kernel(const f4* __restrict__ x, long rows, long count, float* __restrict__ out)
+{
+    constexpr int LPR = RB / 16;
+    f4 acc = {0, 0, 0, 0};
+    const long g = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int sub = threadIdx.x % LPR;
+    for (long i = g; i < count; i += (long)gridDim.x * 256 / LPR) acc += x[(mix((unsigned long long)i) % (unsigned long long)rows) * LPR + sub];
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = 1.f;
+}
+
 int main(int argc, char** argv)
 {
     const char* mode = argc > 1 ? argv[1] : "stream";
@@ -49,12 +62,19 @@ int main(int argc, char** argv)
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(a, 0);
+        const int rb = !strncmp(mode, "gatherrow", 9) ? atoi(mode + 9) : 0;      // gatherrow64 | gatherrow128 | gatherrow256 | gatherrow512
         if (!strcmp(mode, "stream")) stream_kernel<<<4096, 256>>>(x, bytes / 16, out);
+        else if (rb == 64) gatherrow_kernel<64><<<8192, 256>>>(x, bytes / 64, count, out);
+        else if (rb == 128) gatherrow_kernel<128><<<8192, 256>>>(x, bytes / 128, count, out);
+        else if (rb == 256) gatherrow_kernel<256><<<8192, 256>>>(x, bytes / 256, count, out);
+        else if (rb == 512) gatherrow_kernel<512><<<8192, 256>>>(x, bytes / 512, count, out);
         else gather16_kernel<<<4096, 256>>>(x, bytes / 16, count, out);
         hipEventRecord(b, 0);
         hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, a, b);
         if (!strcmp(mode, "stream")) printf("%s: %ld MB in %.1f us = %.2f TB/s\n", mode, mb, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+        else if (rb) printf("%s: %.0f M row gathers of %d B from a %ld MB table in %.1f us = %.2f G rows/s = %.2f TB/s gathered\n", mode, count / 1e6, rb,
+                            bytes >> 20, ms * 1e3, count / (ms * 1e-3) / 1e9, (double)count * rb / (ms * 1e-3) / 1e12);
         else printf("%s: %.0f M gathers of 16 B from a %ld MB table in %.1f us = %.1f G gathers/s, useful %.1f MB\n", mode, count / 1e6, bytes >> 20, ms * 1e3,
                     count / (ms * 1e-3) / 1e9, count * 16 / 1e6);
     }
