@@ -58,6 +58,9 @@ WORKLOADS = {
     # experiments (not BASELINE configs)
     "c4t": (65536, 262144, 64, "BPP", "f32", "EXPERIMENT transposed C4 shape 65536x262144 k=64 BPP fp32"),
     "c4s": (262144, 8192, 64, "BPP", "f32", "EXPERIMENT one 1/8 column shard of C4: 262144x8192 k=64 BPP fp32"),
+    # two ranks of these have exactly the per-rank shard geometry of the 8-GPU runs of C4 / C3 (tests/test_gpu_dist.py)
+    "c4s2": (262144, 16384, 64, "BPP", "f32", "EXPERIMENT two 1/8 column shards of C4: 262144x16384 k=64 BPP fp32 (--gpus 2: the 8-GPU shard geometry per rank)"),
+    "c3s2": (65536, 4096, 32, "HALS", "bf16", "EXPERIMENT two 1/8 column shards of C3: 65536x4096 k=32 HALS bf16 (--gpus 2: the 8-GPU shard geometry per rank)"),
     "c4b": (262144, 65536, 64, "BPP", "bf16", "EXPERIMENT C4 with A held as bf16"),
     "b32": (32768, 8192, 32, "BPP", "f32", "EXPERIMENT 32768x8192 k=32 BPP fp32"),
     "c3t": (16384, 65536, 32, "HALS", "bf16", "EXPERIMENT C3 transposed: 16384x65536 k=32 HALS bf16"),
@@ -167,6 +170,13 @@ def parse_args(argv=None):
     ap.add_argument("--single-copy", action="store_true",
                     help="bf16 workloads under MU / HALS: A without its stored transpose (smk_matrix_create_single_copy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-every-iteration", action="store_true",
+                    help="form the stopping rule's metric (gradients for PG_RATIO, W - Wprev for DELTA_FNORM) and read it back after "
+                         "EVERY timed iteration, as the reference's default run does past min_iter (nmf_solve_generic.hpp:98-121); "
+                         "the default bench line forms no gradients inside the timed region")
+    ap.add_argument("--api-path", action="store_true",
+                    help="N = 1: time the call every reference caller makes -- Nmf(opts, host fp64 A, W, H) = smk_nmf_dense from a "
+                         "host buffer (upload + conversion + transpose + iterations) -- beside the resident number; adds api_path{}")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without torch.distributed: one process, one host thread per device, communicators from "
                          "ncclCommInitAll (smk_comm_init_all)")
@@ -207,7 +217,13 @@ def build_report(args, world, elapsed, windows, rank0, ranks_report, collectives
         "data": "synthetic" if args.data == "uniform" else "synthetic (planted sparse factors of rank k + 0.05 uniform noise)",
         "config": {"workload": desc + (" [single copy of A: no stored transpose]" if args.single_copy else ""), "m": m, "n": n, "k": k, "algorithm": alg, "A_storage": storage,
                    "state": "W,H,Gram fp64; big products: MFMA with fp32 accumulation folded into fp64",
-                   "parallelism": parallelism, "collectives": collectives},
+                   "parallelism": parallelism, "collectives": collectives,
+                   "progress_checks": ("after EVERY timed iteration: the stopping rule's metric is formed (gradients / W - Wprev) and read "
+                                       "back one iteration late with a snapshot, as smk_solver_run does past min_iter -- the reference's "
+                                       "default behaviour (nmf_solve_generic.hpp:98-121)" if args.check_every_iteration else
+                                       "none in the timed region; gradients formed on demand (the reference's solvers form gradW / gradH "
+                                       "every iteration, nmf_solver_mu.hpp:151-164, nmf_solver_bpp.hpp:370-377: dead work unless the "
+                                       "rule is evaluated; --check-every-iteration times the checked loop)")},
         # useful flops (2 k per matrix entry) of the streaming products.  fp32 storage computes them as three fp16
         # MFMAs per product, so its ratio is against the NATIVE fp32 matrix peak that this replaces
         # and may exceed 1; the bound that matters for this path is roofline.frac (HBM).
@@ -262,6 +278,103 @@ def build_report(args, world, elapsed, windows, rank0, ranks_report, collectives
         except Exception:
             pass
     return out
+
+
+def projection_8gpu(m, n, k, alg, one_gpu_ms):
+    """The arithmetic behind DESIGN 7's "about 6.6x at 8 GPUs" for C4 (BPP / MU: row-sharded W update), so that the first SCALE record
+    can be read against it.  NOT a measurement: `assumed_bus_GBps` is an assumption about RCCL over 7 xGMI links, `compute_ms` is
+    the per-rank time of an 8-rank run measured on ONE GPU (bench.py --emulate-world 8, the newest profiles/rNN_bench_c4_emulate8.json)."""
+    import glob
+    kpp = 32 * ((k + 31) // 32)
+    world, chunks, bus = 8, 4, 300.0
+    rs_in = float(m) * kpp * 8                 # (AH')' partial sums, fp64 on the wire, reduce-scattered in `chunks` pieces
+    ag = float(m) * k * 4                      # all-gather of the packed operand of W (two fp16 terms per entry)
+    small = 2.0 * k * k * 8                    # all-reduces of HH' and W'W
+    compute_ms, src = None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_c4_emulate8.json")), reverse=True):
+        try:
+            compute_ms, src = json.load(open(f))["ms_per_step"], os.path.basename(f)
+            break
+        except Exception:
+            continue
+    ms = lambda b: b / (bus * 1e9) * 1e3
+    # the chunk pipeline hides every exchange behind a pass except the LAST reduce-scatter chunk, the FIRST all-gather chunk and the
+    # two small (latency-bound, ~0.03 ms each) all-reduces
+    exposed = ms(rs_in / chunks) + ms(ag / chunks) + 2 * 0.03
+    out = {"for": "C4 on 8 GPUs, column-sharded (DESIGN 7): ARITHMETIC, NOT A MEASUREMENT",
+           "assumed_bus_GBps": bus, "chunks": chunks,
+           "payload_bytes": {"reduce_scatter_of_AHt_in": rs_in, "reduce_scatter_out_per_rank": rs_in / world,
+                             "all_gather_of_packed_W": ag, "small_all_reduces": small},
+           "transfer_ms_if_nothing_overlapped": ms(rs_in) + ms(ag) + 2 * 0.03,
+           "exposed_ms_with_the_chunk_pipeline": exposed,
+           "compute_ms": compute_ms, "compute_ms_source": src, "one_gpu_ms": one_gpu_ms}
+    if compute_ms and one_gpu_ms:
+        out["projected_ms_per_step"] = compute_ms + exposed
+        out["projected_speedup_at_8"] = one_gpu_ms / (compute_ms + exposed)
+        out["compute_only_speedup_at_8"] = one_gpu_ms / compute_ms
+    return out
+
+
+def api_path_report(args, m, n, k, alg, storage, resident_it_s):
+    """The call every reference caller makes (nmf/src/main.cpp:218-233, smallk.cpp:604-619, smallk_lib.pyx:769): Nmf(opts, A, W, H)
+    with A a HOST fp64 column-major buffer.  The reference wraps the buffer as a view (common/src/nmf.cpp:224-226); here it crosses
+    PCIe once (smk_matrix_upload_f64).  Timed in pieces (create, upload incl. the
+    stored transpose, solver set-up + run + factors back) and as the ONE call smk_nmf_dense; matrices that would not leave half of
+    the host's free memory are cut to fewer columns (stated)."""
+    import numpy as np
+    import smallk_amd
+    iters = args.warmup + args.steps
+    try:
+        avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
+    except Exception:
+        avail = 64 << 30
+    n_use = n
+    while m * n_use * 8 > 0.4 * avail and n_use > 1024:
+        n_use //= 2
+    t0 = time.perf_counter()
+    G = smallk_amd.DenseMatrix(m, n_use, storage=storage)
+    G.fill_uniform(42)
+    A = G.download()                     # host fp64 copy of the stored (rounded) values: what a caller would hand over
+    G.close()
+    t_gen = time.perf_counter() - t0
+    W0 = smallk_amd.uniform_host(m, k, 43)
+    H0 = smallk_amd.uniform_host(k, n_use, 44) * (2.0 / k)
+    opts = smallk_amd.make_options(m, n_use, k, alg, min_iter=iters, max_iter=iters)
+    bytes_a = float(m) * n_use * 8.0
+    pieces = []
+    for rep in range(2):                 # the second pass has the pinned pool and the device allocations warm
+        t0 = time.perf_counter()
+        M = smallk_amd.DenseMatrix(m, n_use, storage=storage)
+        t1 = time.perf_counter()
+        M.upload(A)
+        t2 = time.perf_counter()
+        sv = smallk_amd.NmfSolver(M, opts)
+        sv.set_factors(W0, H0)
+        rc, its, us = sv.run()
+        sv.factors()
+        t3 = time.perf_counter()
+        sv.close()
+        M.close()
+        assert rc == 0, rc
+        pieces.append({"create_s": t1 - t0, "upload_s": t2 - t1, "upload_GBps": bytes_a / (t2 - t1) / 1e9,
+                       "solve_s": t3 - t2, "solver_elapsed_s": us * 1e-6, "iterations": its})
+    t0 = time.perf_counter()
+    res = smallk_amd.nmf(A, W0, H0, alg, storage=storage, min_iter=iters, max_iter=iters)
+    t_call = time.perf_counter() - t0
+    assert res.result == 0, res.result
+    best = min(pieces, key=lambda p: p["upload_s"])
+    return {"what": "smk_nmf_dense(opts, HOST fp64 A, W, H): create + upload (PCIe copy, conversion to the stored type, stored transpose) "
+                    "+ solver set-up + iterations + factors back",
+            "m": m, "n": n_use, "k": k, "algorithm": alg, "A_storage": storage, "host_bytes_A": bytes_a,
+            "columns_cut_to_fit_host_memory": n_use != n,
+            "iterations": res.iteration_count, "one_call_s": t_call, "end_to_end_it_s": res.iteration_count / t_call,
+            "solver_elapsed_s": res.elapsed_us * 1e-6,
+            "upload_GBps": best["upload_GBps"], "upload_s": best["upload_s"],
+            "transpose": "inside upload_s (one device pass after the last chunk in mode 0; per column block in modes 1 / 2)",
+            "pieces": pieces, "resident_it_s": resident_it_s,
+            "upload_in_iterations_at_resident_rate": best["upload_s"] * resident_it_s if n_use == n else None,
+            "host_copy_generated_in_s": t_gen,
+            "upload_mode": os.environ.get("SMK_UPLOAD_MODE", "0") + " (0: hipMemcpy2DAsync from the caller's pageable buffer, chunk by chunk; 1: pinned staging with host threads; 2: hipHostRegister per chunk)"}
 
 
 def per_rank_report(rank, args, k, windows, ms0, c0, ms1, c1, msc, cc, msx=0.0, cx=0, mscal=0.0, ccal=0):
@@ -403,7 +516,10 @@ def run_rank(args):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        solver.iterate(args.steps)
+        if args.check_every_iteration:
+            solver.iterate_checked(args.steps)
+        else:
+            solver.iterate(args.steps)
         rcw = solver.sync()
         torch.cuda.synchronize()
         barrier()
@@ -453,8 +569,14 @@ def run_rank(args):
                            ranks_report, collectives, parallelism)
         if world > 1:
             out["rccl_choices"] = rccl_choices()
+        if args.workload == "c4" and args.data == "uniform" and not args.single_copy and not args.check_every_iteration:
+            out["projection"] = projection_8gpu(m, n, k, alg, out["ms_per_step"] if world == 1 and args.emulate_world <= 1 else None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, n, k, alg, 1 if storage == "bf16" else 0, data=args.data)
+        if args.api_path and world == 1 and args.emulate_world <= 1:
+            solver.close()
+            A.close()
+            out["api_path"] = api_path_report(args, m, n, k, alg, storage, out["value"])
         guard.restore()
         print(json.dumps(out), flush=True)
     if rank == 0 and world > 1:

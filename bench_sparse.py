@@ -123,7 +123,10 @@ def run_sparse(args):
     def window():
         torch.cuda.synchronize()
         t = time.perf_counter()
-        solver.iterate(args.steps)
+        if getattr(args, "check_every_iteration", False):
+            solver.iterate_checked(args.steps)
+        else:
+            solver.iterate(args.steps)
         rc = solver.sync()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
@@ -159,6 +162,8 @@ def run_sparse(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "m": m, "n": n, "nnz": int(A.nnz), "k": k, "algorithm": alg,
                    "state": "CSC values, W, H, Gram matrices and every product fp64",
+                   "progress_checks": ("after EVERY timed iteration (smk_solver_iterate_checked)" if getattr(args, "check_every_iteration", False)
+                                       else "none in the timed region; gradients formed on demand"),
                    "generator": f"smallk_amd/synthetic.py:{gen}", "generate_s": round(t_gen, 2),
                    "longest_column": int(np.diff(A.indptr).max()), "longest_row": int(np.diff(A.tocsr().indptr).max())},
         "windows": len(windows), "windows_ms": [round(w * 1e3, 4) for w in windows], "timed_region_s": sum(windows),

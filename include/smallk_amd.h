@@ -185,6 +185,10 @@ int smk_solver_run(smk_solver* s, smk_stats* stats);
 /* enqueue `iters` solver iterations without convergence checks (the min_iter branch, :81-95);
  * asynchronous: returns before the GPU finishes. */
 int smk_solver_iterate(smk_solver* s, int iters);
+/* the same with the stopping rule's metric formed and read back after EVERY iteration, as NmfSolve<> does past min_iter
+ * (common/include/nmf_solve_generic.hpp:98-121; gradients every iteration: nmf_solver_mu.hpp:151-164, nmf_solver_bpp.hpp:370-377),
+ * never stopping: the per-iteration cost of the reference's default run.  MU / HALS / BPP.  last_metric may be NULL. */
+int smk_solver_iterate_checked(smk_solver* s, int iters, double* last_metric);
 int smk_solver_sync(smk_solver* s); /* wait + report solver failures (Result code) */
 /* progress metric of the last iteration that computed one (PG ratio or delta-Fnorm) */
 int smk_solver_progress(smk_solver* s, double* metric);

@@ -106,6 +106,7 @@ SYMBOLS = {
     "smk_solver_set_factors_uniform": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "smk_solver_run": (C.c_int, [_vp, C.POINTER(Stats)]),
     "smk_solver_iterate": (C.c_int, [_vp, C.c_int]),
+    "smk_solver_iterate_checked": (C.c_int, [_vp, C.c_int, _dp]),
     "smk_solver_sync": (C.c_int, [_vp]),
     "smk_solver_progress": (C.c_int, [_vp, _dp]),
     "smk_solver_get_factors": (C.c_int, [_vp, C.c_int, _dp, _i64, _dp, _i64]),

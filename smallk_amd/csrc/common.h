@@ -231,7 +231,17 @@ int launch_nnls_bpp_wide(double* X, double* Y, int k, i64 col_begin, i64 col_end
 int launch_gram_inverse_wide(const double* G, int k, double* scratch, int num_cus, hipStream_t st);
 
 int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st, double* wide_tmp = nullptr);
-int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st);
+// epilogue of the two HALS sweeps (kernels.hip: tile_pack_gram): the sweep also writes the packed operand of the product that
+// follows (bf16 fragments, nsplit terms) and one partial Gram matrix per workgroup into Gp; on return done says whether it did
+// (nblk partials, for launch_gram_reduce) -- when not, the caller runs the separate Gram / pack launch
+struct HalsEpilogue {
+    unsigned char* pack_out = nullptr;
+    double* Gp = nullptr;
+    int KT = 1, nsplit = 3, max_blocks = 0, nblk = 0;
+    i64 nq = 0;
+    bool done = false;
+};
+int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st, HalsEpilogue* ep = nullptr);
 // gradient G*X - R, optional store, projected-gradient partial sums -> pg_accum[slot] += sum
 int launch_grad_pg(const double* X, int k, i64 N, PartialView R, const double* G, double* grad_out,
                    double* pg_partials, double* pg_accum, int slot, hipStream_t st, double* wide_tmp = nullptr);
@@ -242,12 +252,17 @@ int launch_sum_partials(const double* partials, int n, double* out, hipStream_t 
 int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,
                     PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,
                     int flag_slot, hipStream_t st);
+// the same + the snapshot of (W', H, W'W) in the gradient launch, and the totals written to `host_out` (pinned host memory, 8
+// doubles) by the summing launch as well: two launches, no copy packet, per checked iteration.  snap may be NULL.
+int launch_grad_pg2_fused(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,
+                          PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,
+                          int flag_slot, double* snap, double* host_out, hipStream_t st);
 // projected-gradient sum from an existing gradient array
 int launch_pg_from_grad(const double* X, const double* Y, int k, i64 N, double* pg_partials, double* pg_accum,
                         int slot, hipStream_t st);
 // HALS W update (all k columns, k+1 launches); norms scratch: [k][nblocks] + ...
 int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, int num_cus,
-                         int* fail_flag, int parity, int force_multi, hipStream_t st);
+                         int* fail_flag, int parity, int force_multi, hipStream_t st, HalsEpilogue* ep = nullptr);
 int hals_w_scratch_init(double* scratch, int k, i64 M, hipStream_t st);
 size_t hals_w_scratch_elems(int k, i64 M);
 // BPP / NNLS block principal pivoting over all columns

@@ -1162,6 +1162,130 @@ __global__ __launch_bounds__(256) void hals_sweep_kernel(double* __restrict__ X,
     if (valid) store4(X + j * KP + 4 * s, x);
 }
 
+// ---- epilogue of the two HALS sweeps (round 6): packed operand + Gram partial from the tile a workgroup has just updated ---------
+// Until round 6 a HALS iteration at k <= 32 ran gram_pack_kernel after each sweep: a launch that re-reads the factor to write
+// (a) the MFMA operand fragments of the streaming product that follows and (b) partial Gram matrices.  Both sweeps hold the new
+// values in registers when they finish, so they leave them in an LDS tile ([column of the factor][component], leading dimension
+// KP + 1: conflict-free for the row-wise writes and the fragment reads) and this function does (a) and (b) from there --
+// gram_pack_kernel's arithmetic and layouts: fragment lane (r = component, h) holds 8 consecutive operand rows as bf16 terms, the
+// Gram partial is v_mfma_f64_16x16x4 over the tile's columns, the waves' shares added in wave order.  C3: two launches of 11 us
+// fewer per iteration (profiles/r06_c3_epilogues.txt).  ncols: multiple of 16, (ncols / waves) a multiple of 4.
+template <int KP>
+__device__ __forceinline__ void tile_pack_gram(const double* tile, int ncols, i64 col0, i64 N, int k, int KT, int nsplit, i64 nq,
+                                               bool last_wg, unsigned char* __restrict__ out, double* __restrict__ Gp_block,
+                                               double* red /* LDS, KP * KP */)
+{
+    constexpr int T = KP / 16;
+    constexpr int LD = KP + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    // ---- fragments: chunk pair q covers operand rows 16 q .. 16 q + 15 (= columns of the factor)
+    {
+        const int npairs = ncols / 16;
+        const i64 q0 = col0 / 16;
+        const int h = lane >> 5;
+        for (int qi = wave; qi < npairs; qi += nwaves) {
+            const i64 q = q0 + qi;
+            if (q >= nq) continue;
+            for (int kt = 0; kt < KT; ++kt) {
+                const int r = kt * 32 + (lane & 31);
+                const int lrow0 = (2 * qi + h) * 8;
+                double res[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) res[e] = (col0 + lrow0 + e < N && r < k) ? tile[(lrow0 + e) * LD + r] : 0.0;
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    if (sp < nsplit) {
+                        unsigned short hb[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            hb[e] = f32_to_bf16_rne((float)res[e]);
+                            res[e] -= (double)bf16_bits_to_f32(hb[e]);
+                        }
+                        u32x4_t w;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = (unsigned)hb[2 * e] | ((unsigned)hb[2 * e + 1] << 16);
+                        *(u32x4_t*)(out + (((q * nsplit + sp) * KT + kt) * 64 + lane) * 16) = w;
+                    }
+                }
+            }
+        }
+        if (last_wg) {               // zero padding of the operand up to nq chunk pairs
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            for (i64 q = q0 + npairs + wave; q < nq; q += nwaves)
+                for (int kt = 0; kt < KT; ++kt)
+                    for (int sp = 0; sp < nsplit; ++sp) *(u32x4_t*)(out + (((q * nsplit + sp) * KT + kt) * 64 + lane) * 16) = z;
+        }
+    }
+    // ---- Gram partial of the tile's columns
+    f64x4_t acc[T][T];
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = 0; b < T; ++b) acc[a][b] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const int kc = lane >> 4, r16 = lane & 15;
+    const int cpw = ncols / nwaves;
+    for (int c0 = wave * cpw; c0 < (wave + 1) * cpw; c0 += 4) {
+        double f[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) f[t] = tile[(c0 + kc) * LD + 16 * t + r16];          // columns past N hold zeros
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+            for (int b = 0; b < T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], acc[a][b], 0, 0, 0);
+    }
+    for (int w = 0; w < nwaves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int b = 0; b < T; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * a + kc + 4 * r, colm = 16 * b + r16;
+                        const int idx = colm * KP + row;
+                        red[idx] = (w == 0) ? acc[a][b][r] : red[idx] + acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < KP * KP; i += blockDim.x) Gp_block[i] = red[i];
+}
+
+// hals_sweep_kernel + the epilogue above (UpdateH_Hals, nmf_solver_hals.hpp:26-62)
+template <int KP>
+__global__ __launch_bounds__(256) void hals_sweep_pack_kernel(double* __restrict__ X, int k, i64 N, PartialView R,
+                                                              const double* __restrict__ G, unsigned char* __restrict__ pack_out,
+                                                              double* __restrict__ Gp, int KT, i64 nq, int nsplit)
+{
+    COLTILE_PROLOGUE(KP)
+    constexpr int CPW = 256 / LPC;                  // columns per workgroup
+    __shared__ double tile[CPW * (KP + 1)];
+    __shared__ double red[KP * KP];
+    double x[4], b[4];
+    load4(X + jc * KP + 4 * s, x);
+    load_rhs4(R, jc, 4 * s, b);
+#pragma unroll
+    for (int r = 0; r < KP; ++r) {
+        if (r < k) {
+            const double dot = group_sum<LPC>(dot_row<KP>(gs, r, s, x));
+            if (s == r / 4) {
+                double v = x[r % 4] + (b[r % 4] - dot) / gs[r * KP + r];
+                if (isnan(v) || v < 0.0) v = 0.0;
+                x[r % 4] = v;
+            }
+        }
+    }
+    if (valid) store4(X + j * KP + 4 * s, x);
+    {
+        double* t = tile + (threadIdx.x / LPC) * (KP + 1) + 4 * s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = valid ? x[e] : 0.0;
+    }
+    __syncthreads();
+    tile_pack_gram<KP>(tile, CPW, (i64)blockIdx.x * CPW, N, k, KT, nsplit, nq, blockIdx.x == gridDim.x - 1, pack_out,
+                       Gp + (i64)blockIdx.x * KP * KP, red);
+}
+
 // ---- gradient g = G x - R, projected-gradient partial sums ---------------------------
 //      (mu :156-161, hals :181-195, bpp :370-371; projected_gradient.hpp:125-171)
 // one workgroup of the gradient / projected-gradient pass over the column tile `bid` of X
@@ -1222,6 +1346,64 @@ __global__ __launch_bounds__(256) void grad_pg2_kernel(const double* __restrict_
     else grad_pg_body<KP>(X2, k, N2, R2, G2, nullptr, part2, blockIdx.x - grid1, gs, sh);
 }
 
+// The progress check of a PG_RATIO run in TWO launches and no copy packet (round 6): both gradient sums as grad_pg2_kernel plus the
+// snapshot of (W', H, W'W) that lets the driver undo a speculated iteration (snapshot_kernel's layout; the tiles are in registers
+// anyway), then sum_partials2_host_kernel: the two totals in sum_partials2_kernel's order and the failure flag, written straight
+// into the PINNED HOST slot the driver reads after the event.  Before: four stream operations per checked iteration (gradients,
+// sums, a 64-byte copy, the snapshot); the reference forms its gradients and evaluates the rule every iteration
+// (nmf_solve_generic.hpp:98-121).  (ONE launch with a last-arriver sum was built first and measured 20 - 30 % SLOWER on every
+// configuration: the agent-scope fence each workgroup needs before its ticket writes back the XCD's L2, which this very kernel
+// fills with the snapshot -- profiles/r06_progress_check.txt.)
+template <int KP>
+__global__ __launch_bounds__(256) void grad_pg2_snap_kernel(const double* __restrict__ X1, i64 N1, PartialView R1,
+                                                            const double* __restrict__ G1, double* __restrict__ part1,
+                                                            int grid1, const double* __restrict__ X2, i64 N2, PartialView R2,
+                                                            const double* __restrict__ G2, double* __restrict__ part2, int k,
+                                                            double* __restrict__ snap, int k2)
+{
+    constexpr int LPC = KP / 4;
+    __shared__ double sh[16];
+    extern __shared__ __attribute__((aligned(16))) double gs[];      // KP * KP doubles
+    const bool side1 = (int)blockIdx.x < grid1;
+    const int bid = side1 ? (int)blockIdx.x : (int)blockIdx.x - grid1;
+    if (side1) grad_pg_body<KP>(X1, k, N1, R1, G1, nullptr, part1, bid, gs, sh);
+    else grad_pg_body<KP>(X2, k, N2, R2, G2, nullptr, part2, bid, gs, sh);
+    if (snap) {
+        // snapshot_kernel's layout: [W': N1 columns of k2 / 2 pairs][H: N2 columns][W'W = G2: KP * KP / 2 pairs]
+        const int h2 = k2 / 2;
+        const i64 gtid = (i64)bid * blockDim.x + threadIdx.x;
+        const i64 j = gtid / LPC;
+        const int sl = (int)(gtid % LPC);
+        const double* X = side1 ? X1 : X2;
+        const i64 N = side1 ? N1 : N2;
+        f64x2_t* b2 = (f64x2_t*)snap + (side1 ? 0 : N1 * h2);
+        if (j < N) {
+            const f64x2_t a = *(const f64x2_t*)(X + j * KP + 4 * sl), b = *(const f64x2_t*)(X + j * KP + 4 * sl + 2);
+            if (2 * sl < h2) b2[j * h2 + 2 * sl] = a;
+            if (2 * sl + 1 < h2) b2[j * h2 + 2 * sl + 1] = b;
+        }
+        if (!side1 && bid == 0) {        // gs holds G2 = W'W
+            f64x2_t* g2 = (f64x2_t*)snap + (N1 + N2) * h2;
+            for (int i = threadIdx.x; i < KP * KP / 2; i += blockDim.x) g2[i] = *(const f64x2_t*)(gs + 2 * i);
+        }
+    }
+}
+
+// sum_partials2_kernel in ONE workgroup that also writes the result where the host reads it (pinned memory: no copy packet)
+__global__ __launch_bounds__(256) void sum_partials2_host_kernel(const double* __restrict__ p0, int n0, const double* __restrict__ p1, int n1,
+                                                                 double* __restrict__ out, double* __restrict__ host_out,
+                                                                 const int* __restrict__ flag, int flag_slot)
+{
+    __shared__ double sh[16];
+    const double t0 = block_sum_array(p0, n0, sh);
+    const double t1 = block_sum_array(p1, n1, sh);
+    if (threadIdx.x == 0) {
+        const double f = flag ? (double)*flag : 0.0;
+        out[0] = t0; out[1] = t1; out[flag_slot] = f;
+        host_out[0] = t0; host_out[1] = t1; host_out[flag_slot] = f;
+    }
+}
+
 __global__ __launch_bounds__(256) void pg_from_grad_kernel(const double* __restrict__ X, const double* __restrict__ Y,
                                                            i64 count, double* __restrict__ partials)
 {
@@ -1269,10 +1451,20 @@ int launch_mu_update(double* X, int k, i64 N, PartialView R, const double* G, hi
     return 0;
 }
 
-int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st)
+int launch_hals_sweep(double* X, int k, i64 N, PartialView R, const double* G, hipStream_t st, HalsEpilogue* ep)
 {
+    if (ep) ep->done = false;
     if (is_wide(k)) return launch_hals_sweep_wide(X, k, N, R, G, st);
     const int KPv = kp_of(k), grid = coltile_grid(KPv, N);
+    if (ep && ep->pack_out && ep->Gp && (KPv == 16 || KPv == 32) && grid <= ep->max_blocks) {
+        const int lds = KPv * KPv * (int)sizeof(double);
+        if (KPv == 16) hals_sweep_pack_kernel<16><<<grid, 256, lds, st>>>(X, k, N, R, G, ep->pack_out, ep->Gp, ep->KT, ep->nq, ep->nsplit);
+        else hals_sweep_pack_kernel<32><<<grid, 256, lds, st>>>(X, k, N, R, G, ep->pack_out, ep->Gp, ep->KT, ep->nq, ep->nsplit);
+        SMK_HIP(hipGetLastError());
+        ep->nblk = grid;
+        ep->done = true;
+        return 0;
+    }
     COLTILE_LAUNCH(hals_sweep_kernel, grid, X, k, N, R, G);
     SMK_HIP(hipGetLastError());
     return 0;
@@ -1317,6 +1509,19 @@ int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, 
     COLTILE_LAUNCH(grad_pg2_kernel, g1 + g2, X1, N1, R1, G1, part1, g1, X2, N2, R2, G2, part2, k);
     SMK_HIP(hipGetLastError());
     sum_partials2_kernel<<<2, 256, 0, st>>>(part1, g1, part2, g2, pg_accum, flag, flag_slot);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_grad_pg2_fused(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,
+                          PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,
+                          int flag_slot, double* snap, double* host_out, hipStream_t st)
+{
+    const int KPv = kp_of(k), g1 = coltile_grid(KPv, N1), g2 = coltile_grid(KPv, N2);
+    const int k2 = (k + 1) / 2 * 2;
+    COLTILE_LAUNCH(grad_pg2_snap_kernel, g1 + g2, X1, N1, R1, G1, part1, g1, X2, N2, R2, G2, part2, k, snap, k2);
+    SMK_HIP(hipGetLastError());
+    sum_partials2_host_kernel<<<1, 256, 0, st>>>(part1, g1, part2, g2, pg_accum, host_out, flag, flag_slot);
     SMK_HIP(hipGetLastError());
     return 0;
 }
@@ -1591,9 +1796,12 @@ __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ W
                                                           const double* __restrict__ G,
                                                           unsigned long long* __restrict__ slots,
                                                           unsigned long long* __restrict__ slots_other, int nblk,
-                                                          int* __restrict__ fail_flag, unsigned spin_max, int two_level)
+                                                          int* __restrict__ fail_flag, unsigned spin_max, int two_level,
+                                                          unsigned char* __restrict__ pack_out, double* __restrict__ Gp_out,
+                                                          int KT, i64 nq, int nsplit)
 {
     __shared__ __attribute__((aligned(16))) double gs[KP * KP];
+    extern __shared__ double ep_tile[];             // NT x (KP + 1) doubles, only when pack_out != nullptr (tile_pack_gram)
     __shared__ double sh[40];
     for (int t = threadIdx.x; t < KP * KP; t += NT) gs[t] = G[t];
     // the other slot buffer (used by the previous sweep, which is complete) is re-armed for the next one: no memset
@@ -1636,6 +1844,16 @@ __global__ __launch_bounds__(NT) void hals_w_fused_kernel(double* __restrict__ W
             *(f64x2_t*)(p + j) = v;
         }
     }
+    if constexpr (KP == 16 || KP == 32) {
+        if (pack_out) {                             // uniform: the packed operand and the Gram partial of this workgroup's NT rows
+            double* t = ep_tile + threadIdx.x * (KP + 1);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) t[j] = valid ? w[j] : 0.0;
+            __syncthreads();                        // (also: gs is free now and serves as the reduction buffer)
+            tile_pack_gram<KP>(ep_tile, NT, (i64)blockIdx.x * NT, M, k, KT, nsplit, nq, blockIdx.x == gridDim.x - 1, pack_out,
+                               Gp_out + (i64)blockIdx.x * KP * KP, gs);
+        }
+    }
 }
 
 static inline bool hals_w_use_blocked(int k)
@@ -1662,8 +1880,9 @@ int hals_w_scratch_init(double* scratch, int k, i64 M, hipStream_t st)
 }
 
 int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* G, double* scratch, int num_cus,
-                         int* fail_flag, int parity, int force_multi, hipStream_t st)
+                         int* fail_flag, int parity, int force_multi, hipStream_t st, HalsEpilogue* ep)
 {
+    if (ep) ep->done = false;
     if (hals_w_use_blocked(k)) return launch_hals_w_update_blocked(Wt, k, M, R, G, scratch, st);
     if (is_wide(k)) return launch_hals_w_update_wide(Wt, k, M, R, G, scratch, st);
     const int KPv = kp_of(k);
@@ -1694,7 +1913,20 @@ int launch_hals_w_update(double* Wt, int k, i64 M, PartialView R, const double* 
         // all-to-all's contention.  Kept selectable as the record of that measurement (profiles/r04_hals_exchange_two_level.txt).
         static const int mode = [] { const char* e = getenv("SMK_HALS_EXCHANGE"); return e ? atoi(e) : 1; }();
         const int two_level = (mode == 2 && nb >= 16 && nb <= 512 && k * 8 <= nt) ? 1 : 0;
-#define SMK_FUSED(KPX, NTX) hals_w_fused_kernel<KPX, NTX><<<nb, NTX, 0, st>>>(Wt, k, M, R, G, slots, other, nb, fail_flag, spin_max, two_level)
+        // the epilogue (packed operand + Gram partial per workgroup) rides along at KP = 16 / 32 with 256-thread workgroups
+        const bool with_ep = ep && ep->pack_out && ep->Gp && (KPv == 16 || KPv == 32) && nt == 256 && nb <= ep->max_blocks;
+        const int ep_lds = with_ep ? 256 * (KPv + 1) * (int)sizeof(double) : 0;
+        unsigned char* ep_out = with_ep ? ep->pack_out : nullptr;
+        double* ep_gp = with_ep ? ep->Gp : nullptr;
+        const int ep_kt = with_ep ? ep->KT : 1, ep_ns = with_ep ? ep->nsplit : 3;
+        const i64 ep_nq = with_ep ? ep->nq : 0;
+        if (with_ep) {
+            if (KPv == 16) SMK_HIP(hipFuncSetAttribute((const void*)hals_w_fused_kernel<16, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, ep_lds));
+            else SMK_HIP(hipFuncSetAttribute((const void*)hals_w_fused_kernel<32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, ep_lds));
+            ep->nblk = nb;
+            ep->done = true;
+        }
+#define SMK_FUSED(KPX, NTX) hals_w_fused_kernel<KPX, NTX><<<nb, NTX, (NTX == 256 ? ep_lds : 0), st>>>(Wt, k, M, R, G, slots, other, nb, fail_flag, spin_max, two_level, (NTX == 256 ? ep_out : nullptr), ep_gp, ep_kt, ep_nq, ep_ns)
         switch (KPv) {
             case 8: if (nt == 256) SMK_FUSED(8, 256); else if (nt == 512) SMK_FUSED(8, 512); else SMK_FUSED(8, 1024); break;
             case 16: if (nt == 256) SMK_FUSED(16, 256); else if (nt == 512) SMK_FUSED(16, 512); else SMK_FUSED(16, 1024); break;

@@ -24,9 +24,11 @@
 #include <cstring>
 #include <functional>
 #include <vector>
+#include <deque>
 #include <algorithm>
 #include <thread>
 #include <mutex>
+#include <condition_variable>
 
 struct smk_matrix;
 
@@ -155,7 +157,8 @@ struct smk_solver {
     // RANK2 (rank2.hip): scratch of the fused solve / progress kernels (ticket + partial sums), W'W of the W just solved
     // (before its normalisation), and -- sparse A -- compact N x 2 copies of the factors for the gather products
     double *r2_scratch = nullptr, *r2_prog = nullptr, *Graw = nullptr, *Hc = nullptr, *Wc = nullptr;
-    double* pin_r2[2] = {nullptr, nullptr};      // pinned copies of the progress partials (the host sums them)
+    static constexpr int PROG_SLOTS = 4;         // progress checks in flight + 1 (solver_run_once / smk_solver_iterate_checked)
+    double* pin_r2[PROG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};      // pinned copies of the progress partials (the host sums them)
     // the whole RANK2 factorisation as one resident launch (rank2_persist.hip): second H buffer, the rows of (AH')', partial
     // sums, barrier words, result slots (device + pinned); latched off after an aborted launch
     double *r2p_hc1 = nullptr, *r2p_r2c = nullptr, *r2p_part = nullptr, *r2p_out = nullptr, *r2p_pin = nullptr;
@@ -174,6 +177,7 @@ struct smk_solver {
     bool wc_valid = false;
     double* nnls_scratch = nullptr;       // BPP: inverses of W'W and HH' + path selectors (k > 32), two halves
     unsigned* nnls_defer = nullptr;       // BPP, k in (32, 64]: work list between nnls_bpp_g16_kernel and the wave-per-column kernel
+    int hals_ep_blocks = 0;               // HALS, k <= 32: Gram partials the sweeps' epilogues may write into gram_scratch (0: epilogues off)
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
     bool inv_pending[2] = {false, false};
@@ -237,8 +241,8 @@ struct smk_solver {
     // snapshot of (W, H, W'W) per checked iteration so that a speculative iteration can be undone
     struct ProgSlot { double h[8]; int flag; int fused; };     // fused: the flag travels in h[5]
     ProgSlot* pin = nullptr;
-    hipEvent_t pev[2] = {nullptr, nullptr};
-    double* snap[2] = {nullptr, nullptr};
+    hipEvent_t pev[PROG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    double* snap[PROG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     // timing
     bool timing = false;
     // a pair of event records around a launch costs ~11 us of idle time (5.7 us in front of the kernel, 5.8 behind it: measured
@@ -511,10 +515,67 @@ static int matrix_make_transpose(smk_matrix* a)
     return launch_transpose_store(a->A, a->ldA, a->At, a->ldAt, a->storage, a->m, a->n, g_stream);
 }
 
-int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
+// ---- host fp64 -> resident matrix ---------------------------------------------------------------------------------------
+// The reference wraps the caller's buffer as a view, no copy (common/src/nmf.cpp:224-226); here A has to cross PCIe once, and this
+// is the path every reference caller takes (nmf/src/main.cpp:218-233, smallk.cpp:604-619, smallk_lib.pyx:769).  Round 6: a
+// pipeline (SMK_UPLOAD_MODE=1) beside the copy -> convert -> synchronise per chunk loop from pageable memory (mode 0, the default:
+// it measured FASTER, see below):
+//   host threads gather the chunk's columns into one of NB pinned buffers  (pageable -> pinned, SMK_UPLOAD_THREADS, default 8)
+//   -> hipMemcpyAsync to a device staging buffer on a copy stream          (full PCIe rate from pinned memory)
+//   -> convert_f64 to the stored type + the transpose of the column block  (main stream, behind an event)
+// The host only ever waits for the event of the chunk that used the same pinned buffer NB chunks earlier; the device never idles on
+// the host between chunks.  SMK_UPLOAD_MODE=0 keeps the round-5 loop (A/B), =2 pins the caller's buffer in place
+// (hipHostRegister per chunk) instead of staging through pinned buffers.  bench.py --api-path reports the rate.
+namespace {
+struct CopyPool {          // a few persistent threads for the pageable -> pinned gathers of one upload
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    std::function<void(int, int)> job;        // (worker index, worker count)
+    int gen = 0, remaining = 0;
+    bool stop = false;
+    explicit CopyPool(int n)
+    {
+        for (int t = 0; t < n; ++t)
+            th.emplace_back([this, t, n] {
+                int seen = 0;
+                for (;;) {
+                    std::function<void(int, int)> j;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        j = job;
+                    }
+                    j(t, n);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--remaining == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    void run(std::function<void(int, int)> j)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        job = std::move(j);
+        remaining = (int)th.size();
+        ++gen;
+        cv.notify_all();
+        cv_done.wait(lk, [&] { return remaining == 0; });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+}  // namespace
+
+static int upload_f64_serial(smk_matrix* a, const double* host, int64_t ld)       // the plain loop (SMK_UPLOAD_MODE=0, default)
 {
-    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; a->colnorm_max = a->rownorm_max = -1.0; }     // new contents: scale, column spread and norms are measured again on first use
-    if (!a || !host || ld < a->m || a->sparse) return SMK_BAD_PARAM;
     const size_t budget = (size_t)64 << 20;   // staging bytes
     i64 chunk = (i64)(budget / ((size_t)a->m * sizeof(double)));
     if (chunk < 1) chunk = 1;
@@ -536,6 +597,103 @@ int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
     rc = matrix_make_transpose(a);
     if (rc) return rc;
     SMK_HIP(hipStreamSynchronize(g_stream));
+    return SMK_OK;
+}
+
+int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
+{
+    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; a->colnorm_max = a->rownorm_max = -1.0; }     // new contents: scale, column spread and norms are measured again on first use
+    if (!a || !host || ld < a->m || a->sparse) return SMK_BAD_PARAM;
+    // Measured on the pool's boxes (profiles/r06_upload_rates.txt, C3's 8.6 GB of fp64): the plain loop -- hipMemcpy2DAsync straight
+    // from the caller's pageable buffer, which the runtime pins in place piece by piece -- moves 50 - 55 GB/s; staging through
+    // pinned buffers with host threads (mode 1) 41 GB/s whatever the thread count; hipHostRegister per chunk (mode 2) 52 GB/s.
+    // The plain loop is therefore the default; the other two stay selectable.
+    static const int mode = [] { const char* e = getenv("SMK_UPLOAD_MODE"); return e ? atoi(e) : 0; }();
+    const size_t col_bytes = (size_t)a->m * sizeof(double);
+    if (mode == 0 || (size_t)a->n * col_bytes < ((size_t)8 << 20)) return upload_f64_serial(a, host, ld);      // small matrices: nothing to overlap
+    constexpr int NB = 3;
+    static const size_t chunk_bytes = [] { const char* e = getenv("SMK_UPLOAD_CHUNK_MB"); return (size_t)(e && atoi(e) > 0 ? atoi(e) : 32) << 20; }();
+    static const int nthreads = [] {
+        const char* e = getenv("SMK_UPLOAD_THREADS");
+        int t = e ? atoi(e) : 8;
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && t > hw) t = hw;
+        return t < 1 ? 1 : t;
+    }();
+    i64 chunk = (i64)(chunk_bytes / col_bytes);
+    if (chunk < 1) chunk = 1;
+    if (chunk > a->n) chunk = a->n;
+    const size_t es = (size_t)elem_size(a->storage);
+    const bool in_place = mode == 2;
+    double* pinned[NB] = {nullptr, nullptr, nullptr};
+    double* stage[NB] = {nullptr, nullptr, nullptr};
+    hipEvent_t e_copied[NB] = {nullptr, nullptr, nullptr}, e_conv[NB] = {nullptr, nullptr, nullptr};
+    const void* registered[NB] = {nullptr, nullptr, nullptr};
+    hipStream_t st_copy = nullptr;
+    int rc = SMK_OK;
+    auto cleanup = [&]() {
+        if (st_copy) { (void)hipStreamSynchronize(st_copy); }
+        (void)hipStreamSynchronize(g_stream);
+        for (int b = 0; b < NB; ++b) {
+            if (registered[b]) (void)hipHostUnregister(const_cast<void*>(registered[b]));
+            if (pinned[b]) (void)hipHostFree(pinned[b]);
+            if (stage[b]) (void)smk::dev_free(stage[b]);
+            if (e_copied[b]) (void)hipEventDestroy(e_copied[b]);
+            if (e_conv[b]) (void)hipEventDestroy(e_conv[b]);
+        }
+        if (st_copy) (void)hipStreamDestroy(st_copy);
+    };
+#define SMK_UP(call) do { if ((call) != hipSuccess) { set_error(std::string(#call) + ": " + hipGetErrorString(hipGetLastError())); cleanup(); return SMK_DEVICE_ERROR; } } while (0)
+    SMK_UP(hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking));
+    for (int b = 0; b < NB; ++b) {
+        if (!in_place) SMK_UP(hipHostMalloc((void**)&pinned[b], (size_t)chunk * col_bytes));
+        if (dev_alloc(&stage[b], (size_t)a->m * chunk)) { cleanup(); return SMK_DEVICE_ERROR; }
+        SMK_UP(hipEventCreateWithFlags(&e_copied[b], hipEventDisableTiming));
+        SMK_UP(hipEventCreateWithFlags(&e_conv[b], hipEventDisableTiming));
+    }
+    {
+        CopyPool pool(in_place ? 0 : nthreads);
+        i64 i = 0;
+        for (i64 c = 0; c < a->n; c += chunk, ++i) {
+            const int b = (int)(i % NB);
+            const i64 nc = (a->n - c < chunk) ? (a->n - c) : chunk;
+            if (i >= NB) SMK_UP(hipEventSynchronize(e_copied[b]));      // the transfer that last read pinned[b]: long finished in steady state
+            if (i >= NB) SMK_UP(hipStreamWaitEvent(st_copy, e_conv[b], 0));   // stage[b] has been converted
+            if (in_place) {
+                if (registered[b]) { (void)hipHostUnregister(const_cast<void*>(registered[b])); registered[b] = nullptr; }
+                const double* src = host + c * ld;
+                const size_t span = ((size_t)(nc - 1) * (size_t)ld + (size_t)a->m) * sizeof(double);
+                SMK_UP(hipHostRegister(const_cast<double*>(src), span, hipHostRegisterDefault));
+                registered[b] = src;
+                SMK_UP(hipMemcpy2DAsync(stage[b], col_bytes, src, (size_t)ld * sizeof(double), col_bytes, (size_t)nc, hipMemcpyHostToDevice, st_copy));
+            } else {
+                double* dst = pinned[b];
+                const i64 m = a->m;
+                pool.run([=](int t, int nt) {
+                    // every worker takes a contiguous share of the chunk's bytes (columns are contiguous runs of m doubles)
+                    if (ld == m) {
+                        const size_t total = (size_t)nc * (size_t)m * sizeof(double);
+                        const size_t lo = total * (size_t)t / (size_t)nt / 64 * 64, hi = (t + 1 == nt) ? total : total * (size_t)(t + 1) / (size_t)nt / 64 * 64;
+                        if (hi > lo) memcpy((char*)dst + lo, (const char*)(host + c * ld) + lo, hi - lo);
+                    } else {
+                        for (i64 j = nc * t / nt; j < nc * (t + 1) / nt; ++j) memcpy(dst + j * m, host + (c + j) * ld, (size_t)m * sizeof(double));
+                    }
+                });
+                SMK_UP(hipMemcpyAsync(stage[b], pinned[b], (size_t)nc * col_bytes, hipMemcpyHostToDevice, st_copy));
+            }
+            SMK_UP(hipEventRecord(e_copied[b], st_copy));
+            SMK_UP(hipStreamWaitEvent(g_stream, e_copied[b], 0));
+            rc = launch_convert_f64(stage[b], a->m, (unsigned char*)a->A + (size_t)c * a->ldA * es, a->storage, a->ldA, a->m, nc, g_stream);
+            // the stored transpose of this column block, while the next chunk travels
+            if (!rc && !a->single)
+                rc = launch_transpose_store((const unsigned char*)a->A + (size_t)c * a->ldA * es, a->ldA, (unsigned char*)a->At + (size_t)c * es, a->ldAt,
+                                            a->storage, a->m, nc, g_stream);
+            if (rc) { cleanup(); return rc; }
+            SMK_UP(hipEventRecord(e_conv[b], g_stream));
+        }
+    }
+#undef SMK_UP
+    cleanup();          // waits for both streams
     return SMK_OK;
 }
 
@@ -1243,6 +1401,11 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
     rc |= dev_alloc(&s->Gh_own, kk);
     {
         size_t gs = gram_scratch_elems(s->k, GRAM_BLOCKS);
+        if (opts->algorithm == SMK_ALG_HALS && !a->sparse && (s->KP == 16 || s->KP == 32)) {
+            // the sweeps' own Gram partials (HalsEpilogue): one per workgroup -- 1024 / KP columns of H, 256 rows of W
+            const i64 need = std::max<i64>((s->n * s->KP + 1023) / 1024, (s->m + 255) / 256);
+            if (need <= 4096) { s->hals_ep_blocks = (int)std::max<i64>(need, 1); gs = std::max(gs, gram_scratch_elems(s->k, s->hals_ep_blocks)); }
+        }
         if (s->KP == 16 && opts->algorithm == SMK_ALG_BPP) gs = std::max(gs, (size_t)NNLS_GRAM_MAX * (256 + 16) + 8);   // partials from the NNLS launch
         rc |= dev_alloc(&s->gram_scratch, gs);
         if (s->o.algorithm == SMK_ALG_RANK2) {
@@ -1311,7 +1474,7 @@ void smk_solver_destroy(smk_solver* s)
     for (int w = 0; w < 6; ++w)
         for (auto& e : s->ev[w]) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     if (s->ev_cal) (void)hipEventDestroy(s->ev_cal);
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < smk_solver::PROG_SLOTS; ++b) {
         if (s->snap[b]) (void)smk::dev_free(s->snap[b]);
         if (s->pev[b]) (void)hipEventDestroy(s->pev[b]);
     }
@@ -1321,7 +1484,7 @@ void smk_solver_destroy(smk_solver* s)
     if (s->guard_ev) (void)hipEventDestroy(s->guard_ev);
     { void* r2p[] = {s->r2p_hc1, s->r2p_r2c, s->r2p_part, s->r2p_out, s->r2p_sync}; for (void* q : r2p) if (q) (void)smk::dev_free(q); }
     if (s->r2p_pin) (void)hipHostFree(s->r2p_pin);
-    for (int b = 0; b < 2; ++b) if (s->pin_r2[b]) (void)hipHostFree(s->pin_r2[b]);
+    for (int b = 0; b < smk_solver::PROG_SLOTS; ++b) if (s->pin_r2[b]) (void)hipHostFree(s->pin_r2[b]);
     for (int b = 0; b < 2; ++b) if (s->seg_pieces[b]) (void)smk::dev_free(s->seg_pieces[b]);
     if (s->nnls_defer) (void)smk::dev_free(s->nnls_defer);
     if (s->comm_ws) (void)smk::dev_free(s->comm_ws);
@@ -2143,15 +2306,35 @@ static int solver_iteration(smk_solver* s)
             rc = gram_w(s);   if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
             break;
-        case SMK_ALG_HALS: // nmf_solver_hals.hpp:166-199
+        case SMK_ALG_HALS: { // nmf_solver_hals.hpp:166-199
+            // round 6: at k <= 32 on one GPU both sweeps also leave the packed operand of the product that follows and their Gram
+            // partials (kernels.hip: tile_pack_gram) -- the separate gram_pack launches (11 us each at C3) go, only the 5 us
+            // reductions stay.  SMK_HALS_EPILOGUE=0: the launches of before.
+            static const bool ep_on = [] { const char* e = getenv("SMK_HALS_EPILOGUE"); return !(e && e[0] == '0'); }();
+            const bool bf16_frag = s->a->storage == SMK_STORE_BF16 || s->nsplit >= 2;
+            const bool ep_ok = ep_on && !s->a->sparse && !is_dist(s) && !s->comm && (s->KP == 16 || s->KP == 32) && bf16_frag && s->nsplit >= 1 && s->nsplit <= 3 &&
+                               s->ng == 1 && s->hals_ep_blocks > 0;
+            HalsEpilogue epw, eph;
+            if (ep_ok) {
+                epw.pack_out = (unsigned char*)s->packW; epw.Gp = s->gram_scratch; epw.KT = kt_of(s->k); epw.nsplit = s->nsplit;
+                epw.max_blocks = s->hals_ep_blocks; epw.nq = round_up(s->m, 128) / 16;
+                eph = epw;
+                eph.pack_out = (unsigned char*)s->packH; eph.nq = round_up(s->n, 128) / 16;
+            }
             rc = wait_r2(s);  if (rc) return rc;
-            rc = launch_hals_w_update(s->Wt, s->k, s->m, r2, s->Gh, s->hals_scratch, g_cus, s->fail_flag, s->hals_calls++, s->hals_multi ? 1 : 0, s->st); if (rc) return rc;
-            rc = gram_w(s);   if (rc) return rc;
+            rc = launch_hals_w_update(s->Wt, s->k, s->m, r2, s->Gh, s->hals_scratch, g_cus, s->fail_flag, s->hals_calls++, s->hals_multi ? 1 : 0, s->st,
+                                      ep_ok ? &epw : nullptr); if (rc) return rc;
+            if (epw.done) { rc = launch_gram_reduce(s->gram_scratch, epw.nblk, s->k, s->Gw, s->st, nullptr, nullptr, 1.0); s->packed_fresh[0] = true; }
+            else rc = gram_w(s);
+            if (rc) return rc;
             rc = prod1(s);    if (rc) return rc;
-            rc = launch_hals_sweep(s->H, s->k, s->n, r1, s->Gw, s->st); if (rc) return rc;
-            rc = gram_h(s);   if (rc) return rc;
+            rc = launch_hals_sweep(s->H, s->k, s->n, r1, s->Gw, s->st, ep_ok ? &eph : nullptr); if (rc) return rc;
+            if (eph.done) { rc = launch_gram_reduce(s->gram_scratch, eph.nblk, s->k, s->Gh, s->st, nullptr, nullptr, 1.0); s->packed_fresh[1] = true; }
+            else rc = gram_h(s);
+            if (rc) return rc;
             rc = prod2(s);    if (rc) return rc;
             break;
+        }
         case SMK_ALG_BPP:  // nmf_solver_bpp.hpp:342-377
             rc = nnls_side(s, 0, s->H, 0, s->n, r1, s->Gw); if (rc) return rc;
             rc = gram_h(s);   if (rc) return rc;
@@ -2309,10 +2492,10 @@ static int update_progress(smk_solver* s, int iter_index, double* metric)
 static int progress_prealloc(smk_solver* s)
 {
     if (!s->pin) {
-        SMK_HIP(hipHostMalloc((void**)&s->pin, 2 * sizeof(smk_solver::ProgSlot)));
-        for (int i = 0; i < 2; ++i) SMK_HIP(hipEventCreateWithFlags(&s->pev[i], hipEventDisableTiming));
+        SMK_HIP(hipHostMalloc((void**)&s->pin, smk_solver::PROG_SLOTS * sizeof(smk_solver::ProgSlot)));
+        for (int i = 0; i < smk_solver::PROG_SLOTS; ++i) SMK_HIP(hipEventCreateWithFlags(&s->pev[i], hipEventDisableTiming));
     }
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 2; ++b)            // a sharded run keeps ONE check in flight (two slots)
         if (!s->snap[b]) { const int rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
     return 0;
 }
@@ -2320,8 +2503,8 @@ static int progress_prealloc(smk_solver* s)
 static int progress_begin(smk_solver* s, int b, bool snapshot)
 {
     if (!s->pin) {
-        SMK_HIP(hipHostMalloc((void**)&s->pin, 2 * sizeof(smk_solver::ProgSlot)));
-        for (int i = 0; i < 2; ++i) SMK_HIP(hipEventCreateWithFlags(&s->pev[i], hipEventDisableTiming));
+        SMK_HIP(hipHostMalloc((void**)&s->pin, smk_solver::PROG_SLOTS * sizeof(smk_solver::ProgSlot)));
+        for (int i = 0; i < smk_solver::PROG_SLOTS; ++i) SMK_HIP(hipEventCreateWithFlags(&s->pev[i], hipEventDisableTiming));
     }
     int rc = wait_r2(s);
     if (rc) return rc;
@@ -2335,6 +2518,18 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
         if (rc) return rc;
         s->pin[b].fused = 2;             // per-workgroup partials: progress_end adds them up in index order
         SMK_HIP(hipMemcpyAsync(s->pin_r2[b], s->r2_prog, pe * sizeof(double), hipMemcpyDeviceToHost, s->st));
+        SMK_HIP(hipEventRecord(s->pev[b], s->st));
+        return 0;
+    }
+    static const bool fused_check = [] { const char* e = getenv("SMK_PROGRESS_FUSED"); return !(e && e[0] == '0'); }();
+    if (fused_check && s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s) && !is_wide(s->k) && !s->w_sharded) {
+        // round 6: gradients + snapshot in one launch, sums + failure flag written into the pinned slot by a second (kernels.hip:
+        // grad_pg2_snap_kernel, sum_partials2_host_kernel); SMK_PROGRESS_FUSED=0: the four stream operations of before
+        if (snapshot && !s->snap[b]) { rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
+        rc = launch_grad_pg2_fused(s->Wt, s->m, view2(s), s->Gh, s->pg_partials, s->H, s->n, view1(s), s->Gw, s->pg_partials + s->pg_half,
+                                   s->k, s->scal, s->fail_flag, 5, snapshot ? s->snap[b] : nullptr, s->pin[b].h, s->st);
+        if (rc) return rc;
+        s->pin[b].fused = 1;
         SMK_HIP(hipEventRecord(s->pev[b], s->st));
         return 0;
     }
@@ -2360,6 +2555,22 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
     }
     SMK_HIP(hipEventRecord(s->pev[b], s->st));
     return 0;
+}
+
+// How many progress checks may be in flight (round 6).  With ONE (rounds 1 - 5) the host could run only one iteration ahead of the
+// device: it enqueued iteration i + 1, then slept on the event of check i -- and a small problem's iteration (C2: 73 us) is
+// shorter than the wake-up plus the ~7 launches of the next one, so the device idled between iterations of a checked run (C2:
+// 13 700 it/s unchecked, 10 900 checked, although the check itself is two launches).  With three, the check that is waited for is
+// three iterations old: finished long ago.  Every in-flight check owns a slot (pinned result, event, snapshot); the rule is still
+// evaluated for every iteration in order and a run that converges at iteration p is restored from p's snapshot, so results and
+// iteration counts do not change.  Sharded runs keep one (their checks carry collectives); so do problems whose snapshots would
+// take more than 1 GB each.  SMK_PROGRESS_DEPTH=1..3 overrides.
+static int progress_depth(const smk_solver* s)
+{
+    static const int forced = [] { const char* e = getenv("SMK_PROGRESS_DEPTH"); return e ? atoi(e) : 0; }();
+    if (is_dist(s) || s->comm) return 1;
+    if (forced >= 1) return std::min(forced, smk_solver::PROG_SLOTS - 1);
+    return snapshot_elems(s->k, s->m, s->n) * sizeof(double) > ((size_t)1 << 30) ? 1 : smk_solver::PROG_SLOTS - 1;
 }
 
 // wait for slot b; SMK_FAILURE when the device flagged a solver failure up to that iteration
@@ -2624,6 +2835,43 @@ int smk_solver_iterate(smk_solver* s, int iters)
     return SMK_OK;
 }
 
+// `iters` iterations as NmfSolve<> runs them past min_iter (nmf_solve_generic.hpp:98-121): after every iteration the stopping rule's
+// metric is formed (gradients for PG_RATIO, nmf_solver_bpp.hpp:370-377 / nmf_solver_mu.hpp:151-164; W - Wprev for DELTA_FNORM) and
+// read back -- by the same one-iteration-late scheme as smk_solver_run (snapshot, pinned slot, event), with a tolerance that never
+// fires.  What bench.py --check-every-iteration times.  *last_metric (optional): the metric of the last iteration.
+int smk_solver_iterate_checked(smk_solver* s, int iters, double* last_metric)
+{
+    if (!s || iters < 0) return SMK_BAD_PARAM;
+    if (!s->have_factors) { set_error("set_factors() first"); return SMK_BAD_PARAM; }
+    int rc = 0;
+    if (!s->inited) { rc = solver_init(s); if (rc) return rc; }
+    if (s->o.algorithm == SMK_ALG_RANK2) { set_error("iterate_checked: MU / HALS / BPP"); return SMK_UNSUPPORTED; }
+    const int depth = progress_depth(s), NS = smk_solver::PROG_SLOTS;
+    std::deque<int> pend;                           // iterations whose check is outstanding, oldest first
+    double metric = 1.0;
+    for (int i = 0; i < iters; ++i) {
+        rc = solver_iteration(s);
+        if (rc) return rc;
+        rc = guard_step(s);
+        if (rc) return rc;
+        rc = progress_begin(s, i % NS, true);
+        if (rc) return rc;
+        while ((int)pend.size() >= depth) {
+            rc = progress_end(s, pend.front() % NS, s->iter > 1 ? 1 : 0, &metric);
+            if (rc) return rc;
+            pend.pop_front();
+        }
+        pend.push_back(i);
+    }
+    while (!pend.empty()) {
+        rc = progress_end(s, pend.front() % NS, s->iter > 1 ? 1 : 0, &metric);
+        if (rc) return rc;
+        pend.pop_front();
+    }
+    if (last_metric) *last_metric = metric;
+    return SMK_OK;
+}
+
 // which product form the solver is using now (SMK_NSPLIT numbering; 8 = the accurate form), how often the run-time guard has
 // looked and how often it changed the form, and cond * delta of its last look
 int smk_solver_product_form(const smk_solver* s, int* guard_checks, int* guard_fired, double* guard_last)
@@ -2803,10 +3051,11 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
     // runs that loop instead).
     {
         static const bool sync_mode = [] { const char* e = getenv("SMK_SYNC_PROGRESS"); return e && atoi(e) != 0; }();
-        int pending = -1;                              // iteration whose check is outstanding
+        const int depth = progress_depth(s), NS = smk_solver::PROG_SLOTS;
+        std::deque<int> pend;                          // iterations whose check is outstanding, oldest first (at most `depth`)
         auto resolve = [&](int p, bool speculated) -> int {      // 0: go on, 1: converged at p, < 0: error
             double metric = 1.0;
-            int prc = progress_end(s, p & 1, p, &metric);
+            int prc = progress_end(s, p % NS, p, &metric);
             if (prc) { result = prc; return -1; }
             if (p < o.min_iter) return 0;              // iteration 0 only initialises the estimator
             if (o.verbose && ((p + 1 < 10) || ((p + 1) % 10 == 0)))
@@ -2814,7 +3063,7 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
             if (metric <= o.tol) {
                 if (++success_count >= o.tolcount) {
                     if (o.verbose) printf("\nSolution converged after %d iterations.\n\n", p + 1);
-                    if (speculated) { prc = progress_restore(s, p & 1); if (prc) { result = prc; return -1; } s->iter = p + 1; }
+                    if (speculated) { prc = progress_restore(s, p % NS); if (prc) { result = prc; return -1; } s->iter = p + 1; }
                     return 1;
                 }
             } else {
@@ -2830,7 +3079,7 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
             const bool check = (iter == 0) || (iter >= o.min_iter);
             if (sync_mode) {
                 if (!check) { if (o.verbose) printf("%d:\tprogress metric: \t(min_iter)\n", iter + 1); continue; }
-                rc = progress_begin(s, iter & 1, false);
+                rc = progress_begin(s, iter % NS, false);
                 if (rc) { result = rc; goto done; }
                 const int r = resolve(iter, false);
                 if (r < 0) goto failed_check;
@@ -2839,21 +3088,28 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
                 continue;
             }
             if (check) {
-                rc = progress_begin(s, iter & 1, iter >= o.min_iter);
+                rc = progress_begin(s, iter % NS, iter >= o.min_iter);
                 if (rc) { result = rc; goto done; }
             }
-            if (pending >= 0) {
-                const int r = resolve(pending, true);
+            // the oldest outstanding checks, once `depth` of them are in flight (depth 1: the check of the previous iteration,
+            // as in rounds 1 - 5); an unchecked iteration (0 < iter < min_iter) leaves nothing behind, as before
+            while (!pend.empty() && ((int)pend.size() >= depth || !check)) {
+                const int p = pend.front();
+                pend.pop_front();
+                const int r = resolve(p, true);
                 if (r < 0) goto failed_check;
-                if (r == 1) { success = true; iter = pending; pending = -1; break; }
+                if (r == 1) { success = true; iter = p; pend.clear(); break; }
             }
+            if (success) break;
             if (iter < o.min_iter && o.verbose) printf("%d:\tprogress metric: \t(min_iter)\n", iter + 1);
-            pending = check ? iter : -1;
+            if (check) pend.push_back(iter);
         }
-        if (!success && pending >= 0) {                // the last iteration's check: nothing ran after it
-            const int r = resolve(pending, false);
+        while (!success && !pend.empty()) {            // what is still outstanding when the iterations are used up
+            const int p = pend.front();
+            pend.pop_front();
+            const int r = resolve(p, !pend.empty());   // the very last one: nothing ran after it
             if (r < 0) goto failed_check;
-            if (r == 1) { success = true; iter = pending; }
+            if (r == 1) { success = true; iter = p; pend.clear(); }
         }
     }
 

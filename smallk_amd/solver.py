@@ -241,6 +241,12 @@ class NmfSolver:
     def iterate(self, iters):
         L.check(L.lib().smk_solver_iterate(self._h, iters), "smk_solver_iterate")
 
+    def iterate_checked(self, iters) -> float:
+        """`iters` iterations with the stopping rule's metric formed and read back after each (never stopping); returns the last metric"""
+        v = C.c_double(0)
+        L.check(L.lib().smk_solver_iterate_checked(self._h, iters, C.byref(v)), "smk_solver_iterate_checked")
+        return v.value
+
     def sync(self):
         return L.lib().smk_solver_sync(self._h)
 

@@ -47,9 +47,11 @@ def make_matrix(m, n, data, seed, kstar, storage="f32"):
     return A
 
 
-def fast_vs_accurate(A, k, alg, seeds, checkpoints=CHECKPOINTS, fast_env=None):
-    """[(iteration, relF(W_fast, W_acc), relF(H_fast, H_acc))], the forms, and the accurate factors at the last checkpoint."""
-    from smallk_amd import NmfSolver, make_options
+def fast_vs_accurate(A, k, alg, seeds, checkpoints=CHECKPOINTS, fast_env=None, h0_scale=None):
+    """[(iteration, relF(W_fast, W_acc), relF(H_fast, H_acc))], the forms, and the accurate factors at the last checkpoint.
+    h0_scale: start from uniform W0 and h0_scale * uniform H0 (HALS: an unscaled uniform start clamps all of W to zero in its
+    first sweep, the run would then iterate on the epsilon guard columns -- bench.py starts HALS from 2 / k as well)."""
+    from smallk_amd import NmfSolver, make_options, uniform_host
     m, n = A.height, A.width_global
     opts = make_options(m, n, k, alg, normalize=False)
     with _Env(SMK_NSPLIT=fast_env, SMK_BPP_SMALL_ACCURATE="0"):
@@ -57,8 +59,13 @@ def fast_vs_accurate(A, k, alg, seeds, checkpoints=CHECKPOINTS, fast_env=None):
     with _Env(SMK_NSPLIT="8"):
         acc = NmfSolver(A, opts)
     forms = (fast.product_form()[0], acc.product_form()[0])
+    if h0_scale is not None:
+        W0, H0 = uniform_host(m, k, seeds[0]), uniform_host(k, n, seeds[1]) * h0_scale
     for s in (fast, acc):
-        s.set_factors_uniform(seeds[0], seeds[1])
+        if h0_scale is not None:
+            s.set_factors(W0, H0)
+        else:
+            s.set_factors_uniform(seeds[0], seeds[1])
     rows, done = [], 0
     Wa = Ha = None
     for cp in checkpoints:
@@ -116,3 +123,44 @@ def accurate_iteration_vs_oracle(oracle, A, k, alg, data, seed, kstar, seeds, ns
     assert ref.result == 0
     eW = relerr(W1[rws, :], ref.H.T)
     return eH, eW, same
+
+
+def hals_accurate_iteration_vs_oracle(oracle, A, k, data, seed, kstar, seeds, quant, nsample=48):
+    """One accurate-form HALS iteration at full size against the reference's update formulas on sampled rows / columns
+    (nmf_solver_hals.hpp:66-117: the W sweep normalises every column inside the sweep, so a sampled row determines its new value
+    only up to ONE factor nu_c per column -- the norm over all rows, taken from the device -- and every sampled entry must agree
+    on it; nmf_solver_hals.hpp:26-62: the H sweep with the new W is exact on sampled columns).  Returns (largest deviation of a
+    sampled W entry from nu_c W1 relative to the column's largest entry, max relative error of the sampled H columns)."""
+    from oracle import flatclust as of
+    from smallk_amd import NmfSolver, make_options, uniform_host
+    m, n = A.height, A.width_global
+    with _Env(SMK_NSPLIT="8"):
+        s = NmfSolver(A, make_options(m, n, k, "HALS", normalize=False))
+    W0, H0 = uniform_host(m, k, seeds[0]), uniform_host(k, n, seeds[1]) * (2.0 / k)
+    s.set_factors(W0, H0)
+    s.iterate(1)
+    assert s.sync() == 0
+    W1, H1 = s.factors(normalize=False)
+    assert s.product_form()[0] == 8
+    s.close()
+    assert np.allclose(np.sqrt((W1 * W1).sum(axis=0)), 1.0, rtol=1e-10)
+    rng = np.random.default_rng(7)
+    rows = np.sort(rng.choice(m, size=nsample, replace=False))
+    Ar = oracle_block(oracle, data, m, seed, kstar, quant, rows=rows, n=n)
+    G = H0 @ H0.T
+    R = Ar @ H0.T
+    Wc = W0[rows, :].copy()
+    eW = 0.0
+    for c in range(k):
+        t = Wc[:, c] + (R[:, c] - Wc @ G[:, c]) / G[c, c]
+        t[t < 0] = 0.0
+        pos = (t > 0) & (W1[rows, c] > 0)
+        assert pos.sum() >= 8, c
+        nu = np.median(t[pos] / W1[rows, c][pos])
+        eW = max(eW, float(np.max(np.abs(t - nu * W1[rows, c])) / np.max(t)))
+        Wc[:, c] = W1[rows, c]                       # Gauss-Seidel: later columns see the normalised value
+    cols = np.sort(rng.choice(n, size=nsample, replace=False))
+    Ac = oracle_block(oracle, data, m, seed, kstar, quant, cols=cols)
+    _, _, Hs, _ = of.nnls_hals(Ac, W1, H0[:, cols], 1e-30, 1)     # one sweep, W fixed, no normalisation
+    eH = float(np.max(np.abs(H1[:, cols] - Hs)) / max(np.max(np.abs(Hs)), 1e-300))
+    return eW, eH

@@ -639,3 +639,36 @@ def test_matrix_follows_a_stream_set_after_its_creation(gpu):
     D.close()
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
     assert rc == 0 and it == iters and rel(W, ref.W) < TOL and rel(H, ref.H) < TOL
+
+
+@pytest.mark.parametrize("workload", ["c4s2", "c3s2"])
+def test_bench_two_ranks_at_the_shard_geometry_of_the_8_gpu_run(tmp_path, workload):
+    """First-real-run readiness: bench.py under torch.distributed.run with two ranks, each holding exactly the
+    shard an 8-GPU run of C4 (262144 x 8192, k = 64, BPP) / C3 (65536 x 2048, k = 32, HALS) gives a rank -- both ranks on this
+    box's one GPU, gloo instead of RCCL.  The JSON line must carry what the first run on a node will be read by: per-rank
+    products / collectives / exposure, the rccl_choices key, and numbers that add up."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMK_BENCH_SHARE_GPU="1", SMK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env.pop("SMK_BENCH_DUMP_W", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload,
+                        "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "rccl_choices" in out
+    assert len(out["per_rank"]) == 2 and [p["rank"] for p in out["per_rank"]] == [0, 1]
+    for p in out["per_rank"]:
+        for key in ("ms_per_step", "products_ms_per_step", "collectives_ms_per_step", "exposed_comm_ms", "exposed_comm_ms_raw",
+                    "wait_bracket_cost_ms", "outside_products_ms_per_step", "passes_per_step"):
+            assert key in p, key
+        assert 0.0 < p["products_ms_per_step"] <= p["ms_per_step"] * 1.05                   # the passes are part of the step
+        assert abs(p["outside_products_ms_per_step"] - (p["ms_per_step"] - p["products_ms_per_step"])) < 1e-9
+        assert p["exposed_comm_ms"] >= 0.0 and p["exposed_comm_ms"] <= p["ms_per_step"]
+        assert abs(p["passes_per_step"] - 2.0) < 0.01
+    # whole-job rate = steps / the slowest rank's window
+    assert out["value"] <= 1e3 / min(p["ms_per_step"] for p in out["per_rank"]) * 1.05

@@ -191,3 +191,22 @@ def test_column_sharded_run_on_single_copy_shards(gpu, alg, storage, quant):
     fro = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     assert fro(out[0][1], ref.W) < 1e-4 and fro(H, ref.H) < 1e-4, (fro(out[0][1], ref.W), fro(H, ref.H))
     assert np.array_equal(out[0][1], out[world - 1][1])
+
+
+@pytest.mark.parametrize("mode,env", [("guard", {"SMK_GUARD_EVERY": "1", "SMK_GUARD_TAU": "1e-30"}), ("nnls_hals", {})])
+def test_single_copy_that_switches_to_the_accurate_form_in_mid_run(mode, env):
+    """every re-plan (the run-time guard of the product form, NnlsHals' switch to the accurate form, the form agreement of a
+    sharded run) used to keep the transposed-source plan of a single-copy matrix while the solver handed the fp64 factor to it --
+    garbage without an error.  plan_products now builds the stored transpose first.  1300 rows: 0 < m mod 256 <= 128, the shape whose
+    last tile used to read past the padded rows of A."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "single_copy_replan.py"), mode], capture_output=True, text=True,
+                       env=dict(os.environ, **env), cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["single_at_start"] and j["form_start"] != 8 and j["form_end"] == 8 and not j["single_at_end"], j
+    if mode == "guard":
+        assert j["rc"] == 0 and j["guard_fired"] >= 1 and j["relW"] < 1e-4 and j["relH"] < 1e-4, j
+    else:
+        assert j["rc"] == 0 and j["iterations"] == j["ref_iterations"] and j["relH"] < 1e-6, j

@@ -85,6 +85,17 @@ def test_check_every_iteration_loop():
     assert "converged early" in r.stdout
 
 
+def test_progress_check_as_four_stream_operations():
+    """SMK_PROGRESS_FUSED=0: gradients, sums, the 64-byte copy and the snapshot as separate stream operations (the path until
+    round 6; the default is now ONE launch that also writes the pinned slot, kernels.hip: grad_pg2_fused_kernel).  Same sweep as
+    above: iteration counts and factors of tolerance-stopped runs must be the oracle's on both paths."""
+    for env in ({"SMK_PROGRESS_FUSED": "0"}, {}):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "60", "5"], capture_output=True,
+                           text=True, cwd=ROOT, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+        assert "converged early" in r.stdout
+
+
 def test_fused_hals_sweep_fails_soft(tmp_path):
     """SMK_HALS_SPIN=1 makes the grid-wide exchange of the fused W sweep give up at once (what would happen if a
     workgroup could not be resident): the run is repeated from the initial factors on the one-launch-per-column

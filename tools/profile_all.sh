@@ -6,6 +6,7 @@
 #   bench      the bench lines of the round (C4 default, C3, C2, the sparse workloads, the checked variants, --api-path)
 #   tables     rocprofv3 --kernel-trace --stats kernel tables (C4 whole, C3, C2, s_1m, s_reuters)
 #   traffic    separate --pmc FETCH_SIZE / WRITE_SIZE passes -> hbm_traffic.json entries (C4, C3, s_1m)
+#   mfma       MFMA utilisation from counters -> mfma_util.json (C4, C3, C2)
 #   suite      pytest -m gpu
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -74,8 +75,9 @@ bench)
   $B --workload c4 --check-every-iteration 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c4_checked.json
   $B --workload c3 --steps 20 --warmup 3 --check-every-iteration 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c3_checked.json
   $B --workload c2 --steps 200 --warmup 20 --check-every-iteration 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c2_checked.json
+  $B --workload s_reuters --steps 200 --warmup 20 --check-every-iteration 2>/dev/null | tail -1 > $OUT/${TAG}_bench_s_reuters_checked.json
   for n in 2 4 8; do $B --emulate-world $n 2>/dev/null | tail -1 > $OUT/${TAG}_bench_c4_emulate$n.json; done
-  for w in c2 c3; do python3 bench.py --api-path --workload $w 2>/dev/null | tail -1 > $OUT/${TAG}_bench_${w}_api_path.json; done
+  for w in c2 c3 c4s; do python3 bench.py --no-cpu-baseline --api-path --workload $w 2>/dev/null | tail -1 > $OUT/${TAG}_bench_${w}_api_path.json; done
   ;;
 tables)
   kt c4full_bpp_f32 $B --workload c4 --steps 5 --warmup 2
@@ -98,6 +100,20 @@ traffic)
   python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_c3_fetch.db $OUT/pmc_c3_write.db bigprod_kernel c3_n1 $OUT/hbm_traffic.json > /dev/null
   python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_s_1m_fetch.db $OUT/pmc_s_1m_write.db spmm_ s_1m_n1 $OUT/hbm_traffic.json > /dev/null
   rm -f $OUT/pmc_*.db $OUT/pmc_*.log
+  ;;
+mfma)
+  # MFMA utilisation from counters (north_star asks for it by name): one --pmc pass per workload -> mfma_util.json, keyed to bigprod.hip
+  cp $ROOT/profiles/mfma_util.json $OUT/mfma_util.json 2>/dev/null
+  mf() {  # name, steps, workload, kernel needle, key
+    local name=$1 steps=$2 wl=$3 needle=$4 key=$5
+    timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_$name -o x -- python3 $ROOT/bench.py --no-cpu-baseline --workload $wl --steps $steps --warmup 2 > $OUT/pmc_${name}.log 2>&1
+    local DB=$(find $OUT/pmc_$name -name '*.db' | head -1)
+    [ -n "$DB" ] && python3 $ROOT/tools/pmc_mfma.py "$DB" "$needle" $key $OUT/mfma_util.json > $OUT/${TAG}_mfma_${name}.txt
+    rm -rf $OUT/pmc_$name $OUT/pmc_${name}.log
+  }
+  mf c4 3 c4 bigprod_f3_kernel c4_n1
+  mf c3 10 c3 "bigprod_kernel<" c3_n1
+  mf c2 50 c2 bigprod_f3 c2_n1
   ;;
 suite)
   cd $ROOT
