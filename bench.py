@@ -370,11 +370,11 @@ def api_path_report(args, m, n, k, alg, storage, resident_it_s):
             "iterations": res.iteration_count, "one_call_s": t_call, "end_to_end_it_s": res.iteration_count / t_call,
             "solver_elapsed_s": res.elapsed_us * 1e-6,
             "upload_GBps": best["upload_GBps"], "upload_s": best["upload_s"],
-            "transpose": "inside upload_s (one device pass after the last chunk in mode 0; per column block in modes 1 / 2)",
+            "transpose": "inside upload_s (one device pass after the last chunk)",
             "pieces": pieces, "resident_it_s": resident_it_s,
             "upload_in_iterations_at_resident_rate": best["upload_s"] * resident_it_s if n_use == n else None,
             "host_copy_generated_in_s": t_gen,
-            "upload_mode": os.environ.get("SMK_UPLOAD_MODE", "0") + " (0: hipMemcpy2DAsync from the caller's pageable buffer, chunk by chunk; 1: pinned staging with host threads; 2: hipHostRegister per chunk)"}
+            "upload": "hipMemcpy2DAsync from the caller's pageable buffer, 64 MB chunks, conversion per chunk (smk_matrix_upload_f64)"}
 
 
 def per_rank_report(rank, args, k, windows, ms0, c0, ms1, c1, msc, cc, msx=0.0, cx=0, mscal=0.0, ccal=0):

@@ -253,10 +253,11 @@ int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, 
                     PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,
                     int flag_slot, hipStream_t st);
 // the same + the snapshot of (W', H, W'W) in the gradient launch, and the totals written to `host_out` (pinned host memory, 8
-// doubles) by the summing launch as well: two launches, no copy packet, per checked iteration.  snap may be NULL.
+// doubles) by the summing launch as well: two launches, no copy packet, per checked iteration.  snap may be NULL.  skip1: the
+// projected-gradient sum of side 1 is known to be zero (BPP: the gradient is the NNLS's own dual), only its snapshot is taken.
 int launch_grad_pg2_fused(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,
                           PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,
-                          int flag_slot, double* snap, double* host_out, hipStream_t st);
+                          int flag_slot, double* snap, double* host_out, hipStream_t st, int skip1 = 0);
 // projected-gradient sum from an existing gradient array
 int launch_pg_from_grad(const double* X, const double* Y, int k, i64 N, double* pg_partials, double* pg_accum,
                         int slot, hipStream_t st);

@@ -1359,14 +1359,18 @@ __global__ __launch_bounds__(256) void grad_pg2_snap_kernel(const double* __rest
                                                             const double* __restrict__ G1, double* __restrict__ part1,
                                                             int grid1, const double* __restrict__ X2, i64 N2, PartialView R2,
                                                             const double* __restrict__ G2, double* __restrict__ part2, int k,
-                                                            double* __restrict__ snap, int k2)
+                                                            double* __restrict__ snap, int k2, int skip1)
 {
     constexpr int LPC = KP / 4;
     __shared__ double sh[16];
     extern __shared__ __attribute__((aligned(16))) double gs[];      // KP * KP doubles
     const bool side1 = (int)blockIdx.x < grid1;
     const int bid = side1 ? (int)blockIdx.x : (int)blockIdx.x - grid1;
-    if (side1) grad_pg_body<KP>(X1, k, N1, R1, G1, nullptr, part1, bid, gs, sh);
+    // skip1 (BPP): the gradient of side 1 is the dual Y of the NNLS solve that produced W' (nmf_solver_bpp.hpp:362-366) -- zero on the
+    // passive set by construction and non-negative elsewhere, so its projected-gradient sum is exactly 0 and the S slabs of the
+    // right-hand side need not be read again; the workgroups of side 1 only take the snapshot
+    if (side1 && skip1) { if (threadIdx.x == 0) part1[bid] = 0.0; }
+    else if (side1) grad_pg_body<KP>(X1, k, N1, R1, G1, nullptr, part1, bid, gs, sh);
     else grad_pg_body<KP>(X2, k, N2, R2, G2, nullptr, part2, bid, gs, sh);
     if (snap) {
         // snapshot_kernel's layout: [W': N1 columns of k2 / 2 pairs][H: N2 columns][W'W = G2: KP * KP / 2 pairs]
@@ -1515,11 +1519,12 @@ int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, 
 
 int launch_grad_pg2_fused(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,
                           PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,
-                          int flag_slot, double* snap, double* host_out, hipStream_t st)
+                          int flag_slot, double* snap, double* host_out, hipStream_t st, int skip1)
 {
-    const int KPv = kp_of(k), g1 = coltile_grid(KPv, N1), g2 = coltile_grid(KPv, N2);
+    const int KPv = kp_of(k), g2 = coltile_grid(KPv, N2);
+    const int g1 = (skip1 && !snap) ? 0 : coltile_grid(KPv, N1);         // nothing to do for side 1 without a snapshot
     const int k2 = (k + 1) / 2 * 2;
-    COLTILE_LAUNCH(grad_pg2_snap_kernel, g1 + g2, X1, N1, R1, G1, part1, g1, X2, N2, R2, G2, part2, k, snap, k2);
+    COLTILE_LAUNCH(grad_pg2_snap_kernel, g1 + g2, X1, N1, R1, G1, part1, g1, X2, N2, R2, G2, part2, k, snap, k2, skip1);
     SMK_HIP(hipGetLastError());
     sum_partials2_host_kernel<<<1, 256, 0, st>>>(part1, g1, part2, g2, pg_accum, host_out, flag, flag_slot);
     SMK_HIP(hipGetLastError());

@@ -28,7 +28,6 @@
 #include <algorithm>
 #include <thread>
 #include <mutex>
-#include <condition_variable>
 
 struct smk_matrix;
 
@@ -517,65 +516,18 @@ static int matrix_make_transpose(smk_matrix* a)
 
 // ---- host fp64 -> resident matrix ---------------------------------------------------------------------------------------
 // The reference wraps the caller's buffer as a view, no copy (common/src/nmf.cpp:224-226); here A has to cross PCIe once, and this
-// is the path every reference caller takes (nmf/src/main.cpp:218-233, smallk.cpp:604-619, smallk_lib.pyx:769).  Round 6: a
-// pipeline (SMK_UPLOAD_MODE=1) beside the copy -> convert -> synchronise per chunk loop from pageable memory (mode 0, the default:
-// it measured FASTER, see below):
-//   host threads gather the chunk's columns into one of NB pinned buffers  (pageable -> pinned, SMK_UPLOAD_THREADS, default 8)
-//   -> hipMemcpyAsync to a device staging buffer on a copy stream          (full PCIe rate from pinned memory)
-//   -> convert_f64 to the stored type + the transpose of the column block  (main stream, behind an event)
-// The host only ever waits for the event of the chunk that used the same pinned buffer NB chunks earlier; the device never idles on
-// the host between chunks.  SMK_UPLOAD_MODE=0 keeps the round-5 loop (A/B), =2 pins the caller's buffer in place
-// (hipHostRegister per chunk) instead of staging through pinned buffers.  bench.py --api-path reports the rate.
-namespace {
-struct CopyPool {          // a few persistent threads for the pageable -> pinned gathers of one upload
-    std::vector<std::thread> th;
-    std::mutex mu;
-    std::condition_variable cv, cv_done;
-    std::function<void(int, int)> job;        // (worker index, worker count)
-    int gen = 0, remaining = 0;
-    bool stop = false;
-    explicit CopyPool(int n)
-    {
-        for (int t = 0; t < n; ++t)
-            th.emplace_back([this, t, n] {
-                int seen = 0;
-                for (;;) {
-                    std::function<void(int, int)> j;
-                    {
-                        std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return stop || gen != seen; });
-                        if (stop) return;
-                        seen = gen;
-                        j = job;
-                    }
-                    j(t, n);
-                    {
-                        std::lock_guard<std::mutex> lk(mu);
-                        if (--remaining == 0) cv_done.notify_all();
-                    }
-                }
-            });
-    }
-    void run(std::function<void(int, int)> j)
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        job = std::move(j);
-        remaining = (int)th.size();
-        ++gen;
-        cv.notify_all();
-        cv_done.wait(lk, [&] { return remaining == 0; });
-    }
-    ~CopyPool()
-    {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv.notify_all();
-        for (auto& t : th) t.join();
-    }
-};
-}  // namespace
-
-static int upload_f64_serial(smk_matrix* a, const double* host, int64_t ld)       // the plain loop (SMK_UPLOAD_MODE=0, default)
+// is the path every reference caller takes (nmf/src/main.cpp:218-233, smallk.cpp:604-619, smallk_lib.pyx:769).  The loop is plain:
+// hipMemcpy2DAsync straight from the caller's pageable buffer into one 64 MB device staging buffer, conversion to the stored type,
+// synchronise, next chunk; the stored transpose in one device pass at the end.  Round 6 MEASURED it before replacing it
+// (profiles/r06_upload_rates.txt, bench.py --api-path): 50 - 55 GB/s on C3's 8.6 GB, on a C4 shard's 17 GB and on C2's 0.27 GB -- the
+// runtime pins the pageable pages in place piece by piece and the per-chunk synchronisation costs nothing measurable.  Two
+// pipelined variants were built and timed against it on the same box: pinned staging buffers filled by 2 - 16 host threads with the
+// transfer and the conversion overlapped (41 GB/s whatever the thread count, 10 - 19 GB/s on C2's matrix: the pinned allocations)
+// and hipHostRegister of each chunk of the caller's buffer (52 GB/s).  Both slower, both removed.
+int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
 {
+    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; a->colnorm_max = a->rownorm_max = -1.0; }     // new contents: scale, column spread and norms are measured again on first use
+    if (!a || !host || ld < a->m || a->sparse) return SMK_BAD_PARAM;
     const size_t budget = (size_t)64 << 20;   // staging bytes
     i64 chunk = (i64)(budget / ((size_t)a->m * sizeof(double)));
     if (chunk < 1) chunk = 1;
@@ -597,103 +549,6 @@ static int upload_f64_serial(smk_matrix* a, const double* host, int64_t ld)     
     rc = matrix_make_transpose(a);
     if (rc) return rc;
     SMK_HIP(hipStreamSynchronize(g_stream));
-    return SMK_OK;
-}
-
-int smk_matrix_upload_f64(smk_matrix* a, const double* host, int64_t ld)
-{
-    if (a) { a->ascale = 0.f; a->col_spread_log2 = -1; a->colnorm_max = a->rownorm_max = -1.0; }     // new contents: scale, column spread and norms are measured again on first use
-    if (!a || !host || ld < a->m || a->sparse) return SMK_BAD_PARAM;
-    // Measured on the pool's boxes (profiles/r06_upload_rates.txt, C3's 8.6 GB of fp64): the plain loop -- hipMemcpy2DAsync straight
-    // from the caller's pageable buffer, which the runtime pins in place piece by piece -- moves 50 - 55 GB/s; staging through
-    // pinned buffers with host threads (mode 1) 41 GB/s whatever the thread count; hipHostRegister per chunk (mode 2) 52 GB/s.
-    // The plain loop is therefore the default; the other two stay selectable.
-    static const int mode = [] { const char* e = getenv("SMK_UPLOAD_MODE"); return e ? atoi(e) : 0; }();
-    const size_t col_bytes = (size_t)a->m * sizeof(double);
-    if (mode == 0 || (size_t)a->n * col_bytes < ((size_t)8 << 20)) return upload_f64_serial(a, host, ld);      // small matrices: nothing to overlap
-    constexpr int NB = 3;
-    static const size_t chunk_bytes = [] { const char* e = getenv("SMK_UPLOAD_CHUNK_MB"); return (size_t)(e && atoi(e) > 0 ? atoi(e) : 32) << 20; }();
-    static const int nthreads = [] {
-        const char* e = getenv("SMK_UPLOAD_THREADS");
-        int t = e ? atoi(e) : 8;
-        const int hw = (int)std::thread::hardware_concurrency();
-        if (hw > 0 && t > hw) t = hw;
-        return t < 1 ? 1 : t;
-    }();
-    i64 chunk = (i64)(chunk_bytes / col_bytes);
-    if (chunk < 1) chunk = 1;
-    if (chunk > a->n) chunk = a->n;
-    const size_t es = (size_t)elem_size(a->storage);
-    const bool in_place = mode == 2;
-    double* pinned[NB] = {nullptr, nullptr, nullptr};
-    double* stage[NB] = {nullptr, nullptr, nullptr};
-    hipEvent_t e_copied[NB] = {nullptr, nullptr, nullptr}, e_conv[NB] = {nullptr, nullptr, nullptr};
-    const void* registered[NB] = {nullptr, nullptr, nullptr};
-    hipStream_t st_copy = nullptr;
-    int rc = SMK_OK;
-    auto cleanup = [&]() {
-        if (st_copy) { (void)hipStreamSynchronize(st_copy); }
-        (void)hipStreamSynchronize(g_stream);
-        for (int b = 0; b < NB; ++b) {
-            if (registered[b]) (void)hipHostUnregister(const_cast<void*>(registered[b]));
-            if (pinned[b]) (void)hipHostFree(pinned[b]);
-            if (stage[b]) (void)smk::dev_free(stage[b]);
-            if (e_copied[b]) (void)hipEventDestroy(e_copied[b]);
-            if (e_conv[b]) (void)hipEventDestroy(e_conv[b]);
-        }
-        if (st_copy) (void)hipStreamDestroy(st_copy);
-    };
-#define SMK_UP(call) do { if ((call) != hipSuccess) { set_error(std::string(#call) + ": " + hipGetErrorString(hipGetLastError())); cleanup(); return SMK_DEVICE_ERROR; } } while (0)
-    SMK_UP(hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking));
-    for (int b = 0; b < NB; ++b) {
-        if (!in_place) SMK_UP(hipHostMalloc((void**)&pinned[b], (size_t)chunk * col_bytes));
-        if (dev_alloc(&stage[b], (size_t)a->m * chunk)) { cleanup(); return SMK_DEVICE_ERROR; }
-        SMK_UP(hipEventCreateWithFlags(&e_copied[b], hipEventDisableTiming));
-        SMK_UP(hipEventCreateWithFlags(&e_conv[b], hipEventDisableTiming));
-    }
-    {
-        CopyPool pool(in_place ? 0 : nthreads);
-        i64 i = 0;
-        for (i64 c = 0; c < a->n; c += chunk, ++i) {
-            const int b = (int)(i % NB);
-            const i64 nc = (a->n - c < chunk) ? (a->n - c) : chunk;
-            if (i >= NB) SMK_UP(hipEventSynchronize(e_copied[b]));      // the transfer that last read pinned[b]: long finished in steady state
-            if (i >= NB) SMK_UP(hipStreamWaitEvent(st_copy, e_conv[b], 0));   // stage[b] has been converted
-            if (in_place) {
-                if (registered[b]) { (void)hipHostUnregister(const_cast<void*>(registered[b])); registered[b] = nullptr; }
-                const double* src = host + c * ld;
-                const size_t span = ((size_t)(nc - 1) * (size_t)ld + (size_t)a->m) * sizeof(double);
-                SMK_UP(hipHostRegister(const_cast<double*>(src), span, hipHostRegisterDefault));
-                registered[b] = src;
-                SMK_UP(hipMemcpy2DAsync(stage[b], col_bytes, src, (size_t)ld * sizeof(double), col_bytes, (size_t)nc, hipMemcpyHostToDevice, st_copy));
-            } else {
-                double* dst = pinned[b];
-                const i64 m = a->m;
-                pool.run([=](int t, int nt) {
-                    // every worker takes a contiguous share of the chunk's bytes (columns are contiguous runs of m doubles)
-                    if (ld == m) {
-                        const size_t total = (size_t)nc * (size_t)m * sizeof(double);
-                        const size_t lo = total * (size_t)t / (size_t)nt / 64 * 64, hi = (t + 1 == nt) ? total : total * (size_t)(t + 1) / (size_t)nt / 64 * 64;
-                        if (hi > lo) memcpy((char*)dst + lo, (const char*)(host + c * ld) + lo, hi - lo);
-                    } else {
-                        for (i64 j = nc * t / nt; j < nc * (t + 1) / nt; ++j) memcpy(dst + j * m, host + (c + j) * ld, (size_t)m * sizeof(double));
-                    }
-                });
-                SMK_UP(hipMemcpyAsync(stage[b], pinned[b], (size_t)nc * col_bytes, hipMemcpyHostToDevice, st_copy));
-            }
-            SMK_UP(hipEventRecord(e_copied[b], st_copy));
-            SMK_UP(hipStreamWaitEvent(g_stream, e_copied[b], 0));
-            rc = launch_convert_f64(stage[b], a->m, (unsigned char*)a->A + (size_t)c * a->ldA * es, a->storage, a->ldA, a->m, nc, g_stream);
-            // the stored transpose of this column block, while the next chunk travels
-            if (!rc && !a->single)
-                rc = launch_transpose_store((const unsigned char*)a->A + (size_t)c * a->ldA * es, a->ldA, (unsigned char*)a->At + (size_t)c * es, a->ldAt,
-                                            a->storage, a->m, nc, g_stream);
-            if (rc) { cleanup(); return rc; }
-            SMK_UP(hipEventRecord(e_conv[b], g_stream));
-        }
-    }
-#undef SMK_UP
-    cleanup();          // waits for both streams
     return SMK_OK;
 }
 
@@ -2522,12 +2377,16 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
         return 0;
     }
     static const bool fused_check = [] { const char* e = getenv("SMK_PROGRESS_FUSED"); return !(e && e[0] == '0'); }();
+    // BPP: gradW is the dual of the W-side NNLS (nmf_solver_bpp.hpp:362-366), whose projected-gradient sum is exactly zero after a
+    // solve that reached optimality (a solve that did not has raised the failure flag); SMK_BPP_GRADW=1 forms HH' W' - (AH')' anyway
+    static const bool bpp_dual_is_gradient = [] { const char* e = getenv("SMK_BPP_GRADW"); return !(e && e[0] == '1'); }();
     if (fused_check && s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s) && !is_wide(s->k) && !s->w_sharded) {
         // round 6: gradients + snapshot in one launch, sums + failure flag written into the pinned slot by a second (kernels.hip:
         // grad_pg2_snap_kernel, sum_partials2_host_kernel); SMK_PROGRESS_FUSED=0: the four stream operations of before
         if (snapshot && !s->snap[b]) { rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
         rc = launch_grad_pg2_fused(s->Wt, s->m, view2(s), s->Gh, s->pg_partials, s->H, s->n, view1(s), s->Gw, s->pg_partials + s->pg_half,
-                                   s->k, s->scal, s->fail_flag, 5, snapshot ? s->snap[b] : nullptr, s->pin[b].h, s->st);
+                                   s->k, s->scal, s->fail_flag, 5, snapshot ? s->snap[b] : nullptr, s->pin[b].h, s->st,
+                                   (s->o.algorithm == SMK_ALG_BPP && bpp_dual_is_gradient) ? 1 : 0);
         if (rc) return rc;
         s->pin[b].fused = 1;
         SMK_HIP(hipEventRecord(s->pev[b], s->st));
@@ -2557,20 +2416,19 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
     return 0;
 }
 
-// How many progress checks may be in flight (round 6).  With ONE (rounds 1 - 5) the host could run only one iteration ahead of the
-// device: it enqueued iteration i + 1, then slept on the event of check i -- and a small problem's iteration (C2: 73 us) is
-// shorter than the wake-up plus the ~7 launches of the next one, so the device idled between iterations of a checked run (C2:
-// 13 700 it/s unchecked, 10 900 checked, although the check itself is two launches).  With three, the check that is waited for is
-// three iterations old: finished long ago.  Every in-flight check owns a slot (pinned result, event, snapshot); the rule is still
-// evaluated for every iteration in order and a run that converges at iteration p is restored from p's snapshot, so results and
-// iteration counts do not change.  Sharded runs keep one (their checks carry collectives); so do problems whose snapshots would
-// take more than 1 GB each.  SMK_PROGRESS_DEPTH=1..3 overrides.
+// How many progress checks may be in flight.  ONE is the default, as in rounds 1 - 5: the host enqueues iteration i + 1, then waits
+// for the event of check i.  Round 6 suspected that wait of starving the device on small problems (C2: 13 500 it/s unchecked,
+// 11 000 checked) and generalised the loop to a ring of slots (pinned result, event, snapshot per in-flight check; the rule still
+// evaluated for every iteration in order, a run that converges at p restored from p's snapshot) -- measured with two and three
+// checks in flight: 10 980 / 11 100 it/s against 11 010 (profiles/r06_progress_check.txt).  The host is not the limit; what a
+// checked iteration costs is the gradient pass itself, which re-reads the S slabs of both right-hand sides (32 MB at C2).
+// SMK_PROGRESS_DEPTH=2|3 keeps the deeper pipeline selectable; sharded runs always use one (their checks carry collectives).
 static int progress_depth(const smk_solver* s)
 {
     static const int forced = [] { const char* e = getenv("SMK_PROGRESS_DEPTH"); return e ? atoi(e) : 0; }();
-    if (is_dist(s) || s->comm) return 1;
-    if (forced >= 1) return std::min(forced, smk_solver::PROG_SLOTS - 1);
-    return snapshot_elems(s->k, s->m, s->n) * sizeof(double) > ((size_t)1 << 30) ? 1 : smk_solver::PROG_SLOTS - 1;
+    if (is_dist(s) || s->comm || forced <= 1) return 1;
+    if (snapshot_elems(s->k, s->m, s->n) * sizeof(double) > ((size_t)1 << 30)) return 1;
+    return std::min(forced, smk_solver::PROG_SLOTS - 1);
 }
 
 // wait for slot b; SMK_FAILURE when the device flagged a solver failure up to that iteration

@@ -1,5 +1,7 @@
 """Rate of smk_matrix_upload_f64 (host fp64 column-major -> resident matrix incl. the stored transpose) at a given size:
-   python3 tools/upload_rate.py m n [storage] [reps]      (SMK_UPLOAD_MODE / SMK_UPLOAD_THREADS / SMK_UPLOAD_CHUNK_MB select the variant)
+   python3 tools/upload_rate.py m n [storage] [reps]
+(profiles/r06_upload_rates.txt also lists the two pipelined variants that were built, measured slower and removed in round 6:
+ "mode 1" = pinned staging filled by host threads, "mode 2" = hipHostRegister per chunk; "mode 0" = the loop that stayed)
 Prints GB/s of host bytes per repetition; checks the uploaded matrix against the host copy on sampled columns."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,6 +29,5 @@ for r in range(reps):
         assert np.array_equal(B[:, cols], A[:, cols]), "uploaded matrix differs from the host copy"
         del B
     M.close()
-print(f"upload {m}x{n} fp64 ({m * n * 8 / 1e9:.2f} GB) -> {storage}, mode {os.environ.get('SMK_UPLOAD_MODE', '0')}, "
-      f"threads {os.environ.get('SMK_UPLOAD_THREADS', '8')}, chunk {os.environ.get('SMK_UPLOAD_CHUNK_MB', '32')} MB: "
+print(f"upload {m}x{n} fp64 ({m * n * 8 / 1e9:.2f} GB) -> {storage}: "
       + " ".join(f"{x:.1f}" for x in rates) + " GB/s", flush=True)
