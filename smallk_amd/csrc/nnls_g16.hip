@@ -12,7 +12,7 @@
 // Here a 16-lane DPP row owns a column: lane l holds components l, l + 16, ... (E = KP / 16 of them), the compact system
 // (t <= 16 rows: t <= KP / 2 always, so every solve at KP = 32 and the t <= 16 ones at KP = 64) sits one row per lane of the
 // row, and pivot-row values travel by `v_mov_b64_dpp row_newbcast` -- one instruction per fp64 value, the one DPP control
-// gfx90a+ keeps for 64-bit data.  The four columns of a wave run the same unrolled elimination (bound TB = the largest t of the
+// gfx90a+ keeps for 64-bit data.  (Default at KP = 32; KP = 64 is selectable, SMK_NNLS_G16=2 -- see g16_level below.)  The four columns of a wave run the same unrolled elimination (bound TB = the largest t of the
 // four, rounded up to 4), each on its own system, form (complement on Ginv / direct on G) and state machine.  A column of KP = 64
 // whose exchange needs t > 16 is handed over untouched to the wave-per-column kernel through a work list.
 // Arithmetic and order of operations are those of nnls_bpp_inv_kernel (same compact elimination, same accumulation order of
@@ -378,10 +378,16 @@ __global__ __launch_bounds__(NT, WGS) void nnls_bpp_g16_kernel(double* __restric
     if (failed_any && l == 0) atomicMin(fail_flag, iter_tag);
 }
 
-static bool g16_enabled()
+// SMK_NNLS_G16: 0 = off (a wave per column everywhere), 1 = k in (16, 32] (default), 2 = also k in (32, 64].
+// At KP = 64 the kernel is built and bit-identical but NOT the default: measured against the wave-per-column kernel on one box
+// (profiles/r06_nnls_g16_k64.txt) it gains 1.5 % on a C4 shard in steady state (W-side launch 460 -> 295 us), nothing on C4 whole or
+// on rank 0 of an emulated 8, and LOSES 2 % over the first twenty iterations of a cold start (every column's first exchange has
+// t ~ 26 > 16 and is handed over after a wasted first solve) and 5 - 10 % on 16384 x 8192 (three more launches per side on a
+// launch-bound iteration).
+static int g16_level()
 {
-    static const bool on = [] { const char* e = getenv("SMK_NNLS_G16"); return !(e && e[0] == '0'); }();
-    return on;
+    static const int level = [] { const char* e = getenv("SMK_NNLS_G16"); return e ? atoi(e) : 1; }();
+    return level;
 }
 
 // the four-columns-per-wave launch; returns 1 when it was issued (0: not applicable, < 0: error).  KP = 64: `defer` receives the
@@ -391,8 +397,8 @@ int launch_nnls_bpp_g16(double* X, double* Y, int k, i64 col_begin, i64 col_end,
                         unsigned long long* stats)
 {
     const int KPv = kp_of(k);
-    if (!g16_enabled() || (KPv != 32 && KPv != 64)) return 0;
-    if (KPv == 64 && !defer) return 0;
+    if (g16_level() < 1 || (KPv != 32 && KPv != 64)) return 0;
+    if (KPv == 64 && (g16_level() < 2 || !defer)) return 0;
     const i64 ncols = col_end - col_begin;
     if (ncols <= 0) return 0;
     const bool s1 = R.S == 1 && R.f64;
