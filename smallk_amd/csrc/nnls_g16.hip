@@ -62,7 +62,7 @@ __device__ __forceinline__ int g16_top(unsigned long long m) { return m ? 63 - _
 
 // S1: the right-hand side is one fp64 slab (every full-size launch: C4 whole, the sparse workloads), so the loads of the NEXT four
 // columns are issued before the current four are touched; otherwise the slabs are summed on arrival (rhs_elem's order)
-template <int KP, int NT, int WGS, bool S1>
+template <int KP, int NT, int WGS, bool S1, bool FINE = false>
 __global__ __launch_bounds__(NT, WGS) void nnls_bpp_g16_kernel(double* __restrict__ X, double* __restrict__ Y, int k, i64 N, PartialView R,
                                                           const double* __restrict__ G, const double* __restrict__ Ginv,
                                                           const int* __restrict__ status, int* __restrict__ fail_flag, int iter_tag,
@@ -285,9 +285,15 @@ __global__ __launch_bounds__(NT, WGS) void nnls_bpp_g16_kernel(double* __restric
                 for (int e = 0; e < E; ++e) base[e] = comp ? v[e] : -rhs[e];
                 const int mbase = comp ? KP * KP : 0;
                 double u;
-                if (tmax <= 4) u = compact(std::integral_constant<int, 4>{}, mbase, t, tl, sc, base, out);
+                // bounds in steps of 2 (SMK_NNLS_G16_FINE=0: steps of 4): the elimination costs ~TB^2 / 2 broadcast + FMA pairs and the
+                // bound is the LARGEST system of the four columns
+                if (FINE && tmax <= 2) u = compact(std::integral_constant<int, 2>{}, mbase, t, tl, sc, base, out);
+                else if (tmax <= 4) u = compact(std::integral_constant<int, 4>{}, mbase, t, tl, sc, base, out);
+                else if (FINE && tmax <= 6) u = compact(std::integral_constant<int, 6>{}, mbase, t, tl, sc, base, out);
                 else if (tmax <= 8) u = compact(std::integral_constant<int, 8>{}, mbase, t, tl, sc, base, out);
+                else if (FINE && tmax <= 10) u = compact(std::integral_constant<int, 10>{}, mbase, t, tl, sc, base, out);
                 else if (tmax <= 12) u = compact(std::integral_constant<int, 12>{}, mbase, t, tl, sc, base, out);
+                else if (FINE && tmax <= 14) u = compact(std::integral_constant<int, 14>{}, mbase, t, tl, sc, base, out);
                 else u = compact(std::integral_constant<int, 16>{}, mbase, t, tl, sc, base, out);
                 // u back to component positions
                 __builtin_amdgcn_wave_barrier();
@@ -418,6 +424,7 @@ int launch_nnls_bpp_g16(double* X, double* Y, int k, i64 col_begin, i64 col_end,
         };
         if (shape == 1) { if (s1) run(nnls_bpp_g16_kernel<32, 512, 4, true>, 512, 2); else run(nnls_bpp_g16_kernel<32, 512, 4, false>, 512, 2); }
         else if (shape == 2) { if (s1) run(nnls_bpp_g16_kernel<32, 512, 2, true>, 512, 1); else run(nnls_bpp_g16_kernel<32, 512, 2, false>, 512, 1); }
+        else if (shape == 3) { if (s1) run(nnls_bpp_g16_kernel<32, 256, 3, true, true>, 256, 3); else run(nnls_bpp_g16_kernel<32, 256, 3, false, true>, 256, 3); }
         else { if (s1) run(nnls_bpp_g16_kernel<32, 256, 3, true>, 256, 3); else run(nnls_bpp_g16_kernel<32, 256, 3, false>, 256, 3); }
     } else {
         constexpr int NT = 512;
