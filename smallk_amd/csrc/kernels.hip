@@ -1178,10 +1178,8 @@ __device__ __forceinline__ void tile_pack_gram(const double* tile, int ncols, i6
     constexpr int T = KP / 16;
     constexpr int LD = KP + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int dbg_skip = nsplit >> 8;                // TIMING EXPERIMENT ONLY (SMK_HALS_EP_SKIP): 1 = no fragments, 2 = no Gram partial
-    nsplit &= 255;
     // ---- fragments: chunk pair q covers operand rows 16 q .. 16 q + 15 (= columns of the factor)
-    if (!(dbg_skip & 1)) {
+    {
         const int npairs = ncols / 16;
         const i64 q0 = col0 / 16;
         const int h = lane >> 5;
@@ -1218,8 +1216,8 @@ __device__ __forceinline__ void tile_pack_gram(const double* tile, int ncols, i6
                     for (int sp = 0; sp < nsplit; ++sp) *(u32x4_t*)(out + (((q * nsplit + sp) * KT + kt) * 64 + lane) * 16) = z;
         }
     }
-    // ---- Gram partial of the tile's columns
-    if (dbg_skip & 2) return;
+    // ---- Gram partial of the tile's columns (the expensive half of this epilogue: +9.4 us in the W sweep, +6.7 us in the H sweep on
+    // C3 against +4.7 / +1.9 us for the fragments -- profiles/r06_c3_epilogues.txt)
     f64x4_t acc[T][T];
 #pragma unroll
     for (int a = 0; a < T; ++a)

@@ -411,9 +411,10 @@ int launch_nnls_bpp_g16(double* X, double* Y, int k, i64 col_begin, i64 col_end,
     const i64 nquads = (ncols + 3) / 4;
     static const int wgs = [] { const char* e = getenv("SMK_NNLS_G16_WGS"); return e ? atoi(e) : 0; }();
     if (KPv == 32) {
-        // shapes (SMK_NNLS_G16_SHAPE, A/B): 0 = 256 threads, three workgroups per CU at <= 168 registers (no spills; default),
-        // 1 = 512 threads at <= 128 registers (four waves per SIMD, 144 bytes of scratch per lane), 2 = 512 threads, two waves per SIMD
-        static const int shape = [] { const char* e = getenv("SMK_NNLS_G16_SHAPE"); return e ? atoi(e) : 0; }();
+        // shapes (SMK_NNLS_G16_SHAPE, A/B; s_1m it/s on one box): 3 = 256 threads, three workgroups per CU at <= 168 registers (no
+        // spills), elimination bounds in steps of 2 (default: 441); 0 = the same with bounds in steps of 4 (428); 1 = 512 threads at
+        // <= 128 registers (four waves per SIMD, 144 bytes of scratch per lane: 395); 2 = 512 threads, two waves per SIMD (408)
+        static const int shape = [] { const char* e = getenv("SMK_NNLS_G16_SHAPE"); return e ? atoi(e) : 3; }();
         auto run = [&](auto kern, int NT, int wg_per_cu) -> int {
             const int lds = (2 * 32 * 32 + (NT / 64) * 4 * 48) * (int)sizeof(double);
             i64 g2 = (nquads + NT / 64 - 1) / (NT / 64);
@@ -424,8 +425,8 @@ int launch_nnls_bpp_g16(double* X, double* Y, int k, i64 col_begin, i64 col_end,
         };
         if (shape == 1) { if (s1) run(nnls_bpp_g16_kernel<32, 512, 4, true>, 512, 2); else run(nnls_bpp_g16_kernel<32, 512, 4, false>, 512, 2); }
         else if (shape == 2) { if (s1) run(nnls_bpp_g16_kernel<32, 512, 2, true>, 512, 1); else run(nnls_bpp_g16_kernel<32, 512, 2, false>, 512, 1); }
-        else if (shape == 3) { if (s1) run(nnls_bpp_g16_kernel<32, 256, 3, true, true>, 256, 3); else run(nnls_bpp_g16_kernel<32, 256, 3, false, true>, 256, 3); }
-        else { if (s1) run(nnls_bpp_g16_kernel<32, 256, 3, true>, 256, 3); else run(nnls_bpp_g16_kernel<32, 256, 3, false>, 256, 3); }
+        else if (shape == 0) { if (s1) run(nnls_bpp_g16_kernel<32, 256, 3, true>, 256, 3); else run(nnls_bpp_g16_kernel<32, 256, 3, false>, 256, 3); }
+        else { if (s1) run(nnls_bpp_g16_kernel<32, 256, 3, true, true>, 256, 3); else run(nnls_bpp_g16_kernel<32, 256, 3, false, true>, 256, 3); }
     } else {
         constexpr int NT = 512;
         const int lds = (2 * 64 * 64 + (NT / 64) * 4 * 96) * (int)sizeof(double);

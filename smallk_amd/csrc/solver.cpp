@@ -2171,8 +2171,7 @@ static int solver_iteration(smk_solver* s)
                                s->ng == 1 && s->hals_ep_blocks > 0;
             HalsEpilogue epw, eph;
             if (ep_ok) {
-                static const int dbg_skip = [] { const char* e = getenv("SMK_HALS_EP_SKIP"); return e ? atoi(e) : 0; }();      // timing experiment: wrong results
-                epw.pack_out = (unsigned char*)s->packW; epw.Gp = s->gram_scratch; epw.KT = kt_of(s->k); epw.nsplit = s->nsplit | (dbg_skip << 8);
+                epw.pack_out = (unsigned char*)s->packW; epw.Gp = s->gram_scratch; epw.KT = kt_of(s->k); epw.nsplit = s->nsplit;
                 epw.max_blocks = s->hals_ep_blocks; epw.nq = round_up(s->m, 128) / 16;
                 eph = epw;
                 eph.pack_out = (unsigned char*)s->packH; eph.nq = round_up(s->n, 128) / 16;

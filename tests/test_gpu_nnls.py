@@ -157,7 +157,7 @@ def test_four_columns_per_wave_is_bit_identical_to_a_wave_per_column(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     # SMK_NNLS_G16=2: the four-columns-per-wave kernel at k in (32, 64] as well (default: k <= 32 only)
-    for tag, env in (("wave", {"SMK_NNLS_G16": "0"}), ("g16", {"SMK_NNLS_G16": "2"}), ("g16_shape1", {"SMK_NNLS_G16": "2", "SMK_NNLS_G16_SHAPE": "1"}),
+    for tag, env in (("wave", {"SMK_NNLS_G16": "0"}), ("g16", {"SMK_NNLS_G16": "2"}), ("g16_shape1", {"SMK_NNLS_G16": "2", "SMK_NNLS_G16_SHAPE": "1"}), ("g16_shape0", {"SMK_NNLS_G16_SHAPE": "0"}),
                      ("default", {})):
         f = str(tmp_path / f"{tag}.npz")
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "nnls_g16_check.py"), f], capture_output=True, text=True,

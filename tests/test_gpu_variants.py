@@ -45,7 +45,7 @@ def test_hals_w_multi_launch_fallback():
 
 
 @pytest.mark.parametrize("env", [{"SMK_NNLS_INV32": "0"}, {"SMK_GRAM_INVERSE_OLD": "1"}, {"SMK_NNLS_INV": "0"}, {"SMK_LD_SKEW": "0"},
-                                 {"SMK_NNLS_G16": "0"}, {"SMK_NNLS_G16": "2"}, {"SMK_NNLS_G16_SHAPE": "1"}, {"SMK_NNLS_G16_SHAPE": "2"}])
+                                 {"SMK_NNLS_G16": "0"}, {"SMK_NNLS_G16": "2"}, {"SMK_NNLS_G16_SHAPE": "0"}, {"SMK_NNLS_G16_SHAPE": "1"}, {"SMK_NNLS_G16_SHAPE": "2"}])
 def test_older_block_pivoting_routes_stay_selectable(env):
     """k in (16, 32] by masked elimination (the default until late round 4: now through the inverse of the Gram matrix, like
     k in (32, 64]); the 64 x 64 inversion kernel that kept its registers in scratch; no inverse at all; no column-stride skew.
