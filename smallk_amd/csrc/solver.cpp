@@ -2705,6 +2705,7 @@ int smk_solver_iterate_checked(smk_solver* s, int iters, double* last_metric)
     if (!s->inited) { rc = solver_init(s); if (rc) return rc; }
     if (s->o.algorithm == SMK_ALG_RANK2) { set_error("iterate_checked: MU / HALS / BPP"); return SMK_UNSUPPORTED; }
     const int depth = progress_depth(s), NS = smk_solver::PROG_SLOTS;
+    const int base = s->iter;                       // the very first iteration of a run initialises the estimator (PG_RATIO: pg0)
     std::deque<int> pend;                           // iterations whose check is outstanding, oldest first
     double metric = 1.0;
     for (int i = 0; i < iters; ++i) {
@@ -2715,14 +2716,14 @@ int smk_solver_iterate_checked(smk_solver* s, int iters, double* last_metric)
         rc = progress_begin(s, i % NS, true);
         if (rc) return rc;
         while ((int)pend.size() >= depth) {
-            rc = progress_end(s, pend.front() % NS, s->iter > 1 ? 1 : 0, &metric);
+            rc = progress_end(s, pend.front() % NS, base + pend.front(), &metric);
             if (rc) return rc;
             pend.pop_front();
         }
         pend.push_back(i);
     }
     while (!pend.empty()) {
-        rc = progress_end(s, pend.front() % NS, s->iter > 1 ? 1 : 0, &metric);
+        rc = progress_end(s, pend.front() % NS, base + pend.front(), &metric);
         if (rc) return rc;
         pend.pop_front();
     }

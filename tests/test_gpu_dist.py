@@ -672,5 +672,5 @@ def test_bench_two_ranks_at_the_shard_geometry_of_the_8_gpu_run(tmp_path, worklo
         assert abs(p["passes_per_step"] - 2.0) < 0.01
     # whole-job rate = steps / the MEDIAN window (each window = the max over ranks between barrier + synchronize pairs)
     w = sorted(out["windows_ms"])
-    assert abs(out["value"] - out["steps"] / (w[len(w) // 2] * 1e-3)) <= 1e-6 * out["value"]
-    assert abs(out["ms_per_step"] - w[len(w) // 2] / out["steps"]) <= 1e-9 * out["ms_per_step"] + 1e-12
+    assert abs(out["value"] - out["steps"] / (w[len(w) // 2] * 1e-3)) <= 1e-3 * out["value"]          # (windows_ms is rounded to 0.1 us)
+    assert abs(out["ms_per_step"] - w[len(w) // 2] / out["steps"]) <= 1e-3 * out["ms_per_step"]

@@ -1,0 +1,98 @@
+"""Round-6 measurement entries of the C ABI on the GPU: smk_solver_iterate_checked (the reference's check-every-iteration loop,
+common/include/nmf_solve_generic.hpp:98-121), smk_solver_kernel_name, slot 5 of smk_solver_kernel_time, smk_debug_nnls_stats."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("alg,storage,quant,k", [("BPP", "f32", 0, 16), ("BPP", "f32", 0, 24), ("HALS", "bf16", 1, 32), ("MU", "f32", 0, 8)])
+def test_checked_iterations_leave_the_same_factors_and_the_oracles_metric(gpu, alg, storage, quant, k):
+    """smk_solver_iterate_checked(n) = smk_solver_iterate(n) plus the stopping rule's metric after every iteration: the factors must
+    be bit-identical (forming gradients / snapshots must not touch the state) and the last metric must be the one the oracle's
+    NmfSolve<> restatement reports for that iteration (PG_RATIO for HALS / BPP, DELTA_FNORM for MU: smallk.cpp:581-584)."""
+    import oracle
+    m, n, iters = 900, 700, 7
+    A = oracle.fill_uniform(m, n, 71, quant=quant)
+    W0 = oracle.fill_uniform(m, k, 72)
+    H0 = oracle.fill_uniform(k, n, 73) * (2.0 / k)
+    D = gpu.DenseMatrix.from_host(A, storage=storage)
+    opts = gpu.make_options(m, n, k, alg, min_iter=iters, max_iter=iters, normalize=False)
+    s1, s2 = gpu.NmfSolver(D, opts), gpu.NmfSolver(D, opts)
+    for s in (s1, s2):
+        s.set_factors(W0, H0)
+    s1.iterate(iters)
+    assert s1.sync() == 0
+    metric = s2.iterate_checked(iters)
+    assert s2.sync() == 0
+    Wa, Ha = s1.factors(normalize=False)
+    Wb, Hb = s2.factors(normalize=False)
+    assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
+    # the oracle's metric at the same iteration: a run that checks from iteration 1 on and never stops
+    ref = oracle.nmf(A, W0, H0, alg, min_iter=1, max_iter=iters, tol=1e-300, normalize=False)
+    assert ref.iteration_count == iters
+    want = float(ref.metrics[iters - 1])
+    assert np.isfinite(want) and abs(metric - want) <= 1e-6 * max(abs(want), 1e-300), (metric, want)
+    for s in (s1, s2):
+        s.close()
+    D.close()
+
+
+def test_kernel_names_say_which_product_runs(gpu):
+    import scipy.sparse as sp
+    from smallk_amd import synthetic
+    D = gpu.DenseMatrix(2048, 1024, storage="bf16")
+    D.fill_uniform(3)
+    s = gpu.NmfSolver(D, gpu.make_options(2048, 1024, 16, "HALS"))
+    assert s.kernel_name(0).startswith("smk::bigprod_kernel variant") and s.kernel_name(1).startswith("smk::bigprod_kernel variant")
+    s.close()
+    D.close()
+    A = synthetic.term_document(3000, 2000, 60_000, seed=3)                       # ragged columns: entry-balanced segments
+    S = gpu.SparseMatrix(A.data, A.indices, A.indptr, A.shape)
+    s = gpu.NmfSolver(S, gpu.make_options(3000, 2000, 24, "BPP"))
+    assert s.kernel_name(0) == "smk::spmm_seg_kernel" and s.kernel_name(1) == "smk::spmm_seg_kernel"
+    s.close()
+    S.close()
+    Gm = synthetic.community_graph(20000, 16, 8, seed=0)[0]                        # fixed degree: the column-per-lane-group kernel
+    S = gpu.SparseMatrix(Gm.data, Gm.indices, Gm.indptr, Gm.shape)
+    s = gpu.NmfSolver(S, gpu.make_options(20000, 20000, 24, "BPP"))
+    assert s.kernel_name(0) == "smk::spmm_gather_kernel"
+    s.close()
+    S.close()
+
+
+def test_nnls_counters_and_timing_slot():
+    """SMK_NNLS_STATS=1 (own process: the switch is read once): every column of every solve is counted, the exchange histogram adds up
+    to the columns, and slot 5 of smk_solver_kernel_time sees the block-pivoting launches."""
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import ctypes as C, numpy as np, smallk_amd
+from smallk_amd import _lib as L
+smallk_amd.initialize(0)
+m, n, k, iters = 4000, 3000, 24, 4
+D = smallk_amd.DenseMatrix(m, n); D.fill_uniform(5)
+s = smallk_amd.NmfSolver(D, smallk_amd.make_options(m, n, k, "BPP", min_iter=iters, max_iter=iters))
+s.set_factors_uniform(6, 7)
+s.iterate(0); s.sync()
+out = (C.c_uint64 * 256)()
+assert L.lib().smk_debug_nnls_stats(out, 1) == 0
+s.enable_timing(True)
+import os
+s.iterate(iters); assert s.sync() == 0
+assert L.lib().smk_debug_nnls_stats(out, 0) == 0
+c = np.array(out[:], dtype=np.int64)
+assert c[178] == iters * (m + n), c[178]
+assert c[0:16].sum() == c[178]
+assert c[16:81].sum() == c[178]                     # one first solve per column
+ms, cnt = s.kernel_time(5)
+assert cnt >= 1 and ms > 0.0, (ms, cnt)
+print("stats OK", int(c[178]), round(ms, 3), cnt)
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600,
+                       env=dict(os.environ, SMK_NNLS_STATS="1", SMK_TIMING_STRIDE="1"))
+    assert r.returncode == 0 and "stats OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
