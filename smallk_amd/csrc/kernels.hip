@@ -549,28 +549,18 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
 #pragma unroll
         for (int b = 0; b < T; ++b) acc[a][b] = f64x4_t{0.0, 0.0, 0.0, 0.0};
     const int kc = lane >> 4, r16 = lane & 15;
-    // 16 columns (4 MFMA k-steps) per trip, and the loads of trip i + 1 are in flight while trip i is multiplied (round 6: the launch
-    // is one workgroup per CU -- the partials are capped -- so a wave that waits for its own loads leaves its SIMD idle; on 10^6
-    // columns at KP = 32 this kernel ran at 3 TB/s: profiles/r06_s_1m_kernel_stats.md).  Same operations in the same order.
-    auto load_trip = [&](i64 c0, double (&f)[4][T]) {
+    // 16 columns (4 MFMA k-steps) per trip: all loads of the trip are issued before its MFMAs.  (Round 6 tried keeping the loads of
+    // trip i + 1 in flight during the MFMAs of trip i -- the launch is one workgroup per CU and runs at 3 TB/s on 10^6 columns -- and
+    // measured it SLOWER: 85 -> 106 us per launch, s_1m 440 -> 431 it/s.  Reverted.)
+    for (i64 c0 = c_begin; c0 < c_end; c0 += 16) {
+        double f[4][T];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const i64 col = c0 + 4 * u + kc;
             const bool ok = col < c_end;
-            const i64 cc = ok ? col : c_begin;          // clamped, not predicated: every load of the trip is issued at once
 #pragma unroll
-            for (int t = 0; t < T; ++t) { const double v = X[cc * KP + 16 * t + r16]; f[u][t] = ok ? v : 0.0; }
+            for (int t = 0; t < T; ++t) f[u][t] = ok ? X[col * KP + 16 * t + r16] : 0.0;
         }
-    };
-    double fn[4][T];
-    if (c_begin < c_end) load_trip(c_begin, fn);
-    for (i64 c0 = c_begin; c0 < c_end; c0 += 16) {
-        double f[4][T];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int t = 0; t < T; ++t) f[u][t] = fn[u][t];
-        if (c0 + 16 < c_end) load_trip(c0 + 16, fn);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
