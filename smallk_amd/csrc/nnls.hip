@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
             if (__ballot(pj) == 0ull) continue;
             const double piv = group_bcast<GS>(a[j], j);
             if (pj && !(piv > 0.0)) failed = 1;
-            const double f = (i == j || !pj) ? 0.0 : a[j] / piv;
+            // v_rcp_f64 + two Newton steps instead of a division: half the dependent chain of the sequential pivots (round 6: C2
+            // 13 120 -> 13 310 it/s over three runs each; all 116 NNLS cases and the goldens unchanged at their tolerances)
+            const double f = (i == j || !pj) ? 0.0 : a[j] * fast_rcp(piv);
 #pragma unroll
             for (int c = j + 1; c < KP; ++c) a[c] -= f * group_bcast<GS>(a[c], j);
             b -= f * group_bcast<GS>(b, j);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
 #pragma unroll
         for (int c = 0; c < KP; ++c)
             if (c == i) d = a[c];
-        x = passive ? (b / d) : 0.0;
+        x = passive ? (b * fast_rcp(d)) : 0.0;
     };
 
     auto residual = [&]() {          // y = G x - rhs
