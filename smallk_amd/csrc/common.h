@@ -284,10 +284,26 @@ struct NnlsPack {
     i64 nq = 0;                       // 1-KiB chunk pairs of the operand (rows padded to ROW_PAD): the tail past the last column is zeroed
 };
 constexpr int NNLS_PACK_OVERFLOW = -4;
+// riders of a k <= 16 block-pivoting launch that serve the CHECKED iteration loop (round 6, solver.cpp: deferred progress check):
+//   pg_part  the launch first forms the gradient G x - r of its WARM START (= the factor and the products the previous iteration
+//            left: exactly gradH of that iteration, nmf_solver_bpp.hpp:370-371) and leaves one projected-gradient partial sum per
+//            workgroup (projected_gradient.hpp:125-171) -- the stopping rule of iteration i costs no pass of its own in iteration i + 1
+//   snap_x   the solved factor is stored a second time, compact (k2 = k rounded up to even values per column): the snapshot the
+//            driver restores when the rule fires one iteration late
+struct NnlsRiders {
+    double* pg_part = nullptr;
+    int* pg_nblk = nullptr;           // out: partials written
+    double* snap_x = nullptr;
+    int k2 = 0;
+};
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
                     int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st,
                     double* gram_partials = nullptr, int* gram_nblk = nullptr, const NnlsPack* pack = nullptr,
-                    unsigned* defer_ws = nullptr);
+                    unsigned* defer_ws = nullptr, const NnlsRiders* riders = nullptr);
+// totals of a deferred check: out / host_out [0] = 0 (side 1: BPP's dual), [1] = sum of the n partials, [flag_slot] = the failure
+// flag if it names an iteration <= tag_limit (else "none"); also copies the kk doubles of G into snap_g (may be NULL)
+int launch_pg_defer_sum(const double* part, int n, double* out, double* host_out, const int* flag, int flag_slot, int tag_limit,
+                        const double* G, double* snap_g, int kk, hipStream_t st);
 // k in (32, 64]: work list of the four-columns-per-wave kernel (nnls_g16.hip), nnls_defer_elems(ncols) unsigneds per launch
 // in flight; without it launch_nnls_bpp keeps the wave-per-column kernel for every column
 inline size_t nnls_defer_elems(i64 ncols) { return (size_t)ncols + 4; }

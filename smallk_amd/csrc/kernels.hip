@@ -19,6 +19,7 @@
 //   delta_fnorm_kernel  ProgEstGenericDeltaW::Compute    (progress_estimator_generic.hpp:58-69)
 #include "common.h"
 #include "devutil.h"
+#include <climits>
 
 namespace smk {
 
@@ -1516,6 +1517,31 @@ int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, 
     COLTILE_LAUNCH(grad_pg2_kernel, g1 + g2, X1, N1, R1, G1, part1, g1, X2, N2, R2, G2, part2, k);
     SMK_HIP(hipGetLastError());
     sum_partials2_kernel<<<2, 256, 0, st>>>(part1, g1, part2, g2, pg_accum, flag, flag_slot);
+    SMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// totals of a deferred progress check (common.h: NnlsRiders, launch_pg_defer_sum)
+__global__ __launch_bounds__(256) void pg_defer_sum_kernel(const double* __restrict__ part, int n, double* __restrict__ out,
+                                                           double* __restrict__ host_out, const int* __restrict__ flag, int flag_slot,
+                                                           int tag_limit, const double* __restrict__ G, double* __restrict__ snap_g, int kk)
+{
+    __shared__ double sh[16];
+    const double t1 = block_sum_array(part, n, sh);
+    if (snap_g)
+        for (int i = threadIdx.x; i < kk; i += blockDim.x) snap_g[i] = G[i];
+    if (threadIdx.x == 0) {
+        int fv = flag ? *flag : INT_MAX;
+        if (fv != INT_MAX && fv > tag_limit) fv = INT_MAX;        // a failure of the speculated NEXT iteration is not this check's
+        const double f = (double)fv;
+        out[0] = 0.0; out[1] = t1; out[flag_slot] = f;
+        host_out[0] = 0.0; host_out[1] = t1; host_out[flag_slot] = f;
+    }
+}
+int launch_pg_defer_sum(const double* part, int n, double* out, double* host_out, const int* flag, int flag_slot, int tag_limit,
+                        const double* G, double* snap_g, int kk, hipStream_t st)
+{
+    pg_defer_sum_kernel<<<1, 256, 0, st>>>(part, n, out, host_out, flag, flag_slot, tag_limit, G, snap_g, kk);
     SMK_HIP(hipGetLastError());
     return 0;
 }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
                                                        PartialView R, const double* __restrict__ G,
                                                        int* __restrict__ fail_flag, int iter_tag, i64 col_begin,
                                                        const int* __restrict__ skip_if, double* __restrict__ Gp, NnlsPack pk,
-                                                       unsigned long long* __restrict__ stats)
+                                                       unsigned long long* __restrict__ stats, NnlsRiders rd = NnlsRiders())
 {
     constexpr int GS = KP;
     constexpr int GPB = 256 / GS;                   // column groups per block
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
     // the factor on latency-bound problems (C2: 4.6 us + a launch gap per side).
     typedef double f64x4_acc __attribute__((ext_vector_type(4)));
     f64x4_acc gacc = {0.0, 0.0, 0.0, 0.0};
+    double pg_sum = 0.0;                            // NnlsRiders::pg_part
     // grid-stride over blocks of GPB columns: the k in (32, 64] fallback is launched with a small grid so that its
     // usual early exit costs 2 us, not one workgroup per 4 columns; every other launch covers its columns in one trip
     for (i64 vb = blockIdx.x; vb * GPB < N - col_begin; vb += gridDim.x) {
@@ -155,6 +156,13 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
     } else if (comp_ok) {
         rhs = rhs_elem(R, cc, i);
         x = X[cc * KP + i];
+    }
+    if (rd.pg_part) {                               // NnlsRiders: projected gradient of the warm start (uniform branch)
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < KP; ++c) acc += gs[c * KP + i] * group_bcast<GS>(x, c);
+        const double gq = comp_ok ? (acc - rhs) : 0.0;
+        if (col_ok && comp_ok && (gq < 0.0 || x > 0.0)) pg_sum += gq * gq;
     }
     bool passive = comp_ok && (x > 0.0);            // passive_set = (X > 0), nnls.hpp:157
     const unsigned long long kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
         X[col * KP + i] = x;
         if (Y) Y[col * KP + i] = y;
     }
+    if (rd.snap_x && col_ok && i < rd.k2) rd.snap_x[col * rd.k2 + i] = comp_ok ? x : 0.0;
     if (failed && col_ok) atomicMin(fail_flag, iter_tag);
     if constexpr (KP == 16) {
         if (Gp) {
@@ -306,6 +315,11 @@ __global__ __launch_bounds__(256, (KP == 64 ? 3 : 1)) void nnls_bpp_kernel(doubl
             }
         }
     }
+    }
+    if (rd.pg_part) {                               // one partial per workgroup, lanes and waves added in a fixed order
+        __shared__ double pg_sh[8];
+        const double t = block_sum(pg_sum, pg_sh);
+        if (threadIdx.x == 0) rd.pg_part[blockIdx.x] = t;
     }
     if constexpr (KP == 16) {
         if (Gp) {
@@ -936,9 +950,10 @@ int launch_gram_inverse(const double* G, int k, double* scratch, hipStream_t st)
 // inverse_ready != 0: launch_gram_inverse(G, ...) has already been ordered before this call.
 int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G,
                     int* fail_flag, int iter_tag, double* scratch, int inverse_ready, int num_cus, hipStream_t st,
-                    double* gram_partials, int* gram_nblk, const NnlsPack* pack, unsigned* defer_ws)
+                    double* gram_partials, int* gram_nblk, const NnlsPack* pack, unsigned* defer_ws, const NnlsRiders* riders)
 {
     if (gram_nblk) *gram_nblk = 0;
+    if (riders && riders->pg_nblk) *riders->pg_nblk = 0;
     if (nnls_uses_tiles(k)) return launch_nnls_bpp_wide(X, Y, k, col_begin, col_end, R, G, fail_flag, iter_tag, scratch, inverse_ready, num_cus, st);
     const int KPv = kp_of(k);
     const int gpb = 256 / KPv;
@@ -1020,7 +1035,12 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
     if (gram_partials && gram_nblk && KPv == 16 && col_begin == 0 && grid1 == grid && grid <= NNLS_GRAM_MAX) { gp = gram_partials; *gram_nblk = grid; }
     NnlsPack pk;                                           // only together with the Gram partials (one trip per workgroup, all columns)
     if (pack && gp) pk = *pack;
-    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid1, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if, gp, pk, skip_if ? nullptr : nnls_stats_ptr())));
+    NnlsRiders rd;                                         // only the launch that solves by itself (k <= 16) carries them
+    if (riders && !skip_if && KPv <= 16) {
+        rd = *riders;
+        if (rd.pg_nblk) *rd.pg_nblk = rd.pg_part ? grid1 : 0;
+    }
+    KP_DISPATCH(KPv, (nnls_bpp_kernel<KP><<<grid1, 256, 0, st>>>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, skip_if, gp, pk, skip_if ? nullptr : nnls_stats_ptr(), rd)));
     SMK_HIP(hipGetLastError());
     return 0;
 }

@@ -177,6 +177,10 @@ struct smk_solver {
     double* nnls_scratch = nullptr;       // BPP: inverses of W'W and HH' + path selectors (k > 32), two halves
     unsigned* nnls_defer = nullptr;       // BPP, k in (32, 64]: work list between nnls_bpp_g16_kernel and the wave-per-column kernel
     int hals_ep_blocks = 0;               // HALS, k <= 32: Gram partials the sweeps' epilogues may write into gram_scratch (0: epilogues off)
+    // deferred progress check (BPP, k <= 16; check_rides_in_nnls): the slot whose totals the NEXT H-side NNLS launch produces, the
+    // iteration tag up to which a failure counts for it, whether its snapshot is being written by this iteration's NNLS launches
+    int pg_defer_slot = -1, pg_defer_tag = 0, pg_defer_nblk = 0, iter_snap_slot = -1;
+    bool pg_defer_snap = false;
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
     bool inv_pending[2] = {false, false};
@@ -1751,6 +1755,27 @@ static int start_inverse(smk_solver* s, int side, const double* G, hipEvent_t af
     s->inv_pending[side] = true;
     return 0;
 }
+// The checked iteration loop on latency-bound BPP problems (C2: 73 us per iteration, 16 us per check): the stopping rule's gradient
+// of iteration i is gradH_i = W_i'W_i H_i - W_i'A (gradW is the W-side NNLS's dual: projected-gradient sum exactly 0) -- and those
+// three operands are precisely the system matrix, the warm start and the right-hand side of iteration i + 1's H-side NNLS launch.
+// So that launch forms the sum on its way in (NnlsRiders::pg_part), both NNLS launches of an iteration store their result a second
+// time into the snapshot slot (NnlsRiders::snap_x), and a check costs ONE small launch (the totals, written into the pinned slot)
+// instead of a gradient pass over 16 slabs of W'A, a snapshot copy and a sum.  The driver already evaluates the rule one iteration
+// late; when no further iteration follows, progress_end forms the check the old way.  SMK_PROGRESS_DEFER=0: off.
+static bool guard_applies(const smk_solver* s);
+static bool check_rides_in_nnls(const smk_solver* s)
+{
+    static const bool on = [] { const char* e = getenv("SMK_PROGRESS_DEFER"); return !(e && e[0] == '0'); }();
+    static const bool fused = [] { const char* e = getenv("SMK_PROGRESS_FUSED"); return !(e && e[0] == '0'); }();
+    static const bool dual = [] { const char* e = getenv("SMK_BPP_GRADW"); return !(e && e[0] == '1'); }();
+    static const bool guard_env = [] { const char* e = getenv("SMK_GUARD_EVERY"); return e && atoi(e) > 0; }();
+    if (!on || !fused || !dual || guard_env) return false;
+    if (s->o.algorithm != SMK_ALG_BPP || s->KP > 16 || s->o.prog_est_algorithm != SMK_PROG_PG_RATIO) return false;
+    if (is_dist(s) || s->comm || s->w_sharded) return false;
+    const i64 gpb = 256 / s->KP;
+    return (s->n + gpb - 1) / gpb <= (i64)s->pg_half;          // one partial per workgroup of the H-side launch
+}
+
 static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, PartialView R, const double* G)
 {
     if (s->inv_pending[side]) {
@@ -1788,8 +1813,34 @@ static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, Partial
         else { if (te0) (void)hipEventDestroy(te0); te0 = te1 = nullptr; }
     }
     struct Stamp { smk_solver* s; hipEvent_t a, b; ~Stamp() { if (a) { (void)hipEventRecord(b, s->st); s->ev[5].push_back({a, b, 1}); } } } stamp{s, te0, te1};
+    // riders of the checked loop (check_rides_in_nnls): the previous iteration's projected-gradient sum, this iteration's snapshot
+    NnlsRiders rd;
+    bool riders = false;
+    const int k2 = (s->k + 1) / 2 * 2;
+    if (c0 == 0 && c1 == N && (X == s->H || X == s->Wt) && (s->pg_defer_slot >= 0 || s->iter_snap_slot >= 0) && check_rides_in_nnls(s)) {
+        if (side == 0 && s->pg_defer_slot >= 0) { rd.pg_part = s->pg_partials + s->pg_half; rd.pg_nblk = &s->pg_defer_nblk; riders = true; }
+        if (s->iter_snap_slot >= 0) {
+            const int b = s->iter_snap_slot;
+            if (!s->snap[b]) { const int arc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (arc) return arc; }
+            rd.snap_x = s->snap[b] + (side == 0 ? (size_t)s->m * k2 : 0);        // snapshot_kernel's layout: [W'][H][W'W]
+            rd.k2 = k2;
+            riders = true;
+        }
+    }
     const int rc = launch_nnls_bpp(X, nullptr, s->k, c0, c1, R, G, s->fail_flag, s->iter, inv_scratch(s, side), s->inv_done[side] ? 1 : 0, g_cus, s->st,
-                                   want ? s->gram_scratch : nullptr, want ? &s->nnls_gram_nblk[side] : nullptr, pack ? &pk : nullptr, s->nnls_defer);
+                                   want ? s->gram_scratch : nullptr, want ? &s->nnls_gram_nblk[side] : nullptr, pack ? &pk : nullptr, s->nnls_defer,
+                                   riders ? &rd : nullptr);
+    if (!rc && rd.pg_part) {
+        // right behind the launch: the totals of the deferred check (and W'W of the checked iteration, still in place) into its slot
+        if (s->pg_defer_nblk <= 0) { set_error("the deferred progress check was not carried by the NNLS launch"); return SMK_FAILURE; }
+        const int b = s->pg_defer_slot;
+        double* snap_g = s->pg_defer_snap ? s->snap[b] + (size_t)(s->m + s->n) * k2 : nullptr;
+        const int src = launch_pg_defer_sum(rd.pg_part, s->pg_defer_nblk, s->scal, s->pin[b].h, s->fail_flag, 5, s->pg_defer_tag, s->Gw, snap_g,
+                                            s->KP * s->KP, s->st);
+        if (src) return src;
+        SMK_HIP(hipEventRecord(s->pev[b], s->st));
+        s->pg_defer_slot = -1;
+    }
     if (!rc && (X == s->H || X == s->Wt)) {
         s->from_nnls[fx] = c0 == 0 && c1 == N;
         s->nnls_packed[fx] = pack && s->nnls_gram_nblk[side] > 0;
@@ -2124,6 +2175,7 @@ static int solver_init(smk_solver* s)
     s->from_nnls[0] = s->from_nnls[1] = false;
     s->nnls_packed[0] = s->nnls_packed[1] = false;
     s->tail_nblk[0] = s->tail_nblk[1] = 0;
+    s->pg_defer_slot = s->iter_snap_slot = -1;
     if (s->o.algorithm == SMK_ALG_HALS) {
         rc = gram_h(s);  if (rc) return rc;
         rc = prod2(s);   if (rc) return rc;
@@ -2355,7 +2407,7 @@ static int progress_prealloc(smk_solver* s)
     return 0;
 }
 
-static int progress_begin(smk_solver* s, int b, bool snapshot)
+static int progress_begin(smk_solver* s, int b, bool snapshot, bool allow_defer = true)
 {
     if (!s->pin) {
         SMK_HIP(hipHostMalloc((void**)&s->pin, smk_solver::PROG_SLOTS * sizeof(smk_solver::ProgSlot)));
@@ -2363,6 +2415,15 @@ static int progress_begin(smk_solver* s, int b, bool snapshot)
     }
     int rc = wait_r2(s);
     if (rc) return rc;
+    // deferred (check_rides_in_nnls): nothing is enqueued now -- the next H-side NNLS launch forms the sum; a snapshot can be
+    // promised only if this iteration's NNLS launches have been writing it (iter_snap_slot)
+    if (allow_defer && s->pg_defer_slot < 0 && (!snapshot || s->iter_snap_slot == b) && check_rides_in_nnls(s)) {
+        s->pg_defer_slot = b;
+        s->pg_defer_snap = snapshot;
+        s->pg_defer_tag = s->iter - 1;              // the iteration just enqueued
+        s->pin[b].fused = 1;
+        return 0;
+    }
     if (s->o.algorithm == SMK_ALG_RANK2 && s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s)) {
         // one launch: both gradient sums, the failure flag and the snapshot (rank2.hip)
         if (snapshot && !s->snap[b]) { rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
@@ -2434,6 +2495,11 @@ static int progress_depth(const smk_solver* s)
 // wait for slot b; SMK_FAILURE when the device flagged a solver failure up to that iteration
 static int progress_end(smk_solver* s, int b, int iter_index, double* metric)
 {
+    if (s->pg_defer_slot == b) {                    // no further iteration was enqueued: the check is formed the direct way now
+        s->pg_defer_slot = -1;
+        const int frc = progress_begin(s, b, false, false);
+        if (frc) return frc;
+    }
     SMK_HIP(hipEventSynchronize(s->pev[b]));
     if (s->pin[b].fused == 2) {
         const int nb = rank2_progress_blocks(s->m, s->n);
@@ -2709,11 +2775,14 @@ int smk_solver_iterate_checked(smk_solver* s, int iters, double* last_metric)
     std::deque<int> pend;                           // iterations whose check is outstanding, oldest first
     double metric = 1.0;
     for (int i = 0; i < iters; ++i) {
+        s->iter_snap_slot = check_rides_in_nnls(s) ? i % NS : -1;      // this iteration's NNLS launches also write its snapshot
         rc = solver_iteration(s);
+        s->iter_snap_slot = rc ? -1 : s->iter_snap_slot;
         if (rc) return rc;
         rc = guard_step(s);
-        if (rc) return rc;
+        if (rc) { s->iter_snap_slot = -1; return rc; }
         rc = progress_begin(s, i % NS, true);
+        s->iter_snap_slot = -1;
         if (rc) return rc;
         while ((int)pend.size() >= depth) {
             rc = progress_end(s, pend.front() % NS, base + pend.front(), &metric);
@@ -2931,10 +3000,12 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
             return 0;
         };
         for (iter = 0; iter < o.max_iter; ++iter) {
+            // (an iteration whose check will want a snapshot lets its NNLS launches write it: check_rides_in_nnls)
+            s->iter_snap_slot = (!sync_mode && iter >= o.min_iter && check_rides_in_nnls(s)) ? iter % NS : -1;
             rc = solver_iteration(s);
-            if (rc) { result = rc; goto done; }
+            if (rc) { s->iter_snap_slot = -1; result = rc; goto done; }
             rc = guard_step(s);
-            if (rc) { result = rc; goto done; }
+            if (rc) { s->iter_snap_slot = -1; result = rc; goto done; }
             const bool check = (iter == 0) || (iter >= o.min_iter);
             if (sync_mode) {
                 if (!check) { if (o.verbose) printf("%d:\tprogress metric: \t(min_iter)\n", iter + 1); continue; }
@@ -2948,8 +3019,10 @@ static int solver_run_once(smk_solver* s, smk_stats* stats)
             }
             if (check) {
                 rc = progress_begin(s, iter % NS, iter >= o.min_iter);
+                s->iter_snap_slot = -1;
                 if (rc) { result = rc; goto done; }
             }
+            s->iter_snap_slot = -1;
             // the oldest outstanding checks, once `depth` of them are in flight (depth 1: the check of the previous iteration,
             // as in rounds 1 - 5); an unchecked iteration (0 < iter < min_iter) leaves nothing behind, as before
             while (!pend.empty() && ((int)pend.size() >= depth || !check)) {
