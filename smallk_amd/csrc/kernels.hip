@@ -562,26 +562,33 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
 #pragma unroll
             for (int t = 0; t < T; ++t) f[u][t] = ok ? X[col * KP + 16 * t + r16] : 0.0;
         }
+        // only the tile blocks on and above the diagonal (round 6): block (b, a) is the transpose of block (a, b) -- the same products
+        // in the same order, bit for bit -- and the fp64 matrix instructions are what this kernel waits for (3 of 4 at KP = 32, 10
+        // of 16 at KP = 64)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int a = 0; a < T; ++a)
 #pragma unroll
-                for (int b = 0; b < T; ++b)
+                for (int b = a; b < T; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[u][a], f[u][b], acc[a][b], 0, 0, 0);
     }
-    // deterministic in-block sum of the 4 waves
+    // deterministic in-block sum of the 4 waves (the blocks below the diagonal are filled from their mirror images)
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int a = 0; a < T; ++a)
 #pragma unroll
-                for (int b = 0; b < T; ++b)
+                for (int b = a; b < T; ++b)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * a + kc + 4 * r, colm = 16 * b + r16;
                         const int idx = colm * KP + row;
                         red[idx] = (w == 0) ? acc[a][b][r] : red[idx] + acc[a][b][r];
+                        if (a != b) {
+                            const int idm = row * KP + colm;
+                            red[idm] = (w == 0) ? acc[a][b][r] : red[idm] + acc[a][b][r];
+                        }
                     }
         }
         __syncthreads();
