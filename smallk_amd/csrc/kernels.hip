@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const double* __restrict
 #pragma unroll
             for (int a = 0; a < T; ++a)
 #pragma unroll
-                for (int b = 0; b < T; ++b)
+                for (int b = a; b < T; ++b)         // upper blocks only (gram_mfma_kernel's note)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[u][a], f[u][b], acc[a][b], 0, 0, 0);
     }
     // ---- fragments of the same columns: chunk pair q covers rows 16 q .. 16 q + 15 of the operand (= columns of X)
@@ -726,18 +726,22 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const double* __restrict
                 }
             }
     }
-    // ---- deterministic in-block sum of the 4 waves, then the last workgroup sums the blocks in order
+    // ---- deterministic in-block sum of the 4 waves (blocks below the diagonal from their mirror images)
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int a = 0; a < T; ++a)
 #pragma unroll
-                for (int b = 0; b < T; ++b)
+                for (int b = a; b < T; ++b)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * a + kc + 4 * r, colm = 16 * b + r16;
                         const int idx = colm * KP + row;
                         red[idx] = (w == 0) ? acc[a][b][r] : red[idx] + acc[a][b][r];
+                        if (a != b) {
+                            const int idm = row * KP + colm;
+                            red[idm] = (w == 0) ? acc[a][b][r] : red[idm] + acc[a][b][r];
+                        }
                     }
         }
         __syncthreads();
@@ -1242,19 +1246,23 @@ __device__ __forceinline__ void tile_pack_gram(const double* tile, int ncols, i6
 #pragma unroll
         for (int a = 0; a < T; ++a)
 #pragma unroll
-            for (int b = 0; b < T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], acc[a][b], 0, 0, 0);
+            for (int b = a; b < T; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], acc[a][b], 0, 0, 0);   // upper blocks only (gram_mfma_kernel's note)
     }
     for (int w = 0; w < nwaves; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int a = 0; a < T; ++a)
 #pragma unroll
-                for (int b = 0; b < T; ++b)
+                for (int b = a; b < T; ++b)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * a + kc + 4 * r, colm = 16 * b + r16;
                         const int idx = colm * KP + row;
                         red[idx] = (w == 0) ? acc[a][b][r] : red[idx] + acc[a][b][r];
+                        if (a != b) {
+                            const int idm = row * KP + colm;
+                            red[idm] = (w == 0) ? acc[a][b][r] : red[idm] + acc[a][b][r];
+                        }
                     }
         }
         __syncthreads();
