@@ -79,6 +79,28 @@ from bench_launch import (_hb, beat, lim, launch, rccl_choices, rccl_env_default
 
 
 def cpu_baseline(m, n, k, alg, quant, budget_s=20.0, data="uniform"):
+    """cpu_baseline_at() at 16 threads (the oracle's default; the reference's sample runs use 8, pages_smallkAPI.rst:58-92) and, on a
+    host with more hardware threads, at min(threads, 64) as well -- the faster of the two is reported, both are listed: `cores` is
+    what the reported number actually used (round 6: the pool's boxes have 256 hardware threads)."""
+    import oracle
+    tried = {}
+    counts = [min(os.cpu_count() or 1, 16)]
+    if (os.cpu_count() or 1) >= 32 and not os.environ.get("ORACLE_THREADS"):
+        counts.append(min(os.cpu_count(), 64))
+    best = None
+    for t in counts:
+        if not os.environ.get("ORACLE_THREADS"):
+            oracle.set_num_threads(t)
+        r = cpu_baseline_at(m, n, k, alg, quant, budget_s / len(counts), data)
+        tried[str(r["cores"])] = r["value"]
+        if best is None or r["value"] > best["value"]:
+            best = r
+    best["thread_counts_tried_it_s"] = tried
+    oracle.set_num_threads(counts[0])
+    return best
+
+
+def cpu_baseline_at(m, n, k, alg, quant, budget_s=20.0, data="uniform"):
     """The CPU oracle on a bounded sample (same k, algorithm, dtype rounding; fewer rows/cols), timed on this
     host's cores, priced so that the parts add up:
 
