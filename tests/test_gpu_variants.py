@@ -85,6 +85,18 @@ def test_check_every_iteration_loop():
     assert "converged early" in r.stdout
 
 
+@pytest.mark.parametrize("env", [{"SMK_PROGRESS_DEFER": "0"}, {"SMK_PROGRESS_DEPTH": "3"}, {"SMK_BPP_GRADW": "1"}, {"SMK_HALS_EPILOGUE": "0"},
+                                 {"SMK_PROGRESS_DEFER": "0", "SMK_PROGRESS_DEPTH": "2"}])
+def test_round_6_switches_stay_selectable(env):
+    """The non-default values of round 6's switches on the randomised sweep (tolerance-stopped runs included: iteration counts and
+    factors must be the oracle's): the stopping-rule check NOT riding in the next NNLS launch, three checks in flight, BPP's W-side
+    gradient formed although it is the NNLS's dual, the HALS sweeps without their packing / Gram epilogues."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "70", "13"], capture_output=True,
+                       text=True, cwd=ROOT, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "all cases within tolerance" in r.stdout and "converged early" in r.stdout
+
+
 def test_progress_check_as_four_stream_operations():
     """SMK_PROGRESS_FUSED=0: gradients, sums, the 64-byte copy and the snapshot as separate stream operations (the path until
     round 6; the default is now ONE launch that also writes the pinned slot, kernels.hip: grad_pg2_fused_kernel).  Same sweep as
