@@ -95,10 +95,17 @@ traffic)
   pmc c3_write WRITE_SIZE $B --workload c3 --steps 10 --warmup 2
   pmc s_1m_fetch FETCH_SIZE $B --workload s_1m --steps 5 --warmup 2
   pmc s_1m_write WRITE_SIZE $B --workload s_1m --steps 5 --warmup 2
+  for w in s_reuters s_reuters_hals; do
+    pmc ${w}_fetch FETCH_SIZE $B --workload $w --steps 50 --warmup 5
+    pmc ${w}_write WRITE_SIZE $B --workload $w --steps 50 --warmup 5
+  done
   cp $ROOT/profiles/hbm_traffic.json $OUT/hbm_traffic.json 2>/dev/null
   python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_c4_fetch.db $OUT/pmc_c4_write.db bigprod_f3 c4_n1 $OUT/hbm_traffic.json > /dev/null
   python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_c3_fetch.db $OUT/pmc_c3_write.db bigprod_kernel c3_n1 $OUT/hbm_traffic.json > /dev/null
   python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_s_1m_fetch.db $OUT/pmc_s_1m_write.db spmm_ s_1m_n1 $OUT/hbm_traffic.json > /dev/null
+  # (the Reuters shape: the main gather kernel only; its long-column fix-up launch moves a few hundred KB more)
+  python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_s_reuters_fetch.db $OUT/pmc_s_reuters_write.db spmm_seg_kernel s_reuters_n1 $OUT/hbm_traffic.json > /dev/null
+  python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_s_reuters_hals_fetch.db $OUT/pmc_s_reuters_hals_write.db spmm_seg_kernel s_reuters_hals_n1 $OUT/hbm_traffic.json > /dev/null
   rm -f $OUT/pmc_*.db $OUT/pmc_*.log
   ;;
 mfma)
