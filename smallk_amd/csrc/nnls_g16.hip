@@ -18,6 +18,7 @@
 // Arithmetic and order of operations are those of nnls_bpp_inv_kernel (same compact elimination, same accumulation order of
 // Ginv r and of M[:, T] u): the results are bit-identical to that kernel's (tests/test_gpu_nnls.py compares them).
 #include "devutil.h"
+#include "nnls_masked.h"
 
 namespace smk {
 
@@ -73,7 +74,13 @@ __global__ __launch_bounds__(NT, WGS) void nnls_bpp_g16_kernel(double* __restric
     constexpr int E = KP / 16;
     constexpr int NW = NT / 64;
     typedef typename G16Mask<KP>::type mask_t;
-    if (*status == 0) return;                                   // the inverse is not usable: nnls_bpp_kernel<KP> runs instead
+    if (*status == 0) {
+        // the inverse is not usable: the masked elimination solves.  At KP = 32 with 256-thread workgroups it runs right here (the
+        // body of nnls_bpp_kernel<32>, nnls_masked.h) -- the decision is the device's, and a separate launch that returns at once
+        // in every ordinary run cost 4 - 6 us per solve (8 % of an iteration on the Reuters shape); otherwise that launch follows
+        if constexpr (KP == 32 && NT == 256) nnls_bpp_body<32>(X, Y, k, N, R, G, fail_flag, iter_tag, col_begin, nullptr, NnlsPack(), stats, NnlsRiders());
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // both matrices with PERMUTED columns: entry (r, c) at r * KP + pos(c), pos(c) = E (c mod 16) + c / 16, so that the E components
     // of a lane are adjacent (one or two ds_read_b128 per matrix row in the accumulation loops)
@@ -396,7 +403,8 @@ static int g16_level()
     return level;
 }
 
-// the four-columns-per-wave launch; returns 1 when it was issued (0: not applicable, < 0: error).  KP = 64: `defer` receives the
+// the four-columns-per-wave launch; returns 1 when it was issued, 2 when it was issued AND carries the masked-elimination fallback
+// itself (no separate fallback launch needed) (0: not applicable, < 0: error).  KP = 64: `defer` receives the
 // columns that must still be solved by nnls_bpp_inv_kernel (defer[0] = count, zeroed here; defer[1 ..] = column - col_begin)
 int launch_nnls_bpp_g16(double* X, double* Y, int k, i64 col_begin, i64 col_end, PartialView R, const double* G, const double* Ginv,
                         const int* status, int* fail_flag, int iter_tag, unsigned* defer, int num_cus, hipStream_t st,
@@ -427,6 +435,8 @@ int launch_nnls_bpp_g16(double* X, double* Y, int k, i64 col_begin, i64 col_end,
         else if (shape == 2) { if (s1) run(nnls_bpp_g16_kernel<32, 512, 2, true>, 512, 1); else run(nnls_bpp_g16_kernel<32, 512, 2, false>, 512, 1); }
         else if (shape == 0) { if (s1) run(nnls_bpp_g16_kernel<32, 256, 3, true>, 256, 3); else run(nnls_bpp_g16_kernel<32, 256, 3, false>, 256, 3); }
         else { if (s1) run(nnls_bpp_g16_kernel<32, 256, 3, true, true>, 256, 3); else run(nnls_bpp_g16_kernel<32, 256, 3, false, true>, 256, 3); }
+        SMK_HIP(hipGetLastError());
+        return (shape == 1 || shape == 2) ? 1 : 2;
     } else {
         constexpr int NT = 512;
         const int lds = (2 * 64 * 64 + (NT / 64) * 4 * 96) * (int)sizeof(double);
