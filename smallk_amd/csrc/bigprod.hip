@@ -785,6 +785,25 @@ static __device__ __forceinline__ void gram_reduce_tail(const double* __restrict
     }
 }
 
+// the totals of a deferred progress check (pg_defer_sum_kernel's arithmetic: block_sum_array over 256 threads)
+static __device__ __forceinline__ void check_totals_tail(const BigProdPlan::TailCheck& tc, double* __restrict__ sh /* >= 16 doubles */)
+{
+    const double t1 = block_sum_array(tc.part, tc.n, sh);
+    if (tc.snap_g)
+        for (int i = threadIdx.x; i < tc.kk; i += blockDim.x) tc.snap_g[i] = tc.G[i];
+    if (threadIdx.x == 0) {
+        int fv = tc.flag ? *tc.flag : INT_MAX;
+        if (fv != INT_MAX && fv > tc.tag_limit) fv = INT_MAX;     // a failure of the speculated NEXT iteration is not this check's
+        const double f = (double)fv;
+        tc.out[0] = 0.0; tc.out[1] = t1; tc.out[tc.flag_slot] = f;
+        tc.host_out[0] = 0.0; tc.host_out[1] = t1; tc.host_out[tc.flag_slot] = f;
+        if (tc.tag != 0.0) {                 // the host polls the slot: the tag goes out last
+            __threadfence_system();
+            __hip_atomic_store(&tc.host_out[7], tc.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <int KT, int MB, int NSTAGE, int NWL, int FOLD, int WPS, int NS, int FMT, int TAIL = 0>
 __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                                         const unsigned char* __restrict__ Xp,
@@ -792,7 +811,7 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
                                                                         i64 tiles, i64 ncols_pad, int S, int logS, int pstride,
                                                                         const double* __restrict__ oscale, float ascale, int accum,
                                                                         const double* __restrict__ tail_gp, int tail_nblk,
-                                                                        double* __restrict__ tail_g)
+                                                                        double* __restrict__ tail_g, BigProdPlan::TailCheck tc)
 {
     using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -805,7 +824,10 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
         // (measured on C2, 512 product workgroups = every slot of the chip: reducers first 25.8 us per launch, reducers last 26.3,
         // the reduction spread over the first 256 product workgroups behind their first stage loads 26.9; without a tail 24.9)
         if (bid < 16) { gram_reduce_tail(tail_gp, tail_nblk, tail_g, bid, (double*)smem); return; }
-        bid -= 16;
+        // a deferred progress check rides along: eight more workgroups (the tile mapping keeps its XCDs), the first one adds up
+        const int ntail = tc.part ? 24 : 16;
+        if (bid < ntail) { if (bid == 16) check_totals_tail(tc, (double*)smem); return; }
+        bid -= ntail;
     }
     const int xcd = bid & 7;
     const i64 grp = bid >> 3;
@@ -1409,10 +1431,10 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
         } else {
             grid = pl.tiles * pl.S;
         }
-        if (TAIL == 1) grid += 16;
+        if (TAIL == 1) grid += pl.tail_check.part ? 24 : 16;
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
                                                       pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale, pl.accum | (pl.temporal ? 2 : 0),
-                                                      pl.tail_gp, pl.tail_nblk, pl.tail_g);
+                                                      pl.tail_gp, pl.tail_nblk, pl.tail_g, pl.tail_check);
         SMK_HIP(hipGetLastError());
         return 0;
     }

@@ -172,6 +172,19 @@ struct BigProdPlan {
     const double* tail_gp = nullptr;
     int tail_nblk = 0;
     double* tail_g = nullptr;
+    // ... and one more forms the totals of a deferred progress check (solver.cpp: check_rides_in_nnls; what launch_pg_defer_sum does
+    // as a launch of its own): the sum of `n` per-workgroup projected-gradient sums, the failure flag and W'W of the checked
+    // iteration, written to the device scalars, the pinned slot and the snapshot
+    struct TailCheck {
+        const double* part = nullptr;
+        int n = 0, flag_slot = 0, tag_limit = 0, kk = 0;
+        double* out = nullptr;
+        double* host_out = nullptr;
+        const int* flag = nullptr;
+        const double* G = nullptr;
+        double* snap_g = nullptr;
+        double tag = 0.0;            // != 0: stored into host_out[7] last, system scope (the host polls the slot instead of an event)
+    } tail_check;
 };
 bool bigprod_supports_tail(const BigProdPlan& pl);
 BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus);
@@ -257,7 +270,8 @@ int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, 
 // projected-gradient sum of side 1 is known to be zero (BPP: the gradient is the NNLS's own dual), only its snapshot is taken.
 int launch_grad_pg2_fused(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,
                           PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,
-                          int flag_slot, double* snap, double* host_out, hipStream_t st, int skip1 = 0);
+                          int flag_slot, double* snap, double* host_out, hipStream_t st, int skip1 = 0, double host_tag = 0.0);
+// (host_tag != 0: stored into host_out[7] behind the totals, system scope -- the host polls the slot instead of waiting for an event)
 // projected-gradient sum from an existing gradient array
 int launch_pg_from_grad(const double* X, const double* Y, int k, i64 N, double* pg_partials, double* pg_accum,
                         int slot, hipStream_t st);
@@ -303,7 +317,7 @@ int launch_nnls_bpp(double* X, double* Y, int k, i64 col_begin, i64 col_end, Par
 // totals of a deferred check: out / host_out [0] = 0 (side 1: BPP's dual), [1] = sum of the n partials, [flag_slot] = the failure
 // flag if it names an iteration <= tag_limit (else "none"); also copies the kk doubles of G into snap_g (may be NULL)
 int launch_pg_defer_sum(const double* part, int n, double* out, double* host_out, const int* flag, int flag_slot, int tag_limit,
-                        const double* G, double* snap_g, int kk, hipStream_t st);
+                        const double* G, double* snap_g, int kk, hipStream_t st, double host_tag = 0.0);
 // k in (32, 64]: work list of the four-columns-per-wave kernel (nnls_g16.hip), nnls_defer_elems(ncols) unsigneds per launch
 // in flight; without it launch_nnls_bpp keeps the wave-per-column kernel for every column
 inline size_t nnls_defer_elems(i64 ncols) { return (size_t)ncols + 4; }

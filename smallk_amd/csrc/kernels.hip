@@ -1415,7 +1415,7 @@ __global__ __launch_bounds__(256) void grad_pg2_snap_kernel(const double* __rest
 // sum_partials2_kernel in ONE workgroup that also writes the result where the host reads it (pinned memory: no copy packet)
 __global__ __launch_bounds__(256) void sum_partials2_host_kernel(const double* __restrict__ p0, int n0, const double* __restrict__ p1, int n1,
                                                                  double* __restrict__ out, double* __restrict__ host_out,
-                                                                 const int* __restrict__ flag, int flag_slot)
+                                                                 const int* __restrict__ flag, int flag_slot, double host_tag)
 {
     __shared__ double sh[16];
     const double t0 = block_sum_array(p0, n0, sh);
@@ -1424,6 +1424,10 @@ __global__ __launch_bounds__(256) void sum_partials2_host_kernel(const double* _
         const double f = flag ? (double)*flag : 0.0;
         out[0] = t0; out[1] = t1; out[flag_slot] = f;
         host_out[0] = t0; host_out[1] = t1; host_out[flag_slot] = f;
+        if (host_tag != 0.0) {               // the host polls the slot: the tag goes out last
+            __threadfence_system();
+            __hip_atomic_store(&host_out[7], host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1539,7 +1543,8 @@ int launch_grad_pg2(const double* X1, i64 N1, PartialView R1, const double* G1, 
 // totals of a deferred progress check (common.h: NnlsRiders, launch_pg_defer_sum)
 __global__ __launch_bounds__(256) void pg_defer_sum_kernel(const double* __restrict__ part, int n, double* __restrict__ out,
                                                            double* __restrict__ host_out, const int* __restrict__ flag, int flag_slot,
-                                                           int tag_limit, const double* __restrict__ G, double* __restrict__ snap_g, int kk)
+                                                           int tag_limit, const double* __restrict__ G, double* __restrict__ snap_g, int kk,
+                                                           double host_tag)
 {
     __shared__ double sh[16];
     const double t1 = block_sum_array(part, n, sh);
@@ -1551,26 +1556,30 @@ __global__ __launch_bounds__(256) void pg_defer_sum_kernel(const double* __restr
         const double f = (double)fv;
         out[0] = 0.0; out[1] = t1; out[flag_slot] = f;
         host_out[0] = 0.0; host_out[1] = t1; host_out[flag_slot] = f;
+        if (host_tag != 0.0) {               // the host polls the slot: the tag goes out last
+            __threadfence_system();
+            __hip_atomic_store(&host_out[7], host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 int launch_pg_defer_sum(const double* part, int n, double* out, double* host_out, const int* flag, int flag_slot, int tag_limit,
-                        const double* G, double* snap_g, int kk, hipStream_t st)
+                        const double* G, double* snap_g, int kk, hipStream_t st, double host_tag)
 {
-    pg_defer_sum_kernel<<<1, 256, 0, st>>>(part, n, out, host_out, flag, flag_slot, tag_limit, G, snap_g, kk);
+    pg_defer_sum_kernel<<<1, 256, 0, st>>>(part, n, out, host_out, flag, flag_slot, tag_limit, G, snap_g, kk, host_tag);
     SMK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_grad_pg2_fused(const double* X1, i64 N1, PartialView R1, const double* G1, double* part1, const double* X2, i64 N2,
                           PartialView R2, const double* G2, double* part2, int k, double* pg_accum, const int* flag,
-                          int flag_slot, double* snap, double* host_out, hipStream_t st, int skip1)
+                          int flag_slot, double* snap, double* host_out, hipStream_t st, int skip1, double host_tag)
 {
     const int KPv = kp_of(k), g2 = coltile_grid(KPv, N2);
     const int g1 = (skip1 && !snap) ? 0 : coltile_grid(KPv, N1);         // nothing to do for side 1 without a snapshot
     const int k2 = (k + 1) / 2 * 2;
     COLTILE_LAUNCH(grad_pg2_snap_kernel, g1 + g2, X1, N1, R1, G1, part1, g1, X2, N2, R2, G2, part2, k, snap, k2, skip1);
     SMK_HIP(hipGetLastError());
-    sum_partials2_host_kernel<<<1, 256, 0, st>>>(part1, g1, part2, g2, pg_accum, host_out, flag, flag_slot);
+    sum_partials2_host_kernel<<<1, 256, 0, st>>>(part1, g1, part2, g2, pg_accum, host_out, flag, flag_slot, host_tag);
     SMK_HIP(hipGetLastError());
     return 0;
 }

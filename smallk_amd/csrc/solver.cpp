@@ -181,6 +181,8 @@ struct smk_solver {
     // iteration tag up to which a failure counts for it, whether its snapshot is being written by this iteration's NNLS launches
     int pg_defer_slot = -1, pg_defer_tag = 0, pg_defer_nblk = 0, iter_snap_slot = -1;
     bool pg_defer_snap = false;
+    int check_route = 0;                     // how the last progress check was formed (smk_solver_kernel_name(2)): 1 own launches, 2 NNLS riders + totals launch, 3 riders + pass tail
+    int pg_totals_slot = -1;                 // >= 0: the H-side launch has left the partial sums of this slot's check; its totals are due
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
     bool inv_pending[2] = {false, false};
@@ -245,6 +247,7 @@ struct smk_solver {
     struct ProgSlot { double h[8]; int flag; int fused; };     // fused: the flag travels in h[5]
     ProgSlot* pin = nullptr;
     hipEvent_t pev[PROG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    double poll_tag[PROG_SLOTS] = {0, 0, 0, 0};      // != 0: the kernel stores this into h[7] behind the result; progress_end polls the slot (no event)
     double* snap[PROG_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     // timing
     bool timing = false;
@@ -1831,14 +1834,10 @@ static int nnls_side(smk_solver* s, int side, double* X, i64 c0, i64 c1, Partial
                                    want ? s->gram_scratch : nullptr, want ? &s->nnls_gram_nblk[side] : nullptr, pack ? &pk : nullptr, s->nnls_defer,
                                    riders ? &rd : nullptr);
     if (!rc && rd.pg_part) {
-        // right behind the launch: the totals of the deferred check (and W'W of the checked iteration, still in place) into its slot
+        // the totals of the deferred check are due: they ride in the tail of the pass that follows (prod2), or go out as a launch
+        // of their own right in front of it (check_totals)
         if (s->pg_defer_nblk <= 0) { set_error("the deferred progress check was not carried by the NNLS launch"); return SMK_FAILURE; }
-        const int b = s->pg_defer_slot;
-        double* snap_g = s->pg_defer_snap ? s->snap[b] + (size_t)(s->m + s->n) * k2 : nullptr;
-        const int src = launch_pg_defer_sum(rd.pg_part, s->pg_defer_nblk, s->scal, s->pin[b].h, s->fail_flag, 5, s->pg_defer_tag, s->Gw, snap_g,
-                                            s->KP * s->KP, s->st);
-        if (src) return src;
-        SMK_HIP(hipEventRecord(s->pev[b], s->st));
+        s->pg_totals_slot = s->pg_defer_slot;
         s->pg_defer_slot = -1;
     }
     if (!rc && (X == s->H || X == s->Wt)) {
@@ -1979,6 +1978,45 @@ static inline void take_tail(smk_solver* s, int side, BigProdPlan* pl)
     s->tail_nblk[side] = 0;
 }
 
+// The totals of a deferred progress check (nnls_side left the per-workgroup sums): W'W of the checked iteration is still in place
+// until the W-side solve of this iteration has run, so they may be formed anywhere in front of it.  pl != nullptr and the pass
+// carries a tail already: one more tail workgroup forms them (the caller records the slot's event behind the pass: returns 1);
+// otherwise a launch of their own, now.  SMK_PROGRESS_TAIL=0: always the launch.
+// The result of a check is awaited by polling its pinned slot (the kernel that writes the totals stores a tag behind them, system
+// scope) instead of an event: an event record between two launches of a 70 us iteration costs 3 - 4 us of idle stream (C2 checked:
+// 12 650 -> 13 350 it/s).  SMK_PROGRESS_POLL=0: the event.
+static bool progress_polls()
+{
+    static const bool poll = [] { const char* e = getenv("SMK_PROGRESS_POLL"); return !(e && e[0] == '0'); }();
+    return poll;
+}
+
+static int check_totals(smk_solver* s, BigProdPlan* pl)
+{
+    if (s->pg_totals_slot < 0) return 0;
+    static const bool ride = [] { const char* e = getenv("SMK_PROGRESS_TAIL"); return !(e && e[0] == '0'); }();
+    const bool poll = progress_polls();
+    const int b = s->pg_totals_slot, k2 = (s->k + 1) / 2 * 2;
+    double* snap_g = s->pg_defer_snap ? s->snap[b] + (size_t)(s->m + s->n) * k2 : nullptr;
+    const double* part = s->pg_partials + s->pg_half;
+    const double tag = poll ? (double)(s->pg_defer_tag + 2) : 0.0;
+    s->poll_tag[b] = tag;
+    if (ride && pl && pl->tail_nblk > 0) {
+        BigProdPlan::TailCheck& tc = pl->tail_check;
+        tc.part = part;  tc.n = s->pg_defer_nblk;  tc.flag_slot = 5;  tc.tag_limit = s->pg_defer_tag;  tc.kk = s->KP * s->KP;
+        tc.out = s->scal;  tc.host_out = s->pin[b].h;  tc.flag = s->fail_flag;  tc.G = s->Gw;  tc.snap_g = snap_g;  tc.tag = tag;
+        s->check_route = 3;
+        return 1;
+    }
+    s->pg_totals_slot = -1;
+    s->check_route = 2;
+    const int rc = launch_pg_defer_sum(part, s->pg_defer_nblk, s->scal, s->pin[b].h, s->fail_flag, 5, s->pg_defer_tag, s->Gw, snap_g,
+                                       s->KP * s->KP, s->st, tag);
+    if (rc) return rc;
+    if (tag == 0.0) SMK_HIP(hipEventRecord(s->pev[b], s->st));
+    return 0;
+}
+
 static int prod1(smk_solver* s)
 {
     if (s->w_sharded) return prod1_sharded(s);
@@ -2013,6 +2051,10 @@ static int prod2(smk_solver* s)
     begin_pass(s, 1);
     int rc = 0;
     const PartialView pv{s->P2, s->pl2.S, (i64)s->pl2.ncols_pad * s->kpp, s->kpp, 1};
+    if (s->pg_totals_slot >= 0 && (s->a->sparse || s->comm || s->ng != 1 || s->tail_nblk[1] <= 0)) {
+        rc = check_totals(s, nullptr);                  // no tail to ride in
+        if (rc) return rc;
+    }
     if (s->a->sparse) {
         rc = s->Hc ? timed_spmm(s, 1, s->a->colptr_t, s->a->rowidx_t, s->a->val_t, s->m, s->Hc, 2, s->P2)
                    : timed_spmm(s, 1, s->a->colptr_t, s->a->rowidx_t, s->a->val_t, s->m, s->H, s->KP, s->P2);
@@ -2039,8 +2081,14 @@ static int prod2(smk_solver* s)
         for (int g = 0; g < s->ng && !rc; ++g) {
             BigProdPlan pl = s->pg2[g];
             take_tail(s, 1, &pl);
+            const int ride = check_totals(s, &pl);
+            if (ride < 0 || ride > 1) return ride;
             rc = pl.tr ? timed_bigprod(s, 1, pl, s->a->A, s->a->ldA, xh(s->pg2[g]), s->P2 + s->pg2[g].k0)
                        : timed_bigprod(s, 1, pl, s->a->At, s->a->ldAt, xh(s->pg2[g]), s->P2 + s->pg2[g].k0);
+            if (ride == 1 && !rc) {
+                if (s->poll_tag[s->pg_totals_slot] == 0.0) SMK_HIP(hipEventRecord(s->pev[s->pg_totals_slot], s->st));
+                s->pg_totals_slot = -1;
+            }
         }
         if (rc) return rc;
         rc = wait_gh(s);
@@ -2175,7 +2223,7 @@ static int solver_init(smk_solver* s)
     s->from_nnls[0] = s->from_nnls[1] = false;
     s->nnls_packed[0] = s->nnls_packed[1] = false;
     s->tail_nblk[0] = s->tail_nblk[1] = 0;
-    s->pg_defer_slot = s->iter_snap_slot = -1;
+    s->pg_defer_slot = s->iter_snap_slot = s->pg_totals_slot = -1;
     if (s->o.algorithm == SMK_ALG_HALS) {
         rc = gram_h(s);  if (rc) return rc;
         rc = prod2(s);   if (rc) return rc;
@@ -2415,6 +2463,8 @@ static int progress_begin(smk_solver* s, int b, bool snapshot, bool allow_defer 
     }
     int rc = wait_r2(s);
     if (rc) return rc;
+    s->poll_tag[b] = 0.0;
+    s->pin[b].h[7] = 0.0;
     // deferred (check_rides_in_nnls): nothing is enqueued now -- the next H-side NNLS launch forms the sum; a snapshot can be
     // promised only if this iteration's NNLS launches have been writing it (iter_snap_slot)
     if (allow_defer && s->pg_defer_slot < 0 && (!snapshot || s->iter_snap_slot == b) && check_rides_in_nnls(s)) {
@@ -2424,6 +2474,7 @@ static int progress_begin(smk_solver* s, int b, bool snapshot, bool allow_defer 
         s->pin[b].fused = 1;
         return 0;
     }
+    s->check_route = 1;
     if (s->o.algorithm == SMK_ALG_RANK2 && s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s)) {
         // one launch: both gradient sums, the failure flag and the snapshot (rank2.hip)
         if (snapshot && !s->snap[b]) { rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
@@ -2445,12 +2496,14 @@ static int progress_begin(smk_solver* s, int b, bool snapshot, bool allow_defer 
         // round 6: gradients + snapshot in one launch, sums + failure flag written into the pinned slot by a second (kernels.hip:
         // grad_pg2_snap_kernel, sum_partials2_host_kernel); SMK_PROGRESS_FUSED=0: the four stream operations of before
         if (snapshot && !s->snap[b]) { rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
+        const double tag = progress_polls() ? (double)(s->iter + 1) : 0.0;
         rc = launch_grad_pg2_fused(s->Wt, s->m, view2(s), s->Gh, s->pg_partials, s->H, s->n, view1(s), s->Gw, s->pg_partials + s->pg_half,
                                    s->k, s->scal, s->fail_flag, 5, snapshot ? s->snap[b] : nullptr, s->pin[b].h, s->st,
-                                   (s->o.algorithm == SMK_ALG_BPP && bpp_dual_is_gradient) ? 1 : 0);
+                                   (s->o.algorithm == SMK_ALG_BPP && bpp_dual_is_gradient) ? 1 : 0, tag);
         if (rc) return rc;
         s->pin[b].fused = 1;
-        SMK_HIP(hipEventRecord(s->pev[b], s->st));
+        s->poll_tag[b] = tag;
+        if (tag == 0.0) SMK_HIP(hipEventRecord(s->pev[b], s->st));
         return 0;
     }
     if (s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s) && !is_wide(s->k)) {
@@ -2500,7 +2553,25 @@ static int progress_end(smk_solver* s, int b, int iter_index, double* metric)
         const int frc = progress_begin(s, b, false, false);
         if (frc) return frc;
     }
-    SMK_HIP(hipEventSynchronize(s->pev[b]));
+    if (s->poll_tag[b] != 0.0) {
+        // the kernel that forms the totals stores the tag behind them (system scope); the stream going idle without it is an error
+        const volatile double* tagp = &s->pin[b].h[7];
+        const double want = s->poll_tag[b];
+        for (unsigned long spins = 1; *tagp != want; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 0x3FFFF) == 0) {
+                const hipError_t q = hipStreamQuery(s->st);
+                if (q == hipErrorNotReady) continue;
+                if (q == hipSuccess && *tagp == want) break;
+                set_error(q == hipSuccess ? "the progress check's result never arrived in its pinned slot" : hipGetErrorString(q));
+                return q == hipSuccess ? SMK_FAILURE : SMK_DEVICE_ERROR;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        s->poll_tag[b] = 0.0;
+    } else {
+        SMK_HIP(hipEventSynchronize(s->pev[b]));
+    }
     if (s->pin[b].fused == 2) {
         const int nb = rank2_progress_blocks(s->m, s->n);
         const double* p = s->pin_r2[b];
@@ -3259,9 +3330,14 @@ int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* laun
 // launch_bigprod
 int smk_solver_kernel_name(const smk_solver* s, int which, char* out, int cap)
 {
-    if (!s || which < 0 || which > 1 || !out || cap < 8) return SMK_BAD_PARAM;
+    if (!s || which < 0 || which > 2 || !out || cap < 8) return SMK_BAD_PARAM;
     std::string name;
-    if (s->a->sparse) {
+    if (which == 2) {
+        static const char* const route[4] = {"none formed yet", "launches of its own behind the iteration",
+                                             "sums in the next H-side NNLS launch, totals as one launch",
+                                             "sums in the next H-side NNLS launch, totals in the tail of the pass behind it"};
+        name = route[s->check_route & 3];
+    } else if (s->a->sparse) {
         const BlockedCsc& blk = (which == 0) ? s->a->bA : s->a->bAt;
         const SegPlan& seg = (which == 0) ? s->a->segA : s->a->segAt;
         const i64 ncols = which == 0 ? s->n : s->m;

@@ -99,6 +99,42 @@ print("stats OK", int(c[178]), round(ms, 3), cnt)
     assert r.returncode == 0 and "stats OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+def test_check_totals_ride_in_the_pass_tail():
+    """C2's shape (8192 x 4096, k = 16, BPP, fp32), tolerance-stopped: by default the stopping-rule check of iteration i is formed
+    inside iteration i + 1 -- the per-workgroup sums by the H-side NNLS launch, the totals by one more tail workgroup of the pass
+    behind it (bigprod.hip: check_totals_tail), and the host polls the pinned slot for the tag stored behind the result instead of
+    waiting for an event.  SMK_PROGRESS_TAIL=0 (totals as a launch of their own), SMK_PROGRESS_POLL=0 (an event again),
+    SMK_PROGRESS_DEFER=0 (the whole check as launches behind the iteration) and SMK_SYNC_PROGRESS=1 (no speculation at all) must
+    stop at the same iteration with bit-identical factors (nmf_solve_generic.hpp:98-121)."""
+    code = r"""
+import sys, os, hashlib; sys.path.insert(0, %r)
+import numpy as np, smallk_amd as g
+g.initialize(0)
+m, n, k = 8192, 4096, 16
+D = g.DenseMatrix(m, n, storage="f32"); D.fill_planted(5, k, 0.7, 0.05)
+s = g.NmfSolver(D, g.make_options(m, n, k, "BPP", min_iter=3, max_iter=200, tol=float(sys.argv[1]), normalize=False))
+s.set_factors_uniform(6, 7)
+rc, iters, _ = s.run()
+W, H = s.factors(normalize=False)
+print("RESULT", rc, iters, hashlib.sha1(W.tobytes()).hexdigest(), hashlib.sha1(H.tobytes()).hexdigest(), "|", s.kernel_name(2))
+""" % ROOT
+    legs = [({}, "tail of the pass"), ({"SMK_PROGRESS_TAIL": "0"}, "totals as one launch"),
+            ({"SMK_PROGRESS_POLL": "0"}, "tail of the pass"), ({"SMK_PROGRESS_TAIL": "0", "SMK_PROGRESS_POLL": "0"}, "totals as one launch"),
+            ({"SMK_PROGRESS_DEFER": "0"}, "launches of its own"), ({"SMK_PROGRESS_DEFER": "0", "SMK_PROGRESS_POLL": "0"}, "launches of its own"),
+            ({"SMK_SYNC_PROGRESS": "1"}, "launches of its own")]
+    seen = []
+    for env, route in legs:
+        r = subprocess.run([sys.executable, "-c", code, "0.005"], capture_output=True, text=True, cwd=ROOT, timeout=600,
+                           env=dict(os.environ, **env))
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stdout[-1500:] + r.stderr[-1500:]
+        head, how = line[0].split("|")
+        assert route in how, (env, how)
+        seen.append(head.split()[1:])
+    assert int(seen[0][0]) == 0 and 3 < int(seen[0][1]) < 200, seen[0]          # the rule fired, not the iteration limit
+    assert all(x == seen[0] for x in seen), seen
+
+
 @pytest.mark.parametrize("flags", [["--check-every-iteration"], ["--api-path"]])
 def test_bench_flags_of_round_6_run(flags):
     """bench.py --check-every-iteration / --api-path on the smallest workload (C1: 512 x 256, k = 8, MU): one JSON line with the
