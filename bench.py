@@ -591,6 +591,8 @@ def run_rank(args):
                            ranks_report, collectives, parallelism)
         if world > 1:
             out["rccl_choices"] = rccl_choices()
+        if args.check_every_iteration:
+            out["config"]["check_route"] = solver.kernel_name(2)        # where the last check's sums were formed
         if args.workload == "c4" and args.data == "uniform" and not args.single_copy and not args.check_every_iteration:
             out["projection"] = projection_8gpu(m, n, k, alg, out["ms_per_step"] if world == 1 and args.emulate_world <= 1 else None)
         if world == 1 and not args.no_cpu_baseline:

@@ -146,6 +146,7 @@ def run_sparse(args):
     avg_ms = (ms0 + ms1) / max(c0 + c1, 1)
     achieved = 0.5 * (bytes0 + bytes1) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     kernels = sorted({solver.kernel_name(0), solver.kernel_name(1)})
+    check_route = solver.kernel_name(2) if getattr(args, "check_every_iteration", False) else None
     hbm_min = A.nnz * 12.0 + (m + n) * 8.0 * KP                 # every array touched once per launch (average of the two passes)
     peak_g, peak_src = gather_peak(8 * KP, max(m, n) * 8 * KP)
     # the stream of values + indices rides along at 12 B per gathered row: scale the pure-gather ceiling to algorithmic bytes
@@ -164,6 +165,7 @@ def run_sparse(args):
                    "state": "CSC values, W, H, Gram matrices and every product fp64",
                    "progress_checks": ("after EVERY timed iteration (smk_solver_iterate_checked)" if getattr(args, "check_every_iteration", False)
                                        else "none in the timed region; gradients formed on demand"),
+                   "check_route": check_route,
                    "generator": f"smallk_amd/synthetic.py:{gen}", "generate_s": round(t_gen, 2),
                    "longest_column": int(np.diff(A.indptr).max()), "longest_row": int(np.diff(A.tocsr().indptr).max())},
         "windows": len(windows), "windows_ms": [round(w * 1e3, 4) for w in windows], "timed_region_s": sum(windows),

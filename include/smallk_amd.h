@@ -222,8 +222,8 @@ int smk_solver_enable_timing(smk_solver* s, int on);
 int smk_solver_kernel_time(smk_solver* s, int which, double* total_ms, int* launches);
 /* name of the kernel pass `which` (0 = W'A, 1 = H*At) launches for this solver -- the streaming product and its variant, or which of the
  * sparse gather products the plan chose (spmm_seg_kernel on ragged columns, spmm_gather_kernel on fixed-degree graphs, ...): what
- * bench.py attributes `roofline.achieved` to.  which = 2: how the last stopping-rule check of this solver was formed (launches of its
- * own, or riding in the next iteration's NNLS launch and pass: DESIGN.md 6) */
+ * bench.py attributes `roofline.achieved` to.  which = 2: how the stopping-rule checks of this solver were formed so far, with counts
+ * (launches of their own, or riding in the next iteration's NNLS launch and pass: DESIGN.md 6) */
 int smk_solver_kernel_name(const smk_solver* s, int which, char* out, int cap);
 /* diagnostics of the block-pivoting kernels (csrc/nnls.hip), live only in a process started with SMK_NNLS_STATS=1 (else
  * SMK_UNSUPPORTED): 256 counters -- [0..15] exchanges per column (nnls.hpp:192-241 trips), [16..80] size of a column's first

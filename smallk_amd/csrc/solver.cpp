@@ -181,7 +181,7 @@ struct smk_solver {
     // iteration tag up to which a failure counts for it, whether its snapshot is being written by this iteration's NNLS launches
     int pg_defer_slot = -1, pg_defer_tag = 0, pg_defer_nblk = 0, iter_snap_slot = -1;
     bool pg_defer_snap = false;
-    int check_route = 0;                     // how the last progress check was formed (smk_solver_kernel_name(2)): 1 own launches, 2 NNLS riders + totals launch, 3 riders + pass tail
+    unsigned check_routes[4] = {0, 0, 0, 0}; // progress checks formed so far by route (smk_solver_kernel_name(2)): 1 own launches, 2 NNLS riders + totals launch, 3 riders + pass tail
     int pg_totals_slot = -1;                 // >= 0: the H-side launch has left the partial sums of this slot's check; its totals are due
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
@@ -2005,11 +2005,11 @@ static int check_totals(smk_solver* s, BigProdPlan* pl)
         BigProdPlan::TailCheck& tc = pl->tail_check;
         tc.part = part;  tc.n = s->pg_defer_nblk;  tc.flag_slot = 5;  tc.tag_limit = s->pg_defer_tag;  tc.kk = s->KP * s->KP;
         tc.out = s->scal;  tc.host_out = s->pin[b].h;  tc.flag = s->fail_flag;  tc.G = s->Gw;  tc.snap_g = snap_g;  tc.tag = tag;
-        s->check_route = 3;
+        ++s->check_routes[3];
         return 1;
     }
     s->pg_totals_slot = -1;
-    s->check_route = 2;
+    ++s->check_routes[2];
     const int rc = launch_pg_defer_sum(part, s->pg_defer_nblk, s->scal, s->pin[b].h, s->fail_flag, 5, s->pg_defer_tag, s->Gw, snap_g,
                                        s->KP * s->KP, s->st, tag);
     if (rc) return rc;
@@ -2474,7 +2474,7 @@ static int progress_begin(smk_solver* s, int b, bool snapshot, bool allow_defer 
         s->pin[b].fused = 1;
         return 0;
     }
-    s->check_route = 1;
+    ++s->check_routes[1];
     if (s->o.algorithm == SMK_ALG_RANK2 && s->o.prog_est_algorithm == SMK_PROG_PG_RATIO && !is_dist(s)) {
         // one launch: both gradient sums, the failure flag and the snapshot (rank2.hip)
         if (snapshot && !s->snap[b]) { rc = dev_alloc(&s->snap[b], snapshot_elems(s->k, s->m, s->n)); if (rc) return rc; }
@@ -3333,10 +3333,12 @@ int smk_solver_kernel_name(const smk_solver* s, int which, char* out, int cap)
     if (!s || which < 0 || which > 2 || !out || cap < 8) return SMK_BAD_PARAM;
     std::string name;
     if (which == 2) {
-        static const char* const route[4] = {"none formed yet", "launches of its own behind the iteration",
+        static const char* const route[4] = {"", "launches of its own behind the iteration",
                                              "sums in the next H-side NNLS launch, totals as one launch",
                                              "sums in the next H-side NNLS launch, totals in the tail of the pass behind it"};
-        name = route[s->check_route & 3];
+        for (int r = 3; r >= 1; --r)
+            if (s->check_routes[r]) name += (name.empty() ? "" : "; ") + std::to_string(s->check_routes[r]) + " x " + route[r];
+        if (name.empty()) name = "none formed yet";
     } else if (s->a->sparse) {
         const BlockedCsc& blk = (which == 0) ? s->a->bA : s->a->bAt;
         const SegPlan& seg = (which == 0) ? s->a->segA : s->a->segAt;

@@ -278,7 +278,7 @@ class NmfSolver:
         return ms.value, cnt.value
 
     def kernel_name(self, which) -> str:
-        """the kernel pass `which` (0 = W'A, 1 = H*At) launches; which = 2: how the last stopping-rule check was formed"""
+        """the kernel pass `which` (0 = W'A, 1 = H*At) launches; which = 2: how the stopping-rule checks were formed so far (counts per route)"""
         buf = C.create_string_buffer(160)
         L.check(L.lib().smk_solver_kernel_name(self._h, which, buf, 160), "smk_solver_kernel_name")
         return buf.value.decode()

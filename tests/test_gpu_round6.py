@@ -130,6 +130,8 @@ print("RESULT", rc, iters, hashlib.sha1(W.tobytes()).hexdigest(), hashlib.sha1(H
         assert r.returncode == 0 and line, r.stdout[-1500:] + r.stderr[-1500:]
         head, how = line[0].split("|")
         assert route in how, (env, how)
+        for other in ("tail of the pass", "totals as one launch"):
+            assert other == route or other not in how, (env, how)
         seen.append(head.split()[1:])
     assert int(seen[0][0]) == 0 and 3 < int(seen[0][1]) < 200, seen[0]          # the rule fired, not the iteration limit
     assert all(x == seen[0] for x in seen), seen
@@ -152,6 +154,7 @@ def test_bench_flags_of_round_6_run(flags):
     assert out["value"] > 0 and out["n_gpus"] == 1 and out["steps"] == 5
     if "--check-every-iteration" in flags:
         assert out["config"]["progress_checks"].startswith("after EVERY timed iteration")
+        assert out["config"]["check_route"] and "none formed" not in out["config"]["check_route"]
     else:
         assert out["config"]["progress_checks"].startswith("none in the timed region")
         ap = out["api_path"]
