@@ -391,8 +391,15 @@ int launch_rank2_persist(const R2PersistArgs& a, int workgroups, hipStream_t st)
 // sparse A (CSC): out[:, j] = sum_p val[p] * X[:, row[p]] over the nonzeros of column j
 // X: the gathered factor, row pitch ldx doubles (KP, or 2 for the compact copy of a rank-2 factor)
 // nnz_hint: number of stored entries (picks the lanes per column of the rank-2 kernel; <= 0: unknown)
+// `ride`: the Gram inverse the NEXT block-pivoting launch needs, formed by one more workgroup of this launch (gram_inverse.h; k in
+// (16, 64] only -- returns 1 instead of 0 when the launch carried it, so that the caller knows whether it still has to launch one)
+struct InvRide {
+    const double* G = nullptr;       // the Gram matrix, KP x KP (complete before this launch starts)
+    int k = 0;
+    double* Ginv = nullptr;          // KP x KP doubles, then the int status (launch_gram_inverse's layout)
+};
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, i64 nnz_hint, const double* X,
-                       int ldx, int k, double* P, int kpp, hipStream_t st);
+                       int ldx, int k, double* P, int kpp, hipStream_t st, const InvRide* ride = nullptr);
 
 // spmm_seg.hip: the gather product at ranks 3 .. 128, work cut by stored entries.  The plan of one CSC (A or A'): segments of
 // <= spmm_seg_len() consecutive entries = whole columns, or pieces of one long column (summed by a fix-up launch)
@@ -416,7 +423,7 @@ void free_seg_plan(SegPlan* s);
 // `pieces`: the caller's own npieces x 128 doubles for the partial sums of long columns (a solver owns one per pass, so that two
 // solvers on one matrix and different streams do not share it); nullptr: the plan's buffer (one stream at a time)
 int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, const double* X, int k, double* P, int kpp,
-                    hipStream_t st, double* pieces = nullptr);
+                    hipStream_t st, double* pieces = nullptr, const InvRide* ride = nullptr);
 
 // spmm_blocked.hip: the rank-2 gather product with the gathered factor cut into row blocks that stay in one XCD's L2.
 // A matrix regrouped by row block: block b is a CSC of its own (cp[b * (ncols + 1) + j] .. are absolute positions in ri / va)

@@ -19,6 +19,7 @@
 //   delta_fnorm_kernel  ProgEstGenericDeltaW::Compute    (progress_estimator_generic.hpp:58-69)
 #include "common.h"
 #include "devutil.h"
+#include "gram_inverse.h"
 #include <climits>
 
 namespace smk {
@@ -2016,10 +2017,19 @@ template <int KP>
 __global__ __launch_bounds__(256) void spmm_gather_kernel(const i64* __restrict__ colptr,
                                                           const unsigned* __restrict__ rowidx,
                                                           const double* __restrict__ val, i64 ncols,
-                                                          const double* __restrict__ X, double* __restrict__ P, int kpp)
+                                                          const double* __restrict__ X, double* __restrict__ P, int kpp,
+                                                          InvRide ride)
 {
     constexpr int LPC = KP / 4;
-    const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 blk = blockIdx.x;
+    if constexpr (KP == 32 || KP == 64) {
+        // workgroup 0 of a launch that carries the Gram inverse (common.h: InvRide) inverts; the product starts at workgroup 1
+        if (ride.G) {
+            if (blk == 0) { gram_inverse64_body<KP>(ride.G, ride.k, ride.Ginv, (int*)(ride.Ginv + KP * KP)); return; }
+            --blk;
+        }
+    }
+    const i64 gtid = blk * blockDim.x + threadIdx.x;
     const i64 j = gtid / LPC;
     const int s = (int)(gtid % LPC);
     if (j >= ncols) return;
@@ -2082,7 +2092,7 @@ __global__ __launch_bounds__(256) void spmm_gather2_kernel(const i64* __restrict
 }
 
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, i64 nnz_hint, const double* X,
-                       int ldx, int k, double* P, int kpp, hipStream_t st)
+                       int ldx, int k, double* P, int kpp, hipStream_t st, const InvRide* ride_in)
 {
     if (is_wide(k)) return launch_spmm_gather_wide(colptr, rowidx, val, ncols, X, k, P, kpp, st);
     const int KPv = kp_of(k);
@@ -2105,11 +2115,13 @@ int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* 
         return 0;
     }
     if (ldx != KPv) { set_error("spmm: unsupported row pitch of the gathered factor"); return -100; }
-    const int grid = (int)((ncols * (KPv / 4) + 255) / 256);
+    int grid = (int)((ncols * (KPv / 4) + 255) / 256);
     if (grid == 0) return 0;
-    KP_DISPATCH128(KPv, (spmm_gather_kernel<KP><<<grid, 256, 0, st>>>(colptr, rowidx, val, ncols, X, P, kpp)));
+    InvRide ride;
+    if (ride_in && ride_in->G && (KPv == 32 || KPv == 64)) { ride = *ride_in; ++grid; }
+    KP_DISPATCH128(KPv, (spmm_gather_kernel<KP><<<grid, 256, 0, st>>>(colptr, rowidx, val, ncols, X, P, kpp, ride)));
     SMK_HIP(hipGetLastError());
-    return 0;
+    return ride.G ? 1 : 0;                   // 1: the launch carried the Gram inverse
 }
 
 // ==========================================================================

@@ -186,6 +186,7 @@ struct smk_solver {
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
     bool inv_pending[2] = {false, false};
+    bool inv_ride[2] = {false, false};    // sparse BPP, k in (16, 64]: this side's Gram matrix is new, its inverse is to ride in the product launch that follows (timed_spmm)
     double *xscale[2] = {nullptr, nullptr}, *oscale[2] = {nullptr, nullptr};   // fp16 two-term products: row scales of W / H (from the Gram diagonal) and their inverses
     bool packed_fresh[2] = {false, false};   // the fused Gram kernel has already written packW / packH for the next product
     int nnls_gram_nblk[2] = {0, 0};          // > 0: the NNLS launch of this side left that many Gram partials in gram_scratch (k <= 16)
@@ -1306,7 +1307,13 @@ int smk_solver_create(smk_solver** out, const smk_options* opts, const smk_matri
         if (s->KP == 64 && !nnls_uses_tiles(s->k)) rc |= dev_alloc(&s->nnls_defer, nnls_defer_elems(std::max(s->m, s->n)));
         // (above k = 128 the inverse stays in stream order: beside the product it gained 1-2 % -- measured -- and the two sides
         // share one scratch there)
-        if ((s->KP >= 64 || (s->KP == 32 && nnls_inverse_at_32())) && !nnls_uses_tiles(s->k)) {
+        // The second stream pays two event hops per solve (~8 us each way on the main stream): worth it where it hides the 47 us
+        // inversion of k in (32, 64] behind a dense pass; at k in (16, 32] (13 us) stream order is as fast or faster (4096 x 2048,
+        // k = 32: 115 -> 92 us per iteration; 8192 x 4096: 131 -> 125; 32768 x 8192: equal), and with a sparse matrix the inverse
+        // rides in the gather product's launch (start_inverse).  SMK_INV_STREAM=1: the second stream everywhere, =0: nowhere.
+        static const int inv_env = [] { const char* e = getenv("SMK_INV_STREAM"); return e ? atoi(e) : -1; }();
+        const bool inv_beside = inv_env >= 0 ? inv_env != 0 : (!a->sparse && s->KP >= 64);
+        if (inv_beside && (s->KP >= 64 || (s->KP == 32 && nnls_inverse_at_32())) && !nnls_uses_tiles(s->k)) {
             if (hipStreamCreateWithFlags(&s->st_inv, hipStreamNonBlocking) != hipSuccess) rc |= 1;
             for (int i = 0; i < 2 && !rc; ++i) {
                 if (hipEventCreateWithFlags(&s->ev_g[i], hipEventDisableTiming) != hipSuccess) rc |= 1;
@@ -1745,7 +1752,18 @@ static inline double* inv_scratch(smk_solver* s, int side)
 static int start_inverse(smk_solver* s, int side, const double* G, hipEvent_t after = nullptr)
 {
     s->inv_done[side] = false;
-    if (!s->st_inv || s->o.algorithm != SMK_ALG_BPP) return 0;
+    s->inv_ride[side] = false;
+    if (s->o.algorithm != SMK_ALG_BPP) return 0;
+    if (!s->st_inv) {
+        // A small sparse problem pays more for the two event hops of a second stream than the 13 us inversion they hide (the Reuters
+        // shape: 125 us per iteration beside the product, 118 in stream order, ~100 riding): the inverse is formed by one more
+        // workgroup of the gather product that follows this Gram matrix in every BPP schedule (spmm_seg.hip: InvRide); a product
+        // launch that cannot carry it leaves it to launch_nnls_bpp, in stream order.  SMK_INV_RIDE=0: always that.
+        static const bool ride = [] { const char* e = getenv("SMK_INV_RIDE"); return !(e && e[0] == '0'); }();
+        s->inv_ride[side] = ride && s->a->sparse && !after && !is_dist(s) && !s->comm && !nnls_uses_tiles(s->k) &&
+                            (s->KP == 64 || (s->KP == 32 && nnls_inverse_at_32()));
+        return 0;
+    }
     if (after) {
         SMK_HIP(hipStreamWaitEvent(s->st_inv, after, 0));
     } else {
@@ -1891,6 +1909,9 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
     int rc;
     const BlockedCsc& blk = (which == 0) ? s->a->bA : s->a->bAt;
     const SegPlan& seg = (which == 0) ? s->a->segA : s->a->segAt;
+    InvRide ride;                                                   // start_inverse: this side's Gram inverse rides in the launch
+    if (s->inv_ride[which]) { ride.G = which == 0 ? s->Gw : s->Gh; ride.k = s->k; ride.Ginv = inv_scratch(s, which); }
+    s->inv_ride[which] = false;
     if (ldx == 2 && blk.nb > 1) rc = launch_spmm_blocked2(blk, X, P, which == 0 ? s->pl1.ncols_pad : s->pl2.ncols_pad, s->st);
     else if (ldx == s->KP && s->k > 2 && !is_wide(s->k) && seg.ncols == ncols && seg.rowflag && !seg.uniform) {
         // the partial sums of long columns live in the SOLVER (two solvers on one sparse matrix run on their own streams)
@@ -1899,9 +1920,10 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
             set_error("no memory for the long-column partial sums");
             return SMK_DEVICE_ERROR;
         }
-        rc = launch_spmm_seg(seg, colptr, val, X, s->k, P, s->kpp, s->st, s->seg_pieces[which]);
+        rc = launch_spmm_seg(seg, colptr, val, X, s->k, P, s->kpp, s->st, s->seg_pieces[which], &ride);
     }
-    else rc = launch_spmm_gather(colptr, rowidx, val, ncols, s->a->nnz, X, ldx, s->k, P, s->kpp, s->st);
+    else rc = launch_spmm_gather(colptr, rowidx, val, ncols, s->a->nnz, X, ldx, s->k, P, s->kpp, s->st, &ride);
+    if (rc == 1) { s->inv_done[which] = true; rc = 0; }             // the launch carried the inverse
     if (timed) {
         if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         (void)hipEventRecord(e1, s->st);

@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "devutil.h"
+#include "gram_inverse.h"
 
 namespace smk {
 
@@ -46,11 +47,19 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const i64* __restrict__ s
                                                        const unsigned* __restrict__ seg_piece, i64 nseg,
                                                        const i64* __restrict__ colptr, const unsigned* __restrict__ rowflag,
                                                        const double* __restrict__ val, const double* __restrict__ X,
-                                                       double* __restrict__ P, int kpp, double* __restrict__ pieces)
+                                                       double* __restrict__ P, int kpp, double* __restrict__ pieces, InvRide ride)
 {
     constexpr int LPC = KP / 2;
     constexpr int GPB = 256 / LPC;
-    const i64 sg = (i64)blockIdx.x * GPB + threadIdx.x / LPC;
+    i64 blk = blockIdx.x;
+    if constexpr (KP == 32 || KP == 64) {
+        // workgroup 0 of a launch that carries the Gram inverse (common.h: InvRide) inverts; the product starts at workgroup 1
+        if (ride.G) {
+            if (blk == 0) { gram_inverse64_body<KP>(ride.G, ride.k, ride.Ginv, (int*)(ride.Ginv + KP * KP)); return; }
+            --blk;
+        }
+    }
+    const i64 sg = blk * GPB + threadIdx.x / LPC;
     const int l = threadIdx.x % LPC;
     if (sg >= nseg) return;
     const i64 p0 = seg_p0[sg];
@@ -233,7 +242,7 @@ int build_seg_plan(i64 ncols, i64 nnz, const i64* colptr, const unsigned* rowidx
 }
 
 int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, const double* X, int k, double* P, int kpp,
-                    hipStream_t st, double* pieces)
+                    hipStream_t st, double* pieces, const InvRide* ride_in)
 {
     const int KPv = kp_of(k);
     if (!pieces) pieces = sp.pieces;
@@ -241,12 +250,14 @@ int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, con
     if (sp.has_empty) SMK_HIP(hipMemsetAsync(P, 0, (size_t)sp.ncols * kpp * sizeof(double), st));
     if (sp.nseg == 0) return 0;
     const int gpb = 256 / (KPv / 2);
-    const unsigned grid = (unsigned)((sp.nseg + gpb - 1) / gpb);
+    InvRide ride;
+    if (ride_in && ride_in->G && (KPv == 32 || KPv == 64)) ride = *ride_in;
+    const unsigned grid = (unsigned)((sp.nseg + gpb - 1) / gpb) + (ride.G ? 1u : 0u);
     const double* v = val;
     static const int ufix = [] { const char* e = getenv("SMK_SPMM_SEG_U"); return e ? atoi(e) : 0; }();
 #define SMK_SEG(U)                                                                                                                  \
-    KP_DISPATCH128(KPv, (sp.has_empty ? spmm_seg_kernel<KP, U, true><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, pieces) \
-                                      : spmm_seg_kernel<KP, U, false><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, pieces)))
+    KP_DISPATCH128(KPv, (sp.has_empty ? spmm_seg_kernel<KP, U, true><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, pieces, ride) \
+                                      : spmm_seg_kernel<KP, U, false><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, pieces, ride)))
     if (ufix == 4) { SMK_SEG(4); } else if (ufix == 16) { SMK_SEG(16); } else { SMK_SEG(8); }
 #undef SMK_SEG
     SMK_HIP(hipGetLastError());
@@ -255,7 +266,7 @@ int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, con
         KP_DISPATCH128(KPv, (spmm_seg_fixup_kernel<KP><<<g2, 256, 0, st>>>(sp.long_col, sp.long_piece0, sp.nlong, pieces, P, kpp)));
         SMK_HIP(hipGetLastError());
     }
-    return 0;
+    return ride.G ? 1 : 0;
 }
 
 }  // namespace smk

@@ -137,6 +137,44 @@ print("RESULT", rc, iters, hashlib.sha1(W.tobytes()).hexdigest(), hashlib.sha1(H
     assert all(x == seen[0] for x in seen), seen
 
 
+@pytest.mark.parametrize("shape", ["ragged", "fixed_degree"])
+def test_gram_inverse_rides_in_the_sparse_product_launch(shape):
+    """Sparse BPP at k in (16, 64]: the Gram inverse the next block-pivoting launch needs is formed by one more workgroup of the gather
+    product that follows the Gram matrix (spmm_seg.hip / kernels.hip: InvRide; gram_inverse.h) -- on ragged columns (spmm_seg_kernel)
+    and on a fixed-degree graph (spmm_gather_kernel).  In stream order (SMK_INV_RIDE=0) and beside the product on a second stream
+    (SMK_INV_STREAM=1, the route until round 6) the same elimination runs as a launch of its own: bit-identical factors, and the
+    oracle's to the sparse parity bar (nnls.hpp:144-244, nmf_solver_bpp.hpp:342-377)."""
+    code = r"""
+import sys, hashlib; sys.path.insert(0, %r)
+import numpy as np, scipy.sparse as sp, oracle, smallk_amd as g
+g.initialize(0)
+rng = np.random.default_rng(11)
+shape, out = sys.argv[1], []
+for k in (24, 32, 48, 64):
+    m, n = 1500, 1100
+    if shape == "ragged":
+        A = sp.random(m, n, density=0.02, random_state=5, format="csc")
+    else:                                   # 12 stored entries in every column
+        rows = np.concatenate([rng.choice(m, size=12, replace=False) for _ in range(n)])
+        A = sp.csc_matrix((rng.random(12 * n) + 0.1, rows, np.arange(0, 12 * n + 1, 12)), shape=(m, n))
+        A.sort_indices()
+    W0, H0 = oracle.fill_uniform(m, k, 3), oracle.fill_uniform(k, n, 4)
+    got = g.nmf_sparse(A, W0, H0, "BPP", min_iter=6, max_iter=6)
+    ref = oracle.nmf(np.asfortranarray(A.toarray()), W0, H0, "BPP", min_iter=6, max_iter=6)
+    err = max(np.linalg.norm(got.W - ref.W) / np.linalg.norm(ref.W), np.linalg.norm(got.H - ref.H) / np.linalg.norm(ref.H))
+    assert err < 1e-8, (k, err)
+    out.append(hashlib.sha1(got.W.tobytes() + got.H.tobytes()).hexdigest())
+print("RESULT", " ".join(out))
+""" % ROOT
+    seen = []
+    for env in ({}, {"SMK_INV_RIDE": "0"}, {"SMK_INV_STREAM": "1"}):
+        r = subprocess.run([sys.executable, "-c", code, shape], capture_output=True, text=True, cwd=ROOT, timeout=600, env=dict(os.environ, **env))
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stdout[-1500:] + r.stderr[-1500:]
+        seen.append(line[0])
+    assert seen[0] == seen[1] == seen[2], seen
+
+
 @pytest.mark.parametrize("flags", [["--check-every-iteration"], ["--api-path"]])
 def test_bench_flags_of_round_6_run(flags):
     """bench.py --check-every-iteration / --api-path on the smallest workload (C1: 512 x 256, k = 8, MU): one JSON line with the
