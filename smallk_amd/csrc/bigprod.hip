@@ -1,6 +1,7 @@
 // smallk_amd/csrc/bigprod.hip -- the streaming products W'A and H*At (the dominant kernels) and the
 // packing of their skinny operand.  See kernels.hip for the kernel map.
 #include "devutil.h"
+#include "gram_inverse.h"
 #include <type_traits>
 
 namespace smk {
@@ -95,7 +96,8 @@ template <int EBYTES, int KT, int NSPLIT, int MB, int NSTAGE, int CW, int WK, in
 __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                          const unsigned char* __restrict__ Xp,
                                                          double* __restrict__ P, i64 stages, i64 nst,
-                                                         i64 tiles, i64 ncols_pad, int S, int logS, int pstride, int accum)
+                                                         i64 tiles, i64 ncols_pad, int S, int logS, int pstride, int accum,
+                                                         InvRide ride)
 {
     using C = BPCfg<EBYTES, KT, NSPLIT, MB, NSTAGE, CW, WK, NWL>;
     constexpr int KTW = C::KTW;
@@ -104,7 +106,22 @@ __global__ __launch_bounds__(64 * (4 * WK + NWL), 1) void bigprod_kernel(const u
 
     // ---- XCD-aware block -> (tile, split): all blocks of one split share an XCD's L2
     // (block b is dispatched to XCD b % 8; used for speed only).
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    if constexpr (!TRB) {
+        // the Gram inverse of the next block-pivoting launch rides along (common.h: InvRide): eight more workgroups in front (the
+        // tile mapping keeps its XCDs), the first four waves of the first one invert, in the launch's own LDS
+        static_assert(C::STAGE_BYTES * C::NSTAGE >= GRAM_INVERSE_LDS(64) * 8, "the inversion needs 2.6 KB of LDS");
+        if (ride.G) {
+            if (bid < 8) {
+                if (bid == 0 && threadIdx.x < 256) {
+                    if (ride.k <= 32) gram_inverse64_body<32>(ride.G, ride.k, ride.Ginv, (int*)(ride.Ginv + 32 * 32), (double*)smem);
+                    else gram_inverse64_body<64>(ride.G, ride.k, ride.Ginv, (int*)(ride.Ginv + 64 * 64), (double*)smem);
+                }
+                return;
+            }
+            bid -= 8;
+        }
+    }
     const int xcd = bid & 7;
     const i64 grp = bid >> 3;
     i64 tile;
@@ -811,13 +828,28 @@ __global__ __launch_bounds__(64 * (4 + NWL), WPS) void bigprod_f3_kernel(const u
                                                                         i64 tiles, i64 ncols_pad, int S, int logS, int pstride,
                                                                         const double* __restrict__ oscale, float ascale, int accum,
                                                                         const double* __restrict__ tail_gp, int tail_nblk,
-                                                                        double* __restrict__ tail_g, BigProdPlan::TailCheck tc)
+                                                                        double* __restrict__ tail_g, BigProdPlan::TailCheck tc, InvRide ride)
 {
     using C = F3Cfg<KT, MB, NSTAGE, NWL, NS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     static_assert(TAIL != 2 || MB == 32, "transposed source (TAIL == 2): 32-column stages, pieces of two columns");
     int bid = blockIdx.x;
+    if constexpr (TAIL != 2) {
+        // the Gram inverse of the next block-pivoting launch rides along (common.h: InvRide): eight more workgroups in front (the
+        // tile mapping keeps its XCDs), the first four waves of the first one invert, in the launch's own LDS
+        static_assert(C::STAGE_BYTES * NSTAGE >= GRAM_INVERSE_LDS(64) * 8, "the inversion needs 2.6 KB of LDS");
+        if (ride.G) {
+            if (bid < 8) {
+                if (bid == 0 && threadIdx.x < 256) {
+                    if (ride.k <= 32) gram_inverse64_body<32>(ride.G, ride.k, ride.Ginv, (int*)(ride.Ginv + 32 * 32), (double*)smem);
+                    else gram_inverse64_body<64>(ride.G, ride.k, ride.Ginv, (int*)(ride.Ginv + 64 * 64), (double*)smem);
+                }
+                return;
+            }
+            bid -= 8;
+        }
+    }
     if constexpr (TAIL == 1) {
         // the first 16 workgroups (two per XCD, so the tile mapping below keeps its XCD of every other workgroup) reduce
         static_assert(NWL == 0 && C::STAGE_BYTES * NSTAGE >= 16 * 17 * 8, "the tail needs 256 threads and 2176 bytes of LDS");
@@ -1432,11 +1464,13 @@ static int launch_f3_t(const BigProdPlan& pl, const void* B, i64 ldb, const void
             grid = pl.tiles * pl.S;
         }
         if (TAIL == 1) grid += pl.tail_check.part ? 24 : 16;
+        InvRide ride;
+        if (TAIL != 2 && pl.inv_ride.G && pl.inv_ride.k > 16 && pl.inv_ride.k <= 64) { ride = pl.inv_ride; grid += 8; }
         kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * 4, (const unsigned char*)Xp, P, pl.stages,
                                                       pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.oscale, (float)pl.ascale, pl.accum | (pl.temporal ? 2 : 0),
-                                                      pl.tail_gp, pl.tail_nblk, pl.tail_g, pl.tail_check);
+                                                      pl.tail_gp, pl.tail_nblk, pl.tail_g, pl.tail_check, ride);
         SMK_HIP(hipGetLastError());
-        return 0;
+        return ride.G ? 1 : 0;                   // 1: the launch carried the Gram inverse
     }
 }
 
@@ -1476,6 +1510,19 @@ static int launch_f3(const BigProdPlan& pl, const void* B, i64 ldb, const void* 
     }
     set_error("unknown bigprod f3 variant");
     return -100;
+}
+
+// the launches that go to bigprod_f3_kernel from the stored transpose (launch_bigprod's dispatch): they can carry the Gram inverse
+bool bigprod_supports_ride(const BigProdPlan& pl)
+{
+    if (pl.nsplit == NSPLIT_F64) return !pl.tr;                  // the accurate form (bigprod_f64_kernel at k > 2), either storage
+    if (pl.tr) return false;
+    if (pl.storage == STORE_BF16 || pl.variant < 100) return true;  // bigprod_kernel (bf16 storage; fp32 storage in its older forms)
+    if (pl.storage != STORE_F32) return false;
+    const int v = pl.variant - 100;
+    if (pl.nsplit == NSPLIT_F16X2) return v == 8 || (v >= 25 && v <= 29);
+    if (pl.nsplit == 2 || pl.nsplit == 3) return (v >= 0 && v <= 9) || (v >= 25 && v <= 27);
+    return false;
 }
 
 // fp16 two-term form: the variants that won for the bf16 forms
@@ -1535,13 +1582,22 @@ template <int EBYTES, int KT16>
 __global__ __launch_bounds__(256) void bigprod_f64_kernel(const unsigned char* __restrict__ B, i64 ldb_bytes,
                                                           const double* __restrict__ X, int ldx, int kvalid, i64 len,
                                                           double* __restrict__ P, i64 stages, i64 nst, i64 tiles, i64 ncols_pad,
-                                                          int S, int pstride, int ktw, int accum)
+                                                          int S, int pstride, int ktw, int accum, InvRide ride)
 {
     constexpr int MB = 64, NB = 64, KG = 64;
     __shared__ float Bs[NB][MB + 1];
-    __shared__ double Xs[MB][KG + 2];
-    const i64 tile = blockIdx.x / S;
-    const int split = (int)(blockIdx.x % S);
+    __shared__ __attribute__((aligned(16))) double Xs[MB][KG + 2];
+    i64 bid = blockIdx.x;
+    if (ride.G) {            // the Gram inverse of the next block-pivoting launch rides along (common.h: InvRide): workgroup 0 inverts
+        if (bid == 0) {
+            if (ride.k <= 32) gram_inverse64_body<32>(ride.G, ride.k, ride.Ginv, (int*)(ride.Ginv + 32 * 32), &Xs[0][0]);
+            else gram_inverse64_body<64>(ride.G, ride.k, ride.Ginv, (int*)(ride.Ginv + 64 * 64), &Xs[0][0]);
+            return;
+        }
+        --bid;
+    }
+    const i64 tile = bid / S;
+    const int split = (int)(bid % S);
     if (tile >= tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     i64 st0 = (i64)split * nst, st1 = st0 + nst;
@@ -1753,8 +1809,11 @@ static int launch_bigprod_f64(const BigProdPlan& pl, const void* B, i64 ldb, con
         return 0;
     }
     const int kt16 = (kvalid + 15) / 16;                     // live 16-row tiles of this group (1 .. 4)
-#define SMK_F64(EB, T) bigprod_f64_kernel<EB, T><<<(unsigned)grid, 256, 0, st>>>((const unsigned char*)B, ldb * EB, (const double*)X, pl.ldx, kvalid, \
-                                                                              len, P, pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum)
+    InvRide ride;
+    if (pl.inv_ride.G && pl.inv_ride.k > 16 && pl.inv_ride.k <= 64) ride = pl.inv_ride;
+    const i64 grid_r = grid + (ride.G ? 1 : 0);
+#define SMK_F64(EB, T) bigprod_f64_kernel<EB, T><<<(unsigned)grid_r, 256, 0, st>>>((const unsigned char*)B, ldb * EB, (const double*)X, pl.ldx, kvalid, \
+                                                                              len, P, pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, pl.pstride, ktw, pl.accum, ride)
     if (pl.storage == STORE_BF16) {
         switch (kt16) { case 1: SMK_F64(2, 1); break; case 2: SMK_F64(2, 2); break; case 3: SMK_F64(2, 3); break; default: SMK_F64(2, 4); break; }
     } else {
@@ -1762,7 +1821,7 @@ static int launch_bigprod_f64(const BigProdPlan& pl, const void* B, i64 ldb, con
     }
 #undef SMK_F64
     SMK_HIP(hipGetLastError());
-    return 0;
+    return ride.G ? 1 : 0;                       // 1: the launch carried the Gram inverse
 }
 
 constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw, int wk, int nwl);
@@ -1986,10 +2045,12 @@ static int launch_bigprod_t(const BigProdPlan& pl, const void* B, i64 ldb, const
     } else {
         grid = pl.tiles * pl.S;
     }
+    InvRide ride;
+    if (!TRB && pl.inv_ride.G && pl.inv_ride.k > 16 && pl.inv_ride.k <= 64) { ride = pl.inv_ride; grid += 8; }
     kern<<<(unsigned)grid, 64 * C::NW, lds, st>>>((const unsigned char*)B, ldb * EBYTES, (const unsigned char*)Xp, P,
-                                           pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.accum | (pl.temporal ? 2 : 0));
+                                           pl.stages, pl.nst, pl.tiles, pl.ncols_pad, pl.S, logS, pl.pstride, pl.accum | (pl.temporal ? 2 : 0), ride);
     SMK_HIP(hipGetLastError());
-    return 0;
+    return ride.G ? 1 : 0;                       // 1: the launch carried the Gram inverse
 }
 
 constexpr bool bp_fits(int ebytes, int kt, int nsplit, int mb, int nstage, int cw, int wk, int nwl)

@@ -138,6 +138,15 @@ int launch_pack(const double* X, int k, i64 N, int storage, int nsplit, void* ou
 int launch_pack_rows(const double* X, int ldx, int k0, int kg, i64 N, int storage, int nsplit, void* out, hipStream_t st,
                      const double* xscale = nullptr);
 
+// The Gram inverse the NEXT block-pivoting launch needs, formed by one more workgroup of a product launch (gram_inverse.h; k in
+// (16, 64] only): launch_spmm_seg / launch_spmm_gather / launch_bigprod return 1 instead of 0 when the launch carried it, so that the
+// caller knows whether it still has to launch one
+struct InvRide {
+    const double* G = nullptr;       // the Gram matrix, KP x KP (complete before this launch starts)
+    int k = 0;
+    double* Ginv = nullptr;          // KP x KP doubles, then the int status (launch_gram_inverse's layout)
+};
+
 // streaming product: P[s][j][:] = sum over the rows of split s of X[:,row] * B[row, j]
 struct BigProdPlan {
     // k > 64 runs as groups of 64 factor rows (one pass over the big matrix per group); this plan describes ONE group:
@@ -185,8 +194,10 @@ struct BigProdPlan {
         double* snap_g = nullptr;
         double tag = 0.0;            // != 0: stored into host_out[7] last, system scope (the host polls the slot instead of an event)
     } tail_check;
+    InvRide inv_ride;                // bigprod_supports_ride: eight more workgroups, the first one inverts (launch_bigprod returns 1)
 };
 bool bigprod_supports_tail(const BigProdPlan& pl);
+bool bigprod_supports_ride(const BigProdPlan& pl);
 BigProdPlan plan_bigprod(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus);
 // the groups of a k-row factor (1 for k <= 64, 2 up to 128): same row splits, P laid out [S][ncols_pad][32 kt_of(k)]
 int plan_bigprod_groups(int storage, int k, i64 len, i64 ncols, int nsplit, int num_cus, BigProdPlan* out /* 2 */);
@@ -391,13 +402,6 @@ int launch_rank2_persist(const R2PersistArgs& a, int workgroups, hipStream_t st)
 // sparse A (CSC): out[:, j] = sum_p val[p] * X[:, row[p]] over the nonzeros of column j
 // X: the gathered factor, row pitch ldx doubles (KP, or 2 for the compact copy of a rank-2 factor)
 // nnz_hint: number of stored entries (picks the lanes per column of the rank-2 kernel; <= 0: unknown)
-// `ride`: the Gram inverse the NEXT block-pivoting launch needs, formed by one more workgroup of this launch (gram_inverse.h; k in
-// (16, 64] only -- returns 1 instead of 0 when the launch carried it, so that the caller knows whether it still has to launch one)
-struct InvRide {
-    const double* G = nullptr;       // the Gram matrix, KP x KP (complete before this launch starts)
-    int k = 0;
-    double* Ginv = nullptr;          // KP x KP doubles, then the int status (launch_gram_inverse's layout)
-};
 int launch_spmm_gather(const i64* colptr, const unsigned* rowidx, const double* val, i64 ncols, i64 nnz_hint, const double* X,
                        int ldx, int k, double* P, int kpp, hipStream_t st, const InvRide* ride = nullptr);
 

@@ -11,6 +11,8 @@
 
 namespace smk {
 
+#define GRAM_INVERSE_LDS(KP) (5 * (KP) + 2)
+
 // KP = 64: the same elimination with the pivot index split as j = 16 j0 + JE and the sixteen values of JE unrolled, so that the
 // one entry of a thread's row segment that belongs to the pivot COLUMN is a compile-time register.  With a run-time index
 // the compiler kept a[] in scratch memory -- sixteen scratch stores and a dependent scratch load per pivot step, 1.3 - 1.8 us
@@ -20,14 +22,14 @@ namespace smk {
 // Same operations in the same order as gram_inverse_kernel<64>: the result is bit-identical.
 template <int KP>
 __device__ __forceinline__ void gram_inverse64_body(const double* __restrict__ G, int k, double* __restrict__ Ginv,
-                                                    int* __restrict__ status)
+                                                    int* __restrict__ status, double* __restrict__ lds /* GRAM_INVERSE_LDS(KP) doubles, 16-byte aligned */)
 {
     static_assert(KP == 64 || KP == 32, "256 threads hold the matrix as KP rows x (256 / KP) segments");
     constexpr int CQ = 256 / KP, EPT = KP / CQ;               // KP = 64: 4 segments of 16 entries; KP = 32: 8 segments of 4
-    __shared__ __attribute__((aligned(16))) double rowj[2][KP];
-    __shared__ double colj[2][KP];
-    __shared__ double diag0[KP];
-    __shared__ int bad;
+    double* const rowj = lds;                   // [2][KP]
+    double* const colj = lds + 2 * KP;          // [2][KP]
+    double* const diag0 = lds + 4 * KP;         // [KP]
+    int& bad = *(int*)(lds + 5 * KP);
     const int tid = threadIdx.x;
     const int r = tid / CQ, cq = tid % CQ;
     if (tid == 0) bad = 0;
@@ -40,22 +42,22 @@ __device__ __forceinline__ void gram_inverse64_body(const double* __restrict__ G
     }
     if (r == 0) {
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) rowj[0][cq * EPT + e] = a[e];
+        for (int e = 0; e < EPT; ++e) rowj[cq * EPT + e] = a[e];
     }
-    if (cq == 0) colj[0][r] = a[0];
+    if (cq == 0) colj[r] = a[0];
     __syncthreads();
     auto step = [&](int j, auto je_tag) {
         constexpr int JE = decltype(je_tag)::value;
         constexpr int JN = (JE + 1) % EPT;
         const int buf = j & 1;
-        const double piv = rowj[buf][j];
+        const double piv = rowj[buf * KP + j];
         if (tid == 0 && !(piv > 1.0e-9 * diag0[j])) bad = 1;
         const double ip = 1.0 / piv;
-        const double f = colj[buf][r] * ip;
+        const double f = colj[buf * KP + r] * ip;
         const bool my_row = r == j, my_colq = cq == j / EPT;
 #pragma unroll
         for (int e = 0; e < EPT; e += 2) {
-            const f64x2_t rr = *(const f64x2_t*)&rowj[buf][cq * EPT + e];
+            const f64x2_t rr = *(const f64x2_t*)&rowj[buf * KP + cq * EPT + e];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 double val = my_row ? rr[u] * ip : __builtin_fma(-f, rr[u], a[e + u]);
@@ -70,9 +72,9 @@ __device__ __forceinline__ void gram_inverse64_body(const double* __restrict__ G
             const int nb = buf ^ 1;
             if (r == j + 1) {
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) rowj[nb][cq * EPT + e] = a[e];
+                for (int e = 0; e < EPT; ++e) rowj[nb * KP + cq * EPT + e] = a[e];
             }
-            if (cq == (j + 1) / EPT) colj[nb][r] = a[JN];
+            if (cq == (j + 1) / EPT) colj[nb * KP + r] = a[JN];
         }
         __syncthreads();
     };

@@ -2025,7 +2025,11 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const i64* __restrict_
     if constexpr (KP == 32 || KP == 64) {
         // workgroup 0 of a launch that carries the Gram inverse (common.h: InvRide) inverts; the product starts at workgroup 1
         if (ride.G) {
-            if (blk == 0) { gram_inverse64_body<KP>(ride.G, ride.k, ride.Ginv, (int*)(ride.Ginv + KP * KP)); return; }
+            if (blk == 0) {
+                __shared__ __attribute__((aligned(16))) double inv_lds[GRAM_INVERSE_LDS(KP)];
+                gram_inverse64_body<KP>(ride.G, ride.k, ride.Ginv, (int*)(ride.Ginv + KP * KP), inv_lds);
+                return;
+            }
             --blk;
         }
     }

@@ -152,7 +152,8 @@ template <int KP>
 __global__ __launch_bounds__(256) void gram_inverse64_kernel(const double* __restrict__ G, int k, double* __restrict__ Ginv,
                                                              int* __restrict__ status)
 {
-    gram_inverse64_body<KP>(G, k, Ginv, status);
+    __shared__ __attribute__((aligned(16))) double lds[GRAM_INVERSE_LDS(KP)];
+    gram_inverse64_body<KP>(G, k, Ginv, status, lds);
 }
 
 template <int KP, int NT, int WPS, bool FINE = true>

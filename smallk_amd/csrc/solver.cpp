@@ -1754,16 +1754,18 @@ static int start_inverse(smk_solver* s, int side, const double* G, hipEvent_t af
     s->inv_done[side] = false;
     s->inv_ride[side] = false;
     if (s->o.algorithm != SMK_ALG_BPP) return 0;
-    if (!s->st_inv) {
-        // A small sparse problem pays more for the two event hops of a second stream than the 13 us inversion they hide (the Reuters
-        // shape: 125 us per iteration beside the product, 118 in stream order, ~100 riding): the inverse is formed by one more
-        // workgroup of the gather product that follows this Gram matrix in every BPP schedule (spmm_seg.hip: InvRide); a product
-        // launch that cannot carry it leaves it to launch_nnls_bpp, in stream order.  SMK_INV_RIDE=0: always that.
+    {
+        // The inverse is formed by one more workgroup of the product launch that follows this Gram matrix in every BPP schedule
+        // (spmm_seg.hip / kernels.hip / bigprod.hip: InvRide) where that launch can carry it: a second stream pays two event hops
+        // per solve, ~8 us each way on the main stream -- more than the 13 us inversion of k <= 32 they hide (the Reuters shape: 125
+        // us per iteration beside the product, 118 in stream order, 91 riding; dense 4096 x 2048, k = 32: 115 / 92 / 70).  A launch
+        // that cannot carry it leaves it to launch_nnls_bpp, in stream order, or to the second stream.  SMK_INV_RIDE=0: never rides.
         static const bool ride = [] { const char* e = getenv("SMK_INV_RIDE"); return !(e && e[0] == '0'); }();
-        s->inv_ride[side] = ride && s->a->sparse && !after && !is_dist(s) && !s->comm && !nnls_uses_tiles(s->k) &&
-                            (s->KP == 64 || (s->KP == 32 && nnls_inverse_at_32()));
-        return 0;
+        const bool route = !nnls_uses_tiles(s->k) && (s->KP == 64 || (s->KP == 32 && nnls_inverse_at_32()));
+        const bool carrier = s->a->sparse ? true : (s->ng == 1 && bigprod_supports_ride(side == 0 ? s->pg1[0] : s->pg2[0]));
+        if (ride && route && carrier && !after && !is_dist(s) && !s->comm && !s->w_sharded) { s->inv_ride[side] = true; return 0; }
     }
+    if (!s->st_inv) return 0;
     if (after) {
         SMK_HIP(hipStreamWaitEvent(s->st_inv, after, 0));
     } else {
@@ -1878,9 +1880,16 @@ static inline void begin_pass(smk_solver* s, int which)
 }
 
 // one launch of the streaming product, bracketed by events when timing is on; `counts`: this launch completes a pass
-static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl, const void* B, i64 ldb, const void* Xp,
+static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl_in, const void* B, i64 ldb, const void* Xp,
                          double* P, int counts = 1)
 {
+    BigProdPlan pl = pl_in;
+    if (s->inv_ride[which] && bigprod_supports_ride(pl)) {          // start_inverse: this side's Gram inverse rides in the launch
+        pl.inv_ride.G = which == 0 ? s->Gw : s->Gh;
+        pl.inv_ride.k = s->k;
+        pl.inv_ride.Ginv = inv_scratch(s, which);
+    }
+    s->inv_ride[which] = false;
     if (s->timing && s->pass_timed[which]) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         SMK_HIP(hipEventCreate(&e0));
@@ -1888,11 +1897,14 @@ static int timed_bigprod(smk_solver* s, int which, const BigProdPlan& pl, const 
         s->ev[which].push_back({e0, e1, counts});   // owned by the solver from here on (destroyed with it)
         SMK_HIP(hipEventRecord(e0, s->st));
         int rc = launch_bigprod(pl, B, ldb, Xp, P, s->st);
+        if (rc == 1) { s->inv_done[which] = true; rc = 0; }        // the launch carried the inverse
         if (rc) { s->ev[which].pop_back(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         SMK_HIP(hipEventRecord(e1, s->st));
         return 0;
     }
-    return launch_bigprod(pl, B, ldb, Xp, P, s->st);
+    int rc = launch_bigprod(pl, B, ldb, Xp, P, s->st);
+    if (rc == 1) { s->inv_done[which] = true; rc = 0; }
+    return rc;
 }
 
 // R1 = W'A  (k x n, local columns)

@@ -137,13 +137,15 @@ print("RESULT", rc, iters, hashlib.sha1(W.tobytes()).hexdigest(), hashlib.sha1(H
     assert all(x == seen[0] for x in seen), seen
 
 
-@pytest.mark.parametrize("shape", ["ragged", "fixed_degree"])
-def test_gram_inverse_rides_in_the_sparse_product_launch(shape):
-    """Sparse BPP at k in (16, 64]: the Gram inverse the next block-pivoting launch needs is formed by one more workgroup of the gather
-    product that follows the Gram matrix (spmm_seg.hip / kernels.hip: InvRide; gram_inverse.h) -- on ragged columns (spmm_seg_kernel)
-    and on a fixed-degree graph (spmm_gather_kernel).  In stream order (SMK_INV_RIDE=0) and beside the product on a second stream
-    (SMK_INV_STREAM=1, the route until round 6) the same elimination runs as a launch of its own: bit-identical factors, and the
-    oracle's to the sparse parity bar (nnls.hpp:144-244, nmf_solver_bpp.hpp:342-377)."""
+@pytest.mark.parametrize("shape", ["ragged", "fixed_degree", "dense", "dense_bf16"])
+def test_gram_inverse_rides_in_the_product_launch(shape):
+    """BPP at k in (16, 64]: the Gram inverse the next block-pivoting launch needs is formed by one more workgroup of the product
+    launch that follows the Gram matrix (InvRide; gram_inverse.h) -- the gather product on ragged columns (spmm_seg_kernel) and on a
+    fixed-degree graph (spmm_gather_kernel), the streaming product of a dense matrix (bigprod_f3_kernel for fp32 storage, bigprod_kernel for bf16, bigprod_f64_kernel in
+    the accurate form that small problems take).  In stream order
+    (SMK_INV_RIDE=0) and beside the product on a second stream (+ SMK_INV_STREAM=1, the route until round 6) the same elimination
+    runs as a launch of its own: bit-identical factors, and the oracle's to the parity bar (nnls.hpp:144-244,
+    nmf_solver_bpp.hpp:342-377)."""
     code = r"""
 import sys, hashlib; sys.path.insert(0, %r)
 import numpy as np, scipy.sparse as sp, oracle, smallk_amd as g
@@ -152,6 +154,16 @@ rng = np.random.default_rng(11)
 shape, out = sys.argv[1], []
 for k in (24, 32, 48, 64):
     m, n = 1500, 1100
+    if shape.startswith("dense"):
+        m, n = 4096, 1536
+        A = oracle.fill_uniform(m, n, 5 + k, quant=1 if shape == "dense_bf16" else 0)
+        W0, H0 = oracle.fill_uniform(m, k, 3), oracle.fill_uniform(k, n, 4)
+        got = g.nmf(A, W0, H0, "BPP", min_iter=5, max_iter=5, storage="bf16" if shape == "dense_bf16" else "f32")
+        ref = oracle.nmf(A, W0, H0, "BPP", min_iter=5, max_iter=5)
+        err = max(np.linalg.norm(got.W - ref.W) / np.linalg.norm(ref.W), np.linalg.norm(got.H - ref.H) / np.linalg.norm(ref.H))
+        assert err < 1e-4, (k, err)
+        out.append(hashlib.sha1(got.W.tobytes() + got.H.tobytes()).hexdigest())
+        continue
     if shape == "ragged":
         A = sp.random(m, n, density=0.02, random_state=5, format="csc")
     else:                                   # 12 stored entries in every column
@@ -167,12 +179,12 @@ for k in (24, 32, 48, 64):
 print("RESULT", " ".join(out))
 """ % ROOT
     seen = []
-    for env in ({}, {"SMK_INV_RIDE": "0"}, {"SMK_INV_STREAM": "1"}):
+    for env in ({}, {"SMK_INV_RIDE": "0"}, {"SMK_INV_RIDE": "0", "SMK_INV_STREAM": "1"}, {"SMK_INV_RIDE": "0", "SMK_INV_STREAM": "0"}):
         r = subprocess.run([sys.executable, "-c", code, shape], capture_output=True, text=True, cwd=ROOT, timeout=600, env=dict(os.environ, **env))
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
         assert r.returncode == 0 and line, r.stdout[-1500:] + r.stderr[-1500:]
         seen.append(line[0])
-    assert seen[0] == seen[1] == seen[2], seen
+    assert all(x == seen[0] for x in seen), seen
 
 
 @pytest.mark.parametrize("flags", [["--check-every-iteration"], ["--api-path"]])
