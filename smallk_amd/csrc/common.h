@@ -426,8 +426,19 @@ int build_seg_plan(i64 ncols, i64 nnz, const i64* colptr, const unsigned* rowidx
 void free_seg_plan(SegPlan* s);
 // `pieces`: the caller's own npieces x 128 doubles for the partial sums of long columns (a solver owns one per pass, so that two
 // solvers on one matrix and different streams do not share it); nullptr: the plan's buffer (one stream at a time)
+// `gram`: the Gram matrix of a factor (k in (8, 32]) formed along the way -- its partial sums by extra workgroups of the gather launch
+// (gram_body.h; both only read a factor), their reduction by extra workgroups of the fix-up launch (a launch of its own when the
+// matrix has no long columns).  Return value: bit 0 = the Gram inverse was carried, bit 1 = the Gram matrix was formed.
+struct GramRide {
+    const double* X = nullptr;       // the factor, KP x N
+    i64 N = 0;
+    int max_blocks = 0;              // the blocking of launch_gram_partials(.., max_blocks, ..): the same partial sums in the same order
+    double* Gp = nullptr;            // partial sums ([nblk][KP * KP])
+    double* G = nullptr;             // the result, KP x KP
+};
+void gram_partial_shape(i64 N, int max_blocks, int* nblk_out, i64* cpw_out);
 int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, const double* X, int k, double* P, int kpp,
-                    hipStream_t st, double* pieces = nullptr, const InvRide* ride = nullptr);
+                    hipStream_t st, double* pieces = nullptr, const InvRide* ride = nullptr, const GramRide* gram = nullptr);
 
 // spmm_blocked.hip: the rank-2 gather product with the gathered factor cut into row blocks that stay in one XCD's L2.
 // A matrix regrouped by row block: block b is a CSC of its own (cp[b * (ncols + 1) + j] .. are absolute positions in ri / va)

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "devutil.h"
 #include "gram_inverse.h"
+#include "gram_body.h"
 #include <climits>
 
 namespace smk {
@@ -491,111 +492,13 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const double* __restr
 // fp64 matrix-core version (KP >= 16): v_mfma_f64_16x16x4_f64, 4 columns of X per instruction.
 // A operand lane l: X[16*ti + (l&15)][c0 + (l>>4)], B operand the same with tj -- the Gram matrix
 // needs no second operand load.  D: col = lane&15, row = (lane>>4) + 4*reg (f64 layout).
-typedef __attribute__((ext_vector_type(4))) double f64x4_t;
 
 template <int KP>
 __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ X, i64 N, i64 cols_per_wave,
                                                         double* __restrict__ Gp)
 {
-    constexpr int T = KP / 16;
-    if (KP == 64 && cols_per_wave <= 32) {
-        // KP = 64, short factors (<= 128 columns per workgroup: N <= 32768 with 256 partials; longer ones would re-read more than the
-        // L1 holds -- C4's W side 133 us against ~90): wave w owns tile ROW w of the result (4 of the 16 tiles) over ALL columns of the workgroup, instead of all 16
-        // tiles over a quarter of the columns: the same matrix instructions per wave, the loads four times (the four waves read
-        // the same lines at the same time), and no sum over the waves -- that sum (four turns of 4096 LDS read-modify-writes
-        // between barriers) was 8 of the 19 us this launch took on a 4096-column factor.
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const i64 c_begin = (i64)blockIdx.x * 4 * cols_per_wave;
-        i64 c_end = c_begin + 4 * cols_per_wave;
-        if (c_end > N) c_end = N;
-        f64x4_t acc[T];
-#pragma unroll
-        for (int b = 0; b < T; ++b) acc[b] = f64x4_t{0.0, 0.0, 0.0, 0.0};
-        const int kc = lane >> 4, r16 = lane & 15;
-        for (i64 c0 = c_begin; c0 < c_end; c0 += 16) {
-            double f[4][T];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const i64 col = c0 + 4 * u + kc;
-                const bool ok = col < c_end;
-#pragma unroll
-                for (int t = 0; t < T; ++t) f[u][t] = ok ? X[col * KP + 16 * t + r16] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                double fa = f[u][0];                            // the own tile row's operand (wave is uniform: a select, not an index)
-#pragma unroll
-                for (int t = 1; t < T; ++t) fa = (wave == t) ? f[u][t] : fa;
-#pragma unroll
-                for (int b = 0; b < T; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, f[u][b], acc[b], 0, 0, 0);
-            }
-        }
-        if constexpr (KP == 64) {
-            double* out = Gp + (i64)blockIdx.x * KP * KP;
-#pragma unroll
-            for (int b = 0; b < T; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) out[(16 * b + r16) * KP + 16 * wave + kc + 4 * r] = acc[b][r];
-        }
-        return;
-    }
     __shared__ double red[KP * KP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const i64 wg = (i64)blockIdx.x * 4 + wave;
-    const i64 c_begin = wg * cols_per_wave;
-    i64 c_end = c_begin + cols_per_wave;
-    if (c_end > N) c_end = N;
-    f64x4_t acc[T][T];
-#pragma unroll
-    for (int a = 0; a < T; ++a)
-#pragma unroll
-        for (int b = 0; b < T; ++b) acc[a][b] = f64x4_t{0.0, 0.0, 0.0, 0.0};
-    const int kc = lane >> 4, r16 = lane & 15;
-    // 16 columns (4 MFMA k-steps) per trip: all loads of the trip are issued before its MFMAs.  (Round 6 tried keeping the loads of
-    // trip i + 1 in flight during the MFMAs of trip i -- the launch is one workgroup per CU and runs at 3 TB/s on 10^6 columns -- and
-    // measured it SLOWER: 85 -> 106 us per launch, s_1m 440 -> 431 it/s.  Reverted.)
-    for (i64 c0 = c_begin; c0 < c_end; c0 += 16) {
-        double f[4][T];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const i64 col = c0 + 4 * u + kc;
-            const bool ok = col < c_end;
-#pragma unroll
-            for (int t = 0; t < T; ++t) f[u][t] = ok ? X[col * KP + 16 * t + r16] : 0.0;
-        }
-        // only the tile blocks on and above the diagonal (round 6): block (b, a) is the transpose of block (a, b) -- the same products
-        // in the same order, bit for bit -- and the fp64 matrix instructions are what this kernel waits for (3 of 4 at KP = 32, 10
-        // of 16 at KP = 64)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int a = 0; a < T; ++a)
-#pragma unroll
-                for (int b = a; b < T; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[u][a], f[u][b], acc[a][b], 0, 0, 0);
-    }
-    // deterministic in-block sum of the 4 waves (the blocks below the diagonal are filled from their mirror images)
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int a = 0; a < T; ++a)
-#pragma unroll
-                for (int b = a; b < T; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * a + kc + 4 * r, colm = 16 * b + r16;
-                        const int idx = colm * KP + row;
-                        red[idx] = (w == 0) ? acc[a][b][r] : red[idx] + acc[a][b][r];
-                        if (a != b) {
-                            const int idm = row * KP + colm;
-                            red[idm] = (w == 0) ? acc[a][b][r] : red[idm] + acc[a][b][r];
-                        }
-                    }
-        }
-        __syncthreads();
-    }
-    double* out = Gp + (i64)blockIdx.x * KP * KP;
-    for (int i = threadIdx.x; i < KP * KP; i += 256) out[i] = red[i];
+    gram_mfma_body<KP>(X, N, cols_per_wave, Gp, (i64)blockIdx.x, red);        // gram_body.h
 }
 
 // KP = 128 (k in (64, 128]): the 8 x 8 grid of 16 x 16 tiles does not fit one wave's registers, so a workgroup
@@ -751,42 +654,14 @@ __global__ __launch_bounds__(256) void gram_pack_kernel(const double* __restrict
     for (int i = threadIdx.x; i < KP * KP; i += 256) mine[i] = red[i];
 }
 
-// G[e] = sum_b Gp[b][e]: 16 elements per block, 16 thread groups stride the partials, fixed order
+// G[e] = sum_b Gp[b][e]: 16 elements per block, 16 thread groups stride the partials, fixed order (gram_body.h)
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ Gp, int nblk, int elems,
                                                           double* __restrict__ G, int KP = 0,
                                                           double* __restrict__ xscale = nullptr,
                                                           double* __restrict__ oscale = nullptr, double ascale = 1.0)
 {
     __shared__ double sh[16][17];
-    const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int e = blockIdx.x * 16 + el;
-    double s = 0.0;
-    if (e < elems) {
-#pragma unroll 8
-        for (int b = g; b < nblk; b += 16) s += Gp[(i64)b * elems + e];
-    }
-    sh[g][el] = s;
-    __syncthreads();
-    if (g == 0 && e < elems) {
-        double t = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += sh[i][el];
-        G[e] = t;
-        // fp16 two-term operand: every entry of row r is bounded by sqrt(G_rr); scale the row so that this bound lands
-        // in [2^13, 2^14] (fp16 tops out at 65504, its 11-bit precision holds down to 2^-14)
-        if (xscale && KP > 0 && e % (KP + 1) == 0) {
-            const int r = e / (KP + 1);
-            int ex = 0;
-            double xs = 1.0;
-            if (t > 0.0 && t < 1.0e300) {
-                (void)frexp(t, &ex);                    // t = f 2^ex, f in [0.5, 1)  ->  sqrt(t) <= 2^ceil(ex / 2)
-                const int half = (ex >= 0) ? (ex + 1) / 2 : -((-ex) / 2);
-                xs = ldexp(1.0, 14 - half);
-            }
-            xscale[r] = xs;
-            if (oscale) oscale[r] = 1.0 / (xs * ascale);
-        }
-    }
+    gram_reduce_body(Gp, nblk, elems, G, KP, xscale, oscale, ascale, (int)blockIdx.x, sh);
 }
 
 // KP = 8 (k <= 8: rank-2 hierarchical clustering lives here): one column (64 bytes) per thread per
@@ -1000,6 +875,18 @@ size_t gram_scratch_elems(int k, int max_blocks)
 
 // partial Gram matrices of the columns [0, N) of X into scratch ([*nblk_out][KP * KP]); several calls with scratch
 // offsets (row segments of a factor) followed by ONE launch_gram_reduce give the Gram matrix of the union
+// the blocking of gram_mfma_kernel<16 / 32 / 64> for N columns (also used by the launches that carry the partial sums as riders)
+void gram_partial_shape(i64 N, int max_blocks, int* nblk_out, i64* cpw_out)
+{
+    int nblk = (int)((N + 63) / 64);
+    if (nblk > max_blocks) nblk = max_blocks;
+    if (nblk < 1) nblk = 1;
+    i64 cpw = (N + (i64)nblk * 4 - 1) / ((i64)nblk * 4);
+    cpw = (cpw + 15) / 16 * 16;
+    *nblk_out = nblk;
+    *cpw_out = cpw;
+}
+
 int launch_gram_partials(const double* X, int k, i64 N, double* scratch, int max_blocks, int* nblk_out, hipStream_t st)
 {
     const int KP = kp_of(k);
@@ -1010,11 +897,8 @@ int launch_gram_partials(const double* X, int k, i64 N, double* scratch, int max
     } else if (KP >= 16) {
         // one 16-column trip per wave while that keeps the partials within max_blocks (N <= 64 max_blocks), 64 and more columns
         // per wave above: a factor of 4096 columns was 16 workgroups of 4 sequential trips, 26 us at KP = 64 on an idle chip
-        nblk = (int)((N + 63) / 64);
-        if (nblk > max_blocks) nblk = max_blocks;
-        if (nblk < 1) nblk = 1;
-        i64 cpw = (N + (i64)nblk * 4 - 1) / ((i64)nblk * 4);
-        cpw = (cpw + 15) / 16 * 16;
+        i64 cpw;
+        gram_partial_shape(N, max_blocks, &nblk, &cpw);
         switch (KP) {
             case 16: gram_mfma_kernel<16><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;
             case 32: gram_mfma_kernel<32><<<nblk, 256, 0, st>>>(X, N, cpw, scratch); break;

@@ -186,6 +186,7 @@ struct smk_solver {
     hipStream_t st_inv = nullptr;         // the 0.1 ms single-workgroup inversions run here, beside the streaming products
     hipEvent_t ev_g[2] = {nullptr, nullptr}, ev_inv[2] = {nullptr, nullptr};
     bool inv_pending[2] = {false, false};
+    bool gram_ride[2] = {false, false};   // sparse, k in (8, 32]: this factor's Gram matrix is due and rides in the two launches of the gather product that follows (gram_factor, timed_spmm)
     bool inv_ride[2] = {false, false};    // sparse BPP, k in (16, 64]: this side's Gram matrix is new, its inverse is to ride in the product launch that follows (timed_spmm)
     double *xscale[2] = {nullptr, nullptr}, *oscale[2] = {nullptr, nullptr};   // fp16 two-term products: row scales of W / H (from the Gram diagonal) and their inverses
     bool packed_fresh[2] = {false, false};   // the fused Gram kernel has already written packW / packH for the next product
@@ -1924,15 +1925,27 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
     InvRide ride;                                                   // start_inverse: this side's Gram inverse rides in the launch
     if (s->inv_ride[which]) { ride.G = which == 0 ? s->Gw : s->Gh; ride.k = s->k; ride.Ginv = inv_scratch(s, which); }
     s->inv_ride[which] = false;
+    GramRide gram;                                                  // gram_factor: this factor's Gram matrix is due
+    const bool seg_route = ldx == s->KP && s->k > 2 && !is_wide(s->k) && seg.ncols == ncols && seg.rowflag && !seg.uniform;
+    if (s->gram_ride[which]) {
+        s->gram_ride[which] = false;
+        const double* F = which == 0 ? s->Wt : s->H;
+        const i64 FN = which == 0 ? s->m : s->n;
+        double* G = which == 0 ? s->Gw : s->Gh;
+        if (seg_route && ldx == s->KP) { gram.X = F; gram.N = FN; gram.max_blocks = GRAM_BLOCKS; gram.Gp = s->gram_scratch; gram.G = G; }
+        else { const int grc = launch_gram(F, s->k, FN, G, s->gram_scratch, GRAM_BLOCKS, s->st); if (grc) return grc; }
+    }
     if (ldx == 2 && blk.nb > 1) rc = launch_spmm_blocked2(blk, X, P, which == 0 ? s->pl1.ncols_pad : s->pl2.ncols_pad, s->st);
-    else if (ldx == s->KP && s->k > 2 && !is_wide(s->k) && seg.ncols == ncols && seg.rowflag && !seg.uniform) {
+    else if (seg_route) {
         // the partial sums of long columns live in the SOLVER (two solvers on one sparse matrix run on their own streams)
         if (seg.npieces > 0 && !s->seg_pieces[which] && smk::dev_malloc((void**)&s->seg_pieces[which], (size_t)seg.npieces * 128 * sizeof(double)) != hipSuccess) {
             s->seg_pieces[which] = nullptr;
             set_error("no memory for the long-column partial sums");
             return SMK_DEVICE_ERROR;
         }
-        rc = launch_spmm_seg(seg, colptr, val, X, s->k, P, s->kpp, s->st, s->seg_pieces[which], &ride);
+        rc = launch_spmm_seg(seg, colptr, val, X, s->k, P, s->kpp, s->st, s->seg_pieces[which], &ride, &gram);
+        if (rc > 0 && (rc & 2)) rc &= ~2;                           // ... and the Gram matrix
+        else if (rc >= 0 && gram.X) { set_error("the gather launch did not carry the Gram matrix"); return SMK_FAILURE; }
     }
     else rc = launch_spmm_gather(colptr, rowidx, val, ncols, s->a->nnz, X, ldx, s->k, P, s->kpp, s->st, &ride);
     if (rc == 1) { s->inv_done[which] = true; rc = 0; }             // the launch carried the inverse
@@ -2172,6 +2185,21 @@ static int gram_factor(smk_solver* s, int side)
     const i64 N = side == 0 ? s->m : s->n;
     double* G = side == 0 ? s->Gw : s->Gh;
     s->packed_fresh[side] = false;
+    s->gram_ride[side] = false;
+    {
+        // Sparse A: the gather product that follows in every schedule reads the same factor, and its two launches (segments, long-column
+        // fix-up) carry the Gram matrix along -- partial sums as extra workgroups of the first, their reduction as extra workgroups of
+        // the second (spmm_seg.hip, gram_body.h): four launches become two (the Reuters shape under HALS: 102 -> 84 us per iteration).
+        // Not where block pivoting needs the inverse of this matrix in the SAME launch (k in (16, 32]: that one rides, start_inverse).
+        // A product that takes another route forms the matrix first, as before (timed_spmm).  SMK_GRAM_RIDE=0: never rides.
+        static const bool ride = [] { const char* e = getenv("SMK_GRAM_RIDE"); return !(e && e[0] == '0'); }();
+        const bool inverse_next = s->o.algorithm == SMK_ALG_BPP && (s->KP == 64 || (s->KP == 32 && nnls_inverse_at_32()));
+        if (ride && s->a->sparse && !is_dist(s) && !s->comm && !s->w_sharded && (s->KP == 16 || s->KP == 32) && s->k > 2 && !inverse_next &&
+            s->o.algorithm != SMK_ALG_RANK2) {
+            s->gram_ride[side] = true;
+            return 0;
+        }
+    }
     if (side == 0 && s->w_sharded) {
         // W'W from this rank's own rows, summed over the ranks; the fp16 row scales follow the finished matrix
         int rc = s->n_own > 0 ? launch_gram(s->Wown, s->k, s->n_own, G, s->gram_scratch, GRAM_BLOCKS, s->st)

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "devutil.h"
 #include "gram_inverse.h"
+#include "gram_body.h"
 
 namespace smk {
 
@@ -47,11 +48,24 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const i64* __restrict__ s
                                                        const unsigned* __restrict__ seg_piece, i64 nseg,
                                                        const i64* __restrict__ colptr, const unsigned* __restrict__ rowflag,
                                                        const double* __restrict__ val, const double* __restrict__ X,
-                                                       double* __restrict__ P, int kpp, double* __restrict__ pieces, InvRide ride)
+                                                       double* __restrict__ P, int kpp, double* __restrict__ pieces, InvRide ride,
+                                                       const double* __restrict__ gram_x, i64 gram_n, i64 gram_cpw, int gram_nblk,
+                                                       double* __restrict__ gram_gp)
 {
     constexpr int LPC = KP / 2;
     constexpr int GPB = 256 / LPC;
     i64 blk = blockIdx.x;
+    if constexpr (KP == 16 || KP == 32) {
+        // the first gram_nblk workgroups of a launch that carries a Gram matrix form its partial sums (common.h: GramRide)
+        if (gram_x) {
+            if (blk < gram_nblk) {
+                __shared__ double red[KP * KP];
+                gram_mfma_body<KP>(gram_x, gram_n, gram_cpw, gram_gp, blk, red);
+                return;
+            }
+            blk -= gram_nblk;
+        }
+    }
     if constexpr (KP == 32 || KP == 64) {
         // workgroup 0 of a launch that carries the Gram inverse (common.h: InvRide) inverts; the product starts at workgroup 1
         if (ride.G) {
@@ -112,13 +126,25 @@ __global__ __launch_bounds__(256) void spmm_seg_kernel(const i64* __restrict__ s
 template <int KP>
 __global__ __launch_bounds__(256) void spmm_seg_fixup_kernel(const unsigned* __restrict__ long_col,
                                                              const i64* __restrict__ long_piece0, i64 nlong,
-                                                             const double* __restrict__ pieces, double* __restrict__ P, int kpp)
+                                                             const double* __restrict__ pieces, double* __restrict__ P, int kpp,
+                                                             const double* __restrict__ gram_gp, int gram_nblk, double* __restrict__ gram_g)
 {
+    // the first KP * KP / 16 workgroups of a launch that carries a Gram matrix add up its partial sums (common.h: GramRide)
+    i64 fblk = blockIdx.x;
+    if (gram_gp) {
+        constexpr int RB = KP * KP / 16;
+        if (fblk < RB) {
+            __shared__ double sh[16][17];
+            gram_reduce_body(gram_gp, gram_nblk, KP * KP, gram_g, 0, nullptr, nullptr, 1.0, (int)fblk, sh);
+            return;
+        }
+        fblk -= RB;
+    }
     constexpr int LPC = KP / 2;
     constexpr int G = 64 / LPC;
     __shared__ double part[4][G][KP];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const i64 c = (i64)blockIdx.x * 4 + w;
+    const i64 c = fblk * 4 + w;
     if (c >= nlong) return;
     const int g = lane / LPC, l = lane % LPC;
     const i64 q0 = long_piece0[c], q1 = long_piece0[c + 1];
@@ -246,7 +272,7 @@ int build_seg_plan(i64 ncols, i64 nnz, const i64* colptr, const unsigned* rowidx
 }
 
 int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, const double* X, int k, double* P, int kpp,
-                    hipStream_t st, double* pieces, const InvRide* ride_in)
+                    hipStream_t st, double* pieces, const InvRide* ride_in, const GramRide* gram_in)
 {
     const int KPv = kp_of(k);
     if (!pieces) pieces = sp.pieces;
@@ -256,21 +282,33 @@ int launch_spmm_seg(const SegPlan& sp, const i64* colptr, const double* val, con
     const int gpb = 256 / (KPv / 2);
     InvRide ride;
     if (ride_in && ride_in->G && (KPv == 32 || KPv == 64)) ride = *ride_in;
-    const unsigned grid = (unsigned)((sp.nseg + gpb - 1) / gpb) + (ride.G ? 1u : 0u);
+    GramRide gram;
+    int gnblk = 0;
+    i64 gcpw = 0;
+    if (gram_in && gram_in->X && gram_in->Gp && gram_in->G && (KPv == 16 || KPv == 32) && !ride.G) {
+        gram = *gram_in;
+        gram_partial_shape(gram.N, gram.max_blocks, &gnblk, &gcpw);
+    }
+    const unsigned grid = (unsigned)((sp.nseg + gpb - 1) / gpb) + (ride.G ? 1u : 0u) + (unsigned)gnblk;
     const double* v = val;
     static const int ufix = [] { const char* e = getenv("SMK_SPMM_SEG_U"); return e ? atoi(e) : 0; }();
 #define SMK_SEG(U)                                                                                                                  \
-    KP_DISPATCH128(KPv, (sp.has_empty ? spmm_seg_kernel<KP, U, true><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, pieces, ride) \
-                                      : spmm_seg_kernel<KP, U, false><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, pieces, ride)))
+    KP_DISPATCH128(KPv, (sp.has_empty ? spmm_seg_kernel<KP, U, true><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, pieces, ride, gram.X, gram.N, gcpw, gnblk, gram.Gp) \
+                                      : spmm_seg_kernel<KP, U, false><<<grid, 256, 0, st>>>(sp.seg_p0, sp.seg_len, sp.seg_col, sp.seg_piece, sp.nseg, colptr, sp.rowflag, v, X, P, kpp, pieces, ride, gram.X, gram.N, gcpw, gnblk, gram.Gp)))
     if (ufix == 4) { SMK_SEG(4); } else if (ufix == 16) { SMK_SEG(16); } else { SMK_SEG(8); }
 #undef SMK_SEG
     SMK_HIP(hipGetLastError());
     if (sp.nlong > 0) {
-        const unsigned g2 = (unsigned)((sp.nlong + 3) / 4);
-        KP_DISPATCH128(KPv, (spmm_seg_fixup_kernel<KP><<<g2, 256, 0, st>>>(sp.long_col, sp.long_piece0, sp.nlong, pieces, P, kpp)));
+        // (the reduction of the Gram partial sums rides here: KP * KP / 16 more workgroups)
+        const unsigned g2 = (unsigned)((sp.nlong + 3) / 4) + (gram.X ? (unsigned)(KPv * KPv / 16) : 0u);
+        KP_DISPATCH128(KPv, (spmm_seg_fixup_kernel<KP><<<g2, 256, 0, st>>>(sp.long_col, sp.long_piece0, sp.nlong, pieces, P, kpp,
+                                                                            gram.X ? gram.Gp : nullptr, gnblk, gram.G)));
         SMK_HIP(hipGetLastError());
+    } else if (gram.X) {
+        const int rrc = launch_gram_reduce(gram.Gp, gnblk, k, gram.G, st, nullptr, nullptr, 1.0);
+        if (rrc) return rrc;
     }
-    return ride.G ? 1 : 0;
+    return (ride.G ? 1 : 0) | (gram.X ? 2 : 0);
 }
 
 }  // namespace smk

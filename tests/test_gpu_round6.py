@@ -187,6 +187,42 @@ print("RESULT", " ".join(out))
     assert all(x == seen[0] for x in seen), seen
 
 
+def test_gram_matrix_rides_in_the_sparse_product_launches():
+    """Sparse A, k in (8, 32] (MU, HALS, BPP at k <= 16): the Gram matrix of a factor is formed inside the two launches of the gather
+    product that follows it in every schedule -- partial sums by extra workgroups of spmm_seg_kernel, their reduction by extra
+    workgroups of the fix-up launch (gram_body.h, common.h: GramRide).  The same partial sums in the same order as the launches of
+    their own (SMK_GRAM_RIDE=0): bit-identical factors, and the oracle's (nmf_solver_hals.hpp:166-199, nmf_solver_mu.hpp:121-164).
+    One matrix has long columns (the reduction rides in the fix-up launch), one has none (it goes out as a launch of its own)."""
+    code = r"""
+import sys, hashlib; sys.path.insert(0, %r)
+import numpy as np, scipy.sparse as sp, oracle, smallk_amd as g
+g.initialize(0)
+out = []
+m, n = 1500, 1100
+mats = [sp.random(m, n, density=0.15, random_state=5, format="csc"),            # columns of ~225 entries: long ones among them
+        sp.random(m, n, density=0.02, random_state=6, format="csc")]            # ~30 entries per column: no fix-up launch
+for ai, A in enumerate(mats):
+    Ad = np.asfortranarray(A.toarray())
+    for alg, ks in (("HALS", (12, 16, 24, 32)), ("MU", (16, 32)), ("BPP", (12, 16))):
+        for k in ks:
+            if alg == "HALS" and ai == 1 and k > 12: continue                   # (rows of H collapse there: the run sits on the epsilon guard)
+            W0, H0 = oracle.fill_uniform(m, k, 3), oracle.fill_uniform(k, n, 4) * (2.0 / k)
+            got = g.nmf_sparse(A, W0, H0, alg, min_iter=6, max_iter=6)
+            ref = oracle.nmf(Ad, W0, H0, alg, min_iter=6, max_iter=6)
+            err = max(np.linalg.norm(got.W - ref.W) / np.linalg.norm(ref.W), np.linalg.norm(got.H - ref.H) / np.linalg.norm(ref.H))
+            assert err < 1e-8, (ai, alg, k, err)
+            out.append(hashlib.sha1(got.W.tobytes() + got.H.tobytes()).hexdigest()[:12])
+print("RESULT", " ".join(out))
+""" % ROOT
+    seen = []
+    for env in ({}, {"SMK_GRAM_RIDE": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=900, env=dict(os.environ, **env))
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stdout[-1500:] + r.stderr[-1500:]
+        seen.append(line[0])
+    assert seen[0] == seen[1], seen
+
+
 @pytest.mark.parametrize("flags", [["--check-every-iteration"], ["--api-path"]])
 def test_bench_flags_of_round_6_run(flags):
     """bench.py --check-every-iteration / --api-path on the smallest workload (C1: 512 x 256, k = 8, MU): one JSON line with the

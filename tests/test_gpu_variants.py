@@ -87,7 +87,7 @@ def test_check_every_iteration_loop():
 
 @pytest.mark.parametrize("env", [{"SMK_PROGRESS_DEFER": "0"}, {"SMK_PROGRESS_DEPTH": "3"}, {"SMK_BPP_GRADW": "1"}, {"SMK_HALS_EPILOGUE": "0"},
                                  {"SMK_PROGRESS_DEFER": "0", "SMK_PROGRESS_DEPTH": "2"}, {"SMK_PROGRESS_POLL": "0"},
-                                 {"SMK_PROGRESS_TAIL": "0", "SMK_PROGRESS_DEPTH": "2"}, {"SMK_INV_RIDE": "0"}, {"SMK_INV_RIDE": "0", "SMK_INV_STREAM": "1"}])
+                                 {"SMK_PROGRESS_TAIL": "0", "SMK_PROGRESS_DEPTH": "2"}, {"SMK_INV_RIDE": "0"}, {"SMK_INV_RIDE": "0", "SMK_INV_STREAM": "1"}, {"SMK_GRAM_RIDE": "0"}])
 def test_round_6_switches_stay_selectable(env):
     """The non-default values of round 6's switches on the randomised sweep (tolerance-stopped runs included: iteration counts and
     factors must be the oracle's): the stopping-rule check NOT riding in the next NNLS launch, three checks in flight, BPP's W-side
