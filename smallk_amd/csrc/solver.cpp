@@ -1932,7 +1932,7 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
         const double* F = which == 0 ? s->Wt : s->H;
         const i64 FN = which == 0 ? s->m : s->n;
         double* G = which == 0 ? s->Gw : s->Gh;
-        if (seg_route && ldx == s->KP) { gram.X = F; gram.N = FN; gram.max_blocks = GRAM_BLOCKS; gram.Gp = s->gram_scratch; gram.G = G; }
+        if (seg_route) { gram.X = F; gram.N = FN; gram.max_blocks = GRAM_BLOCKS; gram.Gp = s->gram_scratch; gram.G = G; }
         else { const int grc = launch_gram(F, s->k, FN, G, s->gram_scratch, GRAM_BLOCKS, s->st); if (grc) return grc; }
     }
     if (ldx == 2 && blk.nb > 1) rc = launch_spmm_blocked2(blk, X, P, which == 0 ? s->pl1.ncols_pad : s->pl2.ncols_pad, s->st);
@@ -1945,7 +1945,10 @@ static int timed_spmm(smk_solver* s, int which, const i64* colptr, const unsigne
         }
         rc = launch_spmm_seg(seg, colptr, val, X, s->k, P, s->kpp, s->st, s->seg_pieces[which], &ride, &gram);
         if (rc > 0 && (rc & 2)) rc &= ~2;                           // ... and the Gram matrix
-        else if (rc >= 0 && gram.X) { set_error("the gather launch did not carry the Gram matrix"); return SMK_FAILURE; }
+        else if (rc >= 0 && gram.X) {                               // nothing was launched (a matrix without stored entries): the matrix by itself
+            const int grc = launch_gram(gram.X, s->k, gram.N, gram.G, s->gram_scratch, GRAM_BLOCKS, s->st);
+            if (grc) return grc;
+        }
     }
     else rc = launch_spmm_gather(colptr, rowidx, val, ncols, s->a->nnz, X, ldx, s->k, P, s->kpp, s->st, &ride);
     if (rc == 1) { s->inv_done[which] = true; rc = 0; }             // the launch carried the inverse

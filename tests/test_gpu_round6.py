@@ -212,6 +212,11 @@ for ai, A in enumerate(mats):
             err = max(np.linalg.norm(got.W - ref.W) / np.linalg.norm(ref.W), np.linalg.norm(got.H - ref.H) / np.linalg.norm(ref.H))
             assert err < 1e-8, (ai, alg, k, err)
             out.append(hashlib.sha1(got.W.tobytes() + got.H.tobytes()).hexdigest()[:12])
+# a matrix without stored entries: no gather launch exists to ride in -- the Gram matrix is formed by itself, as on the other route
+E = sp.csc_matrix((200, 150))
+W0, H0 = oracle.fill_uniform(200, 12, 3), oracle.fill_uniform(12, 150, 4)
+got = g.nmf_sparse(E, W0, H0, "MU", min_iter=3, max_iter=3)
+out.append(hashlib.sha1(got.W.tobytes() + got.H.tobytes()).hexdigest()[:12])
 print("RESULT", " ".join(out))
 """ % ROOT
     seen = []
