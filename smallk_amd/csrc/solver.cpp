@@ -2623,7 +2623,9 @@ static int progress_end(smk_solver* s, int b, int iter_index, double* metric)
         const volatile double* tagp = &s->pin[b].h[7];
         const double want = s->poll_tag[b];
         for (unsigned long spins = 1; *tagp != want; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#endif
             if ((spins & 0x3FFFF) == 0) {
                 const hipError_t q = hipStreamQuery(s->st);
                 if (q == hipErrorNotReady) continue;
