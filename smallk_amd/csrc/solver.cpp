@@ -1736,7 +1736,9 @@ static int wait_gh(smk_solver* s)
 static int wait_r2(smk_solver* s)
 {
     if (!s->r2_pending) return 0;
-    const int rc = main_waits_for_comm(s, s->ev_r, s->nchunk);
+    // (the chunk exchanges were recorded on ONE in-order stream: the last event covers the others -- one barrier packet on the
+    // main stream instead of nchunk; tools/mb/mb_event_hop.hip prices them)
+    const int rc = main_waits_for_comm(s, &s->ev_r[s->nchunk - 1], 1);
     if (rc) return rc;
     s->r2_pending = false;
     return 0;
